@@ -1,0 +1,154 @@
+/* qsp_hip.h -- C-ABI of the MI355X-native joint object-optimisation hot path of QSP-SLAM.
+ *
+ * One shared library (libqsp_hip.so) exports every symbol declared here: plain pointers and sizes, int status
+ * returns, no exceptions across the boundary, no torch / Eigen / OpenCV types.  Each entry point names the reference
+ * interface it replaces (paths relative to the reference root, GetOverMassif/QSP-SLAM).
+ *
+ * Threading: a handle (decoder, batch, BA problem) may be used by one host thread at a time; distinct handles are
+ * independent.  The reference calls both paths from the LocalMapping thread under the GIL (include/System.h:61-75).
+ *
+ * Path A  (DeepSDF object refinement)  replaces reconstruct/optimizer.py + reconstruct/loss.py + loss_utils.py
+ * Path B  (joint bundle adjustment)    replaces src/Optimizer.cc, src/Optimizer_util.cc, include/ObjectPoseGraph.h
+ *                                      on top of Thirdparty/g2o (BlockSolver_6_3 + LM + LinearSolverEigen)
+ */
+#ifndef QSP_HIP_H
+#define QSP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * status codes
+ * ------------------------------------------------------------------------------------------------------------ */
+enum {
+    QSP_OK = 0,
+    QSP_ERR_INVALID = 1,      /* bad argument (null pointer, negative size, inconsistent counts)            */
+    QSP_ERR_UNSUPPORTED = 2,  /* decoder architecture outside the supported family (see qsp_decoder_create) */
+    QSP_ERR_DEVICE = 3,       /* a HIP call failed; qsp_last_error() holds the text                          */
+    QSP_ERR_NO_DEVICE = 4     /* no gfx950 device visible -- there is no CPU fallback                        */
+};
+
+const char* qsp_last_error(void);   /* thread-local text of the last failure */
+int qsp_version(void);              /* ABI version, currently 1 */
+int qsp_device_count(void);
+
+/* ===============================================================================================================
+ * Path A -- DeepSDF decoder and object refinement
+ * ============================================================================================================ */
+
+/* Decoder description.  Replaces deep_sdf/workspace.py:202-224 (config_decoder) + deep_sdf/deep_sdf_decoder.py:9-110.
+ * weight[l] is (out_dim[l], in_dim[l]) row-major.  If weight_g != NULL and weight_g[l] != NULL, weight[l] is the
+ * weight-norm direction v and the effective matrix is g * v / ||v||_row (old-style torch weight_norm, dim 0), folded
+ * once at creation instead of on every call as the reference does.
+ * Supported family: n_layers = 9, hidden width 512, code_len = 64, latent_in_layer = 4 (the DSP-SLAM "8 x 512"
+ * decoder: 67->512, 512->512 x2, 512->445, 512->512 x4, 512->1, ReLU, final tanh).  Anything else: QSP_ERR_UNSUPPORTED. */
+typedef struct {
+    int32_t n_layers;
+    int32_t code_len;
+    int32_t latent_in_layer;
+    const int32_t* in_dim;
+    const int32_t* out_dim;
+    const float* const* weight;
+    const float* const* weight_g;   /* may be NULL */
+    const float* const* bias;
+} qsp_decoder_desc;
+
+typedef struct qsp_decoder qsp_decoder;
+
+int qsp_decoder_create(const qsp_decoder_desc* desc, int device, qsp_decoder** out);
+void qsp_decoder_destroy(qsp_decoder* dec);
+
+/* decode_sdf, reconstruct/loss_utils.py:51-79.  Host pointers: code (code_len), xyz (n,3) row-major, sdf_out (n). */
+int qsp_decode_sdf(qsp_decoder* dec, const float* code, const float* xyz, int64_t n, float* sdf_out);
+
+/* get_batch_sdf_jacobian, reconstruct/loss_utils.py:82-103 (out_dim = 1): y (n) and d y / d [code | xyz] (n, code_len+3),
+ * without the weight gradients the reference's autograd also accumulates and never uses.  Host pointers. */
+int qsp_sdf_value_grad(qsp_decoder* dec, const float* code, const float* xyz, int64_t n, float* y, float* grad);
+
+/* The `optimizer` block of the detector-config JSON (configs/config_*.json:21-41) read by
+ * reconstruct/optimizer.py:27-44. */
+typedef struct {
+    float k1, k2, k3, k4;      /* render, sdf, code-prior, rotation-prior weights                    */
+    float b1, b2;              /* Huber thresholds: render, sdf                                       */
+    float lr;                  /* learning_rate                                                       */
+    float s_damp;              /* scale_damping                                                       */
+    float cut_off;             /* cut_off_threshold (SDF -> occupancy)                                */
+    int32_t n_iter;            /* joint_optim.num_iterations                                          */
+    int32_t n_depth;           /* num_depth_samples (<= 64)                                           */
+    int32_t code_len;          /* 64                                                                  */
+} qsp_joint_cfg;
+
+/* A resident batch of refinement hypotheses.  An *object* owns the observations of one detection (surface points,
+ * rays, depths: the arguments src/LocalMapping_util.cc:585-672 assembles); a *hypothesis* is one call of
+ * Optimizer.reconstruct_object (reconstruct/optimizer.py:96-281) on an object from its own initial pose/code -- the
+ * reference makes flip_sample_num (=4) such calls per object, serially (LocalMapping_util.cc:705-760).  All
+ * hypotheses of a batch advance together, one fused launch sequence per Gauss-Newton iteration, with no host
+ * synchronisation inside the iteration loop. */
+typedef struct qsp_refine_batch qsp_refine_batch;
+
+/* pts[o]: (n_pts[o],3) row-major camera-frame points; rays[o]: (n_rays[o],3); depth[o]: (n_fg[o]) observed depth of
+ * the first n_fg[o] rays (the rest are background rays).  hyp_obj[h] = object index of hypothesis h.  Host pointers;
+ * everything is copied to the device here and stays resident. */
+int qsp_refine_batch_create(qsp_decoder* dec, const qsp_joint_cfg* cfg, int32_t n_obj,
+                            const float* const* pts, const int32_t* n_pts,
+                            const float* const* rays, const int32_t* n_rays,
+                            const float* const* depth, const int32_t* n_fg,
+                            int32_t n_hyp, const int32_t* hyp_obj, qsp_refine_batch** out);
+void qsp_refine_batch_destroy(qsp_refine_batch* b);
+
+/* (re)initialise every hypothesis: t_cam_obj (n_hyp,4,4) row-major Sim3 object->camera, code (n_hyp,code_len) or NULL
+ * for the zero code (reconstruct/optimizer.py:111-119).  Clears is_good/loss. */
+int qsp_refine_batch_set_state(qsp_refine_batch* b, const float* t_cam_obj, const float* code);
+
+/* Run n_iter Gauss-Newton iterations (n_iter <= 0: cfg.n_iter) and wait for completion. */
+int qsp_refine_batch_run(qsp_refine_batch* b, int32_t n_iter);
+
+/* Results per hypothesis: t_cam_obj_out (n_hyp,4,4), code_out (n_hyp,code_len), loss_out (n_hyp), is_good_out (n_hyp).
+ * is_good = 0 reproduces the reference's early exits (fewer than 10 ray samples in the unit ball, NaN loss):
+ * the pose/code outputs of such a hypothesis are unspecified, loss is that of the last completed iteration. */
+int qsp_refine_batch_get(qsp_refine_batch* b, float* t_cam_obj_out, float* code_out, float* loss_out,
+                         uint8_t* is_good_out);
+
+/* Introspection of the LAST iteration run, for parity tests: H (n_hyp,71,71), rhs (n_hyp,71), dx (n_hyp,71),
+ * n_valid (n_hyp) ray samples inside the unit ball, n_render (n_hyp) render rows K, loss terms (n_hyp,2) =
+ * (sdf, render).  Any pointer may be NULL. */
+int qsp_refine_batch_trace(qsp_refine_batch* b, float* H, float* rhs, float* dx, int32_t* n_valid,
+                           int32_t* n_render, float* loss_terms);
+
+/* Timing of the last qsp_refine_batch_run, measured with HIP events on the library's own stream. */
+typedef struct {
+    float ms_total;          /* first launch -> last kernel complete                                  */
+    float ms_mlp_jtj;        /* sum over launches of the fused MLP fwd+bwd+JtJ kernel                */
+    float ms_mlp_fwd;        /* sum over launches of the forward-only MLP kernel (ray samples)       */
+    float ms_other;          /* ray sampling, render scan, reduce+solve                              */
+    int32_t n_launch_jtj, n_launch_fwd;
+    int64_t pts_jtj;         /* points through fwd+bwd (sdf points + render rows), all iterations     */
+    int64_t pts_fwd;         /* points through forward only (valid ray samples), all iterations       */
+    int64_t tiles_jtj, tiles_fwd;   /* 64-point tiles actually executed (incl. padding rows)          */
+} qsp_refine_profile;
+int qsp_refine_batch_profile(qsp_refine_batch* b, int enable, qsp_refine_profile* out);
+
+/* One-shot convenience with the reference's per-call semantics, batched over hypotheses:
+ * create + set_state + run + get + destroy.  Optimizer.reconstruct_object, reconstruct/optimizer.py:96-281. */
+int qsp_reconstruct_objects(qsp_decoder* dec, const qsp_joint_cfg* cfg, int32_t n_obj,
+                            const float* const* pts, const int32_t* n_pts,
+                            const float* const* rays, const int32_t* n_rays,
+                            const float* const* depth, const int32_t* n_fg,
+                            int32_t n_hyp, const int32_t* hyp_obj, const float* t_cam_obj, const float* code,
+                            float* t_cam_obj_out, float* code_out, float* loss_out, uint8_t* is_good_out);
+
+/* Optimizer.estimate_pose_cam_obj, reconstruct/optimizer.py:47-93, batched: per item an SE3 t_co (4,4), a scale, surface
+ * points and a code; n_iter SDF-only Gauss-Newton iterations on the 6 pose dimensions (1e-2 damping, raw residual,
+ * inlier filter |res| <= 0.05 after iteration index 4).  t_co_out (n,4,4) SE3.  Host pointers. */
+int qsp_estimate_pose(qsp_decoder* dec, int32_t n, const float* t_co_se3, const float* scale,
+                      const float* const* pts, const int32_t* n_pts, const float* code, int32_t n_iter,
+                      float* t_co_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QSP_HIP_H */

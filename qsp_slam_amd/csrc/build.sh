@@ -1,0 +1,10 @@
+#!/bin/bash
+# Builds libqsp_hip.so (gfx950 only) in-tree.  hipcc cross-compiles without a GPU.
+set -e
+cd "$(dirname "$0")"
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result"
+SRCS="sdf_refine.hip c_abi.cpp"
+[ -f ba_solver.hip ] && SRCS="$SRCS ba_solver.hip"
+$HIPCC $FLAGS -shared -o ../libqsp_hip.so $SRCS "$@"
+echo "built $(cd .. && pwd)/libqsp_hip.so"

@@ -1,0 +1,361 @@
+// sdf_mlp.hpp -- the DeepSDF 8x512 decoder as ONE on-chip pass per 64-point tile (gfx950 / CDNA4).
+//
+// Replaces, for one tile of 64 query points that share a latent code:
+//   forward   deep_sdf/deep_sdf_decoder.py:75-110   (9 Linear layers, ReLU, latent skip at layer 4, tanh)
+//   backward  reconstruct/loss_utils.py:82-103      (d sdf / d [code | xyz], backward-DATA only; the reference's
+//                                                    autograd also forms weight gradients nobody reads)
+//
+// Design (not a translation of the reference's cuBLAS-per-layer sequence):
+//   * a 512-thread workgroup (8 waves, 2 per SIMD) owns a tile of 64 points for the whole network: activations live
+//     in LDS as f32 [64][516] (row padded by one 16-B access so that ds_read_b128 of 16 distinct rows is
+//     conflict-free), accumulators live in registers, nothing but weights is read from memory between the input
+//     and the 71-wide Jacobian row;
+//   * wave w owns output columns [64w, 64w+64) of every layer: 2x2 tiles of v_mfma_f32_32x32x2_f32 (exact f32, the
+//     only MFMA that meets the 1e-4 parity bar without error compensation).  Its B operand (weights) is private to
+//     the wave, so it is streamed global->VGPR with a software prefetch ring and never staged in LDS; the host
+//     pre-packs the weights so that every wave-load is one contiguous 1 KiB line group (dwordx4 per lane);
+//   * the ReLU masks of all 8 hidden layers stay in 16 VGPRs per lane: forward and backward use the same
+//     (wave -> columns, lane -> row/col) map, so the backward pass applies them without any memory traffic;
+//   * layer 3 has 445 outputs and layer 4 consumes [h3 | code | xyz] = 512 inputs exactly: the owners of columns
+//     445..511 write the network input there instead of a ReLU output, which makes every hidden layer a uniform
+//     512x512 GEMM.  In the backward pass the same columns are the skip-connection gradient and go to a stash.
+//
+// K order inside a k-group of 8 is permuted (lane half h takes k = 8g + 4h + e) identically for A and B; this only
+// changes the f32 summation order.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace qsp {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int TILE_P = 64;      // points per tile
+constexpr int HID = 512;        // hidden width
+constexpr int CODE_LEN = 64;    // latent code length
+constexpr int NIN = CODE_LEN + 3;
+constexpr int SKIP_COL = HID - NIN;   // 445: first pass-through column of the latent_in layer's input
+constexpr int K0_PAD = 96;      // layer-0 K (67) padded to a multiple of 8*PF
+constexpr int LDA = HID + 4;    // activation row stride (floats)
+constexpr int LDST = 68;        // stash row stride
+constexpr int LDJ = 96;         // augmented-Jacobian row stride (72 used)
+constexpr int NJ = 72;          // 7 pose + 64 code + 1 residual column
+constexpr int MLP_THREADS = 512;
+constexpr int HT_TILES = 6;     // upper-triangular 32x32 tiles of the 96x96 padded J~^T J~
+
+struct MlpParams {
+    const float4* wf[8];    // forward-packed weights of layers 0..7
+    const float4* wb[8];    // backward-packed weights of layers 0..7
+    const float* bias[8];   // [512] zero-padded
+    const float* w8;        // [512] last layer row
+    float b8;
+};
+
+// LDS carve (bytes): act 132096 | stash 17408 | inp 64*4*4 | code 256 | y 256 | red 2048 | row scale/res 512
+struct __attribute__((aligned(16))) MlpSmem {
+    float act[TILE_P * LDA];
+    float stash[TILE_P * LDST];
+    float xin[TILE_P * 4];      // object-frame xyz per row (4th = 0)
+    float code[CODE_LEN];
+    float y[TILE_P];            // tanh output
+    float red[8 * TILE_P];      // layer-8 partial sums
+    float rscale[TILE_P];       // row scale of the Jacobian (1 for SDF rows, de/ds for render rows, 0 for padding)
+    float rres[TILE_P];         // residual supplied by the caller (render rows)
+};
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// row / column of accumulator register i of a 32x32 tile for this lane (C/D map of v_mfma_f32_32x32x2_f32)
+__device__ __forceinline__ int acc_row(int i, int lane) { return (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5); }
+
+// acc[r][c] += act[32r.., 0..8*KG) * Wpacked, for this wave's two column blocks.
+// w0/w1 already include the lane offset; consecutive k-groups are 64 float4 apart.
+template <int KG, int PF>
+__device__ __forceinline__ void gemm_2x2(const float* __restrict__ act, const float4* __restrict__ w0,
+                                         const float4* __restrict__ w1, f32x16 (&acc)[2][2], int lane) {
+    // w0 / w1 are wave-uniform bases (SGPR); the per-lane part of the address is the single VGPR `lane`.
+    // The prefetch runs PF k-groups past the end of the column block: the packed buffers are over-allocated by the
+    // host (see pack_weights) so those loads stay in bounds; their values are never used.
+    static_assert(KG % PF == 0, "KG must be a multiple of the prefetch depth");
+    float4 q0[PF], q1[PF];
+#pragma unroll
+    for (int d = 0; d < PF; ++d) {
+        q0[d] = w0[d * 64 + lane];
+        q1[d] = w1[d * 64 + lane];
+    }
+    const float* a_row0 = act + (lane & 31) * LDA + 4 * (lane >> 5);
+    const float* a_row1 = a_row0 + 32 * LDA;
+#pragma nounroll
+    for (int kg = 0; kg < KG; kg += PF) {
+#pragma unroll
+        for (int d = 0; d < PF; ++d) {
+            const float4 b0 = q0[d], b1 = q1[d];
+            q0[d] = w0[(kg + d + PF) * 64 + lane];
+            q1[d] = w1[(kg + d + PF) * 64 + lane];
+            const float4 a0 = *reinterpret_cast<const float4*>(a_row0 + 8 * (kg + d));
+            const float4 a1 = *reinterpret_cast<const float4*>(a_row1 + 8 * (kg + d));
+            acc[0][0] = mfma32(a0.x, b0.x, acc[0][0]);
+            acc[0][1] = mfma32(a0.x, b1.x, acc[0][1]);
+            acc[1][0] = mfma32(a1.x, b0.x, acc[1][0]);
+            acc[1][1] = mfma32(a1.x, b1.x, acc[1][1]);
+            acc[0][0] = mfma32(a0.y, b0.y, acc[0][0]);
+            acc[0][1] = mfma32(a0.y, b1.y, acc[0][1]);
+            acc[1][0] = mfma32(a1.y, b0.y, acc[1][0]);
+            acc[1][1] = mfma32(a1.y, b1.y, acc[1][1]);
+            acc[0][0] = mfma32(a0.z, b0.z, acc[0][0]);
+            acc[0][1] = mfma32(a0.z, b1.z, acc[0][1]);
+            acc[1][0] = mfma32(a1.z, b0.z, acc[1][0]);
+            acc[1][1] = mfma32(a1.z, b1.z, acc[1][1]);
+            acc[0][0] = mfma32(a0.w, b0.w, acc[0][0]);
+            acc[0][1] = mfma32(a0.w, b1.w, acc[0][1]);
+            acc[1][0] = mfma32(a1.w, b0.w, acc[1][0]);
+            acc[1][1] = mfma32(a1.w, b1.w, acc[1][1]);
+        }
+    }
+}
+
+// one 32x32 tile over K = 8*KG (used by the 67-column backward of layer 0)
+template <int KG, int PF>
+__device__ __forceinline__ void gemm_1x1(const float* __restrict__ act_rows, const float4* __restrict__ w0,
+                                         f32x16& acc, int lane) {
+    float4 q0[PF];
+#pragma unroll
+    for (int d = 0; d < PF; ++d) q0[d] = w0[d * 64 + lane];
+    const float* a_row0 = act_rows + (lane & 31) * LDA + 4 * (lane >> 5);
+#pragma nounroll
+    for (int kg = 0; kg < KG; kg += PF) {
+#pragma unroll
+        for (int d = 0; d < PF; ++d) {
+            const float4 b0 = q0[d];
+            q0[d] = w0[(kg + d + PF) * 64 + lane];
+            const float4 a0 = *reinterpret_cast<const float4*>(a_row0 + 8 * (kg + d));
+            acc = mfma32(a0.x, b0.x, acc);
+            acc = mfma32(a0.y, b0.y, acc);
+            acc = mfma32(a0.z, b0.z, acc);
+            acc = mfma32(a0.w, b0.w, acc);
+        }
+    }
+}
+
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][2]) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[r][c][i] = 0.f;
+}
+
+// v if bit k of mask is set, else +0: sign-extended 1-bit field extract + AND (no lane-mask SGPRs, no branches)
+__device__ __forceinline__ float mask_sel(float v, uint32_t mask, int k) {
+    const int sel = ((int)(mask << (31 - k))) >> 31;
+    return __int_as_float(__float_as_int(v) & sel);
+}
+
+// Forward write-out of hidden layer L: bias, ReLU, mask capture, pass-through columns of layer 3.
+template <int L>
+__device__ __forceinline__ void fwd_writeout(MlpSmem& s, const float* __restrict__ bias, const f32x16 (&acc)[2][2], int wave,
+                                             int lane, uint32_t& m_lo, uint32_t& m_hi) {
+    const int j = lane & 31;
+    const float bv[2] = {bias[64 * wave + j], bias[64 * wave + 32 + j]};
+    uint32_t lo = 0, hi = 0;
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int col = 64 * wave + 32 * c + j;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = 32 * r + acc_row(i, lane);
+                float v = acc[r][c][i] + bv[c];
+                const bool pos = v > 0.f;
+                const uint32_t bit = pos ? 1u : 0u;
+                if (r == 0) lo |= bit << (c * 16 + i);
+                else hi |= bit << (c * 16 + i);
+                v = pos ? v : 0.f;
+                if (L == 3) {
+                    if (col >= SKIP_COL) {
+                        const int ci = col - SKIP_COL;   // 0..66: code then xyz
+                        v = ci < CODE_LEN ? s.code[ci] : s.xin[row * 4 + (ci - CODE_LEN)];
+                    }
+                }
+                s.act[row * LDA + col] = v;
+            }
+        }
+    // opaque to the optimiser: otherwise it keeps the 64 v_cmp lane masks of every layer alive in SGPRs and spills them
+    asm volatile("" : "+v"(lo), "+v"(hi));
+    m_lo = lo;
+    m_hi = hi;
+}
+
+// Backward write-out of the gradient w.r.t. the INPUT of layer L (= post-ReLU output of layer L-1):
+// apply the ReLU mask of layer L-1; at L == 4 the pass-through columns are the skip gradient -> stash.
+template <int L>
+__device__ __forceinline__ void bwd_writeout(MlpSmem& s, const f32x16 (&acc)[2][2], int wave, int lane, uint32_t m_lo,
+                                             uint32_t m_hi) {
+    const int j = lane & 31;
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int col = 64 * wave + 32 * c + j;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = 32 * r + acc_row(i, lane);
+                float v = mask_sel(acc[r][c][i], r == 0 ? m_lo : m_hi, c * 16 + i);
+                if (L == 4) {
+                    if (col >= SKIP_COL) {
+                        s.stash[row * LDST + (col - SKIP_COL)] = acc[r][c][i];
+                        v = 0.f;
+                    }
+                }
+                s.act[row * LDA + col] = v;
+            }
+        }
+}
+
+// Whole network for the tile whose inputs are staged in s.code / s.xin.
+// On return (all threads, after a barrier):
+//   s.y[row]                         = sdf value
+//   BWD: s.act viewed as G[row*LDST_G + c], c < 67 = d sdf / d [code | xyz] (skip gradient already added)
+constexpr int LDG = 72;
+template <bool BWD, int PF>
+__device__ __forceinline__ void mlp_tile(MlpSmem& s, const MlpParams* __restrict__ Pm) {
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    // The parameter table is read through an index the compiler cannot see through, once per tile: otherwise every
+    // layer's base pointers and per-lane addresses are hoisted out of the caller's tile loop and spill.
+    int oz;
+    asm volatile("s_mov_b32 %0, 0" : "=s"(oz));
+    const MlpParams& P = Pm[oz];
+    uint32_t mlo[8], mhi[8];
+    f32x16 acc[2][2];
+
+    // ---- stage the layer-0 input: [code(64) | xyz(3) | 0 pad] into act[:, 0:96) -------------------------------
+    {
+        const int row = tid >> 3, sub = tid & 7;
+#pragma unroll
+        for (int q = 0; q < 12; ++q) {
+            const int c = sub * 12 + q;
+            float v = 0.f;
+            if (c < CODE_LEN) v = s.code[c];
+            else if (c < NIN) v = s.xin[row * 4 + (c - CODE_LEN)];
+            s.act[row * LDA + c] = v;
+        }
+    }
+    __syncthreads();
+
+    const int cb0 = 2 * wave;   // this wave's first column block
+
+    // ---- layer 0 (K = 96) --------------------------------------------------------------------------------------
+    zero_acc(acc);
+    gemm_2x2<K0_PAD / 8, 4>(s.act, P.wf[0] + (cb0 * (K0_PAD / 8)) * 64, P.wf[0] + ((cb0 + 1) * (K0_PAD / 8)) * 64, acc,
+                            lane);
+    __syncthreads();
+    fwd_writeout<0>(s, P.bias[0], acc, wave, lane, mlo[0], mhi[0]);
+    __syncthreads();
+
+    // ---- layers 1..7 (K = 512) ---------------------------------------------------------------------------------
+#define QSP_FWD_LAYER(L)                                                                                      \
+    zero_acc(acc);                                                                                            \
+    gemm_2x2<HID / 8, PF>(s.act, P.wf[L] + (cb0 * (HID / 8)) * 64, P.wf[L] + ((cb0 + 1) * (HID / 8)) * 64, acc, \
+                          lane);                                                                              \
+    __syncthreads();                                                                                          \
+    fwd_writeout<L>(s, P.bias[L], acc, wave, lane, mlo[L], mhi[L]);                                           \
+    __syncthreads();
+    QSP_FWD_LAYER(1)
+    QSP_FWD_LAYER(2)
+    QSP_FWD_LAYER(3)
+    QSP_FWD_LAYER(4)
+    QSP_FWD_LAYER(5)
+    QSP_FWD_LAYER(6)
+    QSP_FWD_LAYER(7)
+#undef QSP_FWD_LAYER
+
+    // ---- layer 8: 512 -> 1, tanh ---------------------------------------------------------------------------------
+    {
+        // wave = k segment of 64, lane = row
+        const float* a = s.act + lane * LDA + 64 * wave;
+        const float* w = P.w8 + 64 * wave;
+        float part = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const float4 av = *reinterpret_cast<const float4*>(a + 4 * q);
+            const float4 wv = *reinterpret_cast<const float4*>(w + 4 * q);
+            part += av.x * wv.x;
+            part += av.y * wv.y;
+            part += av.z * wv.z;
+            part += av.w * wv.w;
+        }
+        s.red[wave * TILE_P + lane] = part;
+    }
+    __syncthreads();
+    if (tid < TILE_P) {
+        float t = P.b8;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t += s.red[q * TILE_P + tid];
+        s.y[tid] = tanhf(t);
+    }
+    __syncthreads();
+    if (!BWD) return;
+
+    // ---- backward seed: d y / d a7 = (1 - y^2) * w8[col] * [a7 > 0] ----------------------------------------------
+    {
+        const int j = lane & 31;
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int col = 64 * wave + 32 * c + j;
+                const float wv = P.w8[col];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int row = 32 * r + acc_row(i, lane);
+                    const float yy = s.y[row];
+                    s.act[row * LDA + col] = mask_sel((1.f - yy * yy) * wv, r == 0 ? mlo[7] : mhi[7], c * 16 + i);
+                }
+            }
+    }
+    __syncthreads();
+
+    // ---- backward through layers 7..1: g_in = g_a . W_L, masked by layer L-1 ------------------------------------
+#define QSP_BWD_LAYER(L)                                                                                      \
+    zero_acc(acc);                                                                                            \
+    gemm_2x2<HID / 8, PF>(s.act, P.wb[L] + (cb0 * (HID / 8)) * 64, P.wb[L] + ((cb0 + 1) * (HID / 8)) * 64, acc, \
+                          lane);                                                                              \
+    __syncthreads();                                                                                          \
+    bwd_writeout<L>(s, acc, wave, lane, mlo[L - 1], mhi[L - 1]);                                              \
+    __syncthreads();
+    QSP_BWD_LAYER(7)
+    QSP_BWD_LAYER(6)
+    QSP_BWD_LAYER(5)
+    QSP_BWD_LAYER(4)
+    QSP_BWD_LAYER(3)
+    QSP_BWD_LAYER(2)
+    QSP_BWD_LAYER(1)
+#undef QSP_BWD_LAYER
+
+    // ---- backward through layer 0: 67 (padded 96) input columns; waves 0..5 take one 32x32 tile each -------------
+    f32x16 g0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) g0[i] = 0.f;
+    const int r0 = wave / 3, c0 = wave % 3;
+    if (wave < 6) gemm_1x1<HID / 8, PF>(s.act + 32 * r0 * LDA, P.wb[0] + (c0 * (HID / 8)) * 64, g0, lane);
+    __syncthreads();
+    if (wave < 6) {
+        const int col = 32 * c0 + (lane & 31);
+        if (col < NIN) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = 32 * r0 + acc_row(i, lane);
+                s.act[row * LDG + col] = g0[i] + s.stash[row * LDST + col];
+            }
+        }
+    }
+    __syncthreads();
+}
+
+}  // namespace qsp
