@@ -119,6 +119,13 @@ int qsp_refine_batch_get(qsp_refine_batch* b, float* t_cam_obj_out, float* code_
 int qsp_refine_batch_trace(qsp_refine_batch* b, float* H, float* rhs, float* dx, int32_t* n_valid,
                            int32_t* n_render, float* loss_terms);
 
+/* Parity-test tap.  enable != 0 (with NULL outputs) before a run makes the fused kernel also store every augmented Jacobian
+ * row it feeds to the normal equations: [d e/d xi (7) | d e/d code (64) | robust residual] = 72 floats per row.  After
+ * the run, a second call with outputs copies hypothesis `hyp`: rows_sdf (n_pts,72), rows_render (n_render,72) of the LAST
+ * iteration.  Reference quantities: jac_toc / jac_code / robust residual of reconstruct/loss.py:22-43,143-150 and
+ * loss_utils.py:250-265.  enable == 0 frees the tap buffer. */
+int qsp_refine_batch_rows(qsp_refine_batch* b, int enable, int32_t hyp, float* rows_sdf, float* rows_render);
+
 /* Timing of the last qsp_refine_batch_run, measured with HIP events on the library's own stream. */
 typedef struct {
     float ms_total;          /* first launch -> last kernel complete                                  */

@@ -1,0 +1,137 @@
+"""ctypes binding of libqsp_hip.so -- the C-ABI declared in include/qsp_hip.h.
+
+There is NO CPU fallback: if the library is missing or no MI355X is visible the product path raises.  The oracle under
+oracle/ is test infrastructure and is never imported from here.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libqsp_hip.so")
+
+QSP_OK, QSP_ERR_INVALID, QSP_ERR_UNSUPPORTED, QSP_ERR_DEVICE, QSP_ERR_NO_DEVICE = 0, 1, 2, 3, 4
+
+c_float_p = C.POINTER(C.c_float)
+c_double_p = C.POINTER(C.c_double)
+c_int32_p = C.POINTER(C.c_int32)
+c_int64_p = C.POINTER(C.c_int64)
+c_uint8_p = C.POINTER(C.c_uint8)
+
+
+class QspError(RuntimeError):
+    def __init__(self, code, msg):
+        RuntimeError.__init__(self, "qsp_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+class DecoderDesc(C.Structure):
+    _fields_ = [("n_layers", C.c_int32), ("code_len", C.c_int32), ("latent_in_layer", C.c_int32),
+                ("in_dim", c_int32_p), ("out_dim", c_int32_p),
+                ("weight", C.POINTER(c_float_p)), ("weight_g", C.POINTER(c_float_p)), ("bias", C.POINTER(c_float_p))]
+
+
+class JointCfg(C.Structure):
+    _fields_ = [("k1", C.c_float), ("k2", C.c_float), ("k3", C.c_float), ("k4", C.c_float),
+                ("b1", C.c_float), ("b2", C.c_float), ("lr", C.c_float), ("s_damp", C.c_float),
+                ("cut_off", C.c_float), ("n_iter", C.c_int32), ("n_depth", C.c_int32), ("code_len", C.c_int32)]
+
+
+class RefineProfile(C.Structure):
+    _fields_ = [("ms_total", C.c_float), ("ms_mlp_jtj", C.c_float), ("ms_mlp_fwd", C.c_float),
+                ("ms_other", C.c_float), ("n_launch_jtj", C.c_int32), ("n_launch_fwd", C.c_int32),
+                ("pts_jtj", C.c_int64), ("pts_fwd", C.c_int64), ("tiles_jtj", C.c_int64), ("tiles_fwd", C.c_int64)]
+
+
+class BaProfile(C.Structure):
+    _fields_ = [("ms_total", C.c_float), ("ms_linearize", C.c_float), ("ms_schur", C.c_float),
+                ("ms_solve", C.c_float), ("ms_update", C.c_float), ("n_linearize", C.c_int32),
+                ("n_trials", C.c_int32), ("bytes_linearize", C.c_int64)]
+
+
+_lib = None
+
+# every symbol include/qsp_hip.h declares; tests/test_abi.py checks the list against the header
+SYMBOLS = [
+    "qsp_last_error", "qsp_version", "qsp_device_count",
+    "qsp_decoder_create", "qsp_decoder_destroy", "qsp_decode_sdf", "qsp_sdf_value_grad",
+    "qsp_refine_batch_create", "qsp_refine_batch_destroy", "qsp_refine_batch_set_state", "qsp_refine_batch_run",
+    "qsp_refine_batch_get", "qsp_refine_batch_trace", "qsp_refine_batch_profile", "qsp_refine_batch_rows",
+    "qsp_reconstruct_objects", "qsp_estimate_pose",
+]
+
+
+def lib():
+    """Loads the shared library once.  Raises if it was not built (python __graft_entry__.py / csrc/build.sh)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise QspError(QSP_ERR_NO_DEVICE, "libqsp_hip.so not built (%s); run qsp_slam_amd/csrc/build.sh -- there is "
+                       "no CPU fallback" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    L.qsp_last_error.restype = C.c_char_p
+    L.qsp_version.restype = C.c_int
+    L.qsp_device_count.restype = C.c_int
+    vp = C.c_void_p
+    L.qsp_decoder_create.argtypes = [C.POINTER(DecoderDesc), C.c_int, C.POINTER(vp)]
+    L.qsp_decoder_destroy.argtypes = [vp]
+    L.qsp_decoder_destroy.restype = None
+    L.qsp_decode_sdf.argtypes = [vp, c_float_p, c_float_p, C.c_int64, c_float_p]
+    L.qsp_sdf_value_grad.argtypes = [vp, c_float_p, c_float_p, C.c_int64, c_float_p, c_float_p]
+    pp_f = C.POINTER(c_float_p)
+    L.qsp_refine_batch_create.argtypes = [vp, C.POINTER(JointCfg), C.c_int32, pp_f, c_int32_p, pp_f, c_int32_p, pp_f,
+                                          c_int32_p, C.c_int32, c_int32_p, C.POINTER(vp)]
+    L.qsp_refine_batch_destroy.argtypes = [vp]
+    L.qsp_refine_batch_destroy.restype = None
+    L.qsp_refine_batch_set_state.argtypes = [vp, c_float_p, c_float_p]
+    L.qsp_refine_batch_run.argtypes = [vp, C.c_int32]
+    L.qsp_refine_batch_get.argtypes = [vp, c_float_p, c_float_p, c_float_p, c_uint8_p]
+    L.qsp_refine_batch_trace.argtypes = [vp, c_float_p, c_float_p, c_float_p, c_int32_p, c_int32_p, c_float_p]
+    L.qsp_refine_batch_profile.argtypes = [vp, C.c_int, C.POINTER(RefineProfile)]
+    L.qsp_refine_batch_rows.argtypes = [vp, C.c_int, C.c_int32, c_float_p, c_float_p]
+    L.qsp_reconstruct_objects.argtypes = [vp, C.POINTER(JointCfg), C.c_int32, pp_f, c_int32_p, pp_f, c_int32_p, pp_f,
+                                          c_int32_p, C.c_int32, c_int32_p, c_float_p, c_float_p, c_float_p, c_float_p,
+                                          c_float_p, c_uint8_p]
+    L.qsp_estimate_pose.argtypes = [vp, C.c_int32, c_float_p, c_float_p, pp_f, c_int32_p, c_float_p, C.c_int32,
+                                    c_float_p]
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != QSP_OK:
+        raise QspError(rc, lib().qsp_last_error().decode("utf-8", "replace"))
+
+
+def fptr(a):
+    return a.ctypes.data_as(c_float_p)
+
+
+def dptr(a):
+    return a.ctypes.data_as(c_double_p)
+
+
+def i32ptr(a):
+    return a.ctypes.data_as(c_int32_p)
+
+
+def i64ptr(a):
+    return a.ctypes.data_as(c_int64_p)
+
+
+def u8ptr(a):
+    return a.ctypes.data_as(c_uint8_p)
+
+
+def f32c(a):
+    """C-contiguous float32 copy/view.  pybind11 hands Eigen::MatrixXf to Python as Fortran-ordered (M,3) arrays
+    (src/LocalMapping_util.cc:705-706), so non-contiguous inputs are the normal case."""
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def ptr_array(arrs):
+    """C array of float* over a list of contiguous float32 arrays (kept alive by the caller)."""
+    t = c_float_p * len(arrs)
+    return t(*[fptr(a) for a in arrs])

@@ -72,14 +72,45 @@ __device__ __forceinline__ int acc_row(int i, int lane) { return (i & 3) + 8 * (
 
 // acc[r][c] += act[32r.., 0..8*KG) * Wpacked, for this wave's two column blocks.
 // w0/w1 already include the lane offset; consecutive k-groups are 64 float4 apart.
+// Packed weights are read through explicit global-address-space pointers: the bases come out of a table in memory, so
+// without the cast the compiler emits flat_load (which also ties up lgkmcnt and forces vmcnt(0) waits).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) f32x4* gptr4;
+
+__device__ __forceinline__ f32x4 lds4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+#define QSP_MFMA_STEP_2x2(a0, a1, b0, b1)                   \
+    acc[0][0] = mfma32(a0.x, b0.x, acc[0][0]);              \
+    acc[0][1] = mfma32(a0.x, b1.x, acc[0][1]);              \
+    acc[1][0] = mfma32(a1.x, b0.x, acc[1][0]);              \
+    acc[1][1] = mfma32(a1.x, b1.x, acc[1][1]);              \
+    acc[0][0] = mfma32(a0.y, b0.y, acc[0][0]);              \
+    acc[0][1] = mfma32(a0.y, b1.y, acc[0][1]);              \
+    acc[1][0] = mfma32(a1.y, b0.y, acc[1][0]);              \
+    acc[1][1] = mfma32(a1.y, b1.y, acc[1][1]);              \
+    acc[0][0] = mfma32(a0.z, b0.z, acc[0][0]);              \
+    acc[0][1] = mfma32(a0.z, b1.z, acc[0][1]);              \
+    acc[1][0] = mfma32(a1.z, b0.z, acc[1][0]);              \
+    acc[1][1] = mfma32(a1.z, b1.z, acc[1][1]);              \
+    acc[0][0] = mfma32(a0.w, b0.w, acc[0][0]);              \
+    acc[0][1] = mfma32(a0.w, b1.w, acc[0][1]);              \
+    acc[1][0] = mfma32(a1.w, b0.w, acc[1][0]);              \
+    acc[1][1] = mfma32(a1.w, b1.w, acc[1][1]);
+
+// acc[r][c] += act[32r.., 0..8*KG) * Wpacked for this wave's two column blocks.
+//   * w0 / w1 are wave-uniform bases (SGPR); the per-lane part of the address is the single VGPR `lane`.
+//   * weights: ring of PF k-groups in flight (global -> VGPR); activations: one k-group ahead (LDS -> VGPR).
+//   * both prefetches run past the end (PF k-groups of weights, one of activations): the packed buffers are
+//     over-allocated by the host and the LDS over-read stays inside MlpSmem; those values are never used.
+//   * sched_barrier pins "issue next loads, then 16 MFMAs": without it the scheduler sinks each load to just before
+//     its use and the ring degenerates to a load-wait-use sequence.
 template <int KG, int PF>
-__device__ __forceinline__ void gemm_2x2(const float* __restrict__ act, const float4* __restrict__ w0,
-                                         const float4* __restrict__ w1, f32x16 (&acc)[2][2], int lane) {
-    // w0 / w1 are wave-uniform bases (SGPR); the per-lane part of the address is the single VGPR `lane`.
-    // The prefetch runs PF k-groups past the end of the column block: the packed buffers are over-allocated by the
-    // host (see pack_weights) so those loads stay in bounds; their values are never used.
+__device__ __forceinline__ void gemm_2x2(const float* __restrict__ act, const float4* __restrict__ w0_,
+                                         const float4* __restrict__ w1_, f32x16 (&acc)[2][2], int lane) {
     static_assert(KG % PF == 0, "KG must be a multiple of the prefetch depth");
-    float4 q0[PF], q1[PF];
+    gptr4 w0 = (gptr4)w0_;
+    gptr4 w1 = (gptr4)w1_;
+    f32x4 q0[PF], q1[PF];
 #pragma unroll
     for (int d = 0; d < PF; ++d) {
         q0[d] = w0[d * 64 + lane];
@@ -87,54 +118,49 @@ __device__ __forceinline__ void gemm_2x2(const float* __restrict__ act, const fl
     }
     const float* a_row0 = act + (lane & 31) * LDA + 4 * (lane >> 5);
     const float* a_row1 = a_row0 + 32 * LDA;
+    f32x4 a0 = lds4(a_row0), a1 = lds4(a_row1);
 #pragma nounroll
     for (int kg = 0; kg < KG; kg += PF) {
 #pragma unroll
         for (int d = 0; d < PF; ++d) {
-            const float4 b0 = q0[d], b1 = q1[d];
+            const f32x4 b0 = q0[d], b1 = q1[d];
             q0[d] = w0[(kg + d + PF) * 64 + lane];
             q1[d] = w1[(kg + d + PF) * 64 + lane];
-            const float4 a0 = *reinterpret_cast<const float4*>(a_row0 + 8 * (kg + d));
-            const float4 a1 = *reinterpret_cast<const float4*>(a_row1 + 8 * (kg + d));
-            acc[0][0] = mfma32(a0.x, b0.x, acc[0][0]);
-            acc[0][1] = mfma32(a0.x, b1.x, acc[0][1]);
-            acc[1][0] = mfma32(a1.x, b0.x, acc[1][0]);
-            acc[1][1] = mfma32(a1.x, b1.x, acc[1][1]);
-            acc[0][0] = mfma32(a0.y, b0.y, acc[0][0]);
-            acc[0][1] = mfma32(a0.y, b1.y, acc[0][1]);
-            acc[1][0] = mfma32(a1.y, b0.y, acc[1][0]);
-            acc[1][1] = mfma32(a1.y, b1.y, acc[1][1]);
-            acc[0][0] = mfma32(a0.z, b0.z, acc[0][0]);
-            acc[0][1] = mfma32(a0.z, b1.z, acc[0][1]);
-            acc[1][0] = mfma32(a1.z, b0.z, acc[1][0]);
-            acc[1][1] = mfma32(a1.z, b1.z, acc[1][1]);
-            acc[0][0] = mfma32(a0.w, b0.w, acc[0][0]);
-            acc[0][1] = mfma32(a0.w, b1.w, acc[0][1]);
-            acc[1][0] = mfma32(a1.w, b0.w, acc[1][0]);
-            acc[1][1] = mfma32(a1.w, b1.w, acc[1][1]);
+            const f32x4 a0n = lds4(a_row0 + 8 * (kg + d + 1));
+            const f32x4 a1n = lds4(a_row1 + 8 * (kg + d + 1));
+            __builtin_amdgcn_sched_barrier(0);
+            QSP_MFMA_STEP_2x2(a0, a1, b0, b1)
+            __builtin_amdgcn_sched_barrier(0);
+            a0 = a0n;
+            a1 = a1n;
         }
     }
 }
 
 // one 32x32 tile over K = 8*KG (used by the 67-column backward of layer 0)
 template <int KG, int PF>
-__device__ __forceinline__ void gemm_1x1(const float* __restrict__ act_rows, const float4* __restrict__ w0,
+__device__ __forceinline__ void gemm_1x1(const float* __restrict__ act_rows, const float4* __restrict__ w0_,
                                          f32x16& acc, int lane) {
-    float4 q0[PF];
+    gptr4 w0 = (gptr4)w0_;
+    f32x4 q0[PF];
 #pragma unroll
     for (int d = 0; d < PF; ++d) q0[d] = w0[d * 64 + lane];
     const float* a_row0 = act_rows + (lane & 31) * LDA + 4 * (lane >> 5);
+    f32x4 a0 = lds4(a_row0);
 #pragma nounroll
     for (int kg = 0; kg < KG; kg += PF) {
 #pragma unroll
         for (int d = 0; d < PF; ++d) {
-            const float4 b0 = q0[d];
+            const f32x4 b0 = q0[d];
             q0[d] = w0[(kg + d + PF) * 64 + lane];
-            const float4 a0 = *reinterpret_cast<const float4*>(a_row0 + 8 * (kg + d));
+            const f32x4 a0n = lds4(a_row0 + 8 * (kg + d + 1));
+            __builtin_amdgcn_sched_barrier(0);
             acc = mfma32(a0.x, b0.x, acc);
             acc = mfma32(a0.y, b0.y, acc);
             acc = mfma32(a0.z, b0.z, acc);
             acc = mfma32(a0.w, b0.w, acc);
+            __builtin_amdgcn_sched_barrier(0);
+            a0 = a0n;
         }
     }
 }
@@ -176,18 +202,26 @@ __device__ __forceinline__ void fwd_writeout(MlpSmem& s, const float* __restrict
                 else hi |= bit << (c * 16 + i);
                 v = pos ? v : 0.f;
                 if (L == 3) {
-                    if (col >= SKIP_COL) {
-                        const int ci = col - SKIP_COL;   // 0..66: code then xyz
-                        v = ci < CODE_LEN ? s.code[ci] : s.xin[row * 4 + (ci - CODE_LEN)];
-                    }
+                    // columns 445..511 of layer 4's input are the network input, written by pass_through() below
+                    if (col < SKIP_COL) s.act[row * LDA + col] = v;
+                } else {
+                    s.act[row * LDA + col] = v;
                 }
-                s.act[row * LDA + col] = v;
             }
         }
     // opaque to the optimiser: otherwise it keeps the 64 v_cmp lane masks of every layer alive in SGPRs and spills them
     asm volatile("" : "+v"(lo), "+v"(hi));
     m_lo = lo;
     m_hi = hi;
+}
+
+// Layer 4 consumes [h3(445) | code(64) | xyz(3)]: fill columns 445..511 of every row (all 512 threads, same barrier
+// interval as fwd_writeout<3>, disjoint columns).
+__device__ __forceinline__ void pass_through(MlpSmem& s) {
+    for (int e = threadIdx.x; e < TILE_P * NIN; e += MLP_THREADS) {
+        const int row = e / NIN, ci = e - row * NIN;
+        s.act[row * LDA + SKIP_COL + ci] = ci < CODE_LEN ? s.code[ci] : s.xin[row * 4 + (ci - CODE_LEN)];
+    }
 }
 
 // Backward write-out of the gradient w.r.t. the INPUT of layer L (= post-ReLU output of layer L-1):
@@ -205,15 +239,22 @@ __device__ __forceinline__ void bwd_writeout(MlpSmem& s, const f32x16 (&acc)[2][
             for (int i = 0; i < 16; ++i) {
                 const int row = 32 * r + acc_row(i, lane);
                 float v = mask_sel(acc[r][c][i], r == 0 ? m_lo : m_hi, c * 16 + i);
-                if (L == 4) {
-                    if (col >= SKIP_COL) {
-                        s.stash[row * LDST + (col - SKIP_COL)] = acc[r][c][i];
-                        v = 0.f;
-                    }
-                }
+                // L == 4: columns 445..511 are the skip-connection gradient w.r.t. the network input (no ReLU in front
+                // of them); stored raw here, moved to the stash by stash_extract() after a barrier.
+                if (L == 4) v = (col >= SKIP_COL) ? acc[r][c][i] : v;
                 s.act[row * LDA + col] = v;
             }
         }
+}
+
+// Backward counterpart of pass_through(): move d y / d [code | xyz] of the skip connection out of columns 445..511 and
+// zero them (layer 3's backward GEMM must not see them; its packed weights are zero there anyway).
+__device__ __forceinline__ void stash_extract(MlpSmem& s) {
+    for (int e = threadIdx.x; e < TILE_P * NIN; e += MLP_THREADS) {
+        const int row = e / NIN, ci = e - row * NIN;
+        s.stash[row * LDST + ci] = s.act[row * LDA + SKIP_COL + ci];
+        s.act[row * LDA + SKIP_COL + ci] = 0.f;
+    }
 }
 
 // Whole network for the tile whose inputs are staged in s.code / s.xin.
@@ -268,7 +309,12 @@ __device__ __forceinline__ void mlp_tile(MlpSmem& s, const MlpParams* __restrict
     __syncthreads();
     QSP_FWD_LAYER(1)
     QSP_FWD_LAYER(2)
-    QSP_FWD_LAYER(3)
+    zero_acc(acc);
+    gemm_2x2<HID / 8, PF>(s.act, P.wf[3] + (cb0 * (HID / 8)) * 64, P.wf[3] + ((cb0 + 1) * (HID / 8)) * 64, acc, lane);
+    __syncthreads();
+    fwd_writeout<3>(s, P.bias[3], acc, wave, lane, mlo[3], mhi[3]);
+    pass_through(s);
+    __syncthreads();
     QSP_FWD_LAYER(4)
     QSP_FWD_LAYER(5)
     QSP_FWD_LAYER(6)
@@ -333,6 +379,8 @@ __device__ __forceinline__ void mlp_tile(MlpSmem& s, const MlpParams* __restrict
     QSP_BWD_LAYER(6)
     QSP_BWD_LAYER(5)
     QSP_BWD_LAYER(4)
+    stash_extract(s);
+    __syncthreads();
     QSP_BWD_LAYER(3)
     QSP_BWD_LAYER(2)
     QSP_BWD_LAYER(1)

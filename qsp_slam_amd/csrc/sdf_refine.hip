@@ -368,7 +368,8 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void k_mlp_jtj(const HypState* __re
                                                             const float* __restrict__ rend_deds,
                                                             const float* __restrict__ rend_res, int64_t rk_stride,
                                                             const uint8_t* __restrict__ pt_active, int64_t act_stride,
-                                                            float* __restrict__ res_out, float* __restrict__ partials) {
+                                                            float* __restrict__ res_out, float* __restrict__ rows_out, int64_t rows_stride,
+                                                            float* __restrict__ partials) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     MlpSmem& s = *reinterpret_cast<MlpSmem*>(smem_raw);
     __shared__ float Tsh[16];
@@ -463,6 +464,14 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void k_mlp_jtj(const HypState* __re
             }
         }
         __syncthreads();
+        if (rows_out) {   // parity-test tap: the augmented Jacobian rows exactly as the MFMA below consumes them
+            float* ro = rows_out + (int64_t)h * rows_stride * NJ + (int64_t)(is_sdf ? 0 : ov.n_pts) * NJ;
+            for (int e = tid; e < TILE_P * NJ; e += MLP_THREADS) {
+                const int p = e / NJ, c = e - p * NJ;
+                const int v = t * TILE_P + p;
+                if (v < n) ro[(int64_t)v * NJ + c] = Jt[p * LDJ + c];
+            }
+        }
         if (wave < 6) {
             const float* A = Jt + (lane >> 5) * LDJ + 32 * ta + (lane & 31);
             const float* B = Jt + (lane >> 5) * LDJ + 32 * tb + (lane & 31);
@@ -549,10 +558,17 @@ __global__ __launch_bounds__(256) void k_solve(HypState* __restrict__ st, const 
                                                RefineCfg cfg, const float* __restrict__ partials, int nw_sdf,
                                                int nw_total, const uint8_t* __restrict__ pt_active,
                                                int64_t act_stride, float* __restrict__ trH, float* __restrict__ trb,
-                                               float* __restrict__ trdx) {
+                                               float* __restrict__ trdx, unsigned long long* __restrict__ counters) {
     const int h = blockIdx.x;
     HypState& S = st[h];
     if (!S.alive) return;
+    if (threadIdx.x == 0 && counters) {   // work actually done this iteration (for the roofline figures)
+        const ObjView o = objs[S.obj];
+        atomicAdd(&counters[0], (unsigned long long)(o.n_pts + S.n_render));
+        atomicAdd(&counters[1], (unsigned long long)S.n_valid);
+        atomicAdd(&counters[2], (unsigned long long)((o.n_pts + TILE_P - 1) / TILE_P + (S.n_render + TILE_P - 1) / TILE_P));
+        atomicAdd(&counters[3], (unsigned long long)((S.n_valid + TILE_P - 1) / TILE_P));
+    }
     __shared__ double Hd[NH * (NH + 1)];  // augmented [H | b] in f64
     __shared__ float dxs[NH];
     __shared__ float loss_sh[2];
@@ -990,6 +1006,9 @@ struct qsp_refine_batch {
     float *trH = nullptr, *trb = nullptr, *trdx = nullptr;
     uint8_t* pt_active = nullptr;   // pose-only mode
     float* res_buf = nullptr;       // pose-only mode: per-point residual of the current iteration
+    unsigned long long* counters = nullptr;   // [4] points/tiles processed (fwd+bwd, fwd-only)
+    float* rows = nullptr;          // optional tap of the Jacobian rows (qsp_refine_batch_rows)
+    int64_t rows_stride = 0;
     // profiling
     bool prof = false;
     qsp_refine_profile profile{};
@@ -1000,7 +1019,7 @@ static void batch_free(qsp_refine_batch* b) {
     if (!b) return;
     hipSetDevice(b->dec->device);
     void* ptrs[] = {b->st, b->objs, b->pts, b->rays, b->depth, b->valid_rk, b->ray_voff, b->rend_rk, b->sdf_valid,
-                    b->rend_deds, b->rend_res, b->partials, b->trH, b->trb, b->trdx, b->pt_active, b->res_buf};
+                    b->rend_deds, b->rend_res, b->partials, b->trH, b->trb, b->trdx, b->pt_active, b->res_buf, b->rows, b->counters};
     for (void* p : ptrs)
         if (p) hipFree(p);
     for (hipEvent_t e : b->ev) hipEventDestroy(e);
@@ -1071,6 +1090,7 @@ static int batch_create(qsp_decoder* dec, const RefineCfg& cfg, int n_iter, int3
     QSP_ALLOC(b->trH, sizeof(float) * (size_t)n_hyp * NH * NH);
     QSP_ALLOC(b->trb, sizeof(float) * (size_t)n_hyp * NH);
     QSP_ALLOC(b->trdx, sizeof(float) * (size_t)n_hyp * NH);
+    QSP_ALLOC(b->counters, sizeof(unsigned long long) * 4);
     if (!cfg.pose_only) {
         QSP_ALLOC(b->valid_rk, sizeof(int32_t) * (size_t)n_hyp * b->rk_stride);
         QSP_ALLOC(b->ray_voff, sizeof(int32_t) * (size_t)n_hyp * b->ray_stride);
@@ -1174,6 +1194,7 @@ extern "C" int qsp_refine_batch_run(qsp_refine_batch* b, int32_t n_iter) {
     struct Span { hipEvent_t a, b; int kind; };
     std::vector<Span> spans;
     hipEvent_t e_begin = nullptr, e_end = nullptr;
+    QSP_HIP(hipMemsetAsync(b->counters, 0, sizeof(unsigned long long) * 4, s));
     if (b->prof) e_begin = next_event(b, cur);
     for (int it = 0; it < n_iter; ++it) {
         RefineCfg cfg = b->cfg;
@@ -1196,11 +1217,11 @@ extern "C" int qsp_refine_batch_run(qsp_refine_batch* b, int32_t n_iter) {
         if (b->prof) a = next_event(b, cur);
         hipLaunchKernelGGL(k_mlp_jtj, dim3(nw_total, nH), dim3(MLP_THREADS), sizeof(MlpSmem), s, b->st, b->objs, b->pts,
                            b->rays, cfg, b->dec->Pd, b->nw_sdf, b->rend_rk, b->rend_deds, b->rend_res, b->rk_stride,
-                           b->pt_active, b->act_stride, b->res_buf, b->partials);
+                           b->pt_active, b->act_stride, b->res_buf, b->rows, b->rows_stride, b->partials);
         if (b->prof) spans.push_back({a, next_event(b, cur), 0});
         if (b->prof) a = next_event(b, cur);
         hipLaunchKernelGGL(k_solve, dim3(nH), dim3(256), 0, s, b->st, b->objs, cfg, b->partials, b->nw_sdf, nw_total,
-                           b->pt_active, b->act_stride, b->trH, b->trb, b->trdx);
+                           b->pt_active, b->act_stride, b->trH, b->trb, b->trdx, b->counters);
         if (b->prof) spans.push_back({a, next_event(b, cur), 2});
         if (cfg.pose_only && it == 4)   // optimizer.py:80-82
             hipLaunchKernelGGL(k_inlier_filter, dim3((b->max_pts + 255) / 256, nH), dim3(256), 0, s, b->st, b->objs,
@@ -1220,6 +1241,12 @@ extern "C" int qsp_refine_batch_run(qsp_refine_batch* b, int32_t n_iter) {
             else if (sp.kind == 1) { p.ms_mlp_fwd += ms; p.n_launch_fwd++; }
             else p.ms_other += ms;
         }
+        unsigned long long c[4];
+        QSP_HIP(hipMemcpy(c, b->counters, sizeof(c), hipMemcpyDeviceToHost));
+        p.pts_jtj = (int64_t)c[0];
+        p.pts_fwd = (int64_t)c[1];
+        p.tiles_jtj = (int64_t)c[2];
+        p.tiles_fwd = (int64_t)c[3];
     }
     return QSP_OK;
 }
@@ -1289,6 +1316,32 @@ extern "C" int qsp_refine_batch_trace(qsp_refine_batch* b, float* H, float* rhs,
                 loss_terms[2 * h + 1] = hs[h].loss_render;
             }
         }
+    }
+    return QSP_OK;
+}
+
+extern "C" int qsp_refine_batch_rows(qsp_refine_batch* b, int enable, int32_t hyp, float* rows_sdf, float* rows_render) {
+    if (!b) return qsp_fail(QSP_ERR_INVALID, "rows: null batch");
+    QSP_HIP(hipSetDevice(b->dec->device));
+    if (enable && !b->rows) {
+        b->rows_stride = b->act_stride + b->rk_stride;
+        QSP_HIP(hipMalloc((void**)&b->rows, sizeof(float) * (size_t)b->n_hyp * b->rows_stride * NJ));
+    }
+    if (!enable && b->rows) {
+        hipFree(b->rows);
+        b->rows = nullptr;
+    }
+    if (enable && (rows_sdf || rows_render)) {
+        if (hyp < 0 || hyp >= b->n_hyp) return qsp_fail(QSP_ERR_INVALID, "rows: hyp out of range");
+        std::vector<HypState> hs(b->n_hyp);
+        QSP_HIP(hipMemcpy(hs.data(), b->st, sizeof(HypState) * b->n_hyp, hipMemcpyDeviceToHost));
+        const ObjView& ov = b->objs_h[b->hyp_obj[hyp]];
+        const float* base = b->rows + (size_t)hyp * b->rows_stride * NJ;
+        if (rows_sdf && ov.n_pts)
+            QSP_HIP(hipMemcpy(rows_sdf, base, sizeof(float) * (size_t)ov.n_pts * NJ, hipMemcpyDeviceToHost));
+        if (rows_render && hs[hyp].n_render > 0)
+            QSP_HIP(hipMemcpy(rows_render, base + (size_t)ov.n_pts * NJ, sizeof(float) * (size_t)hs[hyp].n_render * NJ,
+                              hipMemcpyDeviceToHost));
     }
     return QSP_OK;
 }

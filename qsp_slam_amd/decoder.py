@@ -1,0 +1,110 @@
+"""DeepSDF decoder handle: weight loading (the only place PyTorch is touched, and only to read a checkpoint) and upload
+through qsp_decoder_create.  Reference: deep_sdf/workspace.py:202-224, deep_sdf/deep_sdf_decoder.py:9-72."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+
+from . import _lib
+
+
+class DeepSdfDecoder(object):
+    """Owns a qsp_decoder*.  `layers` is a list of (weight (out,in) f32, weight_g (out,) f32 | None, bias (out,) f32)."""
+
+    def __init__(self, layers, latent_in=(4,), code_len=64, device=0):
+        L = _lib.lib()
+        if len(latent_in) != 1:
+            raise _lib.QspError(_lib.QSP_ERR_UNSUPPORTED, "exactly one latent_in layer is supported")
+        n = len(layers)
+        self._keep = []
+        in_dim = np.array([l[0].shape[1] for l in layers], np.int32)
+        out_dim = np.array([l[0].shape[0] for l in layers], np.int32)
+        w = [_lib.f32c(l[0]) for l in layers]
+        g = [None if l[1] is None else _lib.f32c(np.asarray(l[1]).reshape(-1)) for l in layers]
+        b = [_lib.f32c(l[2]) for l in layers]
+        fpp = _lib.c_float_p * n
+        wp = fpp(*[_lib.fptr(a) for a in w])
+        gp = fpp(*[(_lib.fptr(a) if a is not None else _lib.c_float_p()) for a in g])
+        bp = fpp(*[_lib.fptr(a) for a in b])
+        self._keep = [w, g, b, in_dim, out_dim]
+        desc = _lib.DecoderDesc(n, int(code_len), int(latent_in[0]), _lib.i32ptr(in_dim), _lib.i32ptr(out_dim),
+                                C.cast(wp, C.POINTER(_lib.c_float_p)), C.cast(gp, C.POINTER(_lib.c_float_p)),
+                                C.cast(bp, C.POINTER(_lib.c_float_p)))
+        h = C.c_void_p()
+        _lib.check(L.qsp_decoder_create(C.byref(desc), int(device), C.byref(h)))
+        self.handle = h
+        self.code_len = int(code_len)
+        self.device = int(device)
+        self.mac_per_point = int(sum(int(i) * int(o) for i, o in zip(in_dim, out_dim)))
+
+    def close(self):
+        if getattr(self, "handle", None):
+            _lib.lib().qsp_decoder_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- constructors -------------------------------------------------------------------------------------------
+    @classmethod
+    def from_state_dict(cls, state, latent_in=(4,), code_len=64, device=0):
+        """`state`: mapping 'lin{l}.weight_v' / '.weight_g' / '.weight' / '.bias' -> array-like ('module.' prefix of
+        DataParallel checkpoints tolerated, deep_sdf/workspace.py:215-220)."""
+        st = {}
+        for k, v in state.items():
+            k = k[len("module."):] if k.startswith("module.") else k
+            st[k] = np.asarray(v.detach().cpu().numpy() if hasattr(v, "detach") else v, dtype=np.float32)
+        layers = []
+        l = 0
+        while ("lin%d.bias" % l) in st:
+            if ("lin%d.weight_v" % l) in st:
+                layers.append((st["lin%d.weight_v" % l], st["lin%d.weight_g" % l], st["lin%d.bias" % l]))
+            else:
+                layers.append((st["lin%d.weight" % l], None, st["lin%d.bias" % l]))
+            l += 1
+        return cls(layers, latent_in=latent_in, code_len=code_len, device=device)
+
+    @classmethod
+    def from_npz(cls, path, device=0):
+        z = np.load(path, allow_pickle=False)
+        meta = eval(str(z["meta"]))
+        return cls.from_state_dict({k: z[k] for k in z.files if k != "meta"}, latent_in=meta["latent_in"],
+                                   code_len=meta["latent_size"], device=device)
+
+    @classmethod
+    def from_experiment_dir(cls, experiment_directory, checkpoint="latest", device=0):
+        """specs.json + ModelParameters/<checkpoint>.pth, as deep_sdf/workspace.py:202-224 reads them."""
+        specs_filename = os.path.join(experiment_directory, "specs.json")
+        if not os.path.isfile(specs_filename):
+            raise Exception('The experiment directory does not include specifications file "specs.json"')
+        specs = json.load(open(specs_filename))
+        import torch  # checkpoint format only
+
+        saved = torch.load(os.path.join(experiment_directory, "ModelParameters", checkpoint + ".pth"),
+                           map_location="cpu")
+        ns = specs["NetworkSpecs"]
+        return cls.from_state_dict(saved["model_state_dict"], latent_in=tuple(ns.get("latent_in", ())),
+                                   code_len=specs["CodeLength"], device=device)
+
+    # ---- entry points of reconstruct/loss_utils.py ----------------------------------------------------------------
+    def decode_sdf(self, code, x):
+        """decode_sdf(decoder, lat_vec, x), loss_utils.py:51-79 -> (N,) float32"""
+        x = _lib.f32c(x)
+        code = _lib.f32c(np.asarray(code)[: self.code_len])
+        out = np.empty(x.shape[0], np.float32)
+        _lib.check(_lib.lib().qsp_decode_sdf(self.handle, _lib.fptr(code), _lib.fptr(x), x.shape[0], _lib.fptr(out)))
+        return out
+
+    def sdf_value_grad(self, code, x):
+        """get_batch_sdf_jacobian(decoder, lat_vec, x, 1), loss_utils.py:82-103 -> y (N,), grad (N, code_len+3)"""
+        x = _lib.f32c(x)
+        code = _lib.f32c(np.asarray(code)[: self.code_len])
+        y = np.empty(x.shape[0], np.float32)
+        g = np.empty((x.shape[0], self.code_len + 3), np.float32)
+        _lib.check(_lib.lib().qsp_sdf_value_grad(self.handle, _lib.fptr(code), _lib.fptr(x), x.shape[0], _lib.fptr(y),
+                                                 _lib.fptr(g)))
+        return y, g

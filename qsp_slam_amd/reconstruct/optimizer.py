@@ -1,0 +1,244 @@
+"""Drop-in for reconstruct/optimizer.py of the reference: same class names, constructor and method signatures, return
+types and failure behaviour; the numerics are batched HIP launches behind the C-ABI (include/qsp_hip.h).
+
+Added on top of the reference interface (not replacing it): `reconstruct_objects_batched`, which runs many objects x
+yaw-flip hypotheses in one resident batch -- what src/LocalMapping_util.cc:705-760 does as 4 serial Python calls per
+object."""
+import ctypes as C
+import math
+import time
+
+import numpy as np
+
+from .. import _lib
+from .utils import ForceKeyErrorDict
+
+
+def _joint_cfg(o):
+    return _lib.JointCfg(o.k1, o.k2, o.k3, o.k4, o.b1, o.b2, o.lr, o.s_damp, o.cut_off, int(o.num_iterations_joint_optim),
+                         int(o.num_depth_samples), int(o.code_len))
+
+
+class RefineBatch(object):
+    """Thin owner of a qsp_refine_batch* (resident device batch)."""
+
+    def __init__(self, decoder, cfg, pts, rays, depth, hyp_obj):
+        L = _lib.lib()
+        self.n_obj = len(pts)
+        self.n_hyp = len(hyp_obj)
+        self.code_len = decoder.code_len
+        self._pts = [_lib.f32c(p).reshape(-1, 3) for p in pts]
+        self._rays = [_lib.f32c(r).reshape(-1, 3) for r in rays]
+        self._depth = [_lib.f32c(d).reshape(-1) for d in depth]
+        n_pts = np.array([p.shape[0] for p in self._pts], np.int32)
+        n_rays = np.array([r.shape[0] for r in self._rays], np.int32)
+        n_fg = np.array([d.shape[0] for d in self._depth], np.int32)
+        hyp = np.ascontiguousarray(hyp_obj, dtype=np.int32)
+        pp, rp, dp = _lib.ptr_array(self._pts), _lib.ptr_array(self._rays), _lib.ptr_array(self._depth)
+        h = C.c_void_p()
+        _lib.check(L.qsp_refine_batch_create(decoder.handle, C.byref(cfg), self.n_obj,
+                                             C.cast(pp, C.POINTER(_lib.c_float_p)), _lib.i32ptr(n_pts),
+                                             C.cast(rp, C.POINTER(_lib.c_float_p)), _lib.i32ptr(n_rays),
+                                             C.cast(dp, C.POINTER(_lib.c_float_p)), _lib.i32ptr(n_fg),
+                                             self.n_hyp, _lib.i32ptr(hyp), C.byref(h)))
+        self.handle = h
+        self.decoder = decoder
+
+    def set_state(self, t_cam_obj, code=None):
+        T = _lib.f32c(t_cam_obj).reshape(self.n_hyp, 16)
+        c = None if code is None else _lib.f32c(code).reshape(self.n_hyp, self.code_len)
+        _lib.check(_lib.lib().qsp_refine_batch_set_state(self.handle, _lib.fptr(T), _lib.fptr(c) if c is not None
+                                                         else _lib.c_float_p()))
+
+    def run(self, n_iter=0):
+        _lib.check(_lib.lib().qsp_refine_batch_run(self.handle, int(n_iter)))
+
+    def get(self):
+        T = np.empty((self.n_hyp, 4, 4), np.float32)
+        code = np.empty((self.n_hyp, self.code_len), np.float32)
+        loss = np.empty(self.n_hyp, np.float32)
+        good = np.empty(self.n_hyp, np.uint8)
+        _lib.check(_lib.lib().qsp_refine_batch_get(self.handle, _lib.fptr(T), _lib.fptr(code), _lib.fptr(loss),
+                                                   _lib.u8ptr(good)))
+        return T, code, loss, good.astype(bool)
+
+    def trace(self):
+        n = self.n_hyp
+        H = np.empty((n, 71, 71), np.float32)
+        b = np.empty((n, 71), np.float32)
+        dx = np.empty((n, 71), np.float32)
+        nv = np.empty(n, np.int32)
+        nr = np.empty(n, np.int32)
+        lt = np.empty((n, 2), np.float32)
+        _lib.check(_lib.lib().qsp_refine_batch_trace(self.handle, _lib.fptr(H), _lib.fptr(b), _lib.fptr(dx),
+                                                     _lib.i32ptr(nv), _lib.i32ptr(nr), _lib.fptr(lt)))
+        return dict(H=H, b=b, dx=dx, n_valid=nv, K=nr, loss_sdf=lt[:, 0], loss_render=lt[:, 1])
+
+    def enable_rows(self, enable=True):
+        _lib.check(_lib.lib().qsp_refine_batch_rows(self.handle, 1 if enable else 0, 0, _lib.c_float_p(),
+                                                    _lib.c_float_p()))
+
+    def rows(self, hyp, n_pts, n_render):
+        """augmented Jacobian rows [J_pose(7) | J_code(64) | robust residual] of the last iteration (parity tests)"""
+        a = np.empty((max(n_pts, 1), 72), np.float32)
+        r = np.empty((max(n_render, 1), 72), np.float32)
+        _lib.check(_lib.lib().qsp_refine_batch_rows(self.handle, 1, int(hyp), _lib.fptr(a), _lib.fptr(r)))
+        return a[:n_pts], r[:n_render]
+
+    def profile(self, enable=True):
+        p = _lib.RefineProfile()
+        _lib.check(_lib.lib().qsp_refine_batch_profile(self.handle, 1 if enable else 0, C.byref(p)))
+        return p
+
+    def close(self):
+        if getattr(self, "handle", None):
+            _lib.lib().qsp_refine_batch_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Optimizer(object):
+    """reconstruct/optimizer.py:26-281.  `decoder` is a qsp_slam_amd.decoder.DeepSdfDecoder."""
+
+    def __init__(self, decoder, configs, debug=False):
+        self.decoder = decoder
+        optim_cfg = configs.optimizer
+        self.k1 = optim_cfg.joint_optim.k1
+        self.k2 = optim_cfg.joint_optim.k2
+        self.k3 = optim_cfg.joint_optim.k3
+        self.k4 = optim_cfg.joint_optim.k4
+        self.b1 = optim_cfg.joint_optim.b1
+        self.b2 = optim_cfg.joint_optim.b2
+        self.lr = optim_cfg.joint_optim.learning_rate
+        self.s_damp = optim_cfg.joint_optim.scale_damping
+        self.num_iterations_joint_optim = optim_cfg.joint_optim.num_iterations
+        self.code_len = optim_cfg.code_len
+        self.num_depth_samples = optim_cfg.num_depth_samples
+        self.cut_off = optim_cfg.cut_off_threshold
+        self.debug = debug
+        if configs.data_type == "KITTI":
+            self.num_iterations_pose_only = optim_cfg.pose_only_optim.num_iterations
+
+    # ---- reference entry point: one object, one hypothesis -----------------------------------------------------------
+    def reconstruct_object(self, t_cam_obj, pts, rays, depth, code=None):
+        """Same contract as the reference: returns an object with attrs t_cam_obj (4,4) f32 | None, code (L,) f32 | None,
+        is_good, loss.  No exception for numeric failure."""
+        r = self.reconstruct_objects_batched([dict(t_cam_obj=t_cam_obj, pts=pts, rays=rays, depth=depth, code=code)],
+                                             flip_sample_num=1, select=False)
+        return r[0][0]
+
+    # ---- batched form: objects x yaw flips in one launch sequence ------------------------------------------------------
+    def reconstruct_objects_batched(self, objects, flip_sample_num=1, select=True):
+        """objects: list of dicts(t_cam_obj, pts, rays, depth, code=None).  For every object `flip_sample_num`
+        hypotheses are refined: hypothesis k starts from t_cam_obj with its ROTATION BLOCK right-multiplied by
+        R_y(k * 2pi / flip_sample_num) (src/LocalMapping_util.cc:713-726).
+        select=False -> list (per object) of lists (per flip) of result objects;
+        select=True  -> list (per object) of the result the reference's selection rule keeps
+                        (LocalMapping_util.cc:748-752: replace if the kept one is not good, or if the new one is good
+                        and has a smaller loss)."""
+        n_obj = len(objects)
+        hyp_obj, T0, codes = [], [], []
+        any_code = any(o.get("code") is not None for o in objects)
+        for i, o in enumerate(objects):
+            T = np.asarray(o["t_cam_obj"], dtype=np.float32).reshape(4, 4)
+            for k in range(flip_sample_num):
+                Tk = T.copy()
+                if k:
+                    a = k * 2.0 * math.pi / flip_sample_num
+                    c, s = math.cos(a), math.sin(a)
+                    Ry = np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]], dtype=np.float32)
+                    Tk[:3, :3] = T[:3, :3] @ Ry
+                hyp_obj.append(i)
+                T0.append(Tk)
+                c0 = o.get("code")
+                codes.append(np.zeros(self.code_len, np.float32) if c0 is None
+                             else np.asarray(c0, np.float32)[: self.code_len])
+        batch = RefineBatch(self.decoder, _joint_cfg(self), [o["pts"] for o in objects], [o["rays"] for o in objects],
+                            [o["depth"] for o in objects], hyp_obj)
+        try:
+            batch.set_state(np.stack(T0), np.stack(codes) if any_code else None)
+            batch.run(0)
+            T, code, loss, good = batch.get()
+        finally:
+            batch.close()
+        out = []
+        for i in range(n_obj):
+            res = []
+            for k in range(flip_sample_num):
+                h = i * flip_sample_num + k
+                if good[h]:
+                    res.append(ForceKeyErrorDict(t_cam_obj=T[h].copy(), code=code[h].copy(), is_good=True,
+                                                 loss=float(loss[h])))
+                else:
+                    res.append(ForceKeyErrorDict(t_cam_obj=None, code=None, is_good=False, loss=float(loss[h])))
+            if select:
+                best = res[0]
+                for r in res[1:]:
+                    if (not best.is_good) or (r.is_good and r.loss < best.loss):
+                        best = r
+                out.append(best)
+            else:
+                out.append(res)
+        return out
+
+    def estimate_pose_cam_obj(self, t_co_se3, scale, pts, code):
+        """reconstruct/optimizer.py:47-93 -> (4,4) float32 SE3 (the reference returns a torch tensor that C++ casts to
+        Eigen::Matrix4f, src/LocalMapping_util.cc:139-140; a numpy array casts the same way)."""
+        T = _lib.f32c(t_co_se3).reshape(1, 16)
+        sc = np.array([scale], np.float32)
+        p = _lib.f32c(pts).reshape(-1, 3)
+        n = np.array([p.shape[0]], np.int32)
+        c = _lib.f32c(np.asarray(code)[: self.code_len]).reshape(1, -1)
+        out = np.empty((1, 4, 4), np.float32)
+        pp = _lib.ptr_array([p])
+        _lib.check(_lib.lib().qsp_estimate_pose(self.decoder.handle, 1, _lib.fptr(T), _lib.fptr(sc),
+                                                C.cast(pp, C.POINTER(_lib.c_float_p)), _lib.i32ptr(n), _lib.fptr(c),
+                                                int(getattr(self, "num_iterations_pose_only", 5)), _lib.fptr(out)))
+        return out[0]
+
+
+def create_voxel_grid(vol_dim=128):
+    """reconstruct/utils.py:98-117, including its true-division quirk: `overall_index.long() / vol_dim` is a float
+    division on torch >= 1.6, so the y and x coordinates keep their fractional part."""
+    i = np.arange(vol_dim ** 3, dtype=np.int64)
+    size = np.float32(2.0 / (vol_dim - 1))
+    v = np.zeros((vol_dim ** 3, 3), np.float32)
+    v[:, 2] = (i % vol_dim).astype(np.float32)
+    v[:, 1] = np.mod((i / vol_dim).astype(np.float32), np.float32(vol_dim))
+    v[:, 0] = np.mod((i / vol_dim).astype(np.float32) / np.float32(vol_dim), np.float32(vol_dim))
+    return v * size - np.float32(1)
+
+
+class MeshExtractor(object):
+    """reconstruct/optimizer.py:284-304.  The SDF grid is decoded on the GPU; marching cubes stays with the caller's
+    implementation (skimage in the reference, reconstruct/utils.py:120-141) and is out of scope of this round --
+    `extract_sdf_grid` returns the (dim,dim,dim) tensor the reference hands to convert_sdf_voxels_to_mesh."""
+
+    def __init__(self, decoder, code_len=64, voxels_dim=64):
+        self.decoder = decoder
+        self.code_len = code_len
+        self.voxels_dim = voxels_dim
+        self.voxel_points = create_voxel_grid(vol_dim=self.voxels_dim)
+
+    def extract_sdf_grid(self, code):
+        sdf = self.decoder.decode_sdf(np.asarray(code, np.float32)[: self.code_len], self.voxel_points)
+        return sdf.reshape(self.voxels_dim, self.voxels_dim, self.voxels_dim)
+
+    def extract_mesh_from_code(self, code):
+        start = time.time()
+        grid = self.extract_sdf_grid(code)
+        try:
+            import skimage.measure as measure
+        except ImportError:
+            raise NotImplementedError("marching cubes needs skimage (as in the reference); extract_sdf_grid() returns "
+                                      "the decoded SDF volume")
+        voxel_size = 2.0 / (self.voxels_dim - 1)
+        verts, faces, _, _ = measure.marching_cubes(grid, level=0.0, spacing=[voxel_size] * 3)
+        verts = verts + np.array([-1.0, -1.0, -1.0])
+        print("Extract mesh takes %f seconds" % (time.time() - start))
+        return ForceKeyErrorDict(vertices=verts.astype("float32"), faces=faces.astype("int32"))

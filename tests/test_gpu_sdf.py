@@ -1,0 +1,205 @@
+"""GPU parity tests of hot path A through the C-ABI (libqsp_hip.so), against
+  (1) the golden vectors produced by running the reference (tests/golden/sdf_*.npz), and
+  (2) the numpy oracle (oracle/sdf_oracle.py) on seeded inputs at other sizes / edge cases.
+Tolerances follow tests/test_oracle_sdf.py (see the notes there on ReLU knife-edge rows, the chaotic free-running map and
+the KITTI rotation prior)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import sdf_oracle as so
+from tests.test_oracle_sdf import JOINT_CASES, cfg_from, relerr, rows_close
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu_decoder(golden_dir):
+    from qsp_slam_amd import DeepSdfDecoder
+    d = DeepSdfDecoder.from_npz(os.path.join(golden_dir, "decoder_8x512.npz"))
+    yield d
+    d.close()
+
+
+def make_cfg(z_or_cfg):
+    from qsp_slam_amd.reconstruct.utils import ForceKeyErrorDict
+    c = cfg_from(z_or_cfg) if not isinstance(z_or_cfg, so.JointConfig) else z_or_cfg
+    return ForceKeyErrorDict(data_type="KITTI", optimizer=dict(
+        code_len=64, num_depth_samples=c.n_depth, cut_off_threshold=c.cut_off,
+        joint_optim=dict(k1=c.k1, k2=c.k2, k3=c.k3, k4=c.k4, b1=c.b1, b2=c.b2, learning_rate=c.lr,
+                         scale_damping=c.s_damp, num_iterations=c.n_iter),
+        pose_only_optim=dict(num_iterations=c.n_iter_pose, learning_rate=1.0)))
+
+
+def test_library_is_the_hip_build():
+    from qsp_slam_amd import _lib
+    assert _lib.lib().qsp_device_count() >= 1
+
+
+def test_decode_and_grad_vs_reference_vectors(gpu_decoder, golden_dir):
+    z = np.load(os.path.join(golden_dir, "sdf_decoder_vectors.npz"))
+    sdf = gpu_decoder.decode_sdf(z["code"], z["x"])
+    assert np.abs(sdf - z["sdf"]).max() < 2e-6
+    y, g = gpu_decoder.sdf_value_grad(z["code"], z["x"])
+    assert np.abs(y - z["y"]).max() < 2e-6
+    assert rows_close(g, z["grad"], tol=1e-5, max_bad=0.01)
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 1000, 4099])
+def test_decode_ragged_sizes_vs_oracle(gpu_decoder, oracle_decoder, n):
+    rng = np.random.default_rng(n)
+    x = rng.uniform(-1, 1, size=(n, 3)).astype(np.float32)
+    code = rng.normal(scale=0.2, size=64).astype(np.float32)
+    ref = so.decode_sdf(oracle_decoder, code, x)
+    assert np.abs(gpu_decoder.decode_sdf(code, x) - ref).max() < 2e-6
+    inp = np.concatenate([np.broadcast_to(code, (n, 64)), x], -1)
+    yr, gr = so.decoder_value_and_input_grad(oracle_decoder, inp)
+    y, g = gpu_decoder.sdf_value_grad(code, x)
+    assert np.abs(y - yr).max() < 2e-6
+    bad_rows = int(np.ceil(0.01 * n)) + 1          # ReLU knife-edge rows, see rows_close
+    assert rows_close(g, gr, tol=1e-5, max_bad=bad_rows / n)
+
+
+def test_decode_empty_is_ok(gpu_decoder):
+    assert gpu_decoder.decode_sdf(np.zeros(64, np.float32), np.zeros((0, 3), np.float32)).shape == (0,)
+
+
+@pytest.mark.parametrize("name", JOINT_CASES)
+def test_every_iteration_teacher_forced_vs_reference(gpu_decoder, golden_dir, name):
+    """Same contract as the oracle's test: restart each iteration from the reference's own state."""
+    from qsp_slam_amd.reconstruct.optimizer import Optimizer, RefineBatch, _joint_cfg
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    cfg = cfg_from(z)
+    opt = Optimizer(gpu_decoder, make_cfg(z))
+    batch = RefineBatch(gpu_decoder, _joint_cfg(opt), [z["pts"]], [z["rays"]], [z["depth"]], [0])
+    tol = 1e-4 if cfg.k4 == 0 else 5e-3
+    n_it = z["it_H"].shape[0]
+    for i in range(n_it):
+        T_co = np.linalg.inv(z["it_T_oc"][i].astype(np.float64)).astype(np.float32)
+        batch.set_state(T_co[None], z["it_code"][i][None])
+        batch.run(1)
+        tr = batch.trace()
+        T, code, loss, good = batch.get()
+        assert good[0]
+        assert int(tr["K"][0]) == int(z["it_K"][i])
+        assert relerr(tr["H"][0], z["it_H"][i]) < tol
+        assert relerr(tr["b"][0], z["it_b"][i]) < tol
+        assert relerr(tr["dx"][0], z["it_dx"][i]) < 20 * tol
+        if i + 1 < n_it:
+            T_oc_new = np.linalg.inv(T[0].astype(np.float64))
+            assert relerr(T_oc_new, z["it_T_oc"][i + 1]) < tol
+            assert np.abs(code[0] - z["it_code"][i + 1]).max() < tol
+    batch.close()
+
+
+@pytest.mark.parametrize("name", JOINT_CASES)
+def test_reconstruct_object_free_running_vs_reference(gpu_decoder, golden_dir, name):
+    from qsp_slam_amd.reconstruct.optimizer import Optimizer
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    opt = Optimizer(gpu_decoder, make_cfg(z))
+    # Fortran-ordered inputs, as pybind11 hands Eigen::MatrixXf over (src/LocalMapping_util.cc:705-706)
+    r = opt.reconstruct_object(z["t_cam_obj"], np.asfortranarray(z["pts"]), np.asfortranarray(z["rays"]), z["depth"])
+    assert r.is_good == bool(z["is_good"])
+    assert r.t_cam_obj.dtype == np.float32 and r.t_cam_obj.shape == (4, 4) and r.code.shape == (64,)
+    assert relerr(r.t_cam_obj, z["out_t_cam_obj"]) < 2e-2
+    assert np.abs(r.code - z["out_code"]).max() < 2e-2
+    assert abs(r.loss - float(z["loss"])) < 5e-2 * abs(float(z["loss"]))
+    with pytest.raises(KeyError):
+        r["no_such_key"]
+
+
+def test_failure_exit_too_few_ray_samples(gpu_decoder, golden_dir):
+    from qsp_slam_amd.reconstruct.optimizer import Optimizer
+    z = np.load(os.path.join(golden_dir, "sdf_joint_fail_norays.npz"))
+    r = Optimizer(gpu_decoder, make_cfg(z)).reconstruct_object(z["t_cam_obj"], z["pts"], z["rays"], z["depth"])
+    assert r.is_good is False and r.t_cam_obj is None and r.code is None
+    assert r.loss == float(z["loss"]) == 0.0
+
+
+def test_pose_only_vs_reference(gpu_decoder, golden_dir):
+    from qsp_slam_amd.reconstruct.optimizer import Optimizer
+    z = np.load(os.path.join(golden_dir, "sdf_pose_only_m250.npz"))
+    opt = Optimizer(gpu_decoder, make_cfg(so.JointConfig()))
+    out = opt.estimate_pose_cam_obj(z["t_co_se3"], float(z["scale"]), z["pts"], z["code"])
+    assert out.shape == (4, 4) and out.dtype == np.float32
+    assert relerr(out, z["out"]) < 1e-4
+
+
+def test_batched_flips_match_single_calls_and_selection_rule(gpu_decoder):
+    """objects x 4 yaw flips in one batch == the same hypotheses run one at a time (bit-exact: fixed-order reductions),
+    and the kept result follows src/LocalMapping_util.cc:748-752."""
+    from qsp_slam_amd import synth
+    from qsp_slam_amd.reconstruct.optimizer import Optimizer
+    objs = synth.make_object_views(5, 3, 500, n_fg=96, n_bg=48)
+    opt = Optimizer(gpu_decoder, make_cfg(so.JointConfig(n_iter=3)))
+    inp = [dict(t_cam_obj=o["t_cam_obj"], pts=o["pts"], rays=o["rays"], depth=o["depth"]) for o in objs]
+    allr = opt.reconstruct_objects_batched(inp, flip_sample_num=4, select=False)
+    kept = opt.reconstruct_objects_batched(inp, flip_sample_num=4, select=True)
+    for i, o in enumerate(objs):
+        best = None
+        for k in range(4):
+            a = k * 2.0 * np.pi / 4
+            T = o["t_cam_obj"].copy()
+            if k:
+                Ry = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]], np.float32)
+                T[:3, :3] = o["t_cam_obj"][:3, :3] @ Ry
+            single = opt.reconstruct_object(T, o["pts"], o["rays"], o["depth"])
+            b = allr[i][k]
+            assert single.is_good == b.is_good
+            if single.is_good:
+                assert np.array_equal(single.t_cam_obj, b.t_cam_obj) and np.array_equal(single.code, b.code)
+                assert single.loss == b.loss
+            if best is None or (not best.is_good) or (b.is_good and b.loss < best.loss):
+                best = b
+        assert kept[i].is_good == best.is_good and kept[i].loss == best.loss
+
+
+@pytest.mark.parametrize("m,n_fg,n_bg,seed", [(64, 40, 20, 1), (130, 64, 32, 2), (1000, 200, 100, 3)])
+def test_one_iteration_vs_oracle_other_sizes(gpu_decoder, oracle_decoder, m, n_fg, n_bg, seed):
+    from qsp_slam_amd import synth
+    from qsp_slam_amd.reconstruct.optimizer import Optimizer, RefineBatch, _joint_cfg
+    o = synth.make_object_views(100 + seed, 1, m, n_fg=n_fg, n_bg=n_bg)[0]
+    cfg = so.JointConfig()
+    opt = Optimizer(gpu_decoder, make_cfg(cfg))
+    batch = RefineBatch(gpu_decoder, _joint_cfg(opt), [o["pts"]], [o["rays"]], [o["depth"]], [0])
+    batch.set_state(o["t_cam_obj"][None], None)
+    batch.run(1)
+    tr = batch.trace()
+    T_oc = np.linalg.inv(o["t_cam_obj"].astype(np.float64)).astype(np.float32)
+    dobs = np.concatenate([o["depth"], np.zeros(n_bg, np.float32)])
+    it = so.gn_iteration(oracle_decoder, cfg, T_oc, np.zeros(64, np.float32), o["pts"], o["rays"], dobs, n_fg)
+    assert it["fail"] is None
+    assert int(tr["n_valid"][0]) == it["n_valid"] and int(tr["K"][0]) == it["K"]
+    assert relerr(tr["H"][0], it["H"]) < 1e-4
+    assert relerr(tr["b"][0], it["b"]) < 1e-4
+    assert abs(float(tr["loss_sdf"][0]) - it["loss_sdf"]) < 1e-4 * it["loss_sdf"]
+    assert abs(float(tr["loss_render"][0]) - it["loss_render"]) < 1e-4 * it["loss_render"]
+    batch.close()
+
+
+@pytest.mark.parametrize("name", JOINT_CASES)
+def test_jacobian_rows_of_fused_kernel_vs_reference(gpu_decoder, golden_dir, name):
+    """Row-by-row check of what the fused MLP+JtJ kernel feeds to the normal equations (tap: qsp_refine_batch_rows),
+    against the reference's compute_sdf_loss / compute_render_loss outputs of iteration 0: same row ORDER (row-major
+    (ray, depth) order of torch.where, loss.py:68), same Jacobians, Huber-weighted residual in the last column."""
+    from qsp_slam_amd.reconstruct.optimizer import Optimizer, RefineBatch, _joint_cfg
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    cfg = cfg_from(z)
+    opt = Optimizer(gpu_decoder, make_cfg(z))
+    batch = RefineBatch(gpu_decoder, _joint_cfg(opt), [z["pts"]], [z["rays"]], [z["depth"]], [0])
+    batch.enable_rows(True)
+    batch.set_state(z["t_cam_obj"][None], None)
+    batch.run(1)
+    K = int(batch.trace()["K"][0])
+    assert K == z["it0_res_render"].shape[0]
+    rs, rr = batch.rows(0, z["pts"].shape[0], K)
+    assert rows_close(rs[:, :7], z["it0_Jp_sdf"])
+    assert rows_close(rs[:, 7:71], z["it0_Jc_sdf"])
+    rob_s, _, _ = so.robust_residual(z["it0_res_sdf"], cfg.b2)
+    assert np.abs(rs[:, 71] - rob_s).max() < 1e-5 * max(np.abs(rob_s).max(), 1e-6) + 1e-7
+    assert rows_close(rr[:, :7], z["it0_Jp_render"], tol=2e-5, max_bad=0.02)
+    assert rows_close(rr[:, 7:71], z["it0_Jc_render"], tol=2e-5, max_bad=0.02)
+    rob_r, _, _ = so.robust_residual(z["it0_res_render"], cfg.b1)
+    assert np.abs(rr[:, 71] - rob_r).max() < 1e-4 * np.abs(rob_r).max()
+    batch.close()
