@@ -156,3 +156,142 @@ def make_object_views(seed, n_obj, n_pts, n_fg=256, n_bg=200, code_scale=0.0, pe
                          rays=rays.astype(np.float32), depth=depth.astype(np.float32),
                          gt_t_cam_obj=T_gt.astype(np.float32), gt_code=code.astype(np.float32)))
     return objs
+
+
+# ----------------------------------------------------------------------------------------------------------
+# path B: joint bundle-adjustment scenes (flattened graph of src/Optimizer_util.cc:309-771)
+# ----------------------------------------------------------------------------------------------------------
+
+def quat_from_R(R):
+    """x y z w, w >= 0"""
+    t = np.trace(R)
+    if t > 0:
+        s = np.sqrt(t + 1.0) * 2
+        q = np.array([(R[2, 1] - R[1, 2]) / s, (R[0, 2] - R[2, 0]) / s, (R[1, 0] - R[0, 1]) / s, 0.25 * s])
+    else:
+        i = int(np.argmax(np.diag(R)))
+        j, k = (i + 1) % 3, (i + 2) % 3
+        s = np.sqrt(R[i, i] - R[j, j] - R[k, k] + 1.0) * 2
+        q = np.zeros(4)
+        q[i] = 0.25 * s
+        q[3] = (R[k, j] - R[j, k]) / s
+        q[j] = (R[j, i] + R[i, j]) / s
+        q[k] = (R[k, i] + R[i, k]) / s
+    if q[3] < 0:
+        q = -q
+    return q / np.linalg.norm(q)
+
+
+def pose7(T):
+    """4x4 -> (tx ty tz qx qy qz qw), the flattened SE3Quat layout of include/qsp_hip.h"""
+    return np.concatenate([T[:3, 3], quat_from_R(T[:3, :3])])
+
+
+def pose7_to_T(p):
+    x, y, z, w = p[3:7]
+    R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                  [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                  [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+    return se3(R, p[:3])
+
+
+def make_ba_scene(seed, n_kf, n_pt, n_obj, stereo_frac=0.0, outlier_frac=0.05, n_fixed=1, obs_per_obj=10,
+                  pixel_noise=1.0):
+    """Seeded scene in the flattened layout of the C-ABI: key-frames on an arc looking inwards,
+    points in the common frustum, each observed by the key-frames that see it, objects observed by ~obs_per_obj
+    key-frames through noisy SE3 detections.  Estimates are perturbed around the ground truth; `outlier_frac` of the
+    observations get a gross 50 px error.  All float64; measurements pass through float32 as in src/Converter.cc.
+
+    returns dict of arrays (see oracle/ba_oracle.py / qsp_slam_amd/ba.py for the field meaning)"""
+    rng = np.random.default_rng(seed)
+    fx, fy, cx, cy = 535.4, 539.2, 320.1, 247.6          # configs/tum_fr1_desk.yaml
+    bf = 40.0
+    W, H = 640, 480
+    # key-frames on an arc of radius 4 m around the origin, 0.3 m apart, looking at the centre
+    kf_T = []
+    for i in range(n_kf):
+        a = (i - n_kf / 2) * 0.3 / 4.0
+        c = np.array([4.0 * np.sin(a), 0.1 * np.sin(0.7 * i), -4.0 * np.cos(a)])      # camera centre, world
+        zc = -c / np.linalg.norm(c)
+        xc = np.cross(np.array([0.0, 1.0, 0.0]), zc)
+        xc /= np.linalg.norm(xc)
+        yc = np.cross(zc, xc)
+        R_wc = np.stack([xc, yc, zc], axis=1)
+        kf_T.append(se3(R_wc.T, -R_wc.T @ c))             # T_cw
+    kf_T = np.array(kf_T)
+    pts = rng.uniform([-2.5, -1.2, -2.0], [2.5, 1.2, 2.5], size=(n_pt, 3))
+    mono_pt, mono_kf, mono_obs, mono_info = [], [], [], []
+    st_pt, st_kf, st_obs, st_info = [], [], [], []
+    max_obs = 8
+    for j in range(n_pt):
+        seen = []
+        for i in rng.permutation(n_kf):
+            pc = kf_T[i, :3, :3] @ pts[j] + kf_T[i, :3, 3]
+            if pc[2] < 0.5:
+                continue
+            u, v = fx * pc[0] / pc[2] + cx, fy * pc[1] / pc[2] + cy
+            if 0 <= u < W and 0 <= v < H:
+                seen.append((i, u, v, pc[2]))
+            if len(seen) >= max_obs:
+                break
+        for (i, u, v, z) in sorted(seen):
+            octave = int(rng.integers(0, 8))
+            inv_sigma2 = 1.0 / (1.2 ** (2 * octave))
+            du, dv = rng.normal(scale=pixel_noise, size=2)
+            if rng.random() < outlier_frac:
+                du += 50.0 * rng.choice([-1, 1])
+            if rng.random() < stereo_frac:
+                st_pt.append(j); st_kf.append(i)
+                st_obs.append([np.float32(u + du), np.float32(v + dv), np.float32(u + du - bf / z)])
+                st_info.append(inv_sigma2)
+            else:
+                mono_pt.append(j); mono_kf.append(i)
+                mono_obs.append([np.float32(u + du), np.float32(v + dv)])
+                mono_info.append(inv_sigma2)
+    # objects: SE3 T_ow, observed by up to obs_per_obj key-frames: Z = T_co = T_cw * T_wo  (+ noise)
+    obj_T, oe_kf, oe_obj, oe_meas = [], [], [], []
+    for o in range(n_obj):
+        c = rng.uniform([-2.0, -0.5, -1.5], [2.0, 0.5, 2.0])
+        T_wo = se3(rot_y(rng.uniform(0, 2 * np.pi)), c)
+        T_ow = np.linalg.inv(T_wo)
+        obj_T.append(T_ow)
+        for i in sorted(rng.permutation(n_kf)[: min(obs_per_obj, n_kf)]):
+            d = np.concatenate([rng.normal(scale=np.deg2rad(1.0), size=3), rng.normal(scale=0.02, size=3)])
+            Z = se3(rodrigues(d[:3]), d[3:]) @ kf_T[i] @ T_wo
+            oe_kf.append(i); oe_obj.append(o)
+            oe_meas.append(pose7(Z.astype(np.float32).astype(np.float64)))
+    # perturbed estimates (float32 round trip: Converter::toSE3Quat reads cv::Mat float32 poses, src/Converter.cc:37-54)
+    kf_pose = []
+    for i in range(n_kf):
+        T = kf_T[i]
+        if i >= n_fixed:
+            d = np.concatenate([rng.normal(scale=np.deg2rad(1.0), size=3), rng.normal(scale=0.05, size=3)])
+            T = se3(rodrigues(d[:3]), d[3:]) @ T
+        kf_pose.append(pose7(T.astype(np.float32).astype(np.float64)))
+    obj_pose = []
+    for T in obj_T:
+        d = np.concatenate([rng.normal(scale=np.deg2rad(2.0), size=3), rng.normal(scale=0.05, size=3)])
+        obj_pose.append(pose7((se3(rodrigues(d[:3]), d[3:]) @ T).astype(np.float32).astype(np.float64)))
+    pt_xyz = (pts + rng.normal(scale=0.02, size=pts.shape)).astype(np.float32).astype(np.float64)
+    kf_id = np.arange(n_kf, dtype=np.int64) * 2            # mnId with gaps, as culled key-frames leave
+    max_kf = int(kf_id.max())
+    pt_mn = rng.permutation(3 * n_pt)[:n_pt].astype(np.int64)
+    pt_id = pt_mn + max_kf + 1
+    obj_id = np.arange(n_obj, dtype=np.int64)[::-1].copy() + max_kf + int(pt_mn.max() if n_pt else 0) + 2
+    fixed = np.zeros(n_kf, np.uint8)
+    fixed[:n_fixed] = 1
+    K = np.tile(np.array([fx, fy, cx, cy, bf]), (n_kf, 1))
+
+    def arr(x, dt, shape):
+        return np.ascontiguousarray(np.array(x, dtype=dt).reshape(shape))
+    return dict(
+        kf_pose=arr(kf_pose, np.float64, (n_kf, 7)), kf_fixed=fixed, kf_id=kf_id, kf_K=arr(K, np.float64, (n_kf, 5)),
+        pt_xyz=arr(pt_xyz, np.float64, (n_pt, 3)), pt_id=pt_id,
+        obj_pose=arr(obj_pose, np.float64, (n_obj, 7)), obj_id=obj_id,
+        mono_pt=arr(mono_pt, np.int32, (-1,)), mono_kf=arr(mono_kf, np.int32, (-1,)),
+        mono_obs=arr(mono_obs, np.float64, (-1, 2)), mono_info=arr(mono_info, np.float64, (-1,)),
+        st_pt=arr(st_pt, np.int32, (-1,)), st_kf=arr(st_kf, np.int32, (-1,)),
+        st_obs=arr(st_obs, np.float64, (-1, 3)), st_info=arr(st_info, np.float64, (-1,)),
+        oe_kf=arr(oe_kf, np.int32, (-1,)), oe_obj=arr(oe_obj, np.int32, (-1,)),
+        oe_meas=arr(oe_meas, np.float64, (-1, 7)), oe_info=1e3,
+        gt_kf=np.array([pose7(T) for T in kf_T]), gt_pt=pts, gt_obj=np.array([pose7(T) for T in obj_T]))
