@@ -155,6 +155,99 @@ int qsp_estimate_pose(qsp_decoder* dec, int32_t n, const float* t_co_se3, const 
                       const float* const* pts, const int32_t* n_pts, const float* code, int32_t n_iter,
                       float* t_co_out);
 
+/* ===============================================================================================================
+ * Path B -- joint bundle adjustment (camera poses, map points, object poses)
+ * ============================================================================================================ */
+
+/* The g2o graph that Optimizer::{Local,}JointBundleAdjustment (src/Optimizer_util.cc:44-307,309-771) and
+ * Optimizer::{Local,}BundleAdjustment (src/Optimizer.cc:54-242,458-783) build with heap-allocated vertices and edges,
+ * flattened into arrays.  Poses are SE3Quat values laid out (tx ty tz qx qy qz qw) -- T_cw for key-frames
+ * (VertexSE3Expmap, estimate = Converter::toSE3Quat(pKF->GetPose())), T_ow for objects (pMO->SE3Tow).
+ * kf_id / pt_id / obj_id are the g2o VERTEX ids the reference assigns (mnId, mnId + maxKFid + 1,
+ * mnId + maxKFid + maxMPid + 2): they define the order of the unknowns (hessian indices), which this library
+ * reproduces exactly.  Edge arrays keep the caller's order; per-edge outputs come back in that order.
+ * All arrays are copied at creation. */
+typedef struct {
+    int32_t n_kf, n_pt, n_obj, n_mono, n_stereo, n_objedge;
+    const double* kf_pose;        /* [n_kf][7]                                                             */
+    const uint8_t* kf_fixed;      /* [n_kf]  vSE3->setFixed(...)                                           */
+    const int64_t* kf_id;         /* [n_kf]                                                                */
+    const double* kf_K;           /* [n_kf][5]  fx fy cx cy bf (pKF->fx ... pKF->mbf)                      */
+    const double* pt_xyz;         /* [n_pt][3]  VertexSBAPointXYZ, marginalised                            */
+    const int64_t* pt_id;
+    const double* obj_pose;       /* [n_obj][7]                                                            */
+    const int64_t* obj_id;
+    const int32_t* mono_pt;       /* EdgeSE3ProjectXYZ: vertex 0 = point, vertex 1 = key-frame             */
+    const int32_t* mono_kf;
+    const double* mono_obs;       /* [n_mono][2]  kpUn.pt                                                  */
+    const double* mono_info;      /* [n_mono]     invSigma2 (information = invSigma2 * I)                  */
+    const int32_t* stereo_pt;     /* EdgeStereoSE3ProjectXYZ                                               */
+    const int32_t* stereo_kf;
+    const double* stereo_obs;     /* [n_stereo][3]  u v u_right                                            */
+    const double* stereo_info;
+    const int32_t* objedge_kf;    /* EdgeSE3LieAlgebra (include/ObjectPoseGraph.h:57-89): vertex 0 = key-frame */
+    const int32_t* objedge_obj;   /*                                                      vertex 1 = object   */
+    const double* objedge_meas;   /* [n_objedge][7]  Z = det->SE3Tco                                        */
+    double objedge_info;          /* information = objedge_info * I6 (1e3 in the reference)                 */
+} qsp_ba_scene;
+
+/* Per-iteration record of one optimize() call (G2OBatchStatistics-like, block_solver.hpp:441-453): the caller provides the
+ * arrays with capacity `cap`. */
+typedef struct {
+    int32_t cap, n;
+    double* chi2;            /* robust chi2 after the iteration                                             */
+    double* lambda;          /* LM damping after the iteration                                              */
+    int32_t* trials;         /* LM trials spent in the iteration (<= 10)                                    */
+    int32_t* accepted;       /* 1 if the last trial was accepted                                            */
+    int32_t result;          /* 0 ran all iterations, 1 terminated by the LM stop rules, 2 stop flag         */
+    int32_t iterations;      /* iterations done                                                              */
+    int32_t n_pose_blocks;   /* free key-frames + objects (reduced system = 6 x this)                        */
+    int32_t n_landmarks;     /* active points                                                                */
+} qsp_ba_trace;
+
+typedef struct {
+    float ms_total;          /* whole optimize() call on the GPU stream                                      */
+    float ms_linearize;      /* sum over linearisations of the three J^T W J kernels (k_lin_*)               */
+    float ms_schur, ms_solve, ms_update;
+    int32_t n_linearize, n_trials;
+    int64_t bytes_linearize; /* ALGORITHMIC bytes of one linearisation: 176 B/mono edge, 184 B/stereo edge,
+                                392 B/free pose or object, 120 B/point, 352 B/object edge */
+} qsp_ba_stats;
+
+typedef struct qsp_ba_problem qsp_ba_problem;
+
+int qsp_ba_create(const qsp_ba_scene* scene, int device, qsp_ba_problem** out);
+void qsp_ba_destroy(qsp_ba_problem* p);
+
+/* g2o edge levels: 1 = excluded from optimisation (e->setLevel(1), src/Optimizer_util.cc:621-654).  NULL = all active. */
+int qsp_ba_set_levels(qsp_ba_problem* p, const uint8_t* mono, const uint8_t* stereo, const uint8_t* objedge);
+
+/* optimizer.initializeOptimization(0); optimizer.optimize(n_iter) -- Levenberg-Marquardt with Schur complement over the
+ * points (Thirdparty/g2o/g2o/core/optimization_algorithm_levenberg.cpp:61-164, block_solver.hpp:354-486).
+ * delta_* are the Huber deltas of RobustKernelHuber (<= 0: no kernel).  stop_flag mirrors setForceStopFlag(pbStopFlag):
+ * polled before every iteration and LM trial; may be NULL.  trace may be NULL. */
+int qsp_ba_optimize(qsp_ba_problem* p, int32_t n_iter, double delta_mono, double delta_stereo, double delta_obj,
+                    const volatile uint8_t* stop_flag, qsp_ba_trace* trace);
+
+/* The two-stage schedule of Optimizer::LocalJointBundleAdjustment (src/Optimizer_util.cc:598-661): optimize(5) with Huber
+ * sqrt(5.991)/sqrt(7.815)/sqrt(1e3); edges with chi2 > 5.991 / 7.815 / 1e3 or non-positive depth go to level 1; kernels
+ * dropped; optimize(10).  Returns early (state of stage 1 kept) when *stop_flag is set, as the reference does. */
+int qsp_ba_local_joint(qsp_ba_problem* p, const volatile uint8_t* stop_flag, qsp_ba_trace* stage1, qsp_ba_trace* stage2);
+
+int qsp_ba_set_state(qsp_ba_problem* p, const double* kf_pose, const double* pt_xyz, const double* obj_pose);
+int qsp_ba_get_state(qsp_ba_problem* p, double* kf_pose, double* pt_xyz, double* obj_pose);
+
+/* Per-edge chi2 = e^T Omega e of the LAST error evaluation (what e->chi2() returns in the reference's outlier checks,
+ * which may belong to a rejected LM trial -- reproduced), and isDepthPositive() from the current estimates. */
+int qsp_ba_get_edges(qsp_ba_problem* p, double* mono_chi2, double* stereo_chi2, double* objedge_chi2,
+                     uint8_t* mono_depth_positive, uint8_t* stereo_depth_positive);
+
+/* hessianIndex of every vertex as g2o's buildIndexMapping assigns it for the last optimize() call (-1: fixed or
+ * inactive): free key-frames and objects in ascending vertex id, then points in ascending vertex id. */
+int qsp_ba_get_index(qsp_ba_problem* p, int32_t* kf_hidx, int32_t* obj_hidx, int32_t* pt_hidx);
+
+int qsp_ba_profile(qsp_ba_problem* p, int enable, qsp_ba_stats* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -44,6 +44,23 @@ class RefineProfile(C.Structure):
                 ("pts_jtj", C.c_int64), ("pts_fwd", C.c_int64), ("tiles_jtj", C.c_int64), ("tiles_fwd", C.c_int64)]
 
 
+class BaScene(C.Structure):
+    _fields_ = [("n_kf", C.c_int32), ("n_pt", C.c_int32), ("n_obj", C.c_int32), ("n_mono", C.c_int32),
+                ("n_stereo", C.c_int32), ("n_objedge", C.c_int32),
+                ("kf_pose", c_double_p), ("kf_fixed", c_uint8_p), ("kf_id", c_int64_p), ("kf_K", c_double_p),
+                ("pt_xyz", c_double_p), ("pt_id", c_int64_p), ("obj_pose", c_double_p), ("obj_id", c_int64_p),
+                ("mono_pt", c_int32_p), ("mono_kf", c_int32_p), ("mono_obs", c_double_p), ("mono_info", c_double_p),
+                ("stereo_pt", c_int32_p), ("stereo_kf", c_int32_p), ("stereo_obs", c_double_p),
+                ("stereo_info", c_double_p), ("objedge_kf", c_int32_p), ("objedge_obj", c_int32_p),
+                ("objedge_meas", c_double_p), ("objedge_info", C.c_double)]
+
+
+class BaTrace(C.Structure):
+    _fields_ = [("cap", C.c_int32), ("n", C.c_int32), ("chi2", c_double_p), ("lam", c_double_p),
+                ("trials", c_int32_p), ("accepted", c_int32_p), ("result", C.c_int32), ("iterations", C.c_int32),
+                ("n_pose_blocks", C.c_int32), ("n_landmarks", C.c_int32)]
+
+
 class BaProfile(C.Structure):
     _fields_ = [("ms_total", C.c_float), ("ms_linearize", C.c_float), ("ms_schur", C.c_float),
                 ("ms_solve", C.c_float), ("ms_update", C.c_float), ("n_linearize", C.c_int32),
@@ -59,6 +76,8 @@ SYMBOLS = [
     "qsp_refine_batch_create", "qsp_refine_batch_destroy", "qsp_refine_batch_set_state", "qsp_refine_batch_run",
     "qsp_refine_batch_get", "qsp_refine_batch_trace", "qsp_refine_batch_profile", "qsp_refine_batch_rows",
     "qsp_reconstruct_objects", "qsp_estimate_pose",
+    "qsp_ba_create", "qsp_ba_destroy", "qsp_ba_set_levels", "qsp_ba_optimize", "qsp_ba_local_joint",
+    "qsp_ba_set_state", "qsp_ba_get_state", "qsp_ba_get_edges", "qsp_ba_get_index", "qsp_ba_profile",
 ]
 
 
@@ -96,6 +115,17 @@ def lib():
                                           c_float_p, c_uint8_p]
     L.qsp_estimate_pose.argtypes = [vp, C.c_int32, c_float_p, c_float_p, pp_f, c_int32_p, c_float_p, C.c_int32,
                                     c_float_p]
+    L.qsp_ba_create.argtypes = [C.POINTER(BaScene), C.c_int, C.POINTER(vp)]
+    L.qsp_ba_destroy.argtypes = [vp]
+    L.qsp_ba_destroy.restype = None
+    L.qsp_ba_set_levels.argtypes = [vp, c_uint8_p, c_uint8_p, c_uint8_p]
+    L.qsp_ba_optimize.argtypes = [vp, C.c_int32, C.c_double, C.c_double, C.c_double, c_uint8_p, C.POINTER(BaTrace)]
+    L.qsp_ba_local_joint.argtypes = [vp, c_uint8_p, C.POINTER(BaTrace), C.POINTER(BaTrace)]
+    L.qsp_ba_set_state.argtypes = [vp, c_double_p, c_double_p, c_double_p]
+    L.qsp_ba_get_state.argtypes = [vp, c_double_p, c_double_p, c_double_p]
+    L.qsp_ba_get_edges.argtypes = [vp, c_double_p, c_double_p, c_double_p, c_uint8_p, c_uint8_p]
+    L.qsp_ba_get_index.argtypes = [vp, c_int32_p, c_int32_p, c_int32_p]
+    L.qsp_ba_profile.argtypes = [vp, C.c_int, C.POINTER(BaProfile)]
     _lib = L
     return L
 

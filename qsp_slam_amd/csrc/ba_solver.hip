@@ -1,0 +1,1255 @@
+// ba_solver.hip -- path B of the hot path: the camera-point-object joint bundle adjustment on gfx950, FP64.
+//
+// Replaces the numeric core that src/Optimizer_util.cc:44-307,309-771 and src/Optimizer.cc:54-242,458-783 of the reference
+// drive through g2o (Thirdparty/g2o: SparseOptimizer + BlockSolver_6_3 + OptimizationAlgorithmLevenberg +
+// LinearSolverEigen, single-threaded, heap-allocated edges walked through pointers):
+//
+//   k_errors          computeActiveErrors + activeRobustChi2            (sparse_optimizer.cpp:61-114)
+//   k_lin_points      per landmark: Jacobians of its edges, Hll, b_l, one 6x3 Hpl block per edge
+//   k_lin_poses       per key-frame: segmented reduction of J^T W J / J^T W e over its edges (Hpp diagonal, b_p)
+//   k_lin_objects     per object: its camera-object edges (Hpp diagonal, off-diagonal blocks, b_p)
+//                                                                       (block_solver.hpp:502-560, base_binary_edge.hpp:55-120)
+//   k_schur_prepare / k_schur_points   Hschur = Hpp + lambda I - sum_l B_l D_l^-1 B_l^T, b - B D^-1 b_l   (block_solver.hpp:381-432)
+//   k_chol_*          blocked dense Cholesky of the reduced system (the reference: Eigen SimplicialLDLT, linear_solver_eigen.h:94-124)
+//   k_trsv            forward/backward substitution
+//   k_update_*        back-substitution x_l = D^-1 (b_l - B^T x_p), oplus on every vertex                 (block_solver.hpp:461-481)
+//
+// Layout: edges are physically re-ordered landmark-major at creation, so the landmark pass streams them; the key-frame
+// pass gathers through a CSR.  Reductions are fixed-order (deterministic) except the Schur accumulation, which uses
+// FP64 atomics into the dense reduced matrix (order-dependent only in the last bit).
+// The Levenberg-Marquardt control flow (optimization_algorithm_levenberg.cpp:61-164) stays on the host: one 32-byte
+// read-back per trial.
+#include <hip/hip_runtime.h>
+#include <float.h>
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "../../include/qsp_hip.h"
+#include "common.hpp"
+
+namespace qsp {
+namespace ba {
+
+constexpr int NB = 64;   // Cholesky block
+
+// ---------------------------------------------------------------------------------------------------------------
+// SE3 helpers on (tx ty tz qx qy qz qw), following g2o's SE3Quat (Thirdparty/g2o/g2o/types/se3quat.h)
+// ---------------------------------------------------------------------------------------------------------------
+__host__ __device__ inline void quat_to_R(const double* q, double* R) {
+    const double x = q[0], y = q[1], z = q[2], w = q[3];
+    const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+    const double twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y,
+                 tyz = tz * y, tzz = tz * z;
+    R[0] = 1 - (tyy + tzz); R[1] = txy - twz; R[2] = txz + twy;
+    R[3] = txy + twz; R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+    R[6] = txz - twy; R[7] = tyz + twx; R[8] = 1 - (txx + tyy);
+}
+__host__ __device__ inline void R_to_quat(const double* m, double* q) {
+    double t = m[0] + m[4] + m[8];
+    if (t > 0) {
+        t = sqrt(t + 1.0);
+        q[3] = 0.5 * t;
+        t = 0.5 / t;
+        q[0] = (m[7] - m[5]) * t; q[1] = (m[2] - m[6]) * t; q[2] = (m[3] - m[1]) * t;
+    } else {
+        int i = 0;
+        if (m[4] > m[0]) i = 1;
+        if (m[8] > m[4 * i]) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        t = sqrt(m[4 * i] - m[4 * j] - m[4 * k] + 1.0);
+        q[i] = 0.5 * t;
+        t = 0.5 / t;
+        q[3] = (m[3 * k + j] - m[3 * j + k]) * t;
+        q[j] = (m[3 * j + i] + m[3 * i + j]) * t;
+        q[k] = (m[3 * k + i] + m[3 * i + k]) * t;
+    }
+}
+__host__ __device__ inline void quat_normalize(double* q) {
+    if (q[3] < 0) { q[0] = -q[0]; q[1] = -q[1]; q[2] = -q[2]; q[3] = -q[3]; }
+    const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    q[0] /= n; q[1] /= n; q[2] /= n; q[3] /= n;
+}
+__host__ __device__ inline void quat_mul(const double* a, const double* b, double* c) {
+    const double ax = a[0], ay = a[1], az = a[2], aw = a[3], bx = b[0], by = b[1], bz = b[2], bw = b[3];
+    c[0] = aw * bx + ax * bw + ay * bz - az * by;
+    c[1] = aw * by + ay * bw + az * bx - ax * bz;
+    c[2] = aw * bz + az * bw + ax * by - ay * bx;
+    c[3] = aw * bw - ax * bx - ay * by - az * bz;
+}
+__host__ __device__ inline void quat_rot(const double* q, const double* v, double* o) {
+    const double ux = q[0], uy = q[1], uz = q[2], w = q[3];
+    const double uvx = 2 * (uy * v[2] - uz * v[1]), uvy = 2 * (uz * v[0] - ux * v[2]), uvz = 2 * (ux * v[1] - uy * v[0]);
+    o[0] = v[0] + w * uvx + (uy * uvz - uz * uvy);
+    o[1] = v[1] + w * uvy + (uz * uvx - ux * uvz);
+    o[2] = v[2] + w * uvz + (ux * uvy - uy * uvx);
+}
+__host__ __device__ inline void se3_mul(const double* a, const double* b, double* c) {
+    double rt[3], q[4];
+    quat_rot(a + 3, b, rt);
+    quat_mul(a + 3, b + 3, q);
+    c[0] = a[0] + rt[0]; c[1] = a[1] + rt[1]; c[2] = a[2] + rt[2];
+    quat_normalize(q);
+    c[3] = q[0]; c[4] = q[1]; c[5] = q[2]; c[6] = q[3];
+}
+__host__ __device__ inline void se3_inv(const double* a, double* c) {
+    const double q[4] = {-a[3], -a[4], -a[5], a[6]}, mt[3] = {-a[0], -a[1], -a[2]};
+    double t[3];
+    quat_rot(q, mt, t);
+    c[0] = t[0]; c[1] = t[1]; c[2] = t[2]; c[3] = q[0]; c[4] = q[1]; c[5] = q[2]; c[6] = q[3];
+}
+__host__ __device__ inline void se3_map(const double* a, const double* x, double* o) {
+    double r[3];
+    quat_rot(a + 3, x, r);
+    o[0] = r[0] + a[0]; o[1] = r[1] + a[1]; o[2] = r[2] + a[2];
+}
+__host__ __device__ inline void skew3(const double* v, double* m) {
+    m[0] = 0; m[1] = -v[2]; m[2] = v[1]; m[3] = v[2]; m[4] = 0; m[5] = -v[0]; m[6] = -v[1]; m[7] = v[0]; m[8] = 0;
+}
+__host__ __device__ inline void mat3mul(const double* a, const double* b, double* c) {
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) c[3 * i + j] = a[3 * i] * b[j] + a[3 * i + 1] * b[3 + j] + a[3 * i + 2] * b[6 + j];
+}
+__device__ inline void se3_exp(const double* u, double* pose) {   // se3quat.h:273-305
+    const double theta = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+    double Om[9], Om2[9], R[9], V[9];
+    skew3(u, Om);
+    mat3mul(Om, Om, Om2);
+    const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    if (theta < 0.00001) {
+        for (int i = 0; i < 9; ++i) { R[i] = I[i] + Om[i] + Om2[i]; V[i] = R[i]; }
+    } else {
+        const double s = sin(theta), c = cos(theta);
+        const double a = s / theta, b = (1 - c) / (theta * theta), g = (theta - s) / pow(theta, 3);
+        for (int i = 0; i < 9; ++i) { R[i] = I[i] + a * Om[i] + b * Om2[i]; V[i] = I[i] + b * Om[i] + g * Om2[i]; }
+    }
+    double q[4];
+    R_to_quat(R, q);
+    quat_normalize(q);
+    for (int i = 0; i < 3; ++i) pose[i] = V[3 * i] * u[3] + V[3 * i + 1] * u[4] + V[3 * i + 2] * u[5];
+    pose[3] = q[0]; pose[4] = q[1]; pose[5] = q[2]; pose[6] = q[3];
+}
+__device__ inline void se3_log(const double* pose, double* out) {   // se3quat.h:228-265
+    double R[9];
+    quat_to_R(pose + 3, R);
+    const double d = 0.5 * (R[0] + R[4] + R[8] - 1);
+    const double dR[3] = {R[7] - R[5], R[2] - R[6], R[3] - R[1]};
+    double om[3], Om[9], Om2[9], Vi[9];
+    const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    if (d > 0.99999) {
+        for (int i = 0; i < 3; ++i) om[i] = 0.5 * dR[i];
+        skew3(om, Om);
+        mat3mul(Om, Om, Om2);
+        for (int i = 0; i < 9; ++i) Vi[i] = I[i] - 0.5 * Om[i] + (1. / 12.) * Om2[i];
+    } else {
+        const double theta = acos(d);
+        const double f = theta / (2 * sqrt(1 - d * d));
+        for (int i = 0; i < 3; ++i) om[i] = f * dR[i];
+        skew3(om, Om);
+        mat3mul(Om, Om, Om2);
+        const double g = (1 - theta / (2 * tan(theta / 2))) / (theta * theta);
+        for (int i = 0; i < 9; ++i) Vi[i] = I[i] - 0.5 * Om[i] + g * Om2[i];
+    }
+    out[0] = om[0]; out[1] = om[1]; out[2] = om[2];
+    for (int i = 0; i < 3; ++i) out[3 + i] = Vi[3 * i] * pose[0] + Vi[3 * i + 1] * pose[1] + Vi[3 * i + 2] * pose[2];
+}
+
+// Huber (g2o/core/robust_kernel_impl.cpp:78-91); delta <= 0: no kernel
+__device__ inline void huber(double e, double delta, double& rho0, double& rho1) {
+    if (delta <= 0 || e <= delta * delta) { rho0 = e; rho1 = 1.0; return; }
+    const double s = sqrt(e);
+    rho0 = 2 * s * delta - delta * delta;
+    rho1 = delta / s;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// projection edges.  D = 2 (EdgeSE3ProjectXYZ) or 3 (EdgeStereoSE3ProjectXYZ); K = fx fy cx cy bf
+// (Thirdparty/g2o/g2o/types/types_six_dof_expmap.h:79-140, .cpp:103-234)
+// ---------------------------------------------------------------------------------------------------------------
+template <int D>
+__device__ inline double proj_error(const double* pose, const double* X, const double* K, const double* obs, double* e,
+                                    double* p) {
+    se3_map(pose, X, p);
+    if (D == 2) {
+        e[0] = obs[0] - (p[0] / p[2] * K[0] + K[2]);
+        e[1] = obs[1] - (p[1] / p[2] * K[1] + K[3]);
+    } else {
+        const float invz = 1.0f / (float)p[2];          // cam_project(): `const float invz`, .cpp:150-157
+        const float bf = (float)K[4];
+        const double u = p[0] * invz * K[0] + K[2], v = p[1] * invz * K[1] + K[3];
+        e[0] = obs[0] - u;
+        e[1] = obs[1] - v;
+        e[2] = obs[2] - (u - bf * invz);
+    }
+    return p[2];
+}
+template <int D>
+__device__ inline void proj_jacobians(const double* pose, const double* p, const double* K, double* Jp /*Dx3*/,
+                                      double* Jx /*Dx6*/) {
+    double R[9];
+    quat_to_R(pose + 3, R);
+    const double fx = K[0], fy = K[1], bf = K[4];
+    const double x = p[0], y = p[1], z = p[2], z2 = z * z;
+    if (D == 2) {
+        const double t[6] = {fx, 0, -x / z * fx, 0, fy, -y / z * fy};
+        for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < 3; ++j)
+                Jp[3 * i + j] = -1. / z * (t[3 * i] * R[j] + t[3 * i + 1] * R[3 + j] + t[3 * i + 2] * R[6 + j]);
+    } else {
+        for (int j = 0; j < 3; ++j) {
+            Jp[j] = -fx * R[j] / z + fx * x * R[6 + j] / z2;
+            Jp[3 + j] = -fy * R[3 + j] / z + fy * y * R[6 + j] / z2;
+            Jp[6 + j] = Jp[j] - bf * R[6 + j] / z2;
+        }
+    }
+    Jx[0] = x * y / z2 * fx; Jx[1] = -(1 + (x * x / z2)) * fx; Jx[2] = y / z * fx;
+    Jx[3] = -1. / z * fx; Jx[4] = 0; Jx[5] = x / z2 * fx;
+    Jx[6] = (1 + y * y / z2) * fy; Jx[7] = -x * y / z2 * fy; Jx[8] = -x / z * fy;
+    Jx[9] = 0; Jx[10] = -1. / z * fy; Jx[11] = y / z2 * fy;
+    if (D == 3) {
+        Jx[12] = Jx[0] - bf * y / z2; Jx[13] = Jx[1] + bf * x / z2; Jx[14] = Jx[2];
+        Jx[15] = Jx[3]; Jx[16] = 0; Jx[17] = Jx[5] - bf / z2;
+    }
+}
+// EdgeSE3LieAlgebra, include/ObjectPoseGraph.h:69-88
+__device__ inline void obj_error(const double* Tcw, const double* Tow, const double* Z, double* e, double* Zi) {
+    double Towi[7], a[7], b[7];
+    se3_inv(Z, Zi);
+    se3_inv(Tow, Towi);
+    se3_mul(Zi, Tcw, a);
+    se3_mul(a, Towi, b);
+    se3_log(b, e);
+}
+__device__ inline void obj_jacobians(const double* e, const double* Zi, double* Ji, double* Jj) {
+    double J[36], W[9], T[9], R[9], TR[9], Tz[9];
+    skew3(e, W);
+    skew3(e + 3, T);
+    for (int i = 0; i < 36; ++i) J[i] = 0;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            J[6 * i + j] = 0.5 * W[3 * i + j];
+            J[6 * (i + 3) + j] = 0.5 * T[3 * i + j];
+            J[6 * (i + 3) + (j + 3)] = 0.5 * W[3 * i + j];
+        }
+    for (int i = 0; i < 6; ++i) J[7 * i] += 1.0;
+    // Adj(Zi) = [[R, 0], [t^ R, R]]   (se3quat.h:307-316)
+    quat_to_R(Zi + 3, R);
+    skew3(Zi, Tz);
+    mat3mul(Tz, R, TR);
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 6; ++j) {
+            double s = 0;
+            for (int k = 0; k < 6; ++k) {
+                double a;
+                if (k < 3) a = (j < 3) ? R[3 * k + j] : 0.0;
+                else a = (j < 3) ? TR[3 * (k - 3) + j] : R[3 * (k - 3) + (j - 3)];
+                s += J[6 * i + k] * a;
+            }
+            Ji[6 * i + j] = s;
+            Jj[6 * i + j] = -J[6 * i + j];
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// device-resident problem
+// ---------------------------------------------------------------------------------------------------------------
+struct Edge {            // one projection edge, landmark-major order
+    double obs[3];
+    double info;
+    int32_t pt, kf;
+    int32_t stereo;      // 0 mono, 1 stereo
+    int32_t user;        // index in the caller's mono / stereo array
+};
+
+struct Dev {
+    int n_kf, n_pt, n_obj, n_edge, n_oe;
+    double *kf_pose, *pt_xyz, *obj_pose, *kf_K;
+    double *kf_bk, *pt_bk, *obj_bk;
+    Edge* edge;
+    uint8_t* edge_level;
+    double* edge_chi2;
+    int32_t *pt_off;             // CSR landmark -> [first,last) in edge[]
+    int32_t *kf_off, *kf_edge;   // CSR key-frame -> edge indices
+    // object edges
+    int32_t *oe_kf, *oe_obj;
+    double* oe_meas;
+    uint8_t* oe_level;
+    double* oe_chi2;
+    int32_t *kfo_off, *kfo_edge; // CSR key-frame -> object-edge indices
+    int32_t *obo_off, *obo_edge; // CSR object    -> object-edge indices
+    double oe_info;
+    // hessian indices
+    int32_t *kf_h, *obj_h, *pt_h;
+    // system
+    double *Hll, *bl, *Dinv, *xl;   // per landmark (indexed by landmark, not by hessian index)
+    double *Hpl;                    // per edge 6x3
+    double *Hdiag;                  // per pose block (hessian index) 6x6
+    double *Hoff;                   // per object edge 6x6 (row = key-frame, col = object)
+    double *bp, *bs, *xp;           // reduced rhs / solution
+    double *Hs;                     // dense reduced matrix, ld = dimp
+    double *partial;                // block partials for reductions
+    double *scal;                   // [0] chi2, [1] scale, [2] maxdiag, [3] chol fail flag (as double)
+};
+
+struct Par {
+    double delta_mono, delta_stereo, delta_obj;
+    double lambda;
+    int dim, dimp, n_pose;
+};
+
+// block-wide sum of one double per thread (256 threads), fixed tree -> thread 0 holds the result
+__device__ inline double block_sum_256(double v, double* sh /*>=4*/) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    return (threadIdx.x == 0) ? ((sh[0] + sh[1]) + (sh[2] + sh[3])) : 0.0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_errors: chi2 per active edge, block partials of the robust chi2
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_errors(Dev d, Par par) {
+    __shared__ double sh[4];
+    double acc = 0;
+    const int n_tot = d.n_edge + d.n_oe;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n_tot; i += gridDim.x * 256) {
+        double r0, r1, e[6];
+        if (i < d.n_edge) {
+            if (d.edge_level[i]) continue;
+            const Edge E = d.edge[i];
+            double p[3];
+            double c;
+            if (E.stereo) {
+                proj_error<3>(d.kf_pose + 7 * E.kf, d.pt_xyz + 3 * E.pt, d.kf_K + 5 * E.kf, E.obs, e, p);
+                c = E.info * (e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
+                huber(c, par.delta_stereo, r0, r1);
+            } else {
+                proj_error<2>(d.kf_pose + 7 * E.kf, d.pt_xyz + 3 * E.pt, d.kf_K + 5 * E.kf, E.obs, e, p);
+                c = E.info * (e[0] * e[0] + e[1] * e[1]);
+                huber(c, par.delta_mono, r0, r1);
+            }
+            d.edge_chi2[i] = c;
+            acc += r0;
+        } else {
+            const int k = i - d.n_edge;
+            if (d.oe_level[k]) continue;
+            double Zi[7];
+            obj_error(d.kf_pose + 7 * d.oe_kf[k], d.obj_pose + 7 * d.oe_obj[k], d.oe_meas + 7 * k, e, Zi);
+            double c = 0;
+            for (int q = 0; q < 6; ++q) c += e[q] * e[q];
+            c *= d.oe_info;
+            d.oe_chi2[k] = c;
+            huber(c, par.delta_obj, r0, r1);
+            acc += r0;
+        }
+    }
+    const double s = block_sum_256(acc, sh);
+    if (threadIdx.x == 0) d.partial[blockIdx.x] = s;
+}
+
+// sums `n` partials in index order into scal[slot]
+__global__ void k_finish_sum(Dev d, int n, int slot) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double s = 0;
+        for (int i = 0; i < n; ++i) s += d.partial[i];
+        d.scal[slot] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_lin_points: one thread per landmark
+// ---------------------------------------------------------------------------------------------------------------
+template <int D>
+__device__ inline void lin_point_edge(const Dev& d, const Edge& E, int ei, double delta, double* Hll, double* bl) {
+    double e[3], p[3], Jp[9], Jx[18], r0, r1;
+    const double* pose = d.kf_pose + 7 * E.kf;
+    proj_error<D>(pose, d.pt_xyz + 3 * E.pt, d.kf_K + 5 * E.kf, E.obs, e, p);
+    proj_jacobians<D>(pose, p, d.kf_K + 5 * E.kf, Jp, Jx);
+    double c = 0;
+    for (int q = 0; q < D; ++q) c += e[q] * e[q];
+    c *= E.info;
+    huber(c, delta, r0, r1);
+    const double w = r1 * E.info;
+    for (int i = 0; i < 3; ++i) {
+        double sb = 0;
+        for (int q = 0; q < D; ++q) sb += Jp[3 * q + i] * (-E.info * e[q]) * r1;
+        bl[i] += sb;
+        for (int j = 0; j < 3; ++j) {
+            double s = 0;
+            for (int q = 0; q < D; ++q) s += Jp[3 * q + i] * Jp[3 * q + j];
+            Hll[3 * i + j] += w * s;
+        }
+    }
+    double* B = d.Hpl + 18 * (size_t)ei;
+    const bool free_pose = d.kf_h[E.kf] >= 0;
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double s = 0;
+            for (int q = 0; q < D; ++q) s += Jx[6 * q + i] * Jp[3 * q + j];
+            B[3 * i + j] = free_pose ? w * s : 0.0;
+        }
+}
+
+__global__ __launch_bounds__(256) void k_lin_points(Dev d, Par par) {
+    const int pt = blockIdx.x * 256 + threadIdx.x;
+    if (pt >= d.n_pt) return;
+    double Hll[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, bl[3] = {0, 0, 0};
+    if (d.pt_h[pt] >= 0) {
+        for (int ei = d.pt_off[pt]; ei < d.pt_off[pt + 1]; ++ei) {
+            if (d.edge_level[ei]) continue;
+            const Edge E = d.edge[ei];
+            if (E.stereo) lin_point_edge<3>(d, E, ei, par.delta_stereo, Hll, bl);
+            else lin_point_edge<2>(d, E, ei, par.delta_mono, Hll, bl);
+        }
+    }
+    for (int i = 0; i < 9; ++i) d.Hll[9 * (size_t)pt + i] = Hll[i];
+    for (int i = 0; i < 3; ++i) d.bl[3 * (size_t)pt + i] = bl[i];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_lin_poses: one 256-thread workgroup per key-frame; upper triangle (21) + rhs (6) reduced in a fixed tree
+// ---------------------------------------------------------------------------------------------------------------
+template <int D>
+__device__ inline void lin_pose_edge(const Dev& d, const Edge& E, double delta, double* A /*21*/, double* b /*6*/) {
+    double e[3], p[3], Jp[9], Jx[18], r0, r1;
+    const double* pose = d.kf_pose + 7 * E.kf;
+    proj_error<D>(pose, d.pt_xyz + 3 * E.pt, d.kf_K + 5 * E.kf, E.obs, e, p);
+    proj_jacobians<D>(pose, p, d.kf_K + 5 * E.kf, Jp, Jx);
+    double c = 0;
+    for (int q = 0; q < D; ++q) c += e[q] * e[q];
+    c *= E.info;
+    huber(c, delta, r0, r1);
+    const double w = r1 * E.info;
+    int t = 0;
+    for (int i = 0; i < 6; ++i) {
+        double sb = 0;
+        for (int q = 0; q < D; ++q) sb += Jx[6 * q + i] * (-E.info * e[q]) * r1;
+        b[i] += sb;
+        for (int j = i; j < 6; ++j) {
+            double s = 0;
+            for (int q = 0; q < D; ++q) s += Jx[6 * q + i] * Jx[6 * q + j];
+            A[t++] += w * s;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_lin_poses(Dev d, Par par) {
+    const int kf = blockIdx.x;
+    const int h = d.kf_h[kf];
+    if (h < 0) return;
+    __shared__ double sh[4];
+    double A[21], b[6];
+    for (int i = 0; i < 21; ++i) A[i] = 0;
+    for (int i = 0; i < 6; ++i) b[i] = 0;
+    for (int q = d.kf_off[kf] + threadIdx.x; q < d.kf_off[kf + 1]; q += 256) {
+        const int ei = d.kf_edge[q];
+        if (d.edge_level[ei]) continue;
+        const Edge E = d.edge[ei];
+        if (E.stereo) lin_pose_edge<3>(d, E, par.delta_stereo, A, b);
+        else lin_pose_edge<2>(d, E, par.delta_mono, A, b);
+    }
+    // camera-object edges of this key-frame: vertex 0, Jacobian Ji
+    for (int q = d.kfo_off[kf] + threadIdx.x; q < d.kfo_off[kf + 1]; q += 256) {
+        const int k = d.kfo_edge[q];
+        if (d.oe_level[k]) continue;
+        double e[6], Zi[7], Ji[36], Jj[36], r0, r1;
+        obj_error(d.kf_pose + 7 * kf, d.obj_pose + 7 * d.oe_obj[k], d.oe_meas + 7 * k, e, Zi);
+        obj_jacobians(e, Zi, Ji, Jj);
+        double c = 0;
+        for (int i = 0; i < 6; ++i) c += e[i] * e[i];
+        c *= d.oe_info;
+        huber(c, par.delta_obj, r0, r1);
+        const double w = r1 * d.oe_info;
+        int t = 0;
+        for (int i = 0; i < 6; ++i) {
+            double sb = 0;
+            for (int qd = 0; qd < 6; ++qd) sb += Ji[6 * qd + i] * (-d.oe_info * e[qd]) * r1;
+            b[i] += sb;
+            for (int j = i; j < 6; ++j) {
+                double s = 0;
+                for (int qd = 0; qd < 6; ++qd) s += Ji[6 * qd + i] * Ji[6 * qd + j];
+                A[t++] += w * s;
+            }
+        }
+    }
+    double red[27];
+    for (int i = 0; i < 21; ++i) red[i] = block_sum_256(A[i], sh);
+    for (int i = 0; i < 6; ++i) red[21 + i] = block_sum_256(b[i], sh);
+    if (threadIdx.x == 0) {
+        double* Hd = d.Hdiag + 36 * (size_t)h;
+        int t = 0;
+        for (int i = 0; i < 6; ++i)
+            for (int j = i; j < 6; ++j) { Hd[6 * i + j] = red[t]; Hd[6 * j + i] = red[t]; ++t; }
+        for (int i = 0; i < 6; ++i) d.bp[6 * h + i] = red[21 + i];
+    }
+}
+
+// one 64-thread workgroup per object; lane 0 walks the object's edges in order (few edges per object)
+__global__ void k_lin_objects(Dev d, Par par) {
+    const int ob = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ob >= d.n_obj) return;
+    const int hj = d.obj_h[ob];
+    if (hj < 0) return;
+    double A[36], b[6];
+    for (int i = 0; i < 36; ++i) A[i] = 0;
+    for (int i = 0; i < 6; ++i) b[i] = 0;
+    for (int q = d.obo_off[ob]; q < d.obo_off[ob + 1]; ++q) {
+        const int k = d.obo_edge[q];
+        if (d.oe_level[k]) continue;
+        const int kf = d.oe_kf[k];
+        double e[6], Zi[7], Ji[36], Jj[36], r0, r1;
+        obj_error(d.kf_pose + 7 * kf, d.obj_pose + 7 * ob, d.oe_meas + 7 * k, e, Zi);
+        obj_jacobians(e, Zi, Ji, Jj);
+        double c = 0;
+        for (int i = 0; i < 6; ++i) c += e[i] * e[i];
+        c *= d.oe_info;
+        huber(c, par.delta_obj, r0, r1);
+        const double w = r1 * d.oe_info;
+        for (int i = 0; i < 6; ++i) {
+            double sb = 0;
+            for (int qd = 0; qd < 6; ++qd) sb += Jj[6 * qd + i] * (-d.oe_info * e[qd]) * r1;
+            b[i] += sb;
+            for (int j = 0; j < 6; ++j) {
+                double s = 0, so = 0;
+                for (int qd = 0; qd < 6; ++qd) { s += Jj[6 * qd + i] * Jj[6 * qd + j]; so += Ji[6 * qd + i] * Jj[6 * qd + j]; }
+                A[6 * i + j] += w * s;
+                d.Hoff[36 * (size_t)k + 6 * i + j] = (d.kf_h[kf] >= 0) ? w * so : 0.0;   // Ji^T W Jj at (kf row, obj col)
+            }
+        }
+    }
+    for (int i = 0; i < 36; ++i) d.Hdiag[36 * (size_t)hj + i] = A[i];
+    for (int i = 0; i < 6; ++i) d.bp[6 * hj + i] = b[i];
+}
+
+// max |diagonal| over all active vertices (computeLambdaInit, optimization_algorithm_levenberg.cpp:166-180)
+__global__ __launch_bounds__(256) void k_maxdiag(Dev d, Par par) {
+    __shared__ double sh[256];
+    double m = 0;
+    for (int i = threadIdx.x; i < par.n_pose * 6; i += 256) m = fmax(m, fabs(d.Hdiag[36 * (size_t)(i / 6) + 7 * (i % 6)]));
+    for (int i = threadIdx.x; i < d.n_pt * 3; i += 256)
+        if (d.pt_h[i / 3] >= 0) m = fmax(m, fabs(d.Hll[9 * (size_t)(i / 3) + 4 * (i % 3)]));
+    sh[threadIdx.x] = m;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) sh[threadIdx.x] = fmax(sh[threadIdx.x], sh[threadIdx.x + o]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) d.scal[2] = sh[0];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Schur complement
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_schur_prepare(Dev d, Par par) {
+    // Hs (dimp x dimp, zeroed by a memset before) <- diagonal blocks + lambda, off-diagonal blocks; identity on the padding
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int nd = par.n_pose * 36;
+    if (i < nd) {
+        const int h = i / 36, r = (i % 36) / 6, c = i % 6;
+        double v = d.Hdiag[i];
+        if (r == c) v += par.lambda;
+        d.Hs[(size_t)(6 * h + r) * par.dimp + 6 * h + c] = v;
+    } else if (i < nd + d.n_oe * 36) {
+        const int k = (i - nd) / 36, r = ((i - nd) % 36) / 6, c = (i - nd) % 6;
+        if (!d.oe_level[k]) {
+            const int hi = d.kf_h[d.oe_kf[k]], hj = d.obj_h[d.oe_obj[k]];
+            if (hi >= 0 && hj >= 0) d.Hs[(size_t)(6 * hi + r) * par.dimp + 6 * hj + c] = d.Hoff[36 * (size_t)k + 6 * r + c];
+        }
+    } else if (i < nd + d.n_oe * 36 + (par.dimp - par.dim)) {
+        const int q = par.dim + (i - nd - d.n_oe * 36);
+        d.Hs[(size_t)q * par.dimp + q] = 1.0;
+    }
+    if (i < par.dimp) d.bs[i] = (i < par.dim) ? d.bp[i] : 0.0;
+}
+
+__device__ inline bool inv3(const double* m, double* o) {
+    const double a = m[0], b = m[1], c = m[2], dd = m[3], e = m[4], f = m[5], g = m[6], h = m[7], i = m[8];
+    const double det = a * (e * i - f * h) - b * (dd * i - f * g) + c * (dd * h - e * g);
+    const double id = 1.0 / det;
+    o[0] = (e * i - f * h) * id; o[1] = (c * h - b * i) * id; o[2] = (b * f - c * e) * id;
+    o[3] = (f * g - dd * i) * id; o[4] = (a * i - c * g) * id; o[5] = (c * dd - a * f) * id;
+    o[6] = (dd * h - e * g) * id; o[7] = (b * g - a * h) * id; o[8] = (a * e - b * dd) * id;
+    return true;
+}
+
+// one thread per landmark: D^-1, then every (i1 <= i2) pair of its free observing poses   (block_solver.hpp:381-432)
+__global__ __launch_bounds__(128) void k_schur_points(Dev d, Par par) {
+    const int pt = blockIdx.x * 128 + threadIdx.x;
+    if (pt >= d.n_pt || d.pt_h[pt] < 0) return;
+    double Dm[9], Di[9];
+    for (int i = 0; i < 9; ++i) Dm[i] = d.Hll[9 * (size_t)pt + i];
+    Dm[0] += par.lambda; Dm[4] += par.lambda; Dm[8] += par.lambda;
+    inv3(Dm, Di);
+    for (int i = 0; i < 9; ++i) d.Dinv[9 * (size_t)pt + i] = Di[i];
+    const double* bl = d.bl + 3 * (size_t)pt;
+    double db[3];
+    for (int i = 0; i < 3; ++i) db[i] = Di[3 * i] * bl[0] + Di[3 * i + 1] * bl[1] + Di[3 * i + 2] * bl[2];
+    const int e0 = d.pt_off[pt], e1 = d.pt_off[pt + 1];
+    for (int a = e0; a < e1; ++a) {
+        if (d.edge_level[a]) continue;
+        const int ha = d.kf_h[d.edge[a].kf];
+        if (ha < 0) continue;
+        const double* Ba = d.Hpl + 18 * (size_t)a;
+        double BD[18];
+        for (int i = 0; i < 6; ++i)
+            for (int j = 0; j < 3; ++j) BD[3 * i + j] = Ba[3 * i] * Di[j] + Ba[3 * i + 1] * Di[3 + j] + Ba[3 * i + 2] * Di[6 + j];
+        for (int i = 0; i < 6; ++i)
+            atomicAdd(&d.bs[6 * ha + i], -(Ba[3 * i] * db[0] + Ba[3 * i + 1] * db[1] + Ba[3 * i + 2] * db[2]));
+        for (int b = e0; b < e1; ++b) {
+            if (d.edge_level[b]) continue;
+            const int hb = d.kf_h[d.edge[b].kf];
+            if (hb < ha || (hb == ha && b != a)) continue;
+            const double* Bb = d.Hpl + 18 * (size_t)b;
+            for (int i = 0; i < 6; ++i)
+                for (int j = 0; j < 6; ++j)
+                    atomicAdd(&d.Hs[(size_t)(6 * ha + i) * par.dimp + 6 * hb + j],
+                              -(BD[3 * i] * Bb[3 * j] + BD[3 * i + 1] * Bb[3 * j + 1] + BD[3 * i + 2] * Bb[3 * j + 2]));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// blocked Cholesky A = U^T U on the upper triangle of the dimp x dimp matrix (dimp multiple of NB), right-looking
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_chol_diag(double* A, int ld, int k, double* scal) {
+    __shared__ double T[NB][NB + 1];
+    const int t = threadIdx.x;
+    for (int e = t; e < NB * NB; e += 256) T[e / NB][e % NB] = A[(size_t)(k * NB + e / NB) * ld + k * NB + e % NB];
+    __syncthreads();
+    for (int j = 0; j < NB; ++j) {
+        if (t == 0) {
+            const double dd = T[j][j];
+            if (!(dd > 0) || !isfinite(dd)) { scal[3] = 1.0; T[j][j] = 1.0; }
+            else T[j][j] = sqrt(dd);
+        }
+        __syncthreads();
+        const double piv = T[j][j];
+        if (t > j && t < NB) T[j][t] /= piv;          // row j of U, right of the diagonal
+        __syncthreads();
+        // trailing update of the upper triangle: T[r][c] -= U[j][r] * U[j][c] for j < r <= c
+        for (int e = t; e < NB * NB; e += 256) {
+            const int r = e / NB, c = e % NB;
+            if (r > j && c >= r) T[r][c] -= T[j][r] * T[j][c];
+        }
+        __syncthreads();
+    }
+    for (int e = t; e < NB * NB; e += 256) {
+        const int r = e / NB, c = e % NB;
+        A[(size_t)(k * NB + r) * ld + k * NB + c] = (c >= r) ? T[r][c] : 0.0;
+    }
+}
+
+// row-panel: A_kj <- U_kk^-T A_kj for block columns j > k (one workgroup per j)
+__global__ __launch_bounds__(256) void k_chol_panel(double* A, int ld, int k) {
+    __shared__ double U[NB][NB + 1];
+    __shared__ double P[NB][NB + 1];
+    const int j = k + 1 + blockIdx.x;
+    const int t = threadIdx.x;
+    for (int e = t; e < NB * NB; e += 256) {
+        U[e / NB][e % NB] = A[(size_t)(k * NB + e / NB) * ld + k * NB + e % NB];
+        P[e / NB][e % NB] = A[(size_t)(k * NB + e / NB) * ld + j * NB + e % NB];
+    }
+    __syncthreads();
+    // solve U^T X = P column by column of P: forward substitution over rows r; thread t < NB owns column t
+    if (t < NB) {
+        for (int r = 0; r < NB; ++r) {
+            double v = P[r][t];
+            for (int q = 0; q < r; ++q) v -= U[q][r] * P[q][t];
+            P[r][t] = v / U[r][r];
+        }
+    }
+    __syncthreads();
+    for (int e = t; e < NB * NB; e += 256) A[(size_t)(k * NB + e / NB) * ld + j * NB + e % NB] = P[e / NB][e % NB];
+}
+
+// trailing update: A_ij -= A_ki^T A_kj for k < i <= j  (grid: x = j - k - 1, y = i - k - 1, skipping i > j)
+__global__ __launch_bounds__(256) void k_chol_update(double* A, int ld, int k) {
+    const int j = k + 1 + blockIdx.x, i = k + 1 + blockIdx.y;
+    if (i > j) return;
+    __shared__ double Pi[NB][NB + 1];
+    __shared__ double Pj[NB][NB + 1];
+    const int t = threadIdx.x;
+    for (int e = t; e < NB * NB; e += 256) {
+        Pi[e / NB][e % NB] = A[(size_t)(k * NB + e / NB) * ld + i * NB + e % NB];
+        Pj[e / NB][e % NB] = A[(size_t)(k * NB + e / NB) * ld + j * NB + e % NB];
+    }
+    __syncthreads();
+    // each thread: 4x4 micro-tile of the 64x64 block
+    const int r0 = (t / 16) * 4, c0 = (t % 16) * 4;
+    double acc[4][4];
+    for (int a = 0; a < 4; ++a)
+        for (int b = 0; b < 4; ++b) acc[a][b] = 0;
+    for (int q = 0; q < NB; ++q) {
+        double x[4], y[4];
+        for (int a = 0; a < 4; ++a) { x[a] = Pi[q][r0 + a]; y[a] = Pj[q][c0 + a]; }
+        for (int a = 0; a < 4; ++a)
+            for (int b = 0; b < 4; ++b) acc[a][b] += x[a] * y[b];
+    }
+    for (int a = 0; a < 4; ++a)
+        for (int b = 0; b < 4; ++b) A[(size_t)(i * NB + r0 + a) * ld + j * NB + c0 + b] -= acc[a][b];
+}
+
+// single-workgroup triangular solves with U (upper, ld = n): y = U^-T b, then x = U^-1 y, in place in x
+__global__ __launch_bounds__(256) void k_trsv(const double* __restrict__ U, int n, const double* __restrict__ b,
+                                              double* __restrict__ x) {
+    __shared__ double xs[NB];
+    const int t = threadIdx.x;
+    for (int i = t; i < n; i += 256) x[i] = b[i];
+    __syncthreads();
+    const int nb = n / NB;
+    // forward: U^T y = b.  For block k: solve the NB x NB lower system, then x[c] -= sum_r U[kNB + r][c] * y[r], c beyond
+    for (int k = 0; k < nb; ++k) {
+        if (t < 64) {   // one wave; sequential over rows, lanes own entries
+            double v = x[k * NB + t];
+            for (int r = 0; r < NB; ++r) {
+                const double yr = __shfl(v, r, 64) / U[(size_t)(k * NB + r) * n + k * NB + r];
+                if (t == r) v = yr;
+                if (t > r) v -= U[(size_t)(k * NB + r) * n + k * NB + t] * yr;
+            }
+            xs[t] = v;
+            x[k * NB + t] = v;
+        }
+        __syncthreads();
+        for (int c = (k + 1) * NB + t; c < n; c += 256) {
+            double s = 0;
+            for (int r = 0; r < NB; ++r) s += U[(size_t)(k * NB + r) * n + c] * xs[r];
+            x[c] -= s;
+        }
+        __syncthreads();
+    }
+    // backward: U x = y.  For block k (last to first): x_k = U_kk^-1 (y_k - sum_{c beyond} U[kNB + r][c] x[c])
+    for (int k = nb - 1; k >= 0; --k) {
+        const int wave = t >> 6, lane = t & 63;
+        for (int r = wave; r < NB; r += 4) {            // wave per row, lanes stride over the columns
+            double s = 0;
+            for (int c = (k + 1) * NB + lane; c < n; c += 64) s += U[(size_t)(k * NB + r) * n + c] * x[c];
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+            if (lane == 0) xs[r] = x[k * NB + r] - s;
+        }
+        __syncthreads();
+        if (t < 64) {
+            double v = xs[t];
+            for (int r = NB - 1; r >= 0; --r) {
+                const double xr = __shfl(v, r, 64) / U[(size_t)(k * NB + r) * n + k * NB + r];
+                if (t == r) v = xr;
+                if (t < r) v -= U[(size_t)(k * NB + t) * n + k * NB + r] * xr;
+            }
+            x[k * NB + t] = v;
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// back-substitution + oplus + the rho denominator   (block_solver.hpp:461-481, sparse_optimizer.cpp:423-435,
+//                                                    optimization_algorithm_levenberg.cpp:182-189)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_update_points(Dev d, Par par) {
+    __shared__ double sh[4];
+    const int pt = blockIdx.x * 256 + threadIdx.x;
+    double sc = 0;
+    if (pt < d.n_pt && d.pt_h[pt] >= 0) {
+        double c[3] = {d.bl[3 * (size_t)pt], d.bl[3 * (size_t)pt + 1], d.bl[3 * (size_t)pt + 2]};
+        for (int a = d.pt_off[pt]; a < d.pt_off[pt + 1]; ++a) {
+            if (d.edge_level[a]) continue;
+            const int ha = d.kf_h[d.edge[a].kf];
+            if (ha < 0) continue;
+            const double* B = d.Hpl + 18 * (size_t)a;
+            for (int j = 0; j < 3; ++j)
+                for (int i = 0; i < 6; ++i) c[j] -= B[3 * i + j] * d.xp[6 * ha + i];
+        }
+        const double* Di = d.Dinv + 9 * (size_t)pt;
+        for (int i = 0; i < 3; ++i) {
+            const double xl = Di[3 * i] * c[0] + Di[3 * i + 1] * c[1] + Di[3 * i + 2] * c[2];
+            d.pt_xyz[3 * (size_t)pt + i] += xl;
+            sc += xl * (par.lambda * xl + d.bl[3 * (size_t)pt + i]);
+        }
+    }
+    const double s = block_sum_256(sc, sh);
+    if (threadIdx.x == 0) d.partial[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(256) void k_update_poses(Dev d, Par par, int n_partial) {
+    // single workgroup: poses and objects, then the final sum of the scale partials
+    __shared__ double sh[4];
+    double sc = 0;
+    for (int v = threadIdx.x; v < d.n_kf + d.n_obj; v += 256) {
+        const bool is_kf = v < d.n_kf;
+        const int h = is_kf ? d.kf_h[v] : d.obj_h[v - d.n_kf];
+        if (h < 0) continue;
+        double* pose = is_kf ? d.kf_pose + 7 * v : d.obj_pose + 7 * (v - d.n_kf);
+        double dl[7], n[7];
+        se3_exp(d.xp + 6 * h, dl);
+        se3_mul(dl, pose, n);
+        for (int i = 0; i < 7; ++i) pose[i] = n[i];
+        for (int i = 0; i < 6; ++i) sc += d.xp[6 * h + i] * (par.lambda * d.xp[6 * h + i] + d.bp[6 * h + i]);
+    }
+    const double s = block_sum_256(sc, sh);
+    if (threadIdx.x == 0) {
+        double tot = s;
+        for (int i = 0; i < n_partial; ++i) tot += d.partial[i];
+        d.scal[1] = tot;
+    }
+}
+
+__global__ void k_depth_positive(Dev d, uint8_t* pos) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= d.n_edge) return;
+    double p[3];
+    se3_map(d.kf_pose + 7 * d.edge[i].kf, d.pt_xyz + 3 * d.edge[i].pt, p);
+    pos[i] = p[2] > 0.0;
+}
+
+}  // namespace ba
+}  // namespace qsp
+
+// =================================================================================================================
+// host side
+// =================================================================================================================
+using namespace qsp;
+using namespace qsp::ba;
+
+struct qsp_ba_problem {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    Dev d{};
+    int n_mono = 0, n_stereo = 0;
+    std::vector<void*> allocs;
+    // host mirrors needed for index building
+    std::vector<Edge> edge_h;
+    std::vector<int32_t> pt_off_h, oe_kf_h, oe_obj_h;
+    std::vector<uint8_t> kf_fixed_h, edge_level_h, oe_level_h;
+    std::vector<int64_t> kf_id_h, pt_id_h, obj_id_h;
+    std::vector<int32_t> mono_pos, st_pos;   // user index -> landmark-major position
+    std::vector<int32_t> kf_h, obj_h, pt_h;
+    int n_pose = 0, n_land = 0, dim = 0, dimp = 0, dimp_max = 0;
+    int n_partial = 0;
+    // LM state that persists inside one optimize call only
+    qsp_ba_stats prof{};
+    bool profiling = false;
+};
+
+template <typename T>
+static int dalloc(qsp_ba_problem* p, T** ptr, size_t n) {
+    void* q = nullptr;
+    QSP_HIP(hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T)));
+    p->allocs.push_back(q);
+    *ptr = (T*)q;
+    return QSP_OK;
+}
+template <typename T>
+static int dupload(qsp_ba_problem* p, T** ptr, const T* src, size_t n) {
+    int rc = dalloc(p, ptr, n);
+    if (rc) return rc;
+    if (n) QSP_HIP(hipMemcpy(*ptr, src, n * sizeof(T), hipMemcpyHostToDevice));
+    return QSP_OK;
+}
+
+static void csr_build(int n_rows, const std::vector<int32_t>& row_of, std::vector<int32_t>& off, std::vector<int32_t>& idx) {
+    off.assign(n_rows + 1, 0);
+    for (int32_t r : row_of) off[r + 1]++;
+    for (int i = 0; i < n_rows; ++i) off[i + 1] += off[i];
+    idx.assign(row_of.size(), 0);
+    std::vector<int32_t> cur(off.begin(), off.end() - 1);
+    for (size_t e = 0; e < row_of.size(); ++e) idx[cur[row_of[e]]++] = (int32_t)e;
+}
+
+extern "C" int qsp_ba_create(const qsp_ba_scene* s, int device, qsp_ba_problem** out) {
+    if (!s || !out) return qsp_fail(QSP_ERR_INVALID, "qsp_ba_create: null argument");
+    if (s->n_kf <= 0 || s->n_pt < 0 || s->n_obj < 0 || s->n_mono < 0 || s->n_stereo < 0 || s->n_objedge < 0)
+        return qsp_fail(QSP_ERR_INVALID, "qsp_ba_create: negative count");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return qsp_fail(QSP_ERR_NO_DEVICE, "no HIP device visible");
+    if (device < 0 || device >= ndev) return qsp_fail(QSP_ERR_INVALID, "device index out of range");
+    for (int e = 0; e < s->n_mono; ++e)
+        if (s->mono_pt[e] < 0 || s->mono_pt[e] >= s->n_pt || s->mono_kf[e] < 0 || s->mono_kf[e] >= s->n_kf)
+            return qsp_fail(QSP_ERR_INVALID, "qsp_ba_create: mono edge index out of range");
+    for (int e = 0; e < s->n_stereo; ++e)
+        if (s->stereo_pt[e] < 0 || s->stereo_pt[e] >= s->n_pt || s->stereo_kf[e] < 0 || s->stereo_kf[e] >= s->n_kf)
+            return qsp_fail(QSP_ERR_INVALID, "qsp_ba_create: stereo edge index out of range");
+    for (int e = 0; e < s->n_objedge; ++e)
+        if (s->objedge_kf[e] < 0 || s->objedge_kf[e] >= s->n_kf || s->objedge_obj[e] < 0 || s->objedge_obj[e] >= s->n_obj)
+            return qsp_fail(QSP_ERR_INVALID, "qsp_ba_create: object edge index out of range");
+    QSP_HIP(hipSetDevice(device));
+    qsp_ba_problem* p = new qsp_ba_problem();
+    p->device = device;
+    Dev& d = p->d;
+    d.n_kf = s->n_kf; d.n_pt = s->n_pt; d.n_obj = s->n_obj; d.n_oe = s->n_objedge;
+    d.n_edge = s->n_mono + s->n_stereo;
+    d.oe_info = s->objedge_info;
+    p->n_mono = s->n_mono; p->n_stereo = s->n_stereo;
+    // landmark-major edge order: stable by (landmark, then mono before stereo, then caller order)
+    std::vector<int32_t> row(d.n_edge);
+    for (int e = 0; e < s->n_mono; ++e) row[e] = s->mono_pt[e];
+    for (int e = 0; e < s->n_stereo; ++e) row[s->n_mono + e] = s->stereo_pt[e];
+    std::vector<int32_t> order;
+    csr_build(d.n_pt, row, p->pt_off_h, order);
+    p->edge_h.resize(d.n_edge);
+    p->mono_pos.assign(s->n_mono, 0);
+    p->st_pos.assign(s->n_stereo, 0);
+    std::vector<int32_t> kf_of(d.n_edge);
+    for (int pos = 0; pos < d.n_edge; ++pos) {
+        const int src = order[pos];
+        Edge& E = p->edge_h[pos];
+        if (src < s->n_mono) {
+            E.obs[0] = s->mono_obs[2 * src]; E.obs[1] = s->mono_obs[2 * src + 1]; E.obs[2] = 0;
+            E.info = s->mono_info[src]; E.pt = s->mono_pt[src]; E.kf = s->mono_kf[src]; E.stereo = 0; E.user = src;
+            p->mono_pos[src] = pos;
+        } else {
+            const int q = src - s->n_mono;
+            E.obs[0] = s->stereo_obs[3 * q]; E.obs[1] = s->stereo_obs[3 * q + 1]; E.obs[2] = s->stereo_obs[3 * q + 2];
+            E.info = s->stereo_info[q]; E.pt = s->stereo_pt[q]; E.kf = s->stereo_kf[q]; E.stereo = 1; E.user = q;
+            p->st_pos[q] = pos;
+        }
+        kf_of[pos] = E.kf;
+    }
+    std::vector<int32_t> kf_off, kf_edge, kfo_off, kfo_edge, obo_off, obo_edge;
+    csr_build(d.n_kf, kf_of, kf_off, kf_edge);
+    p->oe_kf_h.assign(s->objedge_kf, s->objedge_kf + s->n_objedge);
+    p->oe_obj_h.assign(s->objedge_obj, s->objedge_obj + s->n_objedge);
+    csr_build(d.n_kf, p->oe_kf_h, kfo_off, kfo_edge);
+    csr_build(d.n_obj, p->oe_obj_h, obo_off, obo_edge);
+    p->kf_fixed_h.assign(s->kf_fixed, s->kf_fixed + s->n_kf);
+    p->kf_id_h.assign(s->kf_id, s->kf_id + s->n_kf);
+    p->pt_id_h.assign(s->pt_id, s->pt_id + s->n_pt);
+    p->obj_id_h.assign(s->obj_id, s->obj_id + s->n_obj);
+    p->edge_level_h.assign(d.n_edge, 0);
+    p->oe_level_h.assign(d.n_oe, 0);
+    p->dimp_max = ((6 * (d.n_kf + d.n_obj) + NB - 1) / NB) * NB;
+    int rc = QSP_OK;
+#define UP(field, src, n) if (!rc) rc = dupload(p, &d.field, src, (size_t)(n))
+#define AL(field, n) if (!rc) rc = dalloc(p, &d.field, (size_t)(n))
+    UP(kf_pose, s->kf_pose, 7 * d.n_kf);
+    UP(pt_xyz, s->pt_xyz, 3 * d.n_pt);
+    UP(obj_pose, s->obj_pose, 7 * d.n_obj);
+    UP(kf_K, s->kf_K, 5 * d.n_kf);
+    AL(kf_bk, 7 * d.n_kf); AL(pt_bk, 3 * d.n_pt); AL(obj_bk, 7 * d.n_obj);
+    UP(edge, p->edge_h.data(), d.n_edge);
+    AL(edge_level, d.n_edge); AL(edge_chi2, d.n_edge);
+    UP(pt_off, p->pt_off_h.data(), d.n_pt + 1);
+    UP(kf_off, kf_off.data(), d.n_kf + 1);
+    UP(kf_edge, kf_edge.data(), d.n_edge);
+    UP(oe_kf, s->objedge_kf, d.n_oe);
+    UP(oe_obj, s->objedge_obj, d.n_oe);
+    UP(oe_meas, s->objedge_meas, 7 * d.n_oe);
+    AL(oe_level, d.n_oe); AL(oe_chi2, d.n_oe);
+    UP(kfo_off, kfo_off.data(), d.n_kf + 1);
+    UP(kfo_edge, kfo_edge.data(), d.n_oe);
+    UP(obo_off, obo_off.data(), d.n_obj + 1);
+    UP(obo_edge, obo_edge.data(), d.n_oe);
+    AL(kf_h, d.n_kf); AL(obj_h, d.n_obj); AL(pt_h, d.n_pt);
+    AL(Hll, 9 * (size_t)d.n_pt); AL(bl, 3 * (size_t)d.n_pt); AL(Dinv, 9 * (size_t)d.n_pt); AL(xl, 3 * (size_t)d.n_pt);
+    AL(Hpl, 18 * (size_t)d.n_edge);
+    AL(Hdiag, 36 * (size_t)(d.n_kf + d.n_obj));
+    AL(Hoff, 36 * (size_t)d.n_oe);
+    AL(bp, p->dimp_max); AL(bs, p->dimp_max); AL(xp, p->dimp_max);
+    AL(Hs, (size_t)p->dimp_max * p->dimp_max);
+    p->n_partial = 1024;
+    AL(partial, p->n_partial);
+    AL(scal, 8);
+#undef UP
+#undef AL
+    if (!rc) {
+        hipError_t e = hipMemset(d.edge_level, 0, std::max(d.n_edge, 1));
+        if (e == hipSuccess) e = hipMemset(d.oe_level, 0, std::max(d.n_oe, 1));
+        if (e == hipSuccess) e = hipMemset(d.edge_chi2, 0, sizeof(double) * std::max(d.n_edge, 1));
+        if (e == hipSuccess) e = hipMemset(d.oe_chi2, 0, sizeof(double) * std::max(d.n_oe, 1));
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) rc = qsp_fail(QSP_ERR_DEVICE, hipGetErrorString(e));
+    }
+    if (rc) {
+        qsp_ba_destroy(p);
+        return rc;
+    }
+    *out = p;
+    return QSP_OK;
+}
+
+extern "C" void qsp_ba_destroy(qsp_ba_problem* p) {
+    if (!p) return;
+    hipSetDevice(p->device);
+    for (void* q : p->allocs) hipFree(q);
+    if (p->stream) hipStreamDestroy(p->stream);
+    delete p;
+}
+
+extern "C" int qsp_ba_set_levels(qsp_ba_problem* p, const uint8_t* mono, const uint8_t* stereo, const uint8_t* obj) {
+    if (!p) return qsp_fail(QSP_ERR_INVALID, "qsp_ba_set_levels: null problem");
+    QSP_HIP(hipSetDevice(p->device));
+    std::fill(p->edge_level_h.begin(), p->edge_level_h.end(), 0);
+    if (mono) for (int e = 0; e < p->n_mono; ++e) p->edge_level_h[p->mono_pos[e]] = mono[e] ? 1 : 0;
+    if (stereo) for (int e = 0; e < p->n_stereo; ++e) p->edge_level_h[p->st_pos[e]] = stereo[e] ? 1 : 0;
+    for (int e = 0; e < p->d.n_oe; ++e) p->oe_level_h[e] = (obj && obj[e]) ? 1 : 0;
+    if (p->d.n_edge) QSP_HIP(hipMemcpy(p->d.edge_level, p->edge_level_h.data(), p->d.n_edge, hipMemcpyHostToDevice));
+    if (p->d.n_oe) QSP_HIP(hipMemcpy(p->d.oe_level, p->oe_level_h.data(), p->d.n_oe, hipMemcpyHostToDevice));
+    return QSP_OK;
+}
+
+extern "C" int qsp_ba_set_state(qsp_ba_problem* p, const double* kf_pose, const double* pt_xyz, const double* obj_pose) {
+    if (!p) return qsp_fail(QSP_ERR_INVALID, "qsp_ba_set_state: null problem");
+    QSP_HIP(hipSetDevice(p->device));
+    if (kf_pose) QSP_HIP(hipMemcpy(p->d.kf_pose, kf_pose, sizeof(double) * 7 * p->d.n_kf, hipMemcpyHostToDevice));
+    if (pt_xyz && p->d.n_pt) QSP_HIP(hipMemcpy(p->d.pt_xyz, pt_xyz, sizeof(double) * 3 * p->d.n_pt, hipMemcpyHostToDevice));
+    if (obj_pose && p->d.n_obj) QSP_HIP(hipMemcpy(p->d.obj_pose, obj_pose, sizeof(double) * 7 * p->d.n_obj, hipMemcpyHostToDevice));
+    return QSP_OK;
+}
+
+extern "C" int qsp_ba_get_state(qsp_ba_problem* p, double* kf_pose, double* pt_xyz, double* obj_pose) {
+    if (!p) return qsp_fail(QSP_ERR_INVALID, "qsp_ba_get_state: null problem");
+    QSP_HIP(hipSetDevice(p->device));
+    if (kf_pose) QSP_HIP(hipMemcpy(kf_pose, p->d.kf_pose, sizeof(double) * 7 * p->d.n_kf, hipMemcpyDeviceToHost));
+    if (pt_xyz && p->d.n_pt) QSP_HIP(hipMemcpy(pt_xyz, p->d.pt_xyz, sizeof(double) * 3 * p->d.n_pt, hipMemcpyDeviceToHost));
+    if (obj_pose && p->d.n_obj) QSP_HIP(hipMemcpy(obj_pose, p->d.obj_pose, sizeof(double) * 7 * p->d.n_obj, hipMemcpyDeviceToHost));
+    return QSP_OK;
+}
+
+// SparseOptimizer::initializeOptimization(level) + buildIndexMapping (sparse_optimizer.cpp:199-267,166-190)
+static void build_index(qsp_ba_problem* p) {
+    const Dev& d = p->d;
+    std::vector<uint8_t> ka(d.n_kf, 0), oa(d.n_obj, 0), pa(d.n_pt, 0);
+    for (int e = 0; e < d.n_edge; ++e)
+        if (!p->edge_level_h[e]) { ka[p->edge_h[e].kf] = 1; pa[p->edge_h[e].pt] = 1; }
+    for (int e = 0; e < d.n_oe; ++e)
+        if (!p->oe_level_h[e]) { ka[p->oe_kf_h[e]] = 1; oa[p->oe_obj_h[e]] = 1; }
+    std::vector<std::pair<int64_t, int>> v;
+    p->kf_h.assign(d.n_kf, -1); p->obj_h.assign(d.n_obj, -1); p->pt_h.assign(d.n_pt, -1);
+    for (int i = 0; i < d.n_kf; ++i)
+        if (ka[i] && !p->kf_fixed_h[i]) v.push_back({p->kf_id_h[i], i});
+    for (int i = 0; i < d.n_obj; ++i)
+        if (oa[i]) v.push_back({p->obj_id_h[i], d.n_kf + i});
+    std::sort(v.begin(), v.end());
+    for (size_t k = 0; k < v.size(); ++k) {
+        if (v[k].second < d.n_kf) p->kf_h[v[k].second] = (int)k;
+        else p->obj_h[v[k].second - d.n_kf] = (int)k;
+    }
+    p->n_pose = (int)v.size();
+    v.clear();
+    for (int i = 0; i < d.n_pt; ++i)
+        if (pa[i]) v.push_back({p->pt_id_h[i], i});
+    std::sort(v.begin(), v.end());
+    for (size_t k = 0; k < v.size(); ++k) p->pt_h[v[k].second] = (int)k;
+    p->n_land = (int)v.size();
+    p->dim = 6 * p->n_pose;
+    p->dimp = ((p->dim + NB - 1) / NB) * NB;
+}
+
+static int read_scal(qsp_ba_problem* p, double* out4) {
+    QSP_HIP(hipMemcpyAsync(out4, p->d.scal, 4 * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+    QSP_HIP(hipStreamSynchronize(p->stream));
+    return QSP_OK;
+}
+
+static int launch_errors(qsp_ba_problem* p, const Par& par) {
+    const Dev& d = p->d;
+    const int n_tot = d.n_edge + d.n_oe;
+    const int grid = std::max(1, std::min(p->n_partial, (n_tot + 255) / 256));
+    hipLaunchKernelGGL(k_errors, dim3(grid), dim3(256), 0, p->stream, d, par);
+    hipLaunchKernelGGL(k_finish_sum, dim3(1), dim3(64), 0, p->stream, d, grid, 0);
+    return QSP_OK;
+}
+
+extern "C" int qsp_ba_optimize(qsp_ba_problem* p, int32_t n_iter, double delta_mono, double delta_stereo,
+                               double delta_obj, const volatile uint8_t* stop_flag, qsp_ba_trace* tr) {
+    if (!p) return qsp_fail(QSP_ERR_INVALID, "qsp_ba_optimize: null problem");
+    QSP_HIP(hipSetDevice(p->device));
+    Dev& d = p->d;
+    hipStream_t s = p->stream;
+    build_index(p);
+    QSP_HIP(hipMemcpyAsync(d.kf_h, p->kf_h.data(), sizeof(int32_t) * d.n_kf, hipMemcpyHostToDevice, s));
+    if (d.n_obj) QSP_HIP(hipMemcpyAsync(d.obj_h, p->obj_h.data(), sizeof(int32_t) * d.n_obj, hipMemcpyHostToDevice, s));
+    if (d.n_pt) QSP_HIP(hipMemcpyAsync(d.pt_h, p->pt_h.data(), sizeof(int32_t) * d.n_pt, hipMemcpyHostToDevice, s));
+    Par par{delta_mono, delta_stereo, delta_obj, 0.0, p->dim, p->dimp, p->n_pose};
+    if (tr) { tr->n = 0; tr->result = 0; tr->n_pose_blocks = p->n_pose; tr->n_landmarks = p->n_land; }
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, evA = nullptr, evB = nullptr;
+    if (p->profiling) {
+        memset(&p->prof, 0, sizeof(p->prof));
+        hipEventCreate(&ev0); hipEventCreate(&ev1); hipEventCreate(&evA); hipEventCreate(&evB);
+        hipEventRecord(ev0, s);
+    }
+    const int gp = std::max(1, (d.n_pt + 255) / 256);
+    if (gp > p->n_partial) return qsp_fail(QSP_ERR_INVALID, "qsp_ba_optimize: too many landmarks for the partial buffer");
+    double lambda = 0, ni = 2;
+    int nBad = 0, done = 0, result = 0;
+    double sc[4];
+    for (int it = 0; it < n_iter; ++it) {
+        if (stop_flag && *stop_flag) { result = 2; break; }
+        // computeActiveErrors + chi2
+        launch_errors(p, par);
+        // buildSystem
+        if (p->profiling) hipEventRecord(evA, s);
+        QSP_HIP(hipMemsetAsync(d.Hdiag, 0, sizeof(double) * 36 * (size_t)std::max(p->n_pose, 1), s));
+        QSP_HIP(hipMemsetAsync(d.bp, 0, sizeof(double) * std::max(p->dimp, 1), s));
+        hipLaunchKernelGGL(k_lin_points, dim3(gp), dim3(256), 0, s, d, par);
+        hipLaunchKernelGGL(k_lin_poses, dim3(d.n_kf), dim3(256), 0, s, d, par);
+        if (d.n_obj) hipLaunchKernelGGL(k_lin_objects, dim3((d.n_obj + 63) / 64), dim3(64), 0, s, d, par);
+        if (p->profiling) hipEventRecord(evB, s);
+        if (it == 0) hipLaunchKernelGGL(k_maxdiag, dim3(1), dim3(256), 0, s, d, par);
+        int rc = read_scal(p, sc);
+        if (rc) return rc;
+        if (p->profiling) {
+            float ms = 0;
+            hipEventElapsedTime(&ms, evA, evB);
+            p->prof.ms_linearize += ms;
+            p->prof.n_linearize++;
+        }
+        double currentChi = sc[0];
+        const double iniChi = currentChi;
+        if (it == 0) { lambda = 1e-5 * sc[2]; ni = 2; nBad = 0; }
+        double rho = 0;
+        int qmax = 0, accepted = 0;
+        do {
+            par.lambda = lambda;
+            // push
+            QSP_HIP(hipMemcpyAsync(d.kf_bk, d.kf_pose, sizeof(double) * 7 * d.n_kf, hipMemcpyDeviceToDevice, s));
+            if (d.n_obj) QSP_HIP(hipMemcpyAsync(d.obj_bk, d.obj_pose, sizeof(double) * 7 * d.n_obj, hipMemcpyDeviceToDevice, s));
+            if (d.n_pt) QSP_HIP(hipMemcpyAsync(d.pt_bk, d.pt_xyz, sizeof(double) * 3 * d.n_pt, hipMemcpyDeviceToDevice, s));
+            // solve
+            QSP_HIP(hipMemsetAsync(d.scal + 3, 0, sizeof(double), s));
+            if (p->dimp > 0) {
+                QSP_HIP(hipMemsetAsync(d.Hs, 0, sizeof(double) * (size_t)p->dimp * p->dimp, s));
+                const int nprep = p->n_pose * 36 + d.n_oe * 36 + (p->dimp - p->dim);
+                hipLaunchKernelGGL(k_schur_prepare, dim3((std::max(nprep, p->dimp) + 255) / 256), dim3(256), 0, s, d, par);
+                if (d.n_pt) hipLaunchKernelGGL(k_schur_points, dim3((d.n_pt + 127) / 128), dim3(128), 0, s, d, par);
+                const int nb = p->dimp / NB;
+                for (int k = 0; k < nb; ++k) {
+                    hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(256), 0, s, d.Hs, p->dimp, k, d.scal);
+                    if (k + 1 < nb) {
+                        hipLaunchKernelGGL(k_chol_panel, dim3(nb - k - 1), dim3(256), 0, s, d.Hs, p->dimp, k);
+                        hipLaunchKernelGGL(k_chol_update, dim3(nb - k - 1, nb - k - 1), dim3(256), 0, s, d.Hs, p->dimp, k);
+                    }
+                }
+                hipLaunchKernelGGL(k_trsv, dim3(1), dim3(256), 0, s, d.Hs, p->dimp, d.bs, d.xp);
+            } else if (d.n_pt) {
+                hipLaunchKernelGGL(k_schur_points, dim3((d.n_pt + 127) / 128), dim3(128), 0, s, d, par);
+            }
+            // update (oplus) + rho denominator
+            hipLaunchKernelGGL(k_update_points, dim3(gp), dim3(256), 0, s, d, par);
+            hipLaunchKernelGGL(k_update_poses, dim3(1), dim3(256), 0, s, d, par, gp);
+            launch_errors(p, par);
+            rc = read_scal(p, sc);
+            if (rc) return rc;
+            const bool ok2 = sc[3] == 0.0;
+            double tempChi = ok2 ? sc[0] : DBL_MAX;
+            rho = currentChi - tempChi;
+            const double scale = sc[1] + 1e-3;
+            rho /= scale;
+            if (rho > 0 && std::isfinite(tempChi)) {
+                double alpha = 1. - pow(2 * rho - 1, 3);
+                alpha = std::min(alpha, 2. / 3.);
+                lambda *= std::max(1. / 3., alpha);
+                ni = 2;
+                currentChi = tempChi;
+                accepted = 1;
+            } else {
+                lambda *= ni;
+                ni *= 2;
+                QSP_HIP(hipMemcpyAsync(d.kf_pose, d.kf_bk, sizeof(double) * 7 * d.n_kf, hipMemcpyDeviceToDevice, s));
+                if (d.n_obj) QSP_HIP(hipMemcpyAsync(d.obj_pose, d.obj_bk, sizeof(double) * 7 * d.n_obj, hipMemcpyDeviceToDevice, s));
+                if (d.n_pt) QSP_HIP(hipMemcpyAsync(d.pt_xyz, d.pt_bk, sizeof(double) * 3 * d.n_pt, hipMemcpyDeviceToDevice, s));
+                accepted = 0;
+            }
+            qmax++;
+            p->prof.n_trials++;
+        } while (rho < 0 && qmax < 10 && !(stop_flag && *stop_flag));
+        done++;
+        if (tr && tr->n < tr->cap) {
+            tr->chi2[tr->n] = currentChi; tr->lambda[tr->n] = lambda; tr->trials[tr->n] = qmax;
+            tr->accepted[tr->n] = accepted; tr->n++;
+        }
+        if (qmax == 10 || rho == 0) { result = 1; break; }
+        if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0;
+        if (nBad >= 3) { result = 1; break; }
+    }
+    QSP_HIP(hipStreamSynchronize(s));
+    if (p->profiling) {
+        hipEventRecord(ev1, s);
+        hipEventSynchronize(ev1);
+        hipEventElapsedTime(&p->prof.ms_total, ev0, ev1);
+        hipEventDestroy(ev0); hipEventDestroy(ev1); hipEventDestroy(evA); hipEventDestroy(evB);
+        // algorithmic bytes of one linearisation
+        int64_t nm = 0, ns = 0, no = 0;
+        for (int e = 0; e < d.n_edge; ++e)
+            if (!p->edge_level_h[e]) (p->edge_h[e].stereo ? ns : nm)++;
+        for (int e = 0; e < d.n_oe; ++e) if (!p->oe_level_h[e]) no++;
+        p->prof.bytes_linearize = 176 * nm + 184 * ns + 392 * (int64_t)p->n_pose + 120 * (int64_t)p->n_land + 352 * no;
+    }
+    if (tr) tr->result = result;
+    QSP_HIP(hipGetLastError());
+    if (tr) tr->iterations = done;
+    return QSP_OK;
+}
+
+extern "C" int qsp_ba_get_index(qsp_ba_problem* p, int32_t* kf_hidx, int32_t* obj_hidx, int32_t* pt_hidx) {
+    if (!p) return qsp_fail(QSP_ERR_INVALID, "qsp_ba_get_index: null problem");
+    if (kf_hidx) memcpy(kf_hidx, p->kf_h.data(), sizeof(int32_t) * p->kf_h.size());
+    if (obj_hidx) memcpy(obj_hidx, p->obj_h.data(), sizeof(int32_t) * p->obj_h.size());
+    if (pt_hidx) memcpy(pt_hidx, p->pt_h.data(), sizeof(int32_t) * p->pt_h.size());
+    return QSP_OK;
+}
+
+extern "C" int qsp_ba_get_edges(qsp_ba_problem* p, double* mono_chi2, double* stereo_chi2, double* obj_chi2,
+                                uint8_t* mono_depth_pos, uint8_t* stereo_depth_pos) {
+    if (!p) return qsp_fail(QSP_ERR_INVALID, "qsp_ba_get_edges: null problem");
+    QSP_HIP(hipSetDevice(p->device));
+    const Dev& d = p->d;
+    std::vector<double> c(std::max(d.n_edge, 1));
+    std::vector<uint8_t> pos(std::max(d.n_edge, 1));
+    if (d.n_edge) {
+        QSP_HIP(hipMemcpy(c.data(), d.edge_chi2, sizeof(double) * d.n_edge, hipMemcpyDeviceToHost));
+        if (mono_depth_pos || stereo_depth_pos) {
+            uint8_t* dp = nullptr;
+            QSP_HIP(hipMalloc((void**)&dp, d.n_edge));
+            hipLaunchKernelGGL(k_depth_positive, dim3((d.n_edge + 255) / 256), dim3(256), 0, p->stream, d, dp);
+            QSP_HIP(hipMemcpyAsync(pos.data(), dp, d.n_edge, hipMemcpyDeviceToHost, p->stream));
+            QSP_HIP(hipStreamSynchronize(p->stream));
+            hipFree(dp);
+        }
+    }
+    for (int e = 0; e < p->n_mono; ++e) {
+        if (mono_chi2) mono_chi2[e] = c[p->mono_pos[e]];
+        if (mono_depth_pos) mono_depth_pos[e] = pos[p->mono_pos[e]];
+    }
+    for (int e = 0; e < p->n_stereo; ++e) {
+        if (stereo_chi2) stereo_chi2[e] = c[p->st_pos[e]];
+        if (stereo_depth_pos) stereo_depth_pos[e] = pos[p->st_pos[e]];
+    }
+    if (obj_chi2 && d.n_oe) QSP_HIP(hipMemcpy(obj_chi2, d.oe_chi2, sizeof(double) * d.n_oe, hipMemcpyDeviceToHost));
+    return QSP_OK;
+}
+
+extern "C" int qsp_ba_profile(qsp_ba_problem* p, int enable, qsp_ba_stats* out) {
+    if (!p) return qsp_fail(QSP_ERR_INVALID, "qsp_ba_profile: null problem");
+    p->profiling = enable != 0;
+    if (out) *out = p->prof;
+    return QSP_OK;
+}
+
+// Optimizer::LocalJointBundleAdjustment schedule (src/Optimizer_util.cc:598-661)
+extern "C" int qsp_ba_local_joint(qsp_ba_problem* p, const volatile uint8_t* stop_flag, qsp_ba_trace* t1, qsp_ba_trace* t2) {
+    if (!p) return qsp_fail(QSP_ERR_INVALID, "qsp_ba_local_joint: null problem");
+    const float thMono = sqrtf(5.991f), thStereo = sqrtf(7.815f), thObj = sqrtf(1e3f);
+    if (stop_flag && *stop_flag) return QSP_OK;                                   // :589-596
+    int rc = qsp_ba_set_levels(p, nullptr, nullptr, nullptr);
+    if (!rc) rc = qsp_ba_optimize(p, 5, (double)(float)sqrt(5.991), (double)(float)sqrt(7.815), (double)thObj, stop_flag, t1);
+    (void)thMono; (void)thStereo;
+    if (rc) return rc;
+    if (stop_flag && *stop_flag) return QSP_OK;                                   // :603-610 (no write-back by the caller)
+    const Dev& d = p->d;
+    std::vector<double> cm(std::max(p->n_mono, 1)), cs(std::max(p->n_stereo, 1)), co(std::max(d.n_oe, 1));
+    std::vector<uint8_t> pm(std::max(p->n_mono, 1)), ps(std::max(p->n_stereo, 1));
+    rc = qsp_ba_get_edges(p, cm.data(), cs.data(), co.data(), pm.data(), ps.data());
+    if (rc) return rc;
+    std::vector<uint8_t> lm(std::max(p->n_mono, 1)), ls(std::max(p->n_stereo, 1)), lo(std::max(d.n_oe, 1));
+    for (int e = 0; e < p->n_mono; ++e) lm[e] = (cm[e] > 5.991 || !pm[e]) ? 1 : 0;   // :621-626
+    for (int e = 0; e < p->n_stereo; ++e) ls[e] = (cs[e] > 7.815 || !ps[e]) ? 1 : 0; // :636-641
+    for (int e = 0; e < d.n_oe; ++e) lo[e] = (co[e] > 1e3) ? 1 : 0;                  // :650-654
+    rc = qsp_ba_set_levels(p, lm.data(), ls.data(), lo.data());
+    if (!rc) rc = qsp_ba_optimize(p, 10, 0.0, 0.0, 0.0, stop_flag, t2);              // robust kernels dropped, :628,643,655
+    return rc;
+}

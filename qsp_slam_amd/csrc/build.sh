@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -Wno-unused-value"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wno-unused-result -Wno-unused-value"
 SRCS="sdf_refine.hip c_abi.cpp"
 [ -f ba_solver.hip ] && SRCS="$SRCS ba_solver.hip"
 $HIPCC $FLAGS -shared -o ../libqsp_hip.so $SRCS "$@"

@@ -202,7 +202,7 @@ def make_ba_scene(seed, n_kf, n_pt, n_obj, stereo_frac=0.0, outlier_frac=0.05, n
     key-frames through noisy SE3 detections.  Estimates are perturbed around the ground truth; `outlier_frac` of the
     observations get a gross 50 px error.  All float64; measurements pass through float32 as in src/Converter.cc.
 
-    returns dict of arrays (see oracle/ba_oracle.py / qsp_slam_amd/ba.py for the field meaning)"""
+    returns dict of arrays (see qsp_ba_scene in include/qsp_hip.h for the field meaning)"""
     rng = np.random.default_rng(seed)
     fx, fy, cx, cy = 535.4, 539.2, 320.1, 247.6          # configs/tum_fr1_desk.yaml
     bf = 40.0
