@@ -29,11 +29,11 @@ sys.path.insert(0, ROOT)
 
 WORKLOADS = {
     # name: (n_kf, n_obj, n_pts, n_fg, n_bg, n_iter, cfg-name)
-    "c2": dict(n_kf=20, n_obj=8, n_pts=2000, n_fg=256, n_bg=200, n_iter=5,
+    "c2": dict(n_kf=20, n_obj=8, n_pts=2000, n_fg=256, n_bg=200, n_iter=5, n_map=2000,
                desc="C2: synthetic 20 KF / 8 objects / 2k SDF samples, 4 yaw flips x 5 GN iterations"),
-    "c4": dict(n_kf=50, n_obj=64, n_pts=8000, n_fg=256, n_bg=200, n_iter=5,
+    "c4": dict(n_kf=50, n_obj=64, n_pts=8000, n_fg=256, n_bg=200, n_iter=5, n_map=5000,
                desc="C4: synthetic 50 KF / 64 objects / 8k SDF samples, 4 yaw flips x 5 GN iterations"),
-    "c5": dict(n_kf=200, n_obj=256, n_pts=250, n_fg=250, n_bg=200, n_iter=10,
+    "c5": dict(n_kf=200, n_obj=256, n_pts=250, n_fg=250, n_bg=200, n_iter=10, n_map=20000,
                desc="C5 stand-in: synthetic 200 KF / 256 objects / 250 LiDAR points, 4 yaw flips x 10 GN iterations"),
 }
 FLOP_FWD = 2.0 * 1835520          # per point, decoder forward            
@@ -65,9 +65,12 @@ def flip_states(objs, flips):
     return np.stack(T0), hyp
 
 
-def cpu_baseline(w, objs, budget_s=20.0):
-    """The oracle (numpy restatement of the reference, kind "port") timed on this box's host cores on a bounded sample
-    of the same workload: whole Gauss-Newton iterations of single hypotheses until ~budget_s of CPU time is spent."""
+def cpu_baseline(w, objs, scene, n_hyp, budget_s=20.0):
+    """The oracle (kind "port": numpy restatement of path A, C restatement of path B) timed on this box's host cores on
+    a bounded sample of the same workload: whole Gauss-Newton iterations of single hypotheses until ~budget_s of CPU time
+    is spent, plus ONE full local joint BA of the scene (single thread, as the reference's g2o runs).  `value` is the
+    step rate extrapolated from that sample to the full step (all hypotheses + the BA)."""
+    from oracle import ba_oracle as bo
     from oracle import sdf_oracle as so
     dec = so.load_decoder_npz(os.path.join(ROOT, "tests", "golden", "decoder_8x512.npz"))
     cfg = so.JointConfig(n_iter=w["n_iter"])
@@ -89,9 +92,18 @@ def cpu_baseline(w, objs, budget_s=20.0):
         if time.time() - t0 > budget_s:
             break
     dt = time.time() - t0
-    return dict(value=iters / dt, unit="iters/s", cores=cores, kind="port",
-                sample="%d hypothesis x %d GN iterations of the same scene (numpy+BLAS oracle, %d threads), %.1f s"
-                       % (hyps, cfg.n_iter, cores, dt))
+    t1 = time.time()
+    prob = bo.BaProblem(scene)
+    b1, b2 = prob.local_joint_ba()
+    dt_ba = time.time() - t1
+    ba_iters = int(b1["iterations"] + b2["iterations"])
+    step_iters = n_hyp * cfg.n_iter + ba_iters
+    step_s = (dt / max(iters, 1)) * n_hyp * cfg.n_iter + dt_ba
+    return dict(value=step_iters / step_s, unit="iters/s", cores=cores, kind="port",
+                sample="A: %d hypotheses x %d GN iterations (numpy+BLAS oracle, %d threads) in %.1f s, extrapolated to %d "
+                       "hypotheses; B: one full local joint BA (C oracle, 1 thread, %d LM iterations) in %.2f s"
+                       % (hyps, cfg.n_iter, cores, dt, n_hyp, ba_iters, dt_ba),
+                sdf_iters_per_s=iters / dt, ba_ms=1e3 * dt_ba)
 
 
 def main():
@@ -116,6 +128,7 @@ def main():
     dev = local_rank if world > 1 else 0
 
     from qsp_slam_amd import DeepSdfDecoder, synth
+    from qsp_slam_amd.ba import BaProblem
     from qsp_slam_amd.reconstruct.optimizer import Optimizer, RefineBatch, _joint_cfg
 
     w = WORKLOADS[args.workload]
@@ -126,6 +139,11 @@ def main():
     batch = RefineBatch(dec, _joint_cfg(opt), [o["pts"] for o in objs], [o["rays"] for o in objs],
                         [o["depth"] for o in objs], hyp)          # inputs resident in HBM from here on
     batch.profile(True)
+    scene = synth.make_ba_scene(2000 + rank, w["n_kf"], w["n_map"], w["n_obj"], stereo_frac=0.2)
+    ba = BaProblem(scene, device=dev)                              # flattened graph resident in HBM
+    ba.profile(True)
+    kf0, pt0, ob0 = scene["kf_pose"], scene["pt_xyz"], scene["obj_pose"]
+    ba_stat = dict(ms=0.0, ms_lin=0.0, n_lin=0, bytes_lin=0, iters=0, trials=0)
 
     def sync_all():
         torch.cuda.synchronize(dev)
@@ -133,9 +151,20 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    def step():
+    def step(record=False):
         batch.set_state(T0, None)      # 256 x (16+64) floats H2D: part of the step, as the caller hands poses over
         batch.run(0)
+        ba.set_state(kf0, pt0, ob0)    # the caller's current estimates (float64 poses / points)
+        t_a = time.perf_counter()
+        t1, t2 = ba.local_joint_ba()
+        if record:
+            ba_stat["ms"] += 1e3 * (time.perf_counter() - t_a)
+            ba_stat["iters"] += int(t1["iterations"] + t2["iterations"])
+            ba_stat["trials"] += int(t1["trials"].sum() + t2["trials"].sum())
+            bp = ba.profile(True)      # stage-2 call's record
+            ba_stat["ms_lin"] += bp.ms_linearize
+            ba_stat["n_lin"] += bp.n_linearize
+            ba_stat["bytes_lin"] = bp.bytes_linearize
 
     for _ in range(args.warmup):
         step()
@@ -144,7 +173,7 @@ def main():
     prof = dict(ms_total=0.0, ms_mlp_jtj=0.0, ms_mlp_fwd=0.0, ms_other=0.0, n_jtj=0, n_fwd=0, pts_jtj=0, pts_fwd=0,
                 tiles_jtj=0, tiles_fwd=0)
     for _ in range(args.steps):
-        step()
+        step(record=True)
         p = batch.profile(True)
         prof["ms_total"] += p.ms_total
         prof["ms_mlp_jtj"] += p.ms_mlp_jtj
@@ -165,8 +194,14 @@ def main():
     _, _, loss, good = batch.get()
 
     n_hyp = len(hyp)
-    iters_per_step = n_hyp * w["n_iter"]            # + BA LM iterations once path B is in the step
-    value = world * iters_per_step * args.steps / dt
+    iters_total = n_hyp * w["n_iter"] * args.steps + ba_stat["iters"]
+    if dist is not None:
+        t = torch.tensor([float(iters_total)], device="cuda:%d" % dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        iters_total_all = float(t.item())
+    else:
+        iters_total_all = float(iters_total)
+    value = iters_total_all / dt
     if rank == 0:
         flop_jtj = FLOP_FWDBWD * prof["pts_jtj"] + 2.0 * 72 * 72 * prof["pts_jtj"]
         avg_ms = prof["ms_mlp_jtj"] / max(prof["n_jtj"], 1)
@@ -179,7 +214,10 @@ def main():
             "data": "synthetic (seeded scene, decoder fitted to an analytic shape family)",
             "config": {"workload": w["desc"], "objects_per_gpu": w["n_obj"], "hypotheses_per_gpu": n_hyp,
                        "surface_points": w["n_pts"], "rays": w["n_fg"] + w["n_bg"], "depth_samples": 50,
-                       "gn_iterations": w["n_iter"], "ba": "not in this step yet"},
+                       "gn_iterations": w["n_iter"],
+                       "ba": "local joint BA 5+10 LM iterations: %d KF / %d map points / %d objects, %d mono + %d stereo "
+                             "+ %d camera-object edges" % (w["n_kf"], w["n_map"], w["n_obj"], len(scene["mono_pt"]),
+                                                            len(scene["st_pt"]), len(scene["oe_kf"]))},
             "ms_per_object_refine": 1e3 * dt / args.steps / w["n_obj"],
             "good_hypotheses": int(good.sum()),
             "roofline": {"bound": "mfma", "kernel": "k_mlp_jtj (decoder fwd+bwd+JtJ, f32 MFMA)",
@@ -190,12 +228,19 @@ def main():
                          "tile_padding_overhead": 64.0 * prof["tiles_jtj"] / max(prof["pts_jtj"], 1)},
             "kernels": {"k_mlp_fwd_TFLOPs": fwd_tf, "k_mlp_fwd_frac": fwd_tf / PEAK_F32_MFMA_TFLOPS,
                         "ms_mlp_jtj": prof["ms_mlp_jtj"] / args.steps, "ms_mlp_fwd": prof["ms_mlp_fwd"] / args.steps,
-                        "ms_other": prof["ms_other"] / args.steps, "ms_gpu_total": prof["ms_total"] / args.steps},
+                        "ms_other": prof["ms_other"] / args.steps, "ms_gpu_total": prof["ms_total"] / args.steps,
+                        "ms_ba": ba_stat["ms"] / args.steps, "ba_lm_iterations": ba_stat["iters"] / args.steps,
+                        "ba_lm_trials": ba_stat["trials"] / args.steps,
+                        "ba_linearize_us": 1e3 * ba_stat["ms_lin"] / max(ba_stat["n_lin"], 1),
+                        "ba_linearize_bytes": ba_stat["bytes_lin"],
+                        "ba_linearize_GBps": ba_stat["bytes_lin"] / max(1e-3 * ba_stat["ms_lin"] / max(ba_stat["n_lin"], 1), 1e-12) / 1e9,
+                        "ba_linearize_frac_of_8TBps": ba_stat["bytes_lin"] / max(1e-3 * ba_stat["ms_lin"] / max(ba_stat["n_lin"], 1), 1e-12) / 8e12},
         }
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(w, objs)
+            out["cpu_baseline"] = cpu_baseline(w, objs, scene, n_hyp)
         print(json.dumps(out))
     batch.close()
+    ba.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -1,0 +1,356 @@
+// qsp_optimizer_shim.h -- header-only C++ shim that keeps the ORB-SLAM2 `Optimizer` static API of QSP-SLAM
+// (include/Optimizer.h:78-107 of the reference) and routes the bundle adjustments to libqsp_hip.so.
+//
+// It is compiled INSIDE the QSP-SLAM tree (it needs the reference's KeyFrame.h / MapPoint.h / MapObject.h / Map.h /
+// ObjectDetection.h, hence Eigen + OpenCV, which this repository's build image does not have).  It contains no numerics:
+// it walks the map exactly as src/Optimizer_util.cc:309-385,396-586 (local) and :44-250 (global) do, flattens the graph into
+// a qsp_ba_scene with the reference's vertex-id scheme and edge insertion order, calls the C-ABI, and writes the results
+// back as src/Optimizer_util.cc:686-769 / :252-305 do.  tests/shim_mock/ compiles it against stand-in types and checks the
+// flattening.
+//
+// Usage in the reference tree: add this header and -lqsp_hip, then in src/LocalMapping.cc:239 / src/LoopClosing_util.cc:299
+// call ORB_SLAM2::OptimizerHip::LocalJointBundleAdjustment(...) / GlobalJointBundleAdjustemnt(...) -- or define
+// QSP_HIP_REPLACE_OPTIMIZER before including to alias the names.
+#ifndef QSP_OPTIMIZER_SHIM_H
+#define QSP_OPTIMIZER_SHIM_H
+
+#include <cmath>
+#include <cstdint>
+#include <list>
+#include <map>
+#include <mutex>
+#include <set>
+#include <vector>
+
+#include "qsp_hip.h"
+
+#ifndef QSP_SHIM_MOCK_TYPES      // the real tree
+#include "Converter.h"
+#include "KeyFrame.h"
+#include "Map.h"
+#include "MapObject.h"
+#include "MapPoint.h"
+#include "ObjectDetection.h"
+#endif
+
+namespace ORB_SLAM2 {
+namespace qsp_shim {
+
+// Converter::toSE3Quat(cv::Mat float32 4x4) -> g2o::SE3Quat(R, t): Eigen's matrix->quaternion, then normalizeRotation()
+// (src/Converter.cc:37-46, Thirdparty/g2o/g2o/types/se3quat.h:61-66,328-333).  Output (tx ty tz qx qy qz qw).
+template <typename GetF>
+inline void pose7_from_rt(GetF m, double* p) {
+    const double R[9] = {m(0, 0), m(0, 1), m(0, 2), m(1, 0), m(1, 1), m(1, 2), m(2, 0), m(2, 1), m(2, 2)};
+    double q[4];
+    double t = R[0] + R[4] + R[8];
+    if (t > 0) {
+        t = std::sqrt(t + 1.0);
+        q[3] = 0.5 * t;
+        t = 0.5 / t;
+        q[0] = (R[7] - R[5]) * t; q[1] = (R[2] - R[6]) * t; q[2] = (R[3] - R[1]) * t;
+    } else {
+        int i = 0;
+        if (R[4] > R[0]) i = 1;
+        if (R[8] > R[4 * i]) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        t = std::sqrt(R[4 * i] - R[4 * j] - R[4 * k] + 1.0);
+        q[i] = 0.5 * t;
+        t = 0.5 / t;
+        q[3] = (R[3 * k + j] - R[3 * j + k]) * t;
+        q[j] = (R[3 * j + i] + R[3 * i + j]) * t;
+        q[k] = (R[3 * k + i] + R[3 * i + k]) * t;
+    }
+    if (q[3] < 0) { q[0] = -q[0]; q[1] = -q[1]; q[2] = -q[2]; q[3] = -q[3]; }
+    const double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    p[0] = m(0, 3); p[1] = m(1, 3); p[2] = m(2, 3);
+    p[3] = q[0] / n; p[4] = q[1] / n; p[5] = q[2] / n; p[6] = q[3] / n;
+}
+
+// SE3Quat -> 4x4 float (Converter::toCvMat(SE3Quat), src/Converter.cc:65-87): rotation matrix of the quaternion, float32
+inline void pose7_to_mat(const double* p, float* T /*row-major 4x4*/) {
+    const double x = p[3], y = p[4], z = p[5], w = p[6];
+    const double R[9] = {1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
+                         2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+                         2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)};
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) T[4 * i + j] = (float)R[3 * i + j];
+        T[4 * i + 3] = (float)p[i];
+    }
+    T[12] = T[13] = T[14] = 0.f;
+    T[15] = 1.f;
+}
+
+struct Flat {   // the flattened graph + back-references for the write-back
+    std::vector<KeyFrame*> kfs;
+    std::vector<MapPoint*> pts;
+    std::vector<MapObject*> objs;
+    std::vector<double> kf_pose, kf_K, pt_xyz, obj_pose, mono_obs, mono_info, st_obs, st_info, oe_meas;
+    std::vector<uint8_t> kf_fixed;
+    std::vector<int64_t> kf_id, pt_id, obj_id;
+    std::vector<int32_t> mono_pt, mono_kf, st_pt, st_kf, oe_kf, oe_obj;
+    std::vector<KeyFrame*> mono_kfp, st_kfp, oe_kfp;
+    std::vector<MapPoint*> mono_mp, st_mp;
+    std::vector<MapObject*> oe_mo;
+    unsigned long maxKFid = 0, maxMPid = 0;
+    std::map<KeyFrame*, int> kf_index;
+
+    int add_kf(KeyFrame* pKF, bool fixed) {
+        const int i = (int)kfs.size();
+        kfs.push_back(pKF);
+        kf_index[pKF] = i;
+        double p[7];
+        const cv::Mat Tcw = pKF->GetPose();
+        pose7_from_rt([&](int r, int c) { return (double)Tcw.at<float>(r, c); }, p);
+        kf_pose.insert(kf_pose.end(), p, p + 7);
+        kf_fixed.push_back(fixed ? 1 : 0);
+        kf_id.push_back((int64_t)pKF->mnId);
+        const double K[5] = {pKF->fx, pKF->fy, pKF->cx, pKF->cy, pKF->mbf};
+        kf_K.insert(kf_K.end(), K, K + 5);
+        if (pKF->mnId > maxKFid) maxKFid = pKF->mnId;
+        return i;
+    }
+
+    // one map point: vertex + one edge per observing key-frame that is in the graph (src/Optimizer_util.cc:454-541)
+    void add_point(MapPoint* pMP) {
+        const int ip = (int)pts.size();
+        pts.push_back(pMP);
+        const cv::Mat X = pMP->GetWorldPos();
+        for (int i = 0; i < 3; ++i) pt_xyz.push_back((double)X.at<float>(i));
+        pt_id.push_back((int64_t)pMP->mnId);   // + maxKFid + 1, added in finish()
+        const std::map<KeyFrame*, size_t> observations = pMP->GetObservations();
+        for (std::map<KeyFrame*, size_t>::const_iterator mit = observations.begin(); mit != observations.end(); ++mit) {
+            KeyFrame* pKFi = mit->first;
+            if (pKFi->isBad()) continue;
+            std::map<KeyFrame*, int>::const_iterator f = kf_index.find(pKFi);
+            if (f == kf_index.end()) continue;      // optimizer.vertex(pKFi->mnId) would be NULL in the reference
+            const cv::KeyPoint& kpUn = pKFi->mvKeysUn[mit->second];
+            const float invSigma2 = pKFi->mvInvLevelSigma2[kpUn.octave];
+            if (pKFi->mvuRight[mit->second] < 0) {
+                mono_pt.push_back(ip); mono_kf.push_back(f->second);
+                mono_obs.push_back(kpUn.pt.x); mono_obs.push_back(kpUn.pt.y);
+                mono_info.push_back(invSigma2);
+                mono_kfp.push_back(pKFi); mono_mp.push_back(pMP);
+            } else {
+                st_pt.push_back(ip); st_kf.push_back(f->second);
+                st_obs.push_back(kpUn.pt.x); st_obs.push_back(kpUn.pt.y); st_obs.push_back(pKFi->mvuRight[mit->second]);
+                st_info.push_back(invSigma2);
+                st_kfp.push_back(pKFi); st_mp.push_back(pMP);
+            }
+            if (pMP->mnId > maxMPid) maxMPid = pMP->mnId;
+        }
+    }
+
+    // one static object: SE3 vertex (estimate SE3Tow) + one EdgeSE3LieAlgebra per observing key-frame in the graph
+    // (src/Optimizer_util.cc:544-586)
+    void add_object(MapObject* pMO) {
+        const int io = (int)objs.size();
+        objs.push_back(pMO);
+        double p[7];
+        pose7_from_rt([&](int r, int c) { return (double)pMO->SE3Tow(r, c); }, p);
+        obj_pose.insert(obj_pose.end(), p, p + 7);
+        obj_id.push_back((int64_t)pMO->mnId);    // + maxKFid + maxMPid + 2, added in finish()
+        const std::map<KeyFrame*, size_t> observations = pMO->GetObservations();
+        for (std::map<KeyFrame*, size_t>::const_iterator it = observations.begin(); it != observations.end(); ++it) {
+            KeyFrame* pKFi = it->first;
+            std::map<KeyFrame*, int>::const_iterator f = kf_index.find(pKFi);
+            if (f == kf_index.end() || pKFi->isBad()) continue;
+            auto dets = pKFi->GetObjectDetections();
+            auto det = dets[it->second];
+            pose7_from_rt([&](int r, int c) { return (double)det->SE3Tco(r, c); }, p);
+            oe_meas.insert(oe_meas.end(), p, p + 7);
+            oe_kf.push_back(f->second); oe_obj.push_back(io);
+            oe_kfp.push_back(pKFi); oe_mo.push_back(pMO);
+        }
+    }
+
+    void finish(qsp_ba_scene* s) {
+        for (size_t i = 0; i < pt_id.size(); ++i) pt_id[i] += (int64_t)maxKFid + 1;
+        for (size_t i = 0; i < obj_id.size(); ++i) obj_id[i] += (int64_t)maxKFid + (int64_t)maxMPid + 2;
+        s->n_kf = (int32_t)kfs.size(); s->n_pt = (int32_t)pts.size(); s->n_obj = (int32_t)objs.size();
+        s->n_mono = (int32_t)mono_pt.size(); s->n_stereo = (int32_t)st_pt.size(); s->n_objedge = (int32_t)oe_kf.size();
+        s->kf_pose = kf_pose.data(); s->kf_fixed = kf_fixed.data(); s->kf_id = kf_id.data(); s->kf_K = kf_K.data();
+        s->pt_xyz = pt_xyz.data(); s->pt_id = pt_id.data(); s->obj_pose = obj_pose.data(); s->obj_id = obj_id.data();
+        s->mono_pt = mono_pt.data(); s->mono_kf = mono_kf.data(); s->mono_obs = mono_obs.data(); s->mono_info = mono_info.data();
+        s->stereo_pt = st_pt.data(); s->stereo_kf = st_kf.data(); s->stereo_obs = st_obs.data(); s->stereo_info = st_info.data();
+        s->objedge_kf = oe_kf.data(); s->objedge_obj = oe_obj.data(); s->objedge_meas = oe_meas.data();
+        s->objedge_info = 1e3;   // const float invSigmaObject = 1e3, src/Optimizer_util.cc:447
+    }
+};
+
+}  // namespace qsp_shim
+
+class OptimizerHip {
+public:
+    static int& nBAdone() { static int n = 0; return n; }
+    static int& device() { static int d = 0; return d; }
+
+    // Optimizer::LocalJointBundleAdjustment, src/Optimizer_util.cc:309-771.  with_objects = false gives
+    // Optimizer::LocalBundleAdjustment (src/Optimizer.cc:458-783), whose only behavioural difference besides the missing
+    // object vertices is that an abort after stage 1 still writes back (src/Optimizer.cc:667-673).
+    static void LocalJointBundleAdjustment(KeyFrame* pKF, bool* pbStopFlag, Map* pMap, bool with_objects = true) {
+        using namespace qsp_shim;
+        // ---- local key-frames, points, objects, fixed key-frames: :311-380 ------------------------------------------
+        std::list<KeyFrame*> lLocalKeyFrames;
+        lLocalKeyFrames.push_back(pKF);
+        pKF->mnBALocalForKF = pKF->mnId;
+        const std::vector<KeyFrame*> vNeighKFs = pKF->GetVectorCovisibleKeyFrames();
+        for (size_t i = 0; i < vNeighKFs.size(); ++i) {
+            KeyFrame* pKFi = vNeighKFs[i];
+            pKFi->mnBALocalForKF = pKF->mnId;
+            if (!pKFi->isBad()) lLocalKeyFrames.push_back(pKFi);
+        }
+        std::list<MapPoint*> lLocalMapPoints;
+        std::list<MapObject*> lLocalMapObjects;
+        for (KeyFrame* k : lLocalKeyFrames) {
+            for (MapPoint* pMP : k->GetMapPointMatches())
+                if (pMP && !pMP->isBad() && pMP->mnBALocalForKF != pKF->mnId) {
+                    lLocalMapPoints.push_back(pMP);
+                    pMP->mnBALocalForKF = pKF->mnId;
+                }
+            if (with_objects)
+                for (MapObject* pMO : k->GetMapObjectMatches())
+                    if (pMO && pMO->mnBALocalForKF != pKF->mnId) {
+                        lLocalMapObjects.push_back(pMO);
+                        pMO->mnBALocalForKF = pKF->mnId;
+                    }
+        }
+        std::list<KeyFrame*> lFixedCameras;
+        for (MapPoint* pMP : lLocalMapPoints) {
+            const std::map<KeyFrame*, size_t> observations = pMP->GetObservations();
+            for (std::map<KeyFrame*, size_t>::const_iterator mit = observations.begin(); mit != observations.end(); ++mit) {
+                KeyFrame* pKFi = mit->first;
+                if (pKFi->mnBALocalForKF != pKF->mnId && pKFi->mnBAFixedForKF != pKF->mnId) {
+                    pKFi->mnBAFixedForKF = pKF->mnId;
+                    if (!pKFi->isBad()) lFixedCameras.push_back(pKFi);
+                }
+            }
+        }
+        // ---- flatten: vertices and edges in the reference's insertion order (:396-586) ------------------------------
+        Flat F;
+        for (KeyFrame* k : lLocalKeyFrames) F.add_kf(k, k->mnId == 0);
+        for (KeyFrame* k : lFixedCameras) F.add_kf(k, true);
+        for (MapPoint* pMP : lLocalMapPoints) F.add_point(pMP);
+        for (MapObject* pMO : lLocalMapObjects)
+            if (!pMO->isDynamic()) F.add_object(pMO);
+        qsp_ba_scene scene;
+        F.finish(&scene);
+        if (pbStopFlag && *pbStopFlag) return;                                        // :589-596
+        qsp_ba_problem* prob = nullptr;
+        if (qsp_ba_create(&scene, device(), &prob) != QSP_OK) return;                 // failure = leave the map unchanged
+        const volatile uint8_t* stop = reinterpret_cast<const volatile uint8_t*>(pbStopFlag);
+        if (qsp_ba_local_joint(prob, stop, nullptr, nullptr) != QSP_OK) { qsp_ba_destroy(prob); return; }
+        if (with_objects && pbStopFlag && *pbStopFlag) { qsp_ba_destroy(prob); return; }   // :603-610: no write-back
+        // ---- outlier observations (:665-711), under the map mutex (:714-736) -------------------------------------------
+        std::vector<double> cm(F.mono_pt.size() + 1), cs(F.st_pt.size() + 1), co(F.oe_kf.size() + 1);
+        std::vector<uint8_t> pm(F.mono_pt.size() + 1), ps(F.st_pt.size() + 1);
+        qsp_ba_get_edges(prob, cm.data(), cs.data(), co.data(), pm.data(), ps.data());
+        std::vector<double> kf(F.kf_pose.size()), pt(F.pt_xyz.size() + 1), ob(F.obj_pose.size() + 1);
+        qsp_ba_get_state(prob, kf.data(), pt.data(), ob.data());
+        qsp_ba_destroy(prob);
+        std::unique_lock<std::mutex> lock(pMap->mMutexMapUpdate);
+        for (size_t i = 0; i < F.mono_pt.size(); ++i)
+            if (!F.mono_mp[i]->isBad() && (cm[i] > 5.991 || !pm[i])) {
+                F.mono_kfp[i]->EraseMapPointMatch(F.mono_mp[i]);
+                F.mono_mp[i]->EraseObservation(F.mono_kfp[i]);
+            }
+        for (size_t i = 0; i < F.st_pt.size(); ++i)
+            if (!F.st_mp[i]->isBad() && (cs[i] > 7.815 || !ps[i])) {
+                F.st_kfp[i]->EraseMapPointMatch(F.st_mp[i]);
+                F.st_mp[i]->EraseObservation(F.st_kfp[i]);
+            }
+        for (size_t i = 0; i < F.oe_kf.size(); ++i)
+            if (co[i] > 1e3) {
+                F.oe_kfp[i]->EraseMapObjectMatch(F.oe_mo[i]);
+                F.oe_mo[i]->EraseObservation(F.oe_kfp[i]);
+            }
+        // ---- recover optimised data (:741-768): float32 round trip at the boundary -----------------------------------
+        size_t n_local = lLocalKeyFrames.size();
+        for (size_t i = 0; i < n_local; ++i) {
+            float T[16];
+            pose7_to_mat(&kf[7 * i], T);
+            cv::Mat M(4, 4, CV_32F);
+            for (int r = 0; r < 4; ++r)
+                for (int c = 0; c < 4; ++c) M.at<float>(r, c) = T[4 * r + c];
+            F.kfs[i]->SetPose(M);
+        }
+        for (size_t i = 0; i < F.pts.size(); ++i) {
+            cv::Mat X(3, 1, CV_32F);
+            for (int r = 0; r < 3; ++r) X.at<float>(r) = (float)pt[3 * i + r];
+            F.pts[i]->SetWorldPos(X);
+            F.pts[i]->UpdateNormalAndDepth();
+        }
+        for (size_t i = 0; i < F.objs.size(); ++i) {
+            MapObject* pMO = F.objs[i];
+            if (pMO->isDynamic() || pMO->isBad()) continue;
+            float T[16];
+            pose7_to_mat(&ob[7 * i], T);
+            Eigen::Matrix4f Tow;
+            for (int r = 0; r < 4; ++r)
+                for (int c = 0; c < 4; ++c) Tow(r, c) = T[4 * r + c];
+            pMO->SetObjectPoseSE3(Tow.inverse());            // Converter::toMatrix4f(SE3Tow).inverse(), :764-765
+        }
+        nBAdone()++;
+    }
+
+    static void LocalBundleAdjustment(KeyFrame* pKF, bool* pbStopFlag, Map* pMap) {
+        LocalJointBundleAdjustment(pKF, pbStopFlag, pMap, false);
+    }
+
+    // Optimizer::JointBundleAdjustment / GlobalJointBundleAdjustemnt, src/Optimizer_util.cc:36-307: every key-frame, point
+    // and object; one optimize(nIterations); Huber sqrt(5.99)/sqrt(7.815)/sqrt(0.1*1e3) only if bRobust; results go to the
+    // *GBA members when nLoopKF != 0.
+    static void GlobalJointBundleAdjustemnt(Map* pMap, int nIterations = 5, bool* pbStopFlag = nullptr,
+                                            const unsigned long nLoopKF = 0, const bool bRobust = true) {
+        using namespace qsp_shim;
+        std::vector<KeyFrame*> vpKFs = pMap->GetAllKeyFrames();
+        std::vector<MapPoint*> vpMP = pMap->GetAllMapPoints();
+        std::vector<MapObject*> vpMO = pMap->GetAllMapObjects();
+        Flat F;
+        for (KeyFrame* k : vpKFs)
+            if (!k->isBad()) F.add_kf(k, k->mnId == 0);
+        for (MapPoint* pMP : vpMP)
+            if (!pMP->isBad()) F.add_point(pMP);
+        for (MapObject* pMO : vpMO)
+            if (pMO && !pMO->isDynamic() && !pMO->isBad()) F.add_object(pMO);
+        qsp_ba_scene scene;
+        F.finish(&scene);
+        qsp_ba_problem* prob = nullptr;
+        if (qsp_ba_create(&scene, device(), &prob) != QSP_OK) return;
+        const volatile uint8_t* stop = reinterpret_cast<const volatile uint8_t*>(pbStopFlag);
+        const double dm = bRobust ? (double)(float)std::sqrt(5.99) : 0.0;            // thHuber2D, :80
+        const double ds = bRobust ? (double)(float)std::sqrt(7.815) : 0.0;           // thHuber3D, :81
+        const double dobj = bRobust ? (double)(float)std::sqrt(0.1f * 1e3f) : 0.0;   // :82-83
+        qsp_ba_set_levels(prob, nullptr, nullptr, nullptr);
+        if (qsp_ba_optimize(prob, nIterations, dm, ds, dobj, stop, nullptr) != QSP_OK) { qsp_ba_destroy(prob); return; }
+        std::vector<double> kf(F.kf_pose.size()), pt(F.pt_xyz.size() + 1), ob(F.obj_pose.size() + 1);
+        qsp_ba_get_state(prob, kf.data(), pt.data(), ob.data());
+        qsp_ba_destroy(prob);
+        for (size_t i = 0; i < F.kfs.size(); ++i) {                                   // :252-270
+            float T[16];
+            pose7_to_mat(&kf[7 * i], T);
+            cv::Mat M(4, 4, CV_32F);
+            for (int r = 0; r < 4; ++r)
+                for (int c = 0; c < 4; ++c) M.at<float>(r, c) = T[4 * r + c];
+            if (nLoopKF == 0) F.kfs[i]->SetPose(M);
+            else { F.kfs[i]->mTcwGBA = M.clone(); F.kfs[i]->mnBAGlobalForKF = nLoopKF; }
+        }
+        for (size_t i = 0; i < F.pts.size(); ++i) {                                   // :272-290
+            cv::Mat X(3, 1, CV_32F);
+            for (int r = 0; r < 3; ++r) X.at<float>(r) = (float)pt[3 * i + r];
+            if (nLoopKF == 0) { F.pts[i]->SetWorldPos(X); F.pts[i]->UpdateNormalAndDepth(); }
+            else { F.pts[i]->mPosGBA = X.clone(); F.pts[i]->mnBAGlobalForKF = nLoopKF; }
+        }
+        for (size_t i = 0; i < F.objs.size(); ++i) {                                  // :292-305
+            float T[16];
+            pose7_to_mat(&ob[7 * i], T);
+            Eigen::Matrix4f Tow;
+            for (int r = 0; r < 4; ++r)
+                for (int c = 0; c < 4; ++c) Tow(r, c) = T[4 * r + c];
+            if (nLoopKF == 0) F.objs[i]->SetObjectPoseSE3(Tow.inverse());
+            else { F.objs[i]->mTwoGBA = Tow.inverse(); F.objs[i]->mnBAGlobalForKF = nLoopKF; }
+        }
+    }
+};
+
+}  // namespace ORB_SLAM2
+#endif  // QSP_OPTIMIZER_SHIM_H

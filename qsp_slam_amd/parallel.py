@@ -1,0 +1,73 @@
+"""Multi-GPU layer of the hot path: one process per GPU, `torch.distributed` (backend "nccl" = RCCL on ROCm; "gloo" on
+CPU for tests).  PyTorch is plumbing here (process group + one all_gather), not the product.
+
+Path A shards naturally: the work unit is an object with all of its yaw-flip hypotheses (kept together so that the
+arg-min of src/LocalMapping_util.cc:748-752 is local).  There is NO collective inside the Gauss-Newton iterations; the
+per-object results (4x4 pose, 64 code, loss, is_good = 82 floats) are all-gathered once at the end.
+Path B: independent key-frame windows are replicas (no exchange)."""
+import numpy as np
+
+RESULT_WIDTH = 16 + 64 + 2
+
+
+def shard_objects(n_obj, rank, world):
+    """round-robin by object index: object o lives on rank o % world"""
+    return list(range(rank, n_obj, world))
+
+
+def owner_of(obj, world):
+    return obj % world
+
+
+def pack_results(results):
+    """list of reconstruct_object results (attr-dicts) -> (n, 82) float32 table"""
+    out = np.zeros((len(results), RESULT_WIDTH), np.float32)
+    for i, r in enumerate(results):
+        if r.is_good:
+            out[i, :16] = np.asarray(r.t_cam_obj, np.float32).reshape(-1)
+            out[i, 16:80] = np.asarray(r.code, np.float32)[:64]
+        out[i, 80] = r.loss
+        out[i, 81] = 1.0 if r.is_good else 0.0
+    return out
+
+
+def unpack_results(table):
+    from .reconstruct.utils import ForceKeyErrorDict
+    res = []
+    for row in table:
+        if row[81] > 0.5:
+            res.append(ForceKeyErrorDict(t_cam_obj=row[:16].reshape(4, 4).copy(), code=row[16:80].copy(), is_good=True,
+                                         loss=float(row[80])))
+        else:
+            res.append(ForceKeyErrorDict(t_cam_obj=None, code=None, is_good=False, loss=float(row[80])))
+    return res
+
+
+def gather_object_results(local_table, n_obj, rank, world, device=None):
+    """all_gather of the per-object result rows; returns the full (n_obj, 82) table in object order on every rank.
+    local_table: rows of shard_objects(n_obj, rank, world), in that order."""
+    import torch
+    import torch.distributed as dist
+    if world == 1:
+        return np.asarray(local_table, np.float32)
+    per = (n_obj + world - 1) // world                      # padded shard size
+    buf = torch.zeros(per, RESULT_WIDTH, dtype=torch.float32, device=device)
+    if len(local_table):
+        buf[: len(local_table)] = torch.from_numpy(np.ascontiguousarray(local_table, np.float32)).to(buf.device)
+    parts = [torch.zeros_like(buf) for _ in range(world)]
+    dist.all_gather(parts, buf)
+    full = np.zeros((n_obj, RESULT_WIDTH), np.float32)
+    for r in range(world):
+        idx = shard_objects(n_obj, r, world)
+        full[idx] = parts[r][: len(idx)].cpu().numpy()
+    return full
+
+
+def refine_objects_sharded(optimizer, objects, flip_sample_num, rank, world, device=None):
+    """Every rank refines its shard of `objects` (list of dicts as Optimizer.reconstruct_objects_batched takes) on its own
+    GPU and all ranks end with the complete, selected result list."""
+    mine = shard_objects(len(objects), rank, world)
+    local = optimizer.reconstruct_objects_batched([objects[i] for i in mine], flip_sample_num=flip_sample_num,
+                                                  select=True) if mine else []
+    table = gather_object_results(pack_results(local), len(objects), rank, world, device=device)
+    return unpack_results(table)

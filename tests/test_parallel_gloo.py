@@ -1,0 +1,78 @@
+"""CPU, world_size 2, gloo: the N > 1 host path (object sharding + the single all_gather of results).  The HIP library is
+replaced by a deterministic stand-in optimiser here because this container has no GPU; what is under test is the
+partition, the padding of uneven shards and the re-assembly in object order on every rank."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from qsp_slam_amd import parallel
+from qsp_slam_amd.reconstruct.utils import ForceKeyErrorDict
+
+
+class FakeOptimizer(object):
+    """stands in for reconstruct.optimizer.Optimizer: result is a pure function of the object's inputs"""
+
+    def reconstruct_objects_batched(self, objects, flip_sample_num=1, select=True):
+        out = []
+        for o in objects:
+            tag = float(o["tag"])
+            if int(tag) % 5 == 3:
+                out.append(ForceKeyErrorDict(t_cam_obj=None, code=None, is_good=False, loss=tag))
+            else:
+                out.append(ForceKeyErrorDict(t_cam_obj=np.full((4, 4), tag, np.float32),
+                                             code=np.arange(64, dtype=np.float32) + tag, is_good=True, loss=0.5 * tag))
+        return out
+
+
+def _worker(rank, world, port, n_obj, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    objs = [dict(tag=i) for i in range(n_obj)]
+    res = parallel.refine_objects_sharded(FakeOptimizer(), objs, 4, rank, world)
+    ok = len(res) == n_obj
+    for i, r in enumerate(res):
+        if i % 5 == 3:
+            ok &= (not r.is_good) and r.t_cam_obj is None and r.loss == float(i)
+        else:
+            ok &= r.is_good and float(r.t_cam_obj[2, 1]) == float(i) and float(r.code[7]) == 7.0 + i and r.loss == 0.5 * i
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("n_obj", [8, 7, 1])
+def test_sharded_refinement_gathers_every_object_on_every_rank(n_obj):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_obj, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(got) == [(0, True), (1, True)]
+
+
+def test_partition_is_a_partition():
+    for world in (1, 2, 4, 8):
+        for n in (0, 1, 7, 64, 256):
+            shards = [parallel.shard_objects(n, r, world) for r in range(world)]
+            flat = sorted(i for s in shards for i in s)
+            assert flat == list(range(n))
+            assert all(parallel.owner_of(i, world) == r for r, s in enumerate(shards) for i in s)
+            assert max(len(s) for s in shards) - min(len(s) for s in shards) <= 1
