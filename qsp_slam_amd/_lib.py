@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libqsp_hip.so")
+LIB_PATH = os.environ.get("QSP_HIP_LIB", os.path.join(_HERE, "libqsp_hip.so"))   # override: experiments only
 
 QSP_OK, QSP_ERR_INVALID, QSP_ERR_UNSUPPORTED, QSP_ERR_DEVICE, QSP_ERR_NO_DEVICE = 0, 1, 2, 3, 4
 

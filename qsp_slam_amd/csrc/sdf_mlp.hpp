@@ -30,6 +30,10 @@ namespace qsp {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+#ifndef QSP_EXP_VARIANT
+#define QSP_EXP_VARIANT 0   // timing experiments only (tools/exp_variants.sh): bit 0 = no weight loads in the k-loop,
+#endif                      // bit 1 = no LDS operand reads in the k-loop.  Non-zero variants compute garbage.
+
 constexpr int TILE_P = 64;      // points per tile
 constexpr int HID = 512;        // hidden width
 constexpr int CODE_LEN = 64;    // latent code length
@@ -124,10 +128,22 @@ __device__ __forceinline__ void gemm_2x2(const float* __restrict__ act, const fl
 #pragma unroll
         for (int d = 0; d < PF; ++d) {
             const f32x4 b0 = q0[d], b1 = q1[d];
+#if (QSP_EXP_VARIANT & 8)
+            q0[d] = w0[((kg + d + PF) & 15) * 64 + lane];   // timing experiment: 16 KiB window per stream (L2-resident)
+            q1[d] = w1[((kg + d + PF) & 15) * 64 + lane];
+#elif (QSP_EXP_VARIANT & 4)
+            q0[d] = w0[d * 64 + lane];           // timing experiment: same 1 KiB every time (L1-resident)
+            q1[d] = w1[d * 64 + lane];
+#elif !(QSP_EXP_VARIANT & 1)
             q0[d] = w0[(kg + d + PF) * 64 + lane];
             q1[d] = w1[(kg + d + PF) * 64 + lane];
+#endif
+#if !(QSP_EXP_VARIANT & 2)
             const f32x4 a0n = lds4(a_row0 + 8 * (kg + d + 1));
             const f32x4 a1n = lds4(a_row1 + 8 * (kg + d + 1));
+#else
+            const f32x4 a0n = a1, a1n = a0;
+#endif
             __builtin_amdgcn_sched_barrier(0);
             QSP_MFMA_STEP_2x2(a0, a1, b0, b1)
             __builtin_amdgcn_sched_barrier(0);
