@@ -191,27 +191,30 @@ __device__ inline void proj_jacobians(const double* pose, const double* p, const
                                       double* Jx /*Dx6*/) {
     double R[9];
     quat_to_R(pose + 3, R);
+    // one FP64 reciprocal instead of g2o's ~20 divisions (an FP64 divide is ~30 instructions on CDNA); the results
+    // differ from the reference's in the last bit only
     const double fx = K[0], fy = K[1], bf = K[4];
-    const double x = p[0], y = p[1], z = p[2], z2 = z * z;
+    const double x = p[0], y = p[1];
+    const double iz = 1.0 / p[2], iz2 = iz * iz;
     if (D == 2) {
-        const double t[6] = {fx, 0, -x / z * fx, 0, fy, -y / z * fy};
+        const double t[6] = {fx, 0, -x * iz * fx, 0, fy, -y * iz * fy};
         for (int i = 0; i < 2; ++i)
             for (int j = 0; j < 3; ++j)
-                Jp[3 * i + j] = -1. / z * (t[3 * i] * R[j] + t[3 * i + 1] * R[3 + j] + t[3 * i + 2] * R[6 + j]);
+                Jp[3 * i + j] = -iz * (t[3 * i] * R[j] + t[3 * i + 1] * R[3 + j] + t[3 * i + 2] * R[6 + j]);
     } else {
         for (int j = 0; j < 3; ++j) {
-            Jp[j] = -fx * R[j] / z + fx * x * R[6 + j] / z2;
-            Jp[3 + j] = -fy * R[3 + j] / z + fy * y * R[6 + j] / z2;
-            Jp[6 + j] = Jp[j] - bf * R[6 + j] / z2;
+            Jp[j] = -fx * R[j] * iz + fx * x * R[6 + j] * iz2;
+            Jp[3 + j] = -fy * R[3 + j] * iz + fy * y * R[6 + j] * iz2;
+            Jp[6 + j] = Jp[j] - bf * R[6 + j] * iz2;
         }
     }
-    Jx[0] = x * y / z2 * fx; Jx[1] = -(1 + (x * x / z2)) * fx; Jx[2] = y / z * fx;
-    Jx[3] = -1. / z * fx; Jx[4] = 0; Jx[5] = x / z2 * fx;
-    Jx[6] = (1 + y * y / z2) * fy; Jx[7] = -x * y / z2 * fy; Jx[8] = -x / z * fy;
-    Jx[9] = 0; Jx[10] = -1. / z * fy; Jx[11] = y / z2 * fy;
+    Jx[0] = x * y * iz2 * fx; Jx[1] = -(1 + (x * x * iz2)) * fx; Jx[2] = y * iz * fx;
+    Jx[3] = -iz * fx; Jx[4] = 0; Jx[5] = x * iz2 * fx;
+    Jx[6] = (1 + y * y * iz2) * fy; Jx[7] = -x * y * iz2 * fy; Jx[8] = -x * iz * fy;
+    Jx[9] = 0; Jx[10] = -iz * fy; Jx[11] = y * iz2 * fy;
     if (D == 3) {
-        Jx[12] = Jx[0] - bf * y / z2; Jx[13] = Jx[1] + bf * x / z2; Jx[14] = Jx[2];
-        Jx[15] = Jx[3]; Jx[16] = 0; Jx[17] = Jx[5] - bf / z2;
+        Jx[12] = Jx[0] - bf * y * iz2; Jx[13] = Jx[1] + bf * x * iz2; Jx[14] = Jx[2];
+        Jx[15] = Jx[3]; Jx[16] = 0; Jx[17] = Jx[5] - bf * iz2;
     }
 }
 // EdgeSE3LieAlgebra, include/ObjectPoseGraph.h:69-88
@@ -273,6 +276,12 @@ struct Dev {
     double* edge_chi2;
     int32_t *pt_off;             // CSR landmark -> [first,last) in edge[]
     int32_t *kf_off, *kf_edge;   // CSR key-frame -> edge indices
+    int32_t *chunk_pt;           // [n_chunk + 1] landmark ranges whose edges fit one 256-thread workgroup
+    int32_t n_chunk;
+    int32_t *ksp_kf, *ksp_begin, *ksp_end;   // key-frame pass splits: (kf, [begin,end) in kf_edge)
+    int32_t *ksp_first;          // [n_kf + 1] first split of each key-frame
+    int32_t n_ksplit;
+    double* kpart;               // [n_ksplit][27] partial J^T W J / J^T W e
     // object edges
     int32_t *oe_kf, *oe_obj;
     double* oe_meas;
@@ -363,10 +372,12 @@ __global__ void k_finish_sum(Dev d, int n, int slot) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// k_lin_points: one thread per landmark
+// k_lin_points: edge-parallel.  A workgroup owns a chunk of consecutive landmarks whose edges (contiguous, landmark-
+// major) number at most 256: thread = edge.  Each thread writes its 6x3 Hpl block and parks its J_p^T W J_p (6 unique)
+// and J_p^T W e (3) in LDS; the first `n landmarks` threads then sum their landmark's segment in edge order.
 // ---------------------------------------------------------------------------------------------------------------
 template <int D>
-__device__ inline void lin_point_edge(const Dev& d, const Edge& E, int ei, double delta, double* Hll, double* bl) {
+__device__ inline void lin_point_edge(const Dev& d, const Edge& E, int ei, double delta, double* out9) {
     double e[3], p[3], Jp[9], Jx[18], r0, r1;
     const double* pose = d.kf_pose + 7 * E.kf;
     proj_error<D>(pose, d.pt_xyz + 3 * E.pt, d.kf_K + 5 * E.kf, E.obs, e, p);
@@ -376,15 +387,17 @@ __device__ inline void lin_point_edge(const Dev& d, const Edge& E, int ei, doubl
     c *= E.info;
     huber(c, delta, r0, r1);
     const double w = r1 * E.info;
+    int t = 0;
+    for (int i = 0; i < 3; ++i)
+        for (int j = i; j < 3; ++j) {
+            double s = 0;
+            for (int q = 0; q < D; ++q) s += Jp[3 * q + i] * Jp[3 * q + j];
+            out9[t++] = w * s;
+        }
     for (int i = 0; i < 3; ++i) {
         double sb = 0;
         for (int q = 0; q < D; ++q) sb += Jp[3 * q + i] * (-E.info * e[q]) * r1;
-        bl[i] += sb;
-        for (int j = 0; j < 3; ++j) {
-            double s = 0;
-            for (int q = 0; q < D; ++q) s += Jp[3 * q + i] * Jp[3 * q + j];
-            Hll[3 * i + j] += w * s;
-        }
+        out9[6 + i] = sb;
     }
     double* B = d.Hpl + 18 * (size_t)ei;
     const bool free_pose = d.kf_h[E.kf] >= 0;
@@ -397,24 +410,39 @@ __device__ inline void lin_point_edge(const Dev& d, const Edge& E, int ei, doubl
 }
 
 __global__ __launch_bounds__(256) void k_lin_points(Dev d, Par par) {
-    const int pt = blockIdx.x * 256 + threadIdx.x;
-    if (pt >= d.n_pt) return;
-    double Hll[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, bl[3] = {0, 0, 0};
-    if (d.pt_h[pt] >= 0) {
-        for (int ei = d.pt_off[pt]; ei < d.pt_off[pt + 1]; ++ei) {
-            if (d.edge_level[ei]) continue;
-            const Edge E = d.edge[ei];
-            if (E.stereo) lin_point_edge<3>(d, E, ei, par.delta_stereo, Hll, bl);
-            else lin_point_edge<2>(d, E, ei, par.delta_mono, Hll, bl);
-        }
+    __shared__ double sh[256][9 + 1];
+    const int p0 = d.chunk_pt[blockIdx.x], p1 = d.chunk_pt[blockIdx.x + 1];
+    const int e0 = d.pt_off[p0], e1 = d.pt_off[p1];
+    const int ei = e0 + threadIdx.x;
+    double v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (ei < e1 && !d.edge_level[ei]) {
+        const Edge E = d.edge[ei];
+        if (E.stereo) lin_point_edge<3>(d, E, ei, par.delta_stereo, v);
+        else lin_point_edge<2>(d, E, ei, par.delta_mono, v);
     }
-    for (int i = 0; i < 9; ++i) d.Hll[9 * (size_t)pt + i] = Hll[i];
-    for (int i = 0; i < 3; ++i) d.bl[3 * (size_t)pt + i] = bl[i];
+    for (int i = 0; i < 9; ++i) sh[threadIdx.x][i] = v[i];
+    __syncthreads();
+    const int pt = p0 + threadIdx.x;
+    if (pt < p1) {
+        double a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int q = d.pt_off[pt] - e0; q < d.pt_off[pt + 1] - e0; ++q)
+            for (int i = 0; i < 9; ++i) a[i] += sh[q][i];
+        double* H = d.Hll + 9 * (size_t)pt;
+        H[0] = a[0]; H[1] = a[1]; H[2] = a[2];
+        H[3] = a[1]; H[4] = a[3]; H[5] = a[4];
+        H[6] = a[2]; H[7] = a[4]; H[8] = a[5];
+        double* bl = d.bl + 3 * (size_t)pt;
+        bl[0] = a[6]; bl[1] = a[7]; bl[2] = a[8];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// k_lin_poses: one 256-thread workgroup per key-frame; upper triangle (21) + rhs (6) reduced in a fixed tree
+// k_lin_poses: one 256-thread workgroup per (key-frame, split of <= KSPLIT edges); upper triangle (21) + rhs (6)
+// reduced in a fixed tree into kpart[split]; k_lin_poses_finish adds a key-frame's splits (and its camera-object
+// edges) in order.
 // ---------------------------------------------------------------------------------------------------------------
+constexpr int KSPLIT = 2048;
+
 template <int D>
 __device__ inline void lin_pose_edge(const Dev& d, const Edge& E, double delta, double* A /*21*/, double* b /*6*/) {
     double e[3], p[3], Jp[9], Jx[18], r0, r1;
@@ -440,53 +468,77 @@ __device__ inline void lin_pose_edge(const Dev& d, const Edge& E, double delta, 
 }
 
 __global__ __launch_bounds__(256) void k_lin_poses(Dev d, Par par) {
-    const int kf = blockIdx.x;
-    const int h = d.kf_h[kf];
-    if (h < 0) return;
-    __shared__ double sh[4];
-    double A[21], b[6];
-    for (int i = 0; i < 21; ++i) A[i] = 0;
-    for (int i = 0; i < 6; ++i) b[i] = 0;
-    for (int q = d.kf_off[kf] + threadIdx.x; q < d.kf_off[kf + 1]; q += 256) {
+    const int sp = blockIdx.x;
+    const int kf = d.ksp_kf[sp];
+    if (d.kf_h[kf] < 0) return;
+    __shared__ double sh[4][27];
+    double A[27];
+    for (int i = 0; i < 27; ++i) A[i] = 0;
+    for (int q = d.ksp_begin[sp] + threadIdx.x; q < d.ksp_end[sp]; q += 256) {
         const int ei = d.kf_edge[q];
         if (d.edge_level[ei]) continue;
         const Edge E = d.edge[ei];
-        if (E.stereo) lin_pose_edge<3>(d, E, par.delta_stereo, A, b);
-        else lin_pose_edge<2>(d, E, par.delta_mono, A, b);
+        if (E.stereo) lin_pose_edge<3>(d, E, par.delta_stereo, A, A + 21);
+        else lin_pose_edge<2>(d, E, par.delta_mono, A, A + 21);
     }
-    // camera-object edges of this key-frame: vertex 0, Jacobian Ji
-    for (int q = d.kfo_off[kf] + threadIdx.x; q < d.kfo_off[kf + 1]; q += 256) {
-        const int k = d.kfo_edge[q];
-        if (d.oe_level[k]) continue;
-        double e[6], Zi[7], Ji[36], Jj[36], r0, r1;
-        obj_error(d.kf_pose + 7 * kf, d.obj_pose + 7 * d.oe_obj[k], d.oe_meas + 7 * k, e, Zi);
-        obj_jacobians(e, Zi, Ji, Jj);
-        double c = 0;
-        for (int i = 0; i < 6; ++i) c += e[i] * e[i];
-        c *= d.oe_info;
-        huber(c, par.delta_obj, r0, r1);
-        const double w = r1 * d.oe_info;
-        int t = 0;
-        for (int i = 0; i < 6; ++i) {
-            double sb = 0;
-            for (int qd = 0; qd < 6; ++qd) sb += Ji[6 * qd + i] * (-d.oe_info * e[qd]) * r1;
-            b[i] += sb;
-            for (int j = i; j < 6; ++j) {
-                double s = 0;
-                for (int qd = 0; qd < 6; ++qd) s += Ji[6 * qd + i] * Ji[6 * qd + j];
-                A[t++] += w * s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 27; ++i) {
+        double v = A[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+        if (lane == 0) sh[wave][i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 27)
+        d.kpart[27 * (size_t)sp + threadIdx.x] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+}
+
+// one 64-thread workgroup per key-frame: ordered sum of its splits + its camera-object edges (vertex 0, Jacobian Ji)
+__global__ __launch_bounds__(64) void k_lin_poses_finish(Dev d, Par par) {
+    const int kf = blockIdx.x;
+    const int h = d.kf_h[kf];
+    if (h < 0) return;
+    __shared__ double acc[27];
+    const int t = threadIdx.x;
+    if (t < 27) {
+        double a = 0;
+        for (int sp = d.ksp_first[kf]; sp < d.ksp_first[kf + 1]; ++sp) a += d.kpart[27 * (size_t)sp + t];
+        acc[t] = a;
+    }
+    __syncthreads();
+    if (t == 0) {
+        double A[21], b[6];
+        for (int i = 0; i < 21; ++i) A[i] = acc[i];
+        for (int i = 0; i < 6; ++i) b[i] = acc[21 + i];
+        for (int q = d.kfo_off[kf]; q < d.kfo_off[kf + 1]; ++q) {
+            const int k = d.kfo_edge[q];
+            if (d.oe_level[k]) continue;
+            double e[6], Zi[7], Ji[36], Jj[36], r0, r1;
+            obj_error(d.kf_pose + 7 * kf, d.obj_pose + 7 * d.oe_obj[k], d.oe_meas + 7 * k, e, Zi);
+            obj_jacobians(e, Zi, Ji, Jj);
+            double c = 0;
+            for (int i = 0; i < 6; ++i) c += e[i] * e[i];
+            c *= d.oe_info;
+            huber(c, par.delta_obj, r0, r1);
+            const double w = r1 * d.oe_info;
+            int tt = 0;
+            for (int i = 0; i < 6; ++i) {
+                double sb = 0;
+                for (int qd = 0; qd < 6; ++qd) sb += Ji[6 * qd + i] * (-d.oe_info * e[qd]) * r1;
+                b[i] += sb;
+                for (int j = i; j < 6; ++j) {
+                    double s = 0;
+                    for (int qd = 0; qd < 6; ++qd) s += Ji[6 * qd + i] * Ji[6 * qd + j];
+                    A[tt++] += w * s;
+                }
             }
         }
-    }
-    double red[27];
-    for (int i = 0; i < 21; ++i) red[i] = block_sum_256(A[i], sh);
-    for (int i = 0; i < 6; ++i) red[21 + i] = block_sum_256(b[i], sh);
-    if (threadIdx.x == 0) {
         double* Hd = d.Hdiag + 36 * (size_t)h;
-        int t = 0;
+        int tt = 0;
         for (int i = 0; i < 6; ++i)
-            for (int j = i; j < 6; ++j) { Hd[6 * i + j] = red[t]; Hd[6 * j + i] = red[t]; ++t; }
-        for (int i = 0; i < 6; ++i) d.bp[6 * h + i] = red[21 + i];
+            for (int j = i; j < 6; ++j) { Hd[6 * i + j] = A[tt]; Hd[6 * j + i] = A[tt]; ++tt; }
+        for (int i = 0; i < 6; ++i) d.bp[6 * h + i] = b[i];
     }
 }
 
@@ -578,38 +630,49 @@ __device__ inline bool inv3(const double* m, double* o) {
     return true;
 }
 
-// one thread per landmark: D^-1, then every (i1 <= i2) pair of its free observing poses   (block_solver.hpp:381-432)
-__global__ __launch_bounds__(128) void k_schur_points(Dev d, Par par) {
-    const int pt = blockIdx.x * 128 + threadIdx.x;
-    if (pt >= d.n_pt || d.pt_h[pt] < 0) return;
-    double Dm[9], Di[9];
-    for (int i = 0; i < 9; ++i) Dm[i] = d.Hll[9 * (size_t)pt + i];
-    Dm[0] += par.lambda; Dm[4] += par.lambda; Dm[8] += par.lambda;
-    inv3(Dm, Di);
-    for (int i = 0; i < 9; ++i) d.Dinv[9 * (size_t)pt + i] = Di[i];
-    const double* bl = d.bl + 3 * (size_t)pt;
-    double db[3];
-    for (int i = 0; i < 3; ++i) db[i] = Di[3 * i] * bl[0] + Di[3 * i + 1] * bl[1] + Di[3 * i + 2] * bl[2];
+// one 64-lane wave per landmark: D^-1 (lane 0), then every (i1 <= i2) pair of its free observing poses with lane q < 36
+// owning entry (q/6, q%6) of the 6x6 update and lanes 36..41 the right-hand side   (block_solver.hpp:381-432)
+__global__ __launch_bounds__(256) void k_schur_points(Dev d, Par par) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int pt = blockIdx.x * 4 + wave;
+    const bool live = pt < d.n_pt && d.pt_h[pt] >= 0;
+    __shared__ double Dsh[4][12];
+    if (live && lane == 0) {
+        double Dm[9], Di[9];
+        for (int i = 0; i < 9; ++i) Dm[i] = d.Hll[9 * (size_t)pt + i];
+        Dm[0] += par.lambda; Dm[4] += par.lambda; Dm[8] += par.lambda;
+        inv3(Dm, Di);
+        const double* bl = d.bl + 3 * (size_t)pt;
+        for (int i = 0; i < 9; ++i) { d.Dinv[9 * (size_t)pt + i] = Di[i]; Dsh[wave][i] = Di[i]; }
+        for (int i = 0; i < 3; ++i) Dsh[wave][9 + i] = Di[3 * i] * bl[0] + Di[3 * i + 1] * bl[1] + Di[3 * i + 2] * bl[2];
+    }
+    __syncthreads();
+    if (!live) return;
+    const double* Di = Dsh[wave];
+    const double* db = Dsh[wave] + 9;
     const int e0 = d.pt_off[pt], e1 = d.pt_off[pt + 1];
+    const int i = lane / 6, j = lane % 6;      // entry of the 6x6 block (lanes < 36)
     for (int a = e0; a < e1; ++a) {
         if (d.edge_level[a]) continue;
         const int ha = d.kf_h[d.edge[a].kf];
         if (ha < 0) continue;
         const double* Ba = d.Hpl + 18 * (size_t)a;
-        double BD[18];
-        for (int i = 0; i < 6; ++i)
-            for (int j = 0; j < 3; ++j) BD[3 * i + j] = Ba[3 * i] * Di[j] + Ba[3 * i + 1] * Di[3 + j] + Ba[3 * i + 2] * Di[6 + j];
-        for (int i = 0; i < 6; ++i)
-            atomicAdd(&d.bs[6 * ha + i], -(Ba[3 * i] * db[0] + Ba[3 * i + 1] * db[1] + Ba[3 * i + 2] * db[2]));
-        for (int b = e0; b < e1; ++b) {
-            if (d.edge_level[b]) continue;
-            const int hb = d.kf_h[d.edge[b].kf];
-            if (hb < ha || (hb == ha && b != a)) continue;
-            const double* Bb = d.Hpl + 18 * (size_t)b;
-            for (int i = 0; i < 6; ++i)
-                for (int j = 0; j < 6; ++j)
-                    atomicAdd(&d.Hs[(size_t)(6 * ha + i) * par.dimp + 6 * hb + j],
-                              -(BD[3 * i] * Bb[3 * j] + BD[3 * i + 1] * Bb[3 * j + 1] + BD[3 * i + 2] * Bb[3 * j + 2]));
+        if (lane >= 36 && lane < 42) {
+            const int r = lane - 36;
+            atomicAdd(&d.bs[6 * ha + r], -(Ba[3 * r] * db[0] + Ba[3 * r + 1] * db[1] + Ba[3 * r + 2] * db[2]));
+        }
+        if (lane < 36) {
+            const double bd0 = Ba[3 * i] * Di[0] + Ba[3 * i + 1] * Di[3] + Ba[3 * i + 2] * Di[6];   // row i of B_a D^-1
+            const double bd1 = Ba[3 * i] * Di[1] + Ba[3 * i + 1] * Di[4] + Ba[3 * i + 2] * Di[7];
+            const double bd2 = Ba[3 * i] * Di[2] + Ba[3 * i + 1] * Di[5] + Ba[3 * i + 2] * Di[8];
+            for (int b = e0; b < e1; ++b) {
+                if (d.edge_level[b]) continue;
+                const int hb = d.kf_h[d.edge[b].kf];
+                if (hb < ha || (hb == ha && b != a)) continue;
+                const double* Bb = d.Hpl + 18 * (size_t)b;
+                atomicAdd(&d.Hs[(size_t)(6 * ha + i) * par.dimp + 6 * hb + j],
+                          -(bd0 * Bb[3 * j] + bd1 * Bb[3 * j + 1] + bd2 * Bb[3 * j + 2]));
+            }
         }
     }
 }
@@ -617,32 +680,34 @@ __global__ __launch_bounds__(128) void k_schur_points(Dev d, Par par) {
 // ---------------------------------------------------------------------------------------------------------------
 // blocked Cholesky A = U^T U on the upper triangle of the dimp x dimp matrix (dimp multiple of NB), right-looking
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_chol_diag(double* A, int ld, int k, double* scal) {
-    __shared__ double T[NB][NB + 1];
-    const int t = threadIdx.x;
-    for (int e = t; e < NB * NB; e += 256) T[e / NB][e % NB] = A[(size_t)(k * NB + e / NB) * ld + k * NB + e % NB];
-    __syncthreads();
+// diagonal block: one wave, lane c keeps column c of the 64x64 block in REGISTERS (fully unrolled, static indices);
+// row j of U is broadcast with wave shuffles.  No LDS, no barriers.
+__global__ __launch_bounds__(64) void k_chol_diag(double* A, int ld, int k, double* scal) {
+    const int c = threadIdx.x;
+    double col[NB];
+#pragma unroll
+    for (int r = 0; r < NB; ++r) col[r] = A[(size_t)(k * NB + r) * ld + k * NB + c];
+    bool any_bad = false;
+#pragma unroll
     for (int j = 0; j < NB; ++j) {
-        if (t == 0) {
-            const double dd = T[j][j];
-            if (!(dd > 0) || !isfinite(dd)) { scal[3] = 1.0; T[j][j] = 1.0; }
-            else T[j][j] = sqrt(dd);
+        double dd = __shfl(col[j], j, 64);          // A[j][j] lives in lane j, register j
+        const bool bad = !(dd > 0) || !isfinite(dd);
+        any_bad |= bad;
+        if (bad) dd = 1.0;
+        const double piv = sqrt(dd);
+        double ujc = col[j] / piv;                   // U[j][c] for c > j
+        if (c == j) ujc = piv;
+        if (c >= j) col[j] = ujc;
+        if (c <= j) ujc = 0.0;                       // only columns right of the diagonal take part in the update
+#pragma unroll
+        for (int r = j + 1; r < NB; ++r) {
+            const double ujr = __shfl(ujc, r, 64);   // U[j][r]
+            if (c >= r) col[r] -= ujr * ujc;
         }
-        __syncthreads();
-        const double piv = T[j][j];
-        if (t > j && t < NB) T[j][t] /= piv;          // row j of U, right of the diagonal
-        __syncthreads();
-        // trailing update of the upper triangle: T[r][c] -= U[j][r] * U[j][c] for j < r <= c
-        for (int e = t; e < NB * NB; e += 256) {
-            const int r = e / NB, c = e % NB;
-            if (r > j && c >= r) T[r][c] -= T[j][r] * T[j][c];
-        }
-        __syncthreads();
     }
-    for (int e = t; e < NB * NB; e += 256) {
-        const int r = e / NB, c = e % NB;
-        A[(size_t)(k * NB + r) * ld + k * NB + c] = (c >= r) ? T[r][c] : 0.0;
-    }
+    if (any_bad && c == 0) scal[3] = 1.0;
+#pragma unroll
+    for (int r = 0; r < NB; ++r) A[(size_t)(k * NB + r) * ld + k * NB + c] = (c >= r) ? col[r] : 0.0;
 }
 
 // row-panel: A_kj <- U_kk^-T A_kj for block columns j > k (one workgroup per j)
@@ -695,22 +760,25 @@ __global__ __launch_bounds__(256) void k_chol_update(double* A, int ld, int k) {
         for (int b = 0; b < 4; ++b) A[(size_t)(i * NB + r0 + a) * ld + j * NB + c0 + b] -= acc[a][b];
 }
 
-// single-workgroup triangular solves with U (upper, ld = n): y = U^-T b, then x = U^-1 y, in place in x
+// single-workgroup triangular solves with U (upper, ld = n): y = U^-T b, then x = U^-1 y, in place in x.
+// The 64x64 diagonal block of each step is staged in LDS so that the 64 serial steps pay LDS, not L2, latency.
 __global__ __launch_bounds__(256) void k_trsv(const double* __restrict__ U, int n, const double* __restrict__ b,
                                               double* __restrict__ x) {
     __shared__ double xs[NB];
+    __shared__ double Dg[NB][NB + 1];
     const int t = threadIdx.x;
     for (int i = t; i < n; i += 256) x[i] = b[i];
     __syncthreads();
     const int nb = n / NB;
-    // forward: U^T y = b.  For block k: solve the NB x NB lower system, then x[c] -= sum_r U[kNB + r][c] * y[r], c beyond
-    for (int k = 0; k < nb; ++k) {
-        if (t < 64) {   // one wave; sequential over rows, lanes own entries
+    for (int k = 0; k < nb; ++k) {      // forward: U^T y = b
+        for (int e = t; e < NB * NB; e += 256) Dg[e / NB][e % NB] = U[(size_t)(k * NB + e / NB) * n + k * NB + e % NB];
+        __syncthreads();
+        if (t < 64) {
             double v = x[k * NB + t];
             for (int r = 0; r < NB; ++r) {
-                const double yr = __shfl(v, r, 64) / U[(size_t)(k * NB + r) * n + k * NB + r];
+                const double yr = __shfl(v, r, 64) / Dg[r][r];
                 if (t == r) v = yr;
-                if (t > r) v -= U[(size_t)(k * NB + r) * n + k * NB + t] * yr;
+                if (t > r) v -= Dg[r][t] * yr;
             }
             xs[t] = v;
             x[k * NB + t] = v;
@@ -723,10 +791,10 @@ __global__ __launch_bounds__(256) void k_trsv(const double* __restrict__ U, int 
         }
         __syncthreads();
     }
-    // backward: U x = y.  For block k (last to first): x_k = U_kk^-1 (y_k - sum_{c beyond} U[kNB + r][c] x[c])
-    for (int k = nb - 1; k >= 0; --k) {
+    for (int k = nb - 1; k >= 0; --k) {   // backward: U x = y
         const int wave = t >> 6, lane = t & 63;
-        for (int r = wave; r < NB; r += 4) {            // wave per row, lanes stride over the columns
+        for (int e = t; e < NB * NB; e += 256) Dg[e / NB][e % NB] = U[(size_t)(k * NB + e / NB) * n + k * NB + e % NB];
+        for (int r = wave; r < NB; r += 4) {            // wave per row, lanes stride over the columns beyond the block
             double s = 0;
             for (int c = (k + 1) * NB + lane; c < n; c += 64) s += U[(size_t)(k * NB + r) * n + c] * x[c];
             for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
@@ -736,9 +804,9 @@ __global__ __launch_bounds__(256) void k_trsv(const double* __restrict__ U, int 
         if (t < 64) {
             double v = xs[t];
             for (int r = NB - 1; r >= 0; --r) {
-                const double xr = __shfl(v, r, 64) / U[(size_t)(k * NB + r) * n + k * NB + r];
+                const double xr = __shfl(v, r, 64) / Dg[r][r];
                 if (t == r) v = xr;
-                if (t < r) v -= U[(size_t)(k * NB + t) * n + k * NB + r] * xr;
+                if (t < r) v -= Dg[t][r] * xr;
             }
             x[k * NB + t] = v;
         }
@@ -752,9 +820,9 @@ __global__ __launch_bounds__(256) void k_trsv(const double* __restrict__ U, int 
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_update_points(Dev d, Par par) {
     __shared__ double sh[4];
-    const int pt = blockIdx.x * 256 + threadIdx.x;
     double sc = 0;
-    if (pt < d.n_pt && d.pt_h[pt] >= 0) {
+    for (int pt = blockIdx.x * 256 + threadIdx.x; pt < d.n_pt; pt += gridDim.x * 256) {
+        if (d.pt_h[pt] < 0) continue;
         double c[3] = {d.bl[3 * (size_t)pt], d.bl[3 * (size_t)pt + 1], d.bl[3 * (size_t)pt + 2]};
         for (int a = d.pt_off[pt]; a < d.pt_off[pt + 1]; ++a) {
             if (d.edge_level[a]) continue;
@@ -915,6 +983,35 @@ extern "C" int qsp_ba_create(const qsp_ba_scene* s, int device, qsp_ba_problem**
     p->oe_obj_h.assign(s->objedge_obj, s->objedge_obj + s->n_objedge);
     csr_build(d.n_kf, p->oe_kf_h, kfo_off, kfo_edge);
     csr_build(d.n_obj, p->oe_obj_h, obo_off, obo_edge);
+    // landmark chunks for k_lin_points (<= 256 edges and <= 256 landmarks each) and key-frame splits for k_lin_poses
+    std::vector<int32_t> chunk_pt(1, 0);
+    {
+        int begin = 0;
+        for (int pt = 0; pt < d.n_pt; ++pt) {
+            if (p->pt_off_h[pt + 1] - p->pt_off_h[pt] > 256) {
+                delete p;
+                return qsp_fail(QSP_ERR_UNSUPPORTED, "qsp_ba_create: a map point with more than 256 observations");
+            }
+            if (p->pt_off_h[pt + 1] - p->pt_off_h[begin] > 256 || pt - begin >= 256) {
+                chunk_pt.push_back(pt);
+                begin = pt;
+            }
+        }
+        chunk_pt.push_back(d.n_pt);
+        if (d.n_pt == 0) chunk_pt.assign(2, 0);
+    }
+    d.n_chunk = (d.n_pt == 0) ? 0 : (int)chunk_pt.size() - 1;
+    std::vector<int32_t> ksp_kf, ksp_begin, ksp_end, ksp_first(d.n_kf + 1, 0);
+    for (int k = 0; k < d.n_kf; ++k) {
+        ksp_first[k] = (int)ksp_kf.size();
+        for (int b0 = kf_off[k]; b0 < kf_off[k + 1]; b0 += KSPLIT) {
+            ksp_kf.push_back(k);
+            ksp_begin.push_back(b0);
+            ksp_end.push_back(std::min(b0 + KSPLIT, kf_off[k + 1]));
+        }
+    }
+    ksp_first[d.n_kf] = (int)ksp_kf.size();
+    d.n_ksplit = (int)ksp_kf.size();
     p->kf_fixed_h.assign(s->kf_fixed, s->kf_fixed + s->n_kf);
     p->kf_id_h.assign(s->kf_id, s->kf_id + s->n_kf);
     p->pt_id_h.assign(s->pt_id, s->pt_id + s->n_pt);
@@ -935,6 +1032,12 @@ extern "C" int qsp_ba_create(const qsp_ba_scene* s, int device, qsp_ba_problem**
     UP(pt_off, p->pt_off_h.data(), d.n_pt + 1);
     UP(kf_off, kf_off.data(), d.n_kf + 1);
     UP(kf_edge, kf_edge.data(), d.n_edge);
+    UP(chunk_pt, chunk_pt.data(), chunk_pt.size());
+    UP(ksp_kf, ksp_kf.data(), ksp_kf.size());
+    UP(ksp_begin, ksp_begin.data(), ksp_begin.size());
+    UP(ksp_end, ksp_end.data(), ksp_end.size());
+    UP(ksp_first, ksp_first.data(), ksp_first.size());
+    AL(kpart, 27 * (size_t)std::max(d.n_ksplit, 1));
     UP(oe_kf, s->objedge_kf, d.n_oe);
     UP(oe_obj, s->objedge_obj, d.n_oe);
     UP(oe_meas, s->objedge_meas, 7 * d.n_oe);
@@ -1072,8 +1175,7 @@ extern "C" int qsp_ba_optimize(qsp_ba_problem* p, int32_t n_iter, double delta_m
         hipEventCreate(&ev0); hipEventCreate(&ev1); hipEventCreate(&evA); hipEventCreate(&evB);
         hipEventRecord(ev0, s);
     }
-    const int gp = std::max(1, (d.n_pt + 255) / 256);
-    if (gp > p->n_partial) return qsp_fail(QSP_ERR_INVALID, "qsp_ba_optimize: too many landmarks for the partial buffer");
+    const int gp = std::max(1, std::min(p->n_partial, (d.n_pt + 255) / 256));
     double lambda = 0, ni = 2;
     int nBad = 0, done = 0, result = 0;
     double sc[4];
@@ -1085,8 +1187,9 @@ extern "C" int qsp_ba_optimize(qsp_ba_problem* p, int32_t n_iter, double delta_m
         if (p->profiling) hipEventRecord(evA, s);
         QSP_HIP(hipMemsetAsync(d.Hdiag, 0, sizeof(double) * 36 * (size_t)std::max(p->n_pose, 1), s));
         QSP_HIP(hipMemsetAsync(d.bp, 0, sizeof(double) * std::max(p->dimp, 1), s));
-        hipLaunchKernelGGL(k_lin_points, dim3(gp), dim3(256), 0, s, d, par);
-        hipLaunchKernelGGL(k_lin_poses, dim3(d.n_kf), dim3(256), 0, s, d, par);
+        if (d.n_chunk) hipLaunchKernelGGL(k_lin_points, dim3(d.n_chunk), dim3(256), 0, s, d, par);
+        if (d.n_ksplit) hipLaunchKernelGGL(k_lin_poses, dim3(d.n_ksplit), dim3(256), 0, s, d, par);
+        hipLaunchKernelGGL(k_lin_poses_finish, dim3(d.n_kf), dim3(64), 0, s, d, par);
         if (d.n_obj) hipLaunchKernelGGL(k_lin_objects, dim3((d.n_obj + 63) / 64), dim3(64), 0, s, d, par);
         if (p->profiling) hipEventRecord(evB, s);
         if (it == 0) hipLaunchKernelGGL(k_maxdiag, dim3(1), dim3(256), 0, s, d, par);
@@ -1115,10 +1218,10 @@ extern "C" int qsp_ba_optimize(qsp_ba_problem* p, int32_t n_iter, double delta_m
                 QSP_HIP(hipMemsetAsync(d.Hs, 0, sizeof(double) * (size_t)p->dimp * p->dimp, s));
                 const int nprep = p->n_pose * 36 + d.n_oe * 36 + (p->dimp - p->dim);
                 hipLaunchKernelGGL(k_schur_prepare, dim3((std::max(nprep, p->dimp) + 255) / 256), dim3(256), 0, s, d, par);
-                if (d.n_pt) hipLaunchKernelGGL(k_schur_points, dim3((d.n_pt + 127) / 128), dim3(128), 0, s, d, par);
+                if (d.n_pt) hipLaunchKernelGGL(k_schur_points, dim3((d.n_pt + 3) / 4), dim3(256), 0, s, d, par);
                 const int nb = p->dimp / NB;
                 for (int k = 0; k < nb; ++k) {
-                    hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(256), 0, s, d.Hs, p->dimp, k, d.scal);
+                    hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(64), 0, s, d.Hs, p->dimp, k, d.scal);
                     if (k + 1 < nb) {
                         hipLaunchKernelGGL(k_chol_panel, dim3(nb - k - 1), dim3(256), 0, s, d.Hs, p->dimp, k);
                         hipLaunchKernelGGL(k_chol_update, dim3(nb - k - 1, nb - k - 1), dim3(256), 0, s, d.Hs, p->dimp, k);
@@ -1126,7 +1229,7 @@ extern "C" int qsp_ba_optimize(qsp_ba_problem* p, int32_t n_iter, double delta_m
                 }
                 hipLaunchKernelGGL(k_trsv, dim3(1), dim3(256), 0, s, d.Hs, p->dimp, d.bs, d.xp);
             } else if (d.n_pt) {
-                hipLaunchKernelGGL(k_schur_points, dim3((d.n_pt + 127) / 128), dim3(128), 0, s, d, par);
+                hipLaunchKernelGGL(k_schur_points, dim3((d.n_pt + 3) / 4), dim3(256), 0, s, d, par);
             }
             // update (oplus) + rho denominator
             hipLaunchKernelGGL(k_update_points, dim3(gp), dim3(256), 0, s, d, par);

@@ -71,7 +71,8 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
-// row / column of accumulator register i of a 32x32 tile for this lane (C/D map of v_mfma_f32_32x32x2_f32)
+// D-row of accumulator register i of a 32x32 tile for this lane (C/D map of v_mfma_f32_32x32x2_f32); the D-column is
+// lane & 31.  In the MLP GEMMs D-rows are units and D-columns points; in the J~^T J~ tile both are Jacobian columns.
 __device__ __forceinline__ int acc_row(int i, int lane) { return (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5); }
 
 // acc[r][c] += act[32r.., 0..8*KG) * Wpacked, for this wave's two column blocks.
@@ -83,23 +84,27 @@ typedef const __attribute__((address_space(1))) f32x4* gptr4;
 
 __device__ __forceinline__ f32x4 lds4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
+// The WEIGHT fragment is the MFMA A operand and the ACTIVATION fragment the B operand: D[i = unit][j = point].  A lane
+// then holds, for ONE point (column j = lane & 31), units (reg&3) + 8(reg>>2) + 4(lane>>5) of the column block, i.e. four
+// consecutive units per register quad -> the write-out is a 16-byte ds_write_b128 per quad into the [point][unit] image
+// (with D = [point][unit] it would be sixteen 4-byte stores per tile).
 #define QSP_MFMA_STEP_2x2(a0, a1, b0, b1)                   \
-    acc[0][0] = mfma32(a0.x, b0.x, acc[0][0]);              \
-    acc[0][1] = mfma32(a0.x, b1.x, acc[0][1]);              \
-    acc[1][0] = mfma32(a1.x, b0.x, acc[1][0]);              \
-    acc[1][1] = mfma32(a1.x, b1.x, acc[1][1]);              \
-    acc[0][0] = mfma32(a0.y, b0.y, acc[0][0]);              \
-    acc[0][1] = mfma32(a0.y, b1.y, acc[0][1]);              \
-    acc[1][0] = mfma32(a1.y, b0.y, acc[1][0]);              \
-    acc[1][1] = mfma32(a1.y, b1.y, acc[1][1]);              \
-    acc[0][0] = mfma32(a0.z, b0.z, acc[0][0]);              \
-    acc[0][1] = mfma32(a0.z, b1.z, acc[0][1]);              \
-    acc[1][0] = mfma32(a1.z, b0.z, acc[1][0]);              \
-    acc[1][1] = mfma32(a1.z, b1.z, acc[1][1]);              \
-    acc[0][0] = mfma32(a0.w, b0.w, acc[0][0]);              \
-    acc[0][1] = mfma32(a0.w, b1.w, acc[0][1]);              \
-    acc[1][0] = mfma32(a1.w, b0.w, acc[1][0]);              \
-    acc[1][1] = mfma32(a1.w, b1.w, acc[1][1]);
+    acc[0][0] = mfma32(b0.x, a0.x, acc[0][0]);              \
+    acc[0][1] = mfma32(b1.x, a0.x, acc[0][1]);              \
+    acc[1][0] = mfma32(b0.x, a1.x, acc[1][0]);              \
+    acc[1][1] = mfma32(b1.x, a1.x, acc[1][1]);              \
+    acc[0][0] = mfma32(b0.y, a0.y, acc[0][0]);              \
+    acc[0][1] = mfma32(b1.y, a0.y, acc[0][1]);              \
+    acc[1][0] = mfma32(b0.y, a1.y, acc[1][0]);              \
+    acc[1][1] = mfma32(b1.y, a1.y, acc[1][1]);              \
+    acc[0][0] = mfma32(b0.z, a0.z, acc[0][0]);              \
+    acc[0][1] = mfma32(b1.z, a0.z, acc[0][1]);              \
+    acc[1][0] = mfma32(b0.z, a1.z, acc[1][0]);              \
+    acc[1][1] = mfma32(b1.z, a1.z, acc[1][1]);              \
+    acc[0][0] = mfma32(b0.w, a0.w, acc[0][0]);              \
+    acc[0][1] = mfma32(b1.w, a0.w, acc[0][1]);              \
+    acc[1][0] = mfma32(b0.w, a1.w, acc[1][0]);              \
+    acc[1][1] = mfma32(b1.w, a1.w, acc[1][1]);
 
 // acc[r][c] += act[32r.., 0..8*KG) * Wpacked for this wave's two column blocks.
 //   * w0 / w1 are wave-uniform bases (SGPR); the per-lane part of the address is the single VGPR `lane`.
@@ -171,10 +176,10 @@ __device__ __forceinline__ void gemm_1x1(const float* __restrict__ act_rows, con
             q0[d] = w0[(kg + d + PF) * 64 + lane];
             const f32x4 a0n = lds4(a_row0 + 8 * (kg + d + 1));
             __builtin_amdgcn_sched_barrier(0);
-            acc = mfma32(a0.x, b0.x, acc);
-            acc = mfma32(a0.y, b0.y, acc);
-            acc = mfma32(a0.z, b0.z, acc);
-            acc = mfma32(a0.w, b0.w, acc);
+            acc = mfma32(b0.x, a0.x, acc);
+            acc = mfma32(b0.y, a0.y, acc);
+            acc = mfma32(b0.z, a0.z, acc);
+            acc = mfma32(b0.w, a0.w, acc);
             __builtin_amdgcn_sched_barrier(0);
             a0 = a0n;
         }
@@ -196,33 +201,34 @@ __device__ __forceinline__ float mask_sel(float v, uint32_t mask, int k) {
     return __int_as_float(__float_as_int(v) & sel);
 }
 
-// Forward write-out of hidden layer L: bias, ReLU, mask capture, pass-through columns of layer 3.
+// Forward write-out of hidden layer L: bias, ReLU, mask capture.  Lane = one point per row tile, four register quads of
+// four consecutive units each -> four 16-byte stores per 32x32 tile.
 template <int L>
 __device__ __forceinline__ void fwd_writeout(MlpSmem& s, const float* __restrict__ bias, const f32x16 (&acc)[2][2], int wave,
                                              int lane, uint32_t& m_lo, uint32_t& m_hi) {
-    const int j = lane & 31;
-    const float bv[2] = {bias[64 * wave + j], bias[64 * wave + 32 + j]};
+    const int h = lane >> 5;
     uint32_t lo = 0, hi = 0;
 #pragma unroll
-    for (int r = 0; r < 2; ++r)
+    for (int c = 0; c < 2; ++c)
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const int col = 64 * wave + 32 * c + j;
+        for (int g = 0; g < 4; ++g) {
+            const int u0 = 64 * wave + 32 * c + 8 * g + 4 * h;            // first of 4 consecutive units
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + u0);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int row = 32 * r + acc_row(i, lane);
-                float v = acc[r][c][i] + bv[c];
-                const bool pos = v > 0.f;
-                const uint32_t bit = pos ? 1u : 0u;
-                if (r == 0) lo |= bit << (c * 16 + i);
-                else hi |= bit << (c * 16 + i);
-                v = pos ? v : 0.f;
-                if (L == 3) {
-                    // columns 445..511 of layer 4's input are the network input, written by pass_through() below
-                    if (col < SKIP_COL) s.act[row * LDA + col] = v;
-                } else {
-                    s.act[row * LDA + col] = v;
+            for (int r = 0; r < 2; ++r) {
+                const int p = 32 * r + (lane & 31);
+                f32x4 v;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int i = 4 * g + q;
+                    float x = acc[r][c][i] + bv[q];
+                    const bool pos = x > 0.f;
+                    const uint32_t bit = pos ? 1u : 0u;
+                    if (r == 0) lo |= bit << (c * 16 + i);
+                    else hi |= bit << (c * 16 + i);
+                    v[q] = pos ? x : 0.f;
                 }
+                *reinterpret_cast<f32x4*>(s.act + p * LDA + u0) = v;
             }
         }
     // opaque to the optimiser: otherwise it keeps the 64 v_cmp lane masks of every layer alive in SGPRs and spills them
@@ -231,8 +237,8 @@ __device__ __forceinline__ void fwd_writeout(MlpSmem& s, const float* __restrict
     m_hi = hi;
 }
 
-// Layer 4 consumes [h3(445) | code(64) | xyz(3)]: fill columns 445..511 of every row (all 512 threads, same barrier
-// interval as fwd_writeout<3>, disjoint columns).
+// Layer 4 consumes [h3(445) | code(64) | xyz(3)]: fill columns 445..511 of every row (all 512 threads; runs after a
+// barrier behind fwd_writeout<3>, whose 16-byte stores cover those columns with zeros).
 __device__ __forceinline__ void pass_through(MlpSmem& s) {
     for (int e = threadIdx.x; e < TILE_P * NIN; e += MLP_THREADS) {
         const int row = e / NIN, ci = e - row * NIN;
@@ -240,25 +246,30 @@ __device__ __forceinline__ void pass_through(MlpSmem& s) {
     }
 }
 
-// Backward write-out of the gradient w.r.t. the INPUT of layer L (= post-ReLU output of layer L-1):
-// apply the ReLU mask of layer L-1; at L == 4 the pass-through columns are the skip gradient -> stash.
+// Backward write-out of the gradient w.r.t. the INPUT of layer L (= post-ReLU output of layer L-1): apply the ReLU mask
+// of layer L-1.  At L == 4 columns 445..511 are the skip-connection gradient w.r.t. the network input (no ReLU in front
+// of them): stored raw here, moved to the stash by stash_extract() after a barrier.
 template <int L>
 __device__ __forceinline__ void bwd_writeout(MlpSmem& s, const f32x16 (&acc)[2][2], int wave, int lane, uint32_t m_lo,
                                              uint32_t m_hi) {
-    const int j = lane & 31;
+    const int h = lane >> 5;
 #pragma unroll
-    for (int r = 0; r < 2; ++r)
+    for (int c = 0; c < 2; ++c)
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const int col = 64 * wave + 32 * c + j;
+        for (int g = 0; g < 4; ++g) {
+            const int u0 = 64 * wave + 32 * c + 8 * g + 4 * h;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int row = 32 * r + acc_row(i, lane);
-                float v = mask_sel(acc[r][c][i], r == 0 ? m_lo : m_hi, c * 16 + i);
-                // L == 4: columns 445..511 are the skip-connection gradient w.r.t. the network input (no ReLU in front
-                // of them); stored raw here, moved to the stash by stash_extract() after a barrier.
-                if (L == 4) v = (col >= SKIP_COL) ? acc[r][c][i] : v;
-                s.act[row * LDA + col] = v;
+            for (int r = 0; r < 2; ++r) {
+                const int p = 32 * r + (lane & 31);
+                f32x4 v;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int i = 4 * g + q;
+                    float x = mask_sel(acc[r][c][i], r == 0 ? m_lo : m_hi, c * 16 + i);
+                    if (L == 4) x = (u0 + q >= SKIP_COL) ? acc[r][c][i] : x;
+                    v[q] = x;
+                }
+                *reinterpret_cast<f32x4*>(s.act + p * LDA + u0) = v;
             }
         }
 }
@@ -329,6 +340,7 @@ __device__ __forceinline__ void mlp_tile(MlpSmem& s, const MlpParams* __restrict
     gemm_2x2<HID / 8, PF>(s.act, P.wf[3] + (cb0 * (HID / 8)) * 64, P.wf[3] + ((cb0 + 1) * (HID / 8)) * 64, acc, lane);
     __syncthreads();
     fwd_writeout<3>(s, P.bias[3], acc, wave, lane, mlo[3], mhi[3]);
+    __syncthreads();
     pass_through(s);
     __syncthreads();
     QSP_FWD_LAYER(4)
@@ -364,22 +376,26 @@ __device__ __forceinline__ void mlp_tile(MlpSmem& s, const MlpParams* __restrict
     __syncthreads();
     if (!BWD) return;
 
-    // ---- backward seed: d y / d a7 = (1 - y^2) * w8[col] * [a7 > 0] ----------------------------------------------
+    // ---- backward seed: d y / d a7 = (1 - y^2) * w8[unit] * [a7 > 0] ---------------------------------------------
     {
-        const int j = lane & 31;
+        const int h = lane >> 5;
 #pragma unroll
-        for (int r = 0; r < 2; ++r)
+        for (int r = 0; r < 2; ++r) {
+            const int p = 32 * r + (lane & 31);
+            const float yy = s.y[p];
+            const float dy = 1.f - yy * yy;
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const int col = 64 * wave + 32 * c + j;
-                const float wv = P.w8[col];
+            for (int c = 0; c < 2; ++c)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int row = 32 * r + acc_row(i, lane);
-                    const float yy = s.y[row];
-                    s.act[row * LDA + col] = mask_sel((1.f - yy * yy) * wv, r == 0 ? mlo[7] : mhi[7], c * 16 + i);
+                for (int g = 0; g < 4; ++g) {
+                    const int u0 = 64 * wave + 32 * c + 8 * g + 4 * h;
+                    const f32x4 wv = *reinterpret_cast<const f32x4*>(P.w8 + u0);
+                    f32x4 v;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = mask_sel(dy * wv[q], r == 0 ? mlo[7] : mhi[7], c * 16 + 4 * g + q);
+                    *reinterpret_cast<f32x4*>(s.act + p * LDA + u0) = v;
                 }
-            }
+        }
     }
     __syncthreads();
 
@@ -410,12 +426,17 @@ __device__ __forceinline__ void mlp_tile(MlpSmem& s, const MlpParams* __restrict
     if (wave < 6) gemm_1x1<HID / 8, PF>(s.act + 32 * r0 * LDA, P.wb[0] + (c0 * (HID / 8)) * 64, g0, lane);
     __syncthreads();
     if (wave < 6) {
-        const int col = 32 * c0 + (lane & 31);
-        if (col < NIN) {
+        // D[i = input column within block c0][j = point]: four consecutive input columns per register quad
+        const int p = 32 * r0 + (lane & 31);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int row = 32 * r0 + acc_row(i, lane);
-                s.act[row * LDG + col] = g0[i] + s.stash[row * LDST + col];
+        for (int g = 0; g < 4; ++g) {
+            const int k0 = 32 * c0 + 8 * g + 4 * (lane >> 5);
+            if (k0 < NIN) {     // 64..67 is the last useful quad (67 itself is padding inside both row strides)
+                const f32x4 st = *reinterpret_cast<const f32x4*>(s.stash + p * LDST + k0);
+                f32x4 v;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = g0[4 * g + q] + st[q];
+                *reinterpret_cast<f32x4*>(s.act + p * LDG + k0) = v;
             }
         }
     }

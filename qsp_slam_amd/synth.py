@@ -295,3 +295,28 @@ def make_ba_scene(seed, n_kf, n_pt, n_obj, stereo_frac=0.0, outlier_frac=0.05, n
         oe_kf=arr(oe_kf, np.int32, (-1,)), oe_obj=arr(oe_obj, np.int32, (-1,)),
         oe_meas=arr(oe_meas, np.float64, (-1, 7)), oe_info=1e3,
         gt_kf=np.array([pose7(T) for T in kf_T]), gt_pt=pts, gt_obj=np.array([pose7(T) for T in obj_T]))
+
+
+def make_ba_scene_large(seed, n_kf, n_pt, obs_per_pt=8, n_obj=0):
+    """Vectorised generator for BANDWIDTH measurements of the linearisation kernels (million-edge graphs): every point
+    lies in the region all key-frames see; each is observed by `obs_per_pt` distinct random key-frames (mono)."""
+    rng = np.random.default_rng(seed)
+    small = make_ba_scene(seed, n_kf, 1, n_obj, obs_per_obj=min(10, n_kf))
+    fx, fy, cx, cy = small["kf_K"][0, :4]
+    T = np.array([pose7_to_T(p) for p in small["gt_kf"]])
+    pts = rng.uniform([-0.8, -0.5, -0.5], [0.8, 0.5, 0.8], size=(n_pt, 3))
+    k = min(obs_per_pt, n_kf)
+    kf = np.argsort(rng.random((n_pt, n_kf)), axis=1)[:, :k].astype(np.int32)      # distinct key-frames per point
+    kf.sort(axis=1)
+    pt_idx = np.repeat(np.arange(n_pt, dtype=np.int32), k)
+    kf_idx = kf.reshape(-1)
+    pc = np.einsum("eij,ej->ei", T[kf_idx, :3, :3], pts[pt_idx]) + T[kf_idx, :3, 3]
+    uv = np.stack([fx * pc[:, 0] / pc[:, 2] + cx, fy * pc[:, 1] / pc[:, 2] + cy], 1) + rng.normal(size=(len(pt_idx), 2))
+    out = dict(small)
+    out.update(pt_xyz=(pts + rng.normal(scale=0.02, size=pts.shape)), pt_id=np.arange(n_pt, dtype=np.int64) + int(small["kf_id"].max()) + 1,
+               mono_pt=pt_idx, mono_kf=kf_idx, mono_obs=uv.astype(np.float32).astype(np.float64),
+               mono_info=np.ones(len(pt_idx)), st_pt=np.zeros(0, np.int32), st_kf=np.zeros(0, np.int32),
+               st_obs=np.zeros((0, 3)), st_info=np.zeros(0), gt_pt=pts)
+    if n_obj:
+        out["obj_id"] = np.arange(n_obj, dtype=np.int64) + int(out["pt_id"].max()) + 2
+    return out
