@@ -203,3 +203,86 @@ def test_jacobian_rows_of_fused_kernel_vs_reference(gpu_decoder, golden_dir, nam
     rob_r, _, _ = so.robust_residual(z["it0_res_render"], cfg.b1)
     assert np.abs(rr[:, 71] - rob_r).max() < 1e-4 * np.abs(rob_r).max()
     batch.close()
+
+
+def test_pose_only_more_iterations_exercises_the_inlier_filter(gpu_decoder, oracle_decoder):
+    """With 5 iterations the |res| <= 0.05 filter after iteration index 4 (optimizer.py:80-82) never influences the
+    result; with 8 it does (iterations 5..7 run on the filtered set and a smaller N).  Outliers are planted."""
+    from qsp_slam_amd import synth
+    from qsp_slam_amd.reconstruct.optimizer import Optimizer
+    o = synth.make_object_views(77, 1, 300, n_fg=8, n_bg=4)[0]
+    T = o["t_cam_obj"].astype(np.float64)
+    s = np.linalg.det(T[:3, :3]) ** (1 / 3)
+    T_se3 = T.copy()
+    T_se3[:3, :3] /= s
+    pts = o["pts"].copy()
+    pts[::7] += np.float32(0.25)                      # gross outliers: SDF residual > 0.05
+    cfg = so.JointConfig(n_iter_pose=8)
+    ref = so.estimate_pose_cam_obj(oracle_decoder, cfg, T_se3.astype(np.float32), float(s), pts, np.zeros(64, np.float32))
+    opt = Optimizer(gpu_decoder, make_cfg(cfg))
+    out = opt.estimate_pose_cam_obj(T_se3.astype(np.float32), float(s), pts, np.zeros(64, np.float32))
+    assert relerr(out, ref) < 2e-4
+    ref5 = so.estimate_pose_cam_obj(oracle_decoder, so.JointConfig(n_iter_pose=5), T_se3.astype(np.float32), float(s), pts,
+                                    np.zeros(64, np.float32))
+    assert relerr(ref, ref5) > 1e-3                   # the filter really changed the trajectory
+
+
+def test_initial_code_is_used_and_truncated_to_code_len(gpu_decoder, oracle_decoder):
+    """code != None: `latent_vector = code[:code_len]` (optimizer.py:118-119); one teacher-forced iteration vs the oracle"""
+    from qsp_slam_amd import synth
+    from qsp_slam_amd.reconstruct.optimizer import Optimizer, RefineBatch, _joint_cfg
+    o = synth.make_object_views(55, 1, 400, n_fg=100, n_bg=50, code_scale=0.3)[0]
+    rng = np.random.default_rng(1)
+    code = (0.1 * rng.normal(size=64)).astype(np.float32)
+    cfg = so.JointConfig()
+    opt = Optimizer(gpu_decoder, make_cfg(cfg))
+    batch = RefineBatch(gpu_decoder, _joint_cfg(opt), [o["pts"]], [o["rays"]], [o["depth"]], [0])
+    batch.set_state(o["t_cam_obj"][None], code[None])
+    batch.run(1)
+    tr = batch.trace()
+    T_oc = np.linalg.inv(o["t_cam_obj"].astype(np.float64)).astype(np.float32)
+    dobs = np.concatenate([o["depth"], np.zeros(50, np.float32)])
+    it = so.gn_iteration(oracle_decoder, cfg, T_oc, code, o["pts"], o["rays"], dobs, 100)
+    assert int(tr["K"][0]) == it["K"]
+    assert relerr(tr["H"][0], it["H"]) < 1e-4 and relerr(tr["b"][0], it["b"]) < 1e-4
+    _, c1, _, _ = batch.get()
+    assert np.abs(c1[0] - it["code_new"]).max() < 1e-4
+    batch.close()
+
+
+def test_abi_argument_errors(gpu_decoder):
+    """bad arguments come back as status codes with a message, never as a crash or an exception across the boundary"""
+    import ctypes as C
+    from qsp_slam_amd import DeepSdfDecoder, _lib
+    L = _lib.lib()
+    assert L.qsp_decode_sdf(gpu_decoder.handle, None, None, 5, None) == _lib.QSP_ERR_INVALID
+    assert b"decode" in L.qsp_last_error()
+    # unsupported architecture: 4 x 128 decoder
+    layers = [(np.zeros((128, 67), np.float32), None, np.zeros(128, np.float32))] + \
+             [(np.zeros((128, 128), np.float32), None, np.zeros(128, np.float32)) for _ in range(3)] + \
+             [(np.zeros((1, 128), np.float32), None, np.zeros(1, np.float32))]
+    with pytest.raises(_lib.QspError) as e:
+        DeepSdfDecoder(layers, latent_in=(2,), code_len=64)
+    assert e.value.code == _lib.QSP_ERR_UNSUPPORTED
+    # hyp_obj out of range
+    cfg = _lib.JointCfg(1, 1, 1, 0, 0.2, 0.02, 1, 1, 0.01, 5, 50, 64)
+    pts = np.zeros((4, 3), np.float32)
+    rays = np.zeros((2, 3), np.float32)
+    dep = np.zeros(1, np.float32)
+    h = C.c_void_p()
+    pp, rp, dp = _lib.ptr_array([pts]), _lib.ptr_array([rays]), _lib.ptr_array([dep])
+    rc = L.qsp_refine_batch_create(gpu_decoder.handle, C.byref(cfg), 1, C.cast(pp, C.POINTER(_lib.c_float_p)),
+                                   _lib.i32ptr(np.array([4], np.int32)), C.cast(rp, C.POINTER(_lib.c_float_p)),
+                                   _lib.i32ptr(np.array([2], np.int32)), C.cast(dp, C.POINTER(_lib.c_float_p)),
+                                   _lib.i32ptr(np.array([1], np.int32)), 1, _lib.i32ptr(np.array([3], np.int32)), C.byref(h))
+    assert rc == _lib.QSP_ERR_INVALID
+
+
+def test_zero_surface_points_is_a_failure_not_a_crash(gpu_decoder):
+    """M = 0: mean over an empty set is NaN -> is_good False (optimizer.py:168-169)"""
+    from qsp_slam_amd import synth
+    from qsp_slam_amd.reconstruct.optimizer import Optimizer
+    o = synth.make_object_views(9, 1, 50, n_fg=64, n_bg=32)[0]
+    r = Optimizer(gpu_decoder, make_cfg(so.JointConfig())).reconstruct_object(o["t_cam_obj"], np.zeros((0, 3), np.float32),
+                                                                              o["rays"], o["depth"])
+    assert r.is_good is False and r.loss == 0.0
