@@ -1,0 +1,193 @@
+"""The ORB-SLAM2 `Optimizer` shim (include/qsp_optimizer_shim.h) compiled against stand-in map types (tests/shim_mock/).
+
+CPU: linked with a recording stub of the C-ABI, it must flatten a mock map into exactly the graph the reference would
+build (vertex ids, fixed flags, intrinsics, edge lists, float32->float64 pose conversion) and write results back through
+the same setters, including outlier erasure.
+GPU: linked with the real libqsp_hip.so, its result on the mock map equals qsp_slam_amd.ba.BaProblem on the same graph."""
+import os
+import struct
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+from qsp_slam_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MOCK = os.path.join(ROOT, "tests", "shim_mock")
+
+
+def build_driver(tmp, real):
+    out = os.path.join(tmp, "shim_driver_real" if real else "shim_driver_stub")
+    inc = ["-I" + MOCK, "-I" + os.path.join(ROOT, "include")]
+    subprocess.check_call(["g++", "-std=c++17", "-O1"] + inc + ["-c", os.path.join(MOCK, "shim_driver.cpp"), "-o",
+                                                                  os.path.join(tmp, "drv.o")])
+    if real:
+        lib = os.path.join(ROOT, "qsp_slam_amd")
+        subprocess.check_call(["g++", "-o", out, os.path.join(tmp, "drv.o"), "-L" + lib, "-lqsp_hip", "-Wl,-rpath," + lib])
+    else:
+        subprocess.check_call(["gcc", "-std=c11", "-O1"] + inc + ["-c", os.path.join(MOCK, "stub_qsp.c"), "-o",
+                                                                    os.path.join(tmp, "stub.o")])
+        subprocess.check_call(["g++", "-o", out, os.path.join(tmp, "drv.o"), os.path.join(tmp, "stub.o")])
+    return out
+
+
+def make_map(seed=5, n_kf=9, n_pt=120, n_obj=2):
+    """a synthetic scene re-expressed as what the MAP holds: float32 4x4 poses, key-point pixels + octaves"""
+    rng = np.random.default_rng(seed)
+    sc = synth.make_ba_scene(seed, n_kf, n_pt, n_obj, stereo_frac=0.3, obs_per_obj=4)
+    m = dict(sc=sc)
+    m["kfT"] = np.array([synth.pose7_to_T(p) for p in sc["kf_pose"]], np.float32)
+    m["objT"] = np.array([synth.pose7_to_T(p) for p in sc["obj_pose"]], np.float32)
+    m["oeZ"] = np.array([synth.pose7_to_T(p) for p in sc["oe_meas"]], np.float32)
+    m["kf_local"] = np.array([1 if i < 6 else 0 for i in range(n_kf)], np.int32)
+    m["pt_mn"] = (sc["pt_id"] - int(sc["kf_id"].max()) - 1).astype(np.int64)
+    m["obj_mn"] = np.arange(n_obj, dtype=np.int64) + 3
+    m["mono_oct"] = np.round(-np.log(sc["mono_info"]) / (2 * np.log(1.2))).astype(np.int32)
+    m["st_oct"] = np.round(-np.log(sc["st_info"]) / (2 * np.log(1.2))).astype(np.int32)
+    return m
+
+
+def write_scene(m, path):
+    sc = m["sc"]
+    with open(path, "wb") as f:
+        f.write(struct.pack("<6i", len(sc["kf_pose"]), len(sc["pt_xyz"]), len(sc["obj_pose"]), len(sc["mono_pt"]),
+                            len(sc["st_pt"]), len(sc["oe_kf"])))
+        for a, dt in ((m["kfT"], np.float32), (sc["kf_id"], np.int64), (sc["kf_K"], np.float32), (m["kf_local"], np.int32),
+                      (sc["pt_xyz"], np.float32), (m["pt_mn"], np.int64), (m["objT"], np.float32), (m["obj_mn"], np.int64),
+                      (sc["mono_pt"], np.int32), (sc["mono_kf"], np.int32), (sc["mono_obs"], np.float32),
+                      (m["mono_oct"], np.int32), (sc["st_pt"], np.int32), (sc["st_kf"], np.int32),
+                      (sc["st_obs"], np.float32), (m["st_oct"], np.int32), (sc["oe_kf"], np.int32),
+                      (sc["oe_obj"], np.int32), (m["oeZ"], np.float32)):
+            f.write(np.ascontiguousarray(a, dtype=dt).tobytes())
+
+
+def read_dump(path):
+    b = open(path, "rb").read()
+    o = [0]
+
+    def take(dt, n, shape=None):
+        a = np.frombuffer(b, dtype=dt, count=n, offset=o[0]).copy()
+        o[0] += a.nbytes
+        return a.reshape(shape) if shape else a
+    n_kf, n_pt, n_obj, nm, ns, no = take(np.int32, 6)
+    d = dict(kf_pose=take(np.float64, 7 * n_kf, (n_kf, 7)), kf_fixed=take(np.uint8, n_kf), kf_id=take(np.int64, n_kf),
+             kf_K=take(np.float64, 5 * n_kf, (n_kf, 5)), pt_xyz=take(np.float64, 3 * n_pt, (n_pt, 3)),
+             pt_id=take(np.int64, n_pt), obj_pose=take(np.float64, 7 * n_obj, (n_obj, 7)), obj_id=take(np.int64, n_obj),
+             mono_pt=take(np.int32, nm), mono_kf=take(np.int32, nm), mono_obs=take(np.float64, 2 * nm, (nm, 2)),
+             mono_info=take(np.float64, nm), st_pt=take(np.int32, ns), st_kf=take(np.int32, ns),
+             st_obs=take(np.float64, 3 * ns, (ns, 3)), st_info=take(np.float64, ns), oe_kf=take(np.int32, no),
+             oe_obj=take(np.int32, no), oe_meas=take(np.float64, 7 * no, (no, 7)))
+    d["oe_info"] = float(take(np.float64, 1)[0])
+    return d
+
+
+def read_out(path, n_kf, n_pt, n_obj):
+    b = open(path, "rb").read()
+    kf = np.frombuffer(b, np.float32, 16 * n_kf).reshape(n_kf, 4, 4)
+    off = 64 * n_kf
+    pt = np.frombuffer(b, np.float32, 3 * n_pt, off).reshape(n_pt, 3)
+    off += 12 * n_pt
+    ob = np.frombuffer(b, np.float32, 16 * n_obj, off).reshape(n_obj, 4, 4)
+    off += 64 * n_obj
+    nobs, nba = struct.unpack_from("<2i", b, off)
+    return kf, pt, ob, nobs, nba
+
+
+def test_shim_flattens_the_map_like_the_reference_and_writes_back():
+    m = make_map()
+    sc = m["sc"]
+    with tempfile.TemporaryDirectory() as tmp:
+        drv = build_driver(tmp, real=False)
+        write_scene(m, os.path.join(tmp, "scene.bin"))
+        env = dict(os.environ, QSP_STUB_DUMP=os.path.join(tmp, "dump.bin"))
+        subprocess.check_call([drv, os.path.join(tmp, "scene.bin"), os.path.join(tmp, "out.bin")], env=env)
+        d = read_dump(os.path.join(tmp, "dump.bin"))
+        kf_o, pt_o, ob_o, nobs, nba = read_out(os.path.join(tmp, "out.bin"), len(sc["kf_pose"]), len(sc["pt_xyz"]),
+                                               len(sc["obj_pose"]))
+    n_kf = len(sc["kf_pose"])
+    local = [i for i in range(n_kf) if i == 0 or m["kf_local"][i]]
+    # local map points = points matched in a local key-frame, in discovery order (src/Optimizer_util.cc:330-349)
+    seen, lpts = set(), []
+    edges = [(int(k), int(p)) for p, k in zip(sc["mono_pt"], sc["mono_kf"])] + \
+            [(int(k), int(p)) for p, k in zip(sc["st_pt"], sc["st_kf"])]
+    per_kf = {}
+    for e_i, (k, p) in enumerate(edges):        # the driver appends key-points in edge order: mono first, then stereo
+        per_kf.setdefault(k, []).append(p)
+    for k in local:
+        for p in per_kf.get(k, []):
+            if p not in seen:
+                seen.add(p)
+                lpts.append(p)
+    fixed = sorted({k for (k, p) in edges if p in seen and k not in local})     # std::map<KeyFrame*> = index order here
+    order = local + [k for k in fixed]
+    # fixed cameras are discovered per local point in pointer order; as a set they must match, local part exactly in order
+    assert list(d["kf_id"][: len(local)]) == [int(sc["kf_id"][i]) for i in local]
+    assert sorted(d["kf_id"][len(local):]) == sorted(int(sc["kf_id"][i]) for i in fixed)
+    assert d["kf_fixed"][0] == 1 and list(d["kf_fixed"][1: len(local)]) == [0] * (len(local) - 1)
+    assert all(d["kf_fixed"][len(local):] == 1)
+    # Converter::toSE3Quat on float32 matrices
+    for j, i in enumerate(local):
+        assert np.abs(d["kf_pose"][j] - synth.pose7(m["kfT"][i].astype(np.float64))).max() < 1e-6
+        assert np.allclose(d["kf_K"][j], sc["kf_K"][i].astype(np.float32))
+    max_kf = int(max(sc["kf_id"][i] for i in order))
+    assert list(d["pt_id"]) == [int(m["pt_mn"][p]) + max_kf + 1 for p in lpts]
+    assert np.allclose(d["pt_xyz"], sc["pt_xyz"][lpts].astype(np.float32))
+    max_mp = int(max(m["pt_mn"][p] for p in lpts))
+    assert sorted(d["obj_id"]) == sorted(int(x) + max_kf + max_mp + 2 for x in m["obj_mn"])
+    # every observation of a local point by a key-frame in the graph is an edge, mono/stereo split by mvuRight < 0
+    kf_of = {int(i): n for n, i in enumerate(d["kf_id"])}
+    # (a "stereo" observation whose right coordinate is negative IS a monocular one for ORB-SLAM2: mvuRight < 0)
+    neg = sc["st_obs"][:, 2].astype(np.float32) < 0
+    exp_m = sorted([(int(m["pt_mn"][p]) + max_kf + 1, int(sc["kf_id"][k])) for p, k in zip(sc["mono_pt"], sc["mono_kf"])
+                    if p in seen and int(sc["kf_id"][k]) in kf_of] +
+                   [(int(m["pt_mn"][p]) + max_kf + 1, int(sc["kf_id"][k]))
+                    for p, k, ng in zip(sc["st_pt"], sc["st_kf"], neg) if ng and p in seen and int(sc["kf_id"][k]) in kf_of])
+    got_m = sorted((int(d["pt_id"][p]), int(d["kf_id"][k])) for p, k in zip(d["mono_pt"], d["mono_kf"]))
+    assert got_m == exp_m
+    exp_s = sorted((int(m["pt_mn"][p]) + max_kf + 1, int(sc["kf_id"][k])) for p, k, ng in zip(sc["st_pt"], sc["st_kf"], neg)
+                   if not ng and p in seen and int(sc["kf_id"][k]) in kf_of)
+    got_s = sorted((int(d["pt_id"][p]), int(d["kf_id"][k])) for p, k in zip(d["st_pt"], d["st_kf"]))
+    assert got_s == exp_s
+    assert d["oe_info"] == 1e3 and len(d["oe_kf"]) == sum(1 for k in sc["oe_kf"] if int(sc["kf_id"][k]) in kf_of)
+    assert np.all((d["mono_info"] > 0) & (d["mono_info"] <= 1.0))
+    # write-back of the stub's visible fake update: +0.5 in x for free local key-frames, +0.25 in y for points
+    assert nba == 1
+    for i in local[1:]:
+        assert abs(kf_o[i][0, 3] - (m["kfT"][i][0, 3] + 0.5)) < 1e-5
+    assert abs(kf_o[0][0, 3] - m["kfT"][0][0, 3]) < 1e-6                          # mnId 0 stays fixed
+    for i in fixed:
+        assert np.array_equal(kf_o[i], m["kfT"][i])                               # fixed cameras are not written back
+    for p in lpts:
+        assert abs(pt_o[p][1] - (np.float32(sc["pt_xyz"][p][1]) + 0.25)) < 1e-5
+    assert nobs == len(edges) - 1                                                  # the stub flagged one mono edge as outlier
+
+
+@pytest.mark.gpu
+def test_shim_end_to_end_equals_python_binding_on_the_same_graph():
+    from qsp_slam_amd.ba import BaProblem
+    m = make_map(seed=8, n_kf=8, n_pt=150, n_obj=2)
+    sc = m["sc"]
+    with tempfile.TemporaryDirectory() as tmp:
+        write_scene(m, os.path.join(tmp, "scene.bin"))
+        stub = build_driver(tmp, real=False)
+        subprocess.check_call([stub, os.path.join(tmp, "scene.bin"), os.path.join(tmp, "o0.bin")],
+                              env=dict(os.environ, QSP_STUB_DUMP=os.path.join(tmp, "dump.bin")))
+        d = read_dump(os.path.join(tmp, "dump.bin"))
+        real = build_driver(tmp, real=True)
+        subprocess.check_call([real, os.path.join(tmp, "scene.bin"), os.path.join(tmp, "o1.bin")])
+        kf_o, pt_o, ob_o, nobs, nba = read_out(os.path.join(tmp, "o1.bin"), len(sc["kf_pose"]), len(sc["pt_xyz"]),
+                                               len(sc["obj_pose"]))
+    prob = BaProblem(d)
+    prob.local_joint_ba()
+    kf, pt, ob = prob.state()
+    id2idx = {int(i): n for n, i in enumerate(sc["kf_id"])}
+    n_checked = 0
+    for j, vid in enumerate(d["kf_id"]):
+        if d["kf_fixed"][j] and int(vid) != 0:
+            continue
+        T = synth.pose7_to_T(kf[j]).astype(np.float32)
+        assert np.abs(kf_o[id2idx[int(vid)]] - T).max() < 2e-6
+        n_checked += 1
+    assert n_checked >= 5 and nba == 1
