@@ -248,6 +248,17 @@ int qsp_ba_get_index(qsp_ba_problem* p, int32_t* kf_hidx, int32_t* obj_hidx, int
 
 int qsp_ba_profile(qsp_ba_problem* p, int enable, qsp_ba_stats* out);
 
+/* Multi-GPU: shard ONE scene's landmarks over `world` ranks (one process per GPU, every rank created from the same scene).
+ * Rank r linearises and marginalises the landmarks with pt_id % world == r and the camera-object edges of the objects with
+ * obj_id % world == r; the shared camera/object block is combined with ONE sum all-reduce of the reduced system
+ * (dimp^2 + dimp doubles) per Levenberg-Marquardt trial, plus three tiny ones (pose blocks after linearisation, chi2 and
+ * rho scalars); every rank then solves the reduced system redundantly and updates its own landmarks.  `fn` must sum
+ * `count` doubles at `device_buf` in place over all ranks and be complete (or ordered on `hip_stream`) when it returns;
+ * with torch.distributed this is all_reduce on RCCL ("nccl" backend) over xGMI -- see qsp_slam_amd/parallel.py.
+ * The reference has no counterpart (single process). */
+typedef int (*qsp_allreduce_fn)(void* ctx, double* device_buf, int64_t count, void* hip_stream);
+int qsp_ba_set_shard(qsp_ba_problem* p, int32_t rank, int32_t world, qsp_allreduce_fn fn, void* ctx);
+
 #ifdef __cplusplus
 }
 #endif

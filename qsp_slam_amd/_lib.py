@@ -67,6 +67,8 @@ class BaProfile(C.Structure):
                 ("n_trials", C.c_int32), ("bytes_linearize", C.c_int64)]
 
 
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)   # qsp_allreduce_fn
+
 _lib = None
 
 # every symbol include/qsp_hip.h declares; tests/test_abi.py checks the list against the header
@@ -77,7 +79,7 @@ SYMBOLS = [
     "qsp_refine_batch_get", "qsp_refine_batch_trace", "qsp_refine_batch_profile", "qsp_refine_batch_rows",
     "qsp_reconstruct_objects", "qsp_estimate_pose",
     "qsp_ba_create", "qsp_ba_destroy", "qsp_ba_set_levels", "qsp_ba_optimize", "qsp_ba_local_joint",
-    "qsp_ba_set_state", "qsp_ba_get_state", "qsp_ba_get_edges", "qsp_ba_get_index", "qsp_ba_profile",
+    "qsp_ba_set_state", "qsp_ba_get_state", "qsp_ba_get_edges", "qsp_ba_get_index", "qsp_ba_profile", "qsp_ba_set_shard",
 ]
 
 
@@ -126,6 +128,7 @@ def lib():
     L.qsp_ba_get_edges.argtypes = [vp, c_double_p, c_double_p, c_double_p, c_uint8_p, c_uint8_p]
     L.qsp_ba_get_index.argtypes = [vp, c_int32_p, c_int32_p, c_int32_p]
     L.qsp_ba_profile.argtypes = [vp, C.c_int, C.POINTER(BaProfile)]
+    L.qsp_ba_set_shard.argtypes = [vp, C.c_int32, C.c_int32, ALLREDUCE_FN, C.c_void_p]
     _lib = L
     return L
 

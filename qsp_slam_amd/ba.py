@@ -68,6 +68,19 @@ class BaProblem(object):
         except Exception:
             pass
 
+    def set_shard(self, rank, world, allreduce):
+        """landmark sharding over `world` ranks; `allreduce(dev_ptr: int, count: int, hip_stream: int)` sums `count` float64
+        at the device address in place over all ranks (qsp_slam_amd.parallel.TorchAllreduce wraps torch.distributed)."""
+        def _cb(ctx, buf, n, stream):
+            try:
+                allreduce(int(buf), int(n), int(stream or 0))
+                return 0
+            except Exception as e:          # never let an exception cross the C boundary
+                print("qsp all-reduce callback failed:", repr(e))
+                return 1
+        self._cb = _lib.ALLREDUCE_FN(_cb) if world > 1 else _lib.ALLREDUCE_FN(0)
+        _lib.check(_lib.lib().qsp_ba_set_shard(self.handle, int(rank), int(world), self._cb, None))
+
     def set_levels(self, mono=None, stereo=None, obj=None):
         def p(a):
             return _lib.c_uint8_p() if a is None else _lib.u8ptr(_arr(a, np.uint8))

@@ -307,6 +307,7 @@ struct Par {
     double delta_mono, delta_stereo, delta_obj;
     double lambda;
     int dim, dimp, n_pose;
+    int is_root;   // landmark-sharded runs: only rank 0 contributes the (already all-reduced) pose blocks and padding
 };
 
 // block-wide sum of one double per thread (256 threads), fixed tree -> thread 0 holds the result
@@ -603,10 +604,12 @@ __global__ __launch_bounds__(256) void k_schur_prepare(Dev d, Par par) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int nd = par.n_pose * 36;
     if (i < nd) {
-        const int h = i / 36, r = (i % 36) / 6, c = i % 6;
-        double v = d.Hdiag[i];
-        if (r == c) v += par.lambda;
-        d.Hs[(size_t)(6 * h + r) * par.dimp + 6 * h + c] = v;
+        if (par.is_root) {
+            const int h = i / 36, r = (i % 36) / 6, c = i % 6;
+            double v = d.Hdiag[i];
+            if (r == c) v += par.lambda;
+            d.Hs[(size_t)(6 * h + r) * par.dimp + 6 * h + c] = v;
+        }
     } else if (i < nd + d.n_oe * 36) {
         const int k = (i - nd) / 36, r = ((i - nd) % 36) / 6, c = (i - nd) % 6;
         if (!d.oe_level[k]) {
@@ -615,9 +618,9 @@ __global__ __launch_bounds__(256) void k_schur_prepare(Dev d, Par par) {
         }
     } else if (i < nd + d.n_oe * 36 + (par.dimp - par.dim)) {
         const int q = par.dim + (i - nd - d.n_oe * 36);
-        d.Hs[(size_t)q * par.dimp + q] = 1.0;
+        if (par.is_root) d.Hs[(size_t)q * par.dimp + q] = 1.0;
     }
-    if (i < par.dimp) d.bs[i] = (i < par.dim) ? d.bp[i] : 0.0;
+    if (i < par.dimp) d.bs[i] = (i < par.dim && par.is_root) ? d.bp[i] : 0.0;
 }
 
 __device__ inline bool inv3(const double* m, double* o) {
@@ -856,7 +859,8 @@ __global__ __launch_bounds__(256) void k_update_poses(Dev d, Par par, int n_part
         se3_exp(d.xp + 6 * h, dl);
         se3_mul(dl, pose, n);
         for (int i = 0; i < 7; ++i) pose[i] = n[i];
-        for (int i = 0; i < 6; ++i) sc += d.xp[6 * h + i] * (par.lambda * d.xp[6 * h + i] + d.bp[6 * h + i]);
+        if (par.is_root)
+            for (int i = 0; i < 6; ++i) sc += d.xp[6 * h + i] * (par.lambda * d.xp[6 * h + i] + d.bp[6 * h + i]);
     }
     const double s = block_sum_256(sc, sh);
     if (threadIdx.x == 0) {
@@ -901,7 +905,18 @@ struct qsp_ba_problem {
     // LM state that persists inside one optimize call only
     qsp_ba_stats prof{};
     bool profiling = false;
+    // landmark sharding across ranks: this rank linearises and marginalises the landmarks with
+    // pt_id % world == rank (and the camera-object edges of objects with obj_id % world == rank); one SUM all-reduce of
+    // the reduced system per LM trial
+    int rank = 0, world = 1;
+    qsp_allreduce_fn allreduce = nullptr;
+    void* allreduce_ctx = nullptr;
+    double* comm = nullptr;      // staging buffer for the small all-reduces
+    size_t comm_cap = 0;
+    std::vector<uint8_t> edge_foreign, oe_foreign;
 };
+
+static int upload_levels(qsp_ba_problem* p);
 
 template <typename T>
 static int dalloc(qsp_ba_problem* p, T** ptr, size_t n) {
@@ -1052,7 +1067,7 @@ extern "C" int qsp_ba_create(const qsp_ba_scene* s, int device, qsp_ba_problem**
     AL(Hdiag, 36 * (size_t)(d.n_kf + d.n_obj));
     AL(Hoff, 36 * (size_t)d.n_oe);
     AL(bp, p->dimp_max); AL(bs, p->dimp_max); AL(xp, p->dimp_max);
-    AL(Hs, (size_t)p->dimp_max * p->dimp_max);
+    AL(Hs, (size_t)p->dimp_max * p->dimp_max + p->dimp_max);   // + room for bs right behind the matrix
     p->n_partial = 1024;
     AL(partial, p->n_partial);
     AL(scal, 8);
@@ -1089,9 +1104,7 @@ extern "C" int qsp_ba_set_levels(qsp_ba_problem* p, const uint8_t* mono, const u
     if (mono) for (int e = 0; e < p->n_mono; ++e) p->edge_level_h[p->mono_pos[e]] = mono[e] ? 1 : 0;
     if (stereo) for (int e = 0; e < p->n_stereo; ++e) p->edge_level_h[p->st_pos[e]] = stereo[e] ? 1 : 0;
     for (int e = 0; e < p->d.n_oe; ++e) p->oe_level_h[e] = (obj && obj[e]) ? 1 : 0;
-    if (p->d.n_edge) QSP_HIP(hipMemcpy(p->d.edge_level, p->edge_level_h.data(), p->d.n_edge, hipMemcpyHostToDevice));
-    if (p->d.n_oe) QSP_HIP(hipMemcpy(p->d.oe_level, p->oe_level_h.data(), p->d.n_oe, hipMemcpyHostToDevice));
-    return QSP_OK;
+    return upload_levels(p);
 }
 
 extern "C" int qsp_ba_set_state(qsp_ba_problem* p, const double* kf_pose, const double* pt_xyz, const double* obj_pose) {
@@ -1148,6 +1161,78 @@ static int read_scal(qsp_ba_problem* p, double* out4) {
     return QSP_OK;
 }
 
+static int upload_levels(qsp_ba_problem* p) {
+    // device level = caller's level OR "belongs to another rank"
+    const Dev& d = p->d;
+    std::vector<uint8_t> le(p->edge_level_h), lo(p->oe_level_h);
+    if (p->world > 1) {
+        for (int e = 0; e < d.n_edge; ++e) le[e] |= p->edge_foreign[e];
+        for (int e = 0; e < d.n_oe; ++e) lo[e] |= p->oe_foreign[e];
+    }
+    if (d.n_edge) QSP_HIP(hipMemcpy(d.edge_level, le.data(), d.n_edge, hipMemcpyHostToDevice));
+    if (d.n_oe) QSP_HIP(hipMemcpy(d.oe_level, lo.data(), d.n_oe, hipMemcpyHostToDevice));
+    return QSP_OK;
+}
+
+// in-place SUM over ranks of `n` doubles at `buf` (device); no-op for world == 1
+static int allreduce(qsp_ba_problem* p, double* buf, int64_t n) {
+    if (p->world <= 1 || n <= 0) return QSP_OK;
+    if (p->allreduce(p->allreduce_ctx, buf, n, (void*)p->stream) != 0) return qsp_fail(QSP_ERR_DEVICE, "all-reduce callback failed");
+    return QSP_OK;
+}
+
+// SUM all-reduce of up to 3 scattered device ranges through the staging buffer
+static int allreduce_gather(qsp_ba_problem* p, double* a, size_t na, double* b, size_t nb, double* c, size_t nc) {
+    if (p->world <= 1) return QSP_OK;
+    hipStream_t s = p->stream;
+    const size_t n = na + nb + nc;
+    if (n > p->comm_cap) return qsp_fail(QSP_ERR_INVALID, "all-reduce staging buffer too small");
+    if (na) QSP_HIP(hipMemcpyAsync(p->comm, a, na * 8, hipMemcpyDeviceToDevice, s));
+    if (nb) QSP_HIP(hipMemcpyAsync(p->comm + na, b, nb * 8, hipMemcpyDeviceToDevice, s));
+    if (nc) QSP_HIP(hipMemcpyAsync(p->comm + na + nb, c, nc * 8, hipMemcpyDeviceToDevice, s));
+    int rc = allreduce(p, p->comm, (int64_t)n);
+    if (rc) return rc;
+    if (na) QSP_HIP(hipMemcpyAsync(a, p->comm, na * 8, hipMemcpyDeviceToDevice, s));
+    if (nb) QSP_HIP(hipMemcpyAsync(b, p->comm + na, nb * 8, hipMemcpyDeviceToDevice, s));
+    if (nc) QSP_HIP(hipMemcpyAsync(c, p->comm + na + nb, nc * 8, hipMemcpyDeviceToDevice, s));
+    return QSP_OK;
+}
+
+extern "C" int qsp_ba_set_shard(qsp_ba_problem* p, int32_t rank, int32_t world, qsp_allreduce_fn fn, void* ctx) {
+    if (!p || world < 1 || rank < 0 || rank >= world || (world > 1 && !fn))
+        return qsp_fail(QSP_ERR_INVALID, "qsp_ba_set_shard: bad argument");
+    QSP_HIP(hipSetDevice(p->device));
+    const Dev& d = p->d;
+    p->rank = rank; p->world = world; p->allreduce = fn; p->allreduce_ctx = ctx;
+    p->edge_foreign.assign(std::max(d.n_edge, 1), 0);
+    p->oe_foreign.assign(std::max(d.n_oe, 1), 0);
+    if (world > 1) {
+        for (int e = 0; e < d.n_edge; ++e) p->edge_foreign[e] = (p->pt_id_h[p->edge_h[e].pt] % world) != rank;
+        for (int e = 0; e < d.n_oe; ++e) p->oe_foreign[e] = (p->obj_id_h[p->oe_obj_h[e]] % world) != rank;
+        const size_t need = std::max<size_t>((size_t)36 * (d.n_kf + d.n_obj) + p->dimp_max + 64,
+                                             std::max<size_t>((size_t)3 * d.n_pt + 8, (size_t)d.n_edge + d.n_oe + 8));
+        if (need > p->comm_cap) {
+            void* q = nullptr;
+            QSP_HIP(hipMalloc(&q, need * sizeof(double)));
+            p->allocs.push_back(q);
+            p->comm = (double*)q;
+            p->comm_cap = need;
+        }
+    }
+    return upload_levels(p);
+}
+
+// zero the landmark / object-edge entries this rank does not own, then SUM over ranks: every rank ends with all of them
+__global__ void k_mask_foreign_points(Dev d, int rank, int world, const int64_t* pt_id) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < d.n_pt && (pt_id[i] % world) != rank) { d.pt_xyz[3 * i] = 0; d.pt_xyz[3 * i + 1] = 0; d.pt_xyz[3 * i + 2] = 0; }
+}
+__global__ void k_mask_foreign_chi2(Dev d, const uint8_t* ef, const uint8_t* of) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < d.n_edge && ef[i]) d.edge_chi2[i] = 0;
+    if (i < d.n_oe && of[i]) d.oe_chi2[i] = 0;
+}
+
 static int launch_errors(qsp_ba_problem* p, const Par& par) {
     const Dev& d = p->d;
     const int n_tot = d.n_edge + d.n_oe;
@@ -1156,6 +1241,9 @@ static int launch_errors(qsp_ba_problem* p, const Par& par) {
     hipLaunchKernelGGL(k_finish_sum, dim3(1), dim3(64), 0, p->stream, d, grid, 0);
     return QSP_OK;
 }
+
+// chi2 (scal[0]) and the rho denominator (scal[1]) summed over ranks
+static int reduce_scalars(qsp_ba_problem* p) { return allreduce_gather(p, p->d.scal, 2, nullptr, 0, nullptr, 0); }
 
 extern "C" int qsp_ba_optimize(qsp_ba_problem* p, int32_t n_iter, double delta_mono, double delta_stereo,
                                double delta_obj, const volatile uint8_t* stop_flag, qsp_ba_trace* tr) {
@@ -1167,7 +1255,7 @@ extern "C" int qsp_ba_optimize(qsp_ba_problem* p, int32_t n_iter, double delta_m
     QSP_HIP(hipMemcpyAsync(d.kf_h, p->kf_h.data(), sizeof(int32_t) * d.n_kf, hipMemcpyHostToDevice, s));
     if (d.n_obj) QSP_HIP(hipMemcpyAsync(d.obj_h, p->obj_h.data(), sizeof(int32_t) * d.n_obj, hipMemcpyHostToDevice, s));
     if (d.n_pt) QSP_HIP(hipMemcpyAsync(d.pt_h, p->pt_h.data(), sizeof(int32_t) * d.n_pt, hipMemcpyHostToDevice, s));
-    Par par{delta_mono, delta_stereo, delta_obj, 0.0, p->dim, p->dimp, p->n_pose};
+    Par par{delta_mono, delta_stereo, delta_obj, 0.0, p->dim, p->dimp, p->n_pose, p->rank == 0 ? 1 : 0};
     if (tr) { tr->n = 0; tr->result = 0; tr->n_pose_blocks = p->n_pose; tr->n_landmarks = p->n_land; }
     hipEvent_t ev0 = nullptr, ev1 = nullptr, evA = nullptr, evB = nullptr;
     if (p->profiling) {
@@ -1176,6 +1264,7 @@ extern "C" int qsp_ba_optimize(qsp_ba_problem* p, int32_t n_iter, double delta_m
         hipEventRecord(ev0, s);
     }
     const int gp = std::max(1, std::min(p->n_partial, (d.n_pt + 255) / 256));
+    d.bs = d.Hs + (size_t)p->dimp * p->dimp;      // right behind the reduced matrix: one all-reduce covers both
     double lambda = 0, ni = 2;
     int nBad = 0, done = 0, result = 0;
     double sc[4];
@@ -1192,9 +1281,21 @@ extern "C" int qsp_ba_optimize(qsp_ba_problem* p, int32_t n_iter, double delta_m
         hipLaunchKernelGGL(k_lin_poses_finish, dim3(d.n_kf), dim3(64), 0, s, d, par);
         if (d.n_obj) hipLaunchKernelGGL(k_lin_objects, dim3((d.n_obj + 63) / 64), dim3(64), 0, s, d, par);
         if (p->profiling) hipEventRecord(evB, s);
-        if (it == 0) hipLaunchKernelGGL(k_maxdiag, dim3(1), dim3(256), 0, s, d, par);
-        int rc = read_scal(p, sc);
+        int rc = allreduce_gather(p, d.Hdiag, (size_t)36 * p->n_pose, d.bp, (size_t)p->dim, d.scal, 1);   // pose blocks, b_p, chi2
         if (rc) return rc;
+        if (it == 0) hipLaunchKernelGGL(k_maxdiag, dim3(1), dim3(256), 0, s, d, par);
+        rc = read_scal(p, sc);
+        if (rc) return rc;
+        if (it == 0 && p->world > 1) {   // max over ranks of the local maxima, as a SUM over one-hot slots
+            std::vector<double> slots(p->world, 0.0);
+            slots[p->rank] = sc[2];
+            QSP_HIP(hipMemcpyAsync(p->comm, slots.data(), 8 * p->world, hipMemcpyHostToDevice, s));
+            rc = allreduce(p, p->comm, p->world);
+            if (rc) return rc;
+            QSP_HIP(hipMemcpyAsync(slots.data(), p->comm, 8 * p->world, hipMemcpyDeviceToHost, s));
+            QSP_HIP(hipStreamSynchronize(s));
+            for (double v : slots) sc[2] = std::max(sc[2], v);
+        }
         if (p->profiling) {
             float ms = 0;
             hipEventElapsedTime(&ms, evA, evB);
@@ -1219,6 +1320,8 @@ extern "C" int qsp_ba_optimize(qsp_ba_problem* p, int32_t n_iter, double delta_m
                 const int nprep = p->n_pose * 36 + d.n_oe * 36 + (p->dimp - p->dim);
                 hipLaunchKernelGGL(k_schur_prepare, dim3((std::max(nprep, p->dimp) + 255) / 256), dim3(256), 0, s, d, par);
                 if (d.n_pt) hipLaunchKernelGGL(k_schur_points, dim3((d.n_pt + 3) / 4), dim3(256), 0, s, d, par);
+                rc = allreduce(p, d.Hs, (int64_t)p->dimp * p->dimp + p->dimp);     // reduced matrix + right-hand side
+                if (rc) return rc;
                 const int nb = p->dimp / NB;
                 for (int k = 0; k < nb; ++k) {
                     hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(64), 0, s, d.Hs, p->dimp, k, d.scal);
@@ -1235,6 +1338,8 @@ extern "C" int qsp_ba_optimize(qsp_ba_problem* p, int32_t n_iter, double delta_m
             hipLaunchKernelGGL(k_update_points, dim3(gp), dim3(256), 0, s, d, par);
             hipLaunchKernelGGL(k_update_poses, dim3(1), dim3(256), 0, s, d, par, gp);
             launch_errors(p, par);
+            rc = reduce_scalars(p);
+            if (rc) return rc;
             rc = read_scal(p, sc);
             if (rc) return rc;
             const bool ok2 = sc[3] == 0.0;
@@ -1269,6 +1374,16 @@ extern "C" int qsp_ba_optimize(qsp_ba_problem* p, int32_t n_iter, double delta_m
         if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0;
         if (nBad >= 3) { result = 1; break; }
     }
+    if (p->world > 1 && d.n_pt) {   // every rank leaves with all landmarks: own values, zeros elsewhere, SUM
+        int64_t* ids = nullptr;
+        QSP_HIP(hipMalloc((void**)&ids, sizeof(int64_t) * d.n_pt));
+        QSP_HIP(hipMemcpyAsync(ids, p->pt_id_h.data(), sizeof(int64_t) * d.n_pt, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_mask_foreign_points, dim3((d.n_pt + 255) / 256), dim3(256), 0, s, d, p->rank, p->world, ids);
+        int rc2 = allreduce(p, d.pt_xyz, (int64_t)3 * d.n_pt);
+        QSP_HIP(hipStreamSynchronize(s));
+        hipFree(ids);
+        if (rc2) return rc2;
+    }
     QSP_HIP(hipStreamSynchronize(s));
     if (p->profiling) {
         hipEventRecord(ev1, s);
@@ -1301,6 +1416,18 @@ extern "C" int qsp_ba_get_edges(qsp_ba_problem* p, double* mono_chi2, double* st
     if (!p) return qsp_fail(QSP_ERR_INVALID, "qsp_ba_get_edges: null problem");
     QSP_HIP(hipSetDevice(p->device));
     const Dev& d = p->d;
+    if (p->world > 1) {
+        uint8_t *ef = nullptr, *of = nullptr;
+        QSP_HIP(hipMalloc((void**)&ef, std::max(d.n_edge, 1)));
+        QSP_HIP(hipMalloc((void**)&of, std::max(d.n_oe, 1)));
+        QSP_HIP(hipMemcpyAsync(ef, p->edge_foreign.data(), std::max(d.n_edge, 1), hipMemcpyHostToDevice, p->stream));
+        QSP_HIP(hipMemcpyAsync(of, p->oe_foreign.data(), std::max(d.n_oe, 1), hipMemcpyHostToDevice, p->stream));
+        hipLaunchKernelGGL(k_mask_foreign_chi2, dim3((std::max(d.n_edge, d.n_oe) + 255) / 256), dim3(256), 0, p->stream, d, ef, of);
+        int rc = allreduce_gather(p, d.edge_chi2, (size_t)d.n_edge, d.oe_chi2, (size_t)d.n_oe, nullptr, 0);
+        QSP_HIP(hipStreamSynchronize(p->stream));
+        hipFree(ef); hipFree(of);
+        if (rc) return rc;
+    }
     std::vector<double> c(std::max(d.n_edge, 1));
     std::vector<uint8_t> pos(std::max(d.n_edge, 1));
     if (d.n_edge) {

@@ -71,3 +71,69 @@ def refine_objects_sharded(optimizer, objects, flip_sample_num, rank, world, dev
                                                   select=True) if mine else []
     table = gather_object_results(pack_results(local), len(objects), rank, world, device=device)
     return unpack_results(table)
+
+
+class _DevArray(object):
+    """exposes a raw device address as a CUDA-array-interface object so that torch can view it without a copy"""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = dict(shape=(n,), typestr="<f8", data=(ptr, False), version=2)
+
+
+class TorchAllreduce(object):
+    """The all-reduce hook of qsp_ba_set_shard over torch.distributed: backend "nccl" is RCCL on ROCm, i.e. the sum runs
+    GPU-to-GPU over xGMI.  The library's stream and torch's stream are different streams, so both are synchronised around
+    the collective (the messages are small: one reduced camera system per LM trial)."""
+
+    def __init__(self, device, group=None):
+        self.device = device
+        self.group = group
+
+    def __call__(self, ptr, n, stream):
+        import torch
+        import torch.distributed as dist
+        from . import _lib
+        hip = _hip()
+        hip.hipStreamSynchronize(_lib.C.c_void_p(stream))
+        t = torch.as_tensor(_DevArray(ptr, n), device=torch.device("cuda", self.device))
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        torch.cuda.synchronize(self.device)
+
+
+_HIP = None
+
+
+def _hip():
+    global _HIP
+    if _HIP is None:
+        import ctypes
+        _HIP = ctypes.CDLL("libamdhip64.so")
+    return _HIP
+
+
+class ThreadAllreduce(object):
+    """Test double for ONE GPU: `world` Python threads, each driving its own BaProblem shard on the same device, meet at a
+    barrier; the sum is formed on the host in rank order.  Exercises the sharded algorithm where only one GPU exists."""
+
+    def __init__(self, world):
+        import threading
+        self.world = world
+        self.barrier = threading.Barrier(world)
+        self.slots = [None] * world
+
+    def hook(self, rank):
+        import ctypes
+
+        def fn(ptr, n, stream):
+            hip = _hip()
+            hip.hipStreamSynchronize(ctypes.c_void_p(stream))
+            host = np.empty(n, np.float64)
+            hip.hipMemcpy(host.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(ptr), ctypes.c_size_t(8 * n), 2)
+            self.slots[rank] = host
+            self.barrier.wait()
+            tot = np.zeros(n, np.float64)
+            for r in range(self.world):
+                tot += self.slots[r]
+            self.barrier.wait()
+            hip.hipMemcpy(ctypes.c_void_p(ptr), tot.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(8 * n), 1)
+        return fn
