@@ -106,42 +106,58 @@ __device__ __forceinline__ f32x4 lds4(const float* p) { return *reinterpret_cast
     acc[1][0] = mfma32(b0.w, a1.w, acc[1][0]);              \
     acc[1][1] = mfma32(b1.w, a1.w, acc[1][1]);
 
+// The weight ring: PF k-groups (2 x 1 KiB wave-loads each) in flight per wave, global -> VGPR.  It is owned by mlp_tile
+// and runs ACROSS layers: the last PF steps of a GEMM already fetch the first PF k-groups of the NEXT GEMM, so a layer
+// never starts by waiting out a full L2 round trip behind its barrier.
+template <int PF>
+struct WRing {
+    f32x4 q0[PF], q1[PF];
+};
+
+template <int PF>
+__device__ __forceinline__ void ring_prime(WRing<PF>& R, const float4* __restrict__ w0_, const float4* __restrict__ w1_, int lane) {
+    gptr4 w0 = (gptr4)w0_;
+    gptr4 w1 = (gptr4)w1_;
+#pragma unroll
+    for (int d = 0; d < PF; ++d) {
+        R.q0[d] = w0[d * 64 + lane];
+        R.q1[d] = w1[d * 64 + lane];
+    }
+}
+
 // acc[r][c] += act[32r.., 0..8*KG) * Wpacked for this wave's two column blocks.
-//   * w0 / w1 are wave-uniform bases (SGPR); the per-lane part of the address is the single VGPR `lane`.
-//   * weights: ring of PF k-groups in flight (global -> VGPR); activations: one k-group ahead (LDS -> VGPR).
-//   * both prefetches run past the end (PF k-groups of weights, one of activations): the packed buffers are
-//     over-allocated by the host and the LDS over-read stays inside MlpSmem; those values are never used.
+//   * w0 / w1 (this GEMM) and n0 / n1 (the next GEMM's column blocks) are wave-uniform bases (SGPR); the per-lane part
+//     of the address is the single VGPR `lane`.  On entry the ring holds k-groups 0..PF-1 of this GEMM; on exit it
+//     holds k-groups 0..PF-1 of the next one.
+//   * activations: one k-group ahead (LDS -> VGPR); that prefetch runs one k-group past the end, inside MlpSmem.
 //   * sched_barrier pins "issue next loads, then 16 MFMAs": without it the scheduler sinks each load to just before
 //     its use and the ring degenerates to a load-wait-use sequence.
 template <int KG, int PF>
 __device__ __forceinline__ void gemm_2x2(const float* __restrict__ act, const float4* __restrict__ w0_,
-                                         const float4* __restrict__ w1_, f32x16 (&acc)[2][2], int lane) {
-    static_assert(KG % PF == 0, "KG must be a multiple of the prefetch depth");
+                                         const float4* __restrict__ w1_, const float4* __restrict__ n0_,
+                                         const float4* __restrict__ n1_, WRing<PF>& R, f32x16 (&acc)[2][2], int lane) {
+    static_assert(KG % PF == 0 && KG >= 2 * PF, "KG must be a multiple of the prefetch depth, at least twice it");
     gptr4 w0 = (gptr4)w0_;
     gptr4 w1 = (gptr4)w1_;
-    f32x4 q0[PF], q1[PF];
-#pragma unroll
-    for (int d = 0; d < PF; ++d) {
-        q0[d] = w0[d * 64 + lane];
-        q1[d] = w1[d * 64 + lane];
-    }
+    gptr4 n0 = (gptr4)n0_;
+    gptr4 n1 = (gptr4)n1_;
     const float* a_row0 = act + (lane & 31) * LDA + 4 * (lane >> 5);
     const float* a_row1 = a_row0 + 32 * LDA;
     f32x4 a0 = lds4(a_row0), a1 = lds4(a_row1);
 #pragma nounroll
-    for (int kg = 0; kg < KG; kg += PF) {
+    for (int kg = 0; kg < KG - PF; kg += PF) {
 #pragma unroll
         for (int d = 0; d < PF; ++d) {
-            const f32x4 b0 = q0[d], b1 = q1[d];
+            const f32x4 b0 = R.q0[d], b1 = R.q1[d];
 #if (QSP_EXP_VARIANT & 8)
-            q0[d] = w0[((kg + d + PF) & 15) * 64 + lane];   // timing experiment: 16 KiB window per stream (L2-resident)
-            q1[d] = w1[((kg + d + PF) & 15) * 64 + lane];
+            R.q0[d] = w0[((kg + d + PF) & 15) * 64 + lane];   // timing experiment: 16 KiB window per stream (L2-resident)
+            R.q1[d] = w1[((kg + d + PF) & 15) * 64 + lane];
 #elif (QSP_EXP_VARIANT & 4)
-            q0[d] = w0[d * 64 + lane];           // timing experiment: same 1 KiB every time (L1-resident)
-            q1[d] = w1[d * 64 + lane];
+            R.q0[d] = w0[d * 64 + lane];           // timing experiment: same 1 KiB every time (L1-resident)
+            R.q1[d] = w1[d * 64 + lane];
 #elif !(QSP_EXP_VARIANT & 1)
-            q0[d] = w0[(kg + d + PF) * 64 + lane];
-            q1[d] = w1[(kg + d + PF) * 64 + lane];
+            R.q0[d] = w0[(kg + d + PF) * 64 + lane];
+            R.q1[d] = w1[(kg + d + PF) * 64 + lane];
 #endif
 #if !(QSP_EXP_VARIANT & 2)
             const f32x4 a0n = lds4(a_row0 + 8 * (kg + d + 1));
@@ -156,24 +172,42 @@ __device__ __forceinline__ void gemm_2x2(const float* __restrict__ act, const fl
             a1 = a1n;
         }
     }
+    // last PF k-groups: the ring refills with the NEXT GEMM's first k-groups
+#pragma unroll
+    for (int d = 0; d < PF; ++d) {
+        const f32x4 b0 = R.q0[d], b1 = R.q1[d];
+#if !(QSP_EXP_VARIANT & 1)
+        R.q0[d] = n0[d * 64 + lane];
+        R.q1[d] = n1[d * 64 + lane];
+#endif
+#if !(QSP_EXP_VARIANT & 2)
+        const f32x4 a0n = lds4(a_row0 + 8 * (KG - PF + d + 1));
+        const f32x4 a1n = lds4(a_row1 + 8 * (KG - PF + d + 1));
+#else
+        const f32x4 a0n = a1, a1n = a0;
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        QSP_MFMA_STEP_2x2(a0, a1, b0, b1)
+        __builtin_amdgcn_sched_barrier(0);
+        a0 = a0n;
+        a1 = a1n;
+    }
 }
 
-// one 32x32 tile over K = 8*KG (used by the 67-column backward of layer 0)
+// one 32x32 tile over K = 8*KG (the 67-column backward of layer 0; waves 0..5).  Uses ring half q0, primed by the
+// preceding GEMM; nothing follows it inside a tile, so it does not refill.
 template <int KG, int PF>
-__device__ __forceinline__ void gemm_1x1(const float* __restrict__ act_rows, const float4* __restrict__ w0_,
+__device__ __forceinline__ void gemm_1x1(const float* __restrict__ act_rows, const float4* __restrict__ w0_, WRing<PF>& R,
                                          f32x16& acc, int lane) {
     gptr4 w0 = (gptr4)w0_;
-    f32x4 q0[PF];
-#pragma unroll
-    for (int d = 0; d < PF; ++d) q0[d] = w0[d * 64 + lane];
     const float* a_row0 = act_rows + (lane & 31) * LDA + 4 * (lane >> 5);
     f32x4 a0 = lds4(a_row0);
 #pragma nounroll
     for (int kg = 0; kg < KG; kg += PF) {
 #pragma unroll
         for (int d = 0; d < PF; ++d) {
-            const f32x4 b0 = q0[d];
-            q0[d] = w0[(kg + d + PF) * 64 + lane];
+            const f32x4 b0 = R.q0[d];
+            if (kg + PF < KG) R.q0[d] = w0[(kg + d + PF) * 64 + lane];
             const f32x4 a0n = lds4(a_row0 + 8 * (kg + d + 1));
             __builtin_amdgcn_sched_barrier(0);
             acc = mfma32(b0.x, a0.x, acc);
@@ -317,11 +351,22 @@ __device__ __forceinline__ void mlp_tile(MlpSmem& s, const MlpParams* __restrict
     __syncthreads();
 
     const int cb0 = 2 * wave;   // this wave's first column block
+    constexpr int KG0 = K0_PAD / 8, KGH = HID / 8;
+    // column-block bases of this wave in every packed matrix
+#define QSP_WF(L) (P.wf[L] + (cb0 * ((L) == 0 ? KG0 : KGH)) * 64)
+#define QSP_WF1(L) (P.wf[L] + ((cb0 + 1) * ((L) == 0 ? KG0 : KGH)) * 64)
+#define QSP_WB(L) (P.wb[L] + (cb0 * KGH) * 64)
+#define QSP_WB1(L) (P.wb[L] + ((cb0 + 1) * KGH) * 64)
+    // layer-0 backward: waves 0..5 own one of 3 column blocks; the others prefetch block 0 (never used)
+    const int r0 = wave / 3, c0 = wave % 3;
+    const float4* wb0 = P.wb[0] + ((wave < 6 ? c0 : 0) * KGH) * 64;
 
     // ---- layer 0 (K = 96) --------------------------------------------------------------------------------------
+    static_assert(PF == 4, "the ring depth is shared by all layers; layer 0 has only 12 k-groups");
+    WRing<PF> ring;
+    ring_prime(ring, QSP_WF(0), QSP_WF1(0), lane);
     zero_acc(acc);
-    gemm_2x2<K0_PAD / 8, 4>(s.act, P.wf[0] + (cb0 * (K0_PAD / 8)) * 64, P.wf[0] + ((cb0 + 1) * (K0_PAD / 8)) * 64, acc,
-                            lane);
+    gemm_2x2<KG0, PF>(s.act, QSP_WF(0), QSP_WF1(0), QSP_WF(1), QSP_WF1(1), ring, acc, lane);
     __syncthreads();
     fwd_writeout<0>(s, P.bias[0], acc, wave, lane, mlo[0], mhi[0]);
     __syncthreads();
@@ -329,15 +374,14 @@ __device__ __forceinline__ void mlp_tile(MlpSmem& s, const MlpParams* __restrict
     // ---- layers 1..7 (K = 512) ---------------------------------------------------------------------------------
 #define QSP_FWD_LAYER(L)                                                                                      \
     zero_acc(acc);                                                                                            \
-    gemm_2x2<HID / 8, PF>(s.act, P.wf[L] + (cb0 * (HID / 8)) * 64, P.wf[L] + ((cb0 + 1) * (HID / 8)) * 64, acc, \
-                          lane);                                                                              \
+    gemm_2x2<KGH, PF>(s.act, QSP_WF(L), QSP_WF1(L), QSP_WF((L) + 1), QSP_WF1((L) + 1), ring, acc, lane);       \
     __syncthreads();                                                                                          \
     fwd_writeout<L>(s, P.bias[L], acc, wave, lane, mlo[L], mhi[L]);                                           \
     __syncthreads();
     QSP_FWD_LAYER(1)
     QSP_FWD_LAYER(2)
     zero_acc(acc);
-    gemm_2x2<HID / 8, PF>(s.act, P.wf[3] + (cb0 * (HID / 8)) * 64, P.wf[3] + ((cb0 + 1) * (HID / 8)) * 64, acc, lane);
+    gemm_2x2<KGH, PF>(s.act, QSP_WF(3), QSP_WF1(3), QSP_WF(4), QSP_WF1(4), ring, acc, lane);
     __syncthreads();
     fwd_writeout<3>(s, P.bias[3], acc, wave, lane, mlo[3], mhi[3]);
     __syncthreads();
@@ -346,7 +390,12 @@ __device__ __forceinline__ void mlp_tile(MlpSmem& s, const MlpParams* __restrict
     QSP_FWD_LAYER(4)
     QSP_FWD_LAYER(5)
     QSP_FWD_LAYER(6)
-    QSP_FWD_LAYER(7)
+    zero_acc(acc);
+    if (BWD) gemm_2x2<KGH, PF>(s.act, QSP_WF(7), QSP_WF1(7), QSP_WB(7), QSP_WB1(7), ring, acc, lane);
+    else gemm_2x2<KGH, PF>(s.act, QSP_WF(7), QSP_WF1(7), QSP_WF(0), QSP_WF1(0), ring, acc, lane);
+    __syncthreads();
+    fwd_writeout<7>(s, P.bias[7], acc, wave, lane, mlo[7], mhi[7]);
+    __syncthreads();
 #undef QSP_FWD_LAYER
 
     // ---- layer 8: 512 -> 1, tanh ---------------------------------------------------------------------------------
@@ -402,8 +451,8 @@ __device__ __forceinline__ void mlp_tile(MlpSmem& s, const MlpParams* __restrict
     // ---- backward through layers 7..1: g_in = g_a . W_L, masked by layer L-1 ------------------------------------
 #define QSP_BWD_LAYER(L)                                                                                      \
     zero_acc(acc);                                                                                            \
-    gemm_2x2<HID / 8, PF>(s.act, P.wb[L] + (cb0 * (HID / 8)) * 64, P.wb[L] + ((cb0 + 1) * (HID / 8)) * 64, acc, \
-                          lane);                                                                              \
+    gemm_2x2<KGH, PF>(s.act, QSP_WB(L), QSP_WB1(L), (L) > 1 ? QSP_WB((L) - 1) : wb0, (L) > 1 ? QSP_WB1((L) - 1) : wb0, \
+                      ring, acc, lane);                                                                       \
     __syncthreads();                                                                                          \
     bwd_writeout<L>(s, acc, wave, lane, mlo[L - 1], mhi[L - 1]);                                              \
     __syncthreads();
@@ -422,8 +471,11 @@ __device__ __forceinline__ void mlp_tile(MlpSmem& s, const MlpParams* __restrict
     f32x16 g0;
 #pragma unroll
     for (int i = 0; i < 16; ++i) g0[i] = 0.f;
-    const int r0 = wave / 3, c0 = wave % 3;
-    if (wave < 6) gemm_1x1<HID / 8, PF>(s.act + 32 * r0 * LDA, P.wb[0] + (c0 * (HID / 8)) * 64, g0, lane);
+    if (wave < 6) gemm_1x1<KGH, PF>(s.act + 32 * r0 * LDA, wb0, ring, g0, lane);
+#undef QSP_WF
+#undef QSP_WF1
+#undef QSP_WB
+#undef QSP_WB1
     __syncthreads();
     if (wave < 6) {
         // D[i = input column within block c0][j = point]: four consecutive input columns per register quad
