@@ -65,6 +65,7 @@ struct __attribute__((aligned(16))) MlpSmem {
     float red[8 * TILE_P];      // layer-8 partial sums
     float rscale[TILE_P];       // row scale of the Jacobian (1 for SDF rows, de/ds for render rows, 0 for padding)
     float rres[TILE_P];         // residual supplied by the caller (render rows)
+    float w8[HID];              // last layer's weight row (read by the layer-8 dot product and the backward seed)
 };
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
@@ -132,10 +133,18 @@ __device__ __forceinline__ void ring_prime(WRing<PF>& R, const float4* __restric
 //   * activations: one k-group ahead (LDS -> VGPR); that prefetch runs one k-group past the end, inside MlpSmem.
 //   * sched_barrier pins "issue next loads, then 16 MFMAs": without it the scheduler sinks each load to just before
 //     its use and the ring degenerates to a load-wait-use sequence.
-template <int KG, int PF>
+//   * the forward layers' bias quads for the write-out are fetched here, right BEFORE the next GEMM's prefetch is
+//     issued: vector-memory results return in order, so a bias load issued after that prefetch could only be waited
+//     for with vmcnt(0), i.e. by draining the ring behind every layer's barrier (measured: ~6 us per layer).
+struct BiasQuads {
+    f32x4 v[2][4];   // [column block][register quad]
+};
+
+template <int KG, int PF, bool BIAS>
 __device__ __forceinline__ void gemm_2x2(const float* __restrict__ act, const float4* __restrict__ w0_,
                                          const float4* __restrict__ w1_, const float4* __restrict__ n0_,
-                                         const float4* __restrict__ n1_, WRing<PF>& R, f32x16 (&acc)[2][2], int lane) {
+                                         const float4* __restrict__ n1_, WRing<PF>& R, f32x16 (&acc)[2][2], int lane,
+                                         const float* __restrict__ bias_wave, BiasQuads& bq) {
     static_assert(KG % PF == 0 && KG >= 2 * PF, "KG must be a multiple of the prefetch depth, at least twice it");
     gptr4 w0 = (gptr4)w0_;
     gptr4 w1 = (gptr4)w1_;
@@ -171,6 +180,14 @@ __device__ __forceinline__ void gemm_2x2(const float* __restrict__ act, const fl
             a0 = a0n;
             a1 = a1n;
         }
+    }
+    if (BIAS) {
+        typedef const __attribute__((address_space(1))) f32x4* gq;
+        gq bp = (gq)(bias_wave + 4 * (lane >> 5));      // units 64w + 32c + 8g + 4h .. +3
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bq.v[c][g] = bp[(32 * c + 8 * g) / 4];
     }
     // last PF k-groups: the ring refills with the NEXT GEMM's first k-groups
 #pragma unroll
@@ -238,7 +255,7 @@ __device__ __forceinline__ float mask_sel(float v, uint32_t mask, int k) {
 // Forward write-out of hidden layer L: bias, ReLU, mask capture.  Lane = one point per row tile, four register quads of
 // four consecutive units each -> four 16-byte stores per 32x32 tile.
 template <int L>
-__device__ __forceinline__ void fwd_writeout(MlpSmem& s, const float* __restrict__ bias, const f32x16 (&acc)[2][2], int wave,
+__device__ __forceinline__ void fwd_writeout(MlpSmem& s, const BiasQuads& bq, const f32x16 (&acc)[2][2], int wave,
                                              int lane, uint32_t& m_lo, uint32_t& m_hi) {
     const int h = lane >> 5;
     uint32_t lo = 0, hi = 0;
@@ -247,7 +264,7 @@ __device__ __forceinline__ void fwd_writeout(MlpSmem& s, const float* __restrict
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int u0 = 64 * wave + 32 * c + 8 * g + 4 * h;            // first of 4 consecutive units
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + u0);
+            const f32x4 bv = bq.v[c][g];
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 const int p = 32 * r + (lane & 31);
@@ -337,6 +354,8 @@ __device__ __forceinline__ void mlp_tile(MlpSmem& s, const MlpParams* __restrict
     f32x16 acc[2][2];
 
     // ---- stage the layer-0 input: [code(64) | xyz(3) | 0 pad] into act[:, 0:96) -------------------------------
+    // (and the last layer's row: read from LDS later so that no vector-memory wait has to drain the weight ring)
+    s.w8[tid] = P.w8[tid];
     {
         const int row = tid >> 3, sub = tid & 7;
 #pragma unroll
@@ -366,24 +385,26 @@ __device__ __forceinline__ void mlp_tile(MlpSmem& s, const MlpParams* __restrict
     WRing<PF> ring;
     ring_prime(ring, QSP_WF(0), QSP_WF1(0), lane);
     zero_acc(acc);
-    gemm_2x2<KG0, PF>(s.act, QSP_WF(0), QSP_WF1(0), QSP_WF(1), QSP_WF1(1), ring, acc, lane);
+    BiasQuads bq;
+    gemm_2x2<KG0, PF, true>(s.act, QSP_WF(0), QSP_WF1(0), QSP_WF(1), QSP_WF1(1), ring, acc, lane, P.bias[0] + 64 * wave, bq);
     __syncthreads();
-    fwd_writeout<0>(s, P.bias[0], acc, wave, lane, mlo[0], mhi[0]);
+    fwd_writeout<0>(s, bq, acc, wave, lane, mlo[0], mhi[0]);
     __syncthreads();
 
     // ---- layers 1..7 (K = 512) ---------------------------------------------------------------------------------
 #define QSP_FWD_LAYER(L)                                                                                      \
     zero_acc(acc);                                                                                            \
-    gemm_2x2<KGH, PF>(s.act, QSP_WF(L), QSP_WF1(L), QSP_WF((L) + 1), QSP_WF1((L) + 1), ring, acc, lane);       \
+    gemm_2x2<KGH, PF, true>(s.act, QSP_WF(L), QSP_WF1(L), QSP_WF((L) + 1), QSP_WF1((L) + 1), ring, acc, lane,  \
+                            P.bias[L] + 64 * wave, bq);                                                       \
     __syncthreads();                                                                                          \
-    fwd_writeout<L>(s, P.bias[L], acc, wave, lane, mlo[L], mhi[L]);                                           \
+    fwd_writeout<L>(s, bq, acc, wave, lane, mlo[L], mhi[L]);                                                  \
     __syncthreads();
     QSP_FWD_LAYER(1)
     QSP_FWD_LAYER(2)
     zero_acc(acc);
-    gemm_2x2<KGH, PF>(s.act, QSP_WF(3), QSP_WF1(3), QSP_WF(4), QSP_WF1(4), ring, acc, lane);
+    gemm_2x2<KGH, PF, true>(s.act, QSP_WF(3), QSP_WF1(3), QSP_WF(4), QSP_WF1(4), ring, acc, lane, P.bias[3] + 64 * wave, bq);
     __syncthreads();
-    fwd_writeout<3>(s, P.bias[3], acc, wave, lane, mlo[3], mhi[3]);
+    fwd_writeout<3>(s, bq, acc, wave, lane, mlo[3], mhi[3]);
     __syncthreads();
     pass_through(s);
     __syncthreads();
@@ -391,10 +412,10 @@ __device__ __forceinline__ void mlp_tile(MlpSmem& s, const MlpParams* __restrict
     QSP_FWD_LAYER(5)
     QSP_FWD_LAYER(6)
     zero_acc(acc);
-    if (BWD) gemm_2x2<KGH, PF>(s.act, QSP_WF(7), QSP_WF1(7), QSP_WB(7), QSP_WB1(7), ring, acc, lane);
-    else gemm_2x2<KGH, PF>(s.act, QSP_WF(7), QSP_WF1(7), QSP_WF(0), QSP_WF1(0), ring, acc, lane);
+    if (BWD) gemm_2x2<KGH, PF, true>(s.act, QSP_WF(7), QSP_WF1(7), QSP_WB(7), QSP_WB1(7), ring, acc, lane, P.bias[7] + 64 * wave, bq);
+    else gemm_2x2<KGH, PF, true>(s.act, QSP_WF(7), QSP_WF1(7), QSP_WF(0), QSP_WF1(0), ring, acc, lane, P.bias[7] + 64 * wave, bq);
     __syncthreads();
-    fwd_writeout<7>(s, P.bias[7], acc, wave, lane, mlo[7], mhi[7]);
+    fwd_writeout<7>(s, bq, acc, wave, lane, mlo[7], mhi[7]);
     __syncthreads();
 #undef QSP_FWD_LAYER
 
@@ -402,7 +423,7 @@ __device__ __forceinline__ void mlp_tile(MlpSmem& s, const MlpParams* __restrict
     {
         // wave = k segment of 64, lane = row
         const float* a = s.act + lane * LDA + 64 * wave;
-        const float* w = P.w8 + 64 * wave;
+        const float* w = s.w8 + 64 * wave;
         float part = 0.f;
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
@@ -438,7 +459,7 @@ __device__ __forceinline__ void mlp_tile(MlpSmem& s, const MlpParams* __restrict
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int u0 = 64 * wave + 32 * c + 8 * g + 4 * h;
-                    const f32x4 wv = *reinterpret_cast<const f32x4*>(P.w8 + u0);
+                    const f32x4 wv = *reinterpret_cast<const f32x4*>(s.w8 + u0);
                     f32x4 v;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) v[q] = mask_sel(dy * wv[q], r == 0 ? mlo[7] : mhi[7], c * 16 + 4 * g + q);
@@ -451,8 +472,8 @@ __device__ __forceinline__ void mlp_tile(MlpSmem& s, const MlpParams* __restrict
     // ---- backward through layers 7..1: g_in = g_a . W_L, masked by layer L-1 ------------------------------------
 #define QSP_BWD_LAYER(L)                                                                                      \
     zero_acc(acc);                                                                                            \
-    gemm_2x2<KGH, PF>(s.act, QSP_WB(L), QSP_WB1(L), (L) > 1 ? QSP_WB((L) - 1) : wb0, (L) > 1 ? QSP_WB1((L) - 1) : wb0, \
-                      ring, acc, lane);                                                                       \
+    gemm_2x2<KGH, PF, false>(s.act, QSP_WB(L), QSP_WB1(L), (L) > 1 ? QSP_WB((L) - 1) : wb0,                   \
+                             (L) > 1 ? QSP_WB1((L) - 1) : wb0, ring, acc, lane, nullptr, bq);                 \
     __syncthreads();                                                                                          \
     bwd_writeout<L>(s, acc, wave, lane, mlo[L - 1], mhi[L - 1]);                                              \
     __syncthreads();
