@@ -106,6 +106,16 @@ def cpu_baseline(w, objs, scene, n_hyp, budget_s=20.0):
                 sdf_iters_per_s=iters / dt, ba_ms=1e3 * dt_ba)
 
 
+def pmc_traffic(workload, kernel):
+    """Memory-side bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of this same command
+    (PMC counters cannot be read from inside the process); None when the workload was not profiled."""
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_traffic.json")) as f:
+            return json.load(f)[workload][kernel]["bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -222,7 +232,8 @@ def main():
             "good_hypotheses": int(good.sum()),
             "roofline": {"bound": "mfma", "kernel": "k_mlp_jtj (decoder fwd+bwd+JtJ, f32 MFMA)",
                          "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": pmc_traffic(args.workload, "k_mlp_jtj"),
+                         "traffic_unit": "bytes/launch, rocprofv3 PMC passes of this command (profiles/r01_traffic.json)",
                          "avg_launch_ms": avg_ms, "launches": prof["n_jtj"],
                          "points_per_launch": prof["pts_jtj"] / max(prof["n_jtj"], 1),
                          "tile_padding_overhead": 64.0 * prof["tiles_jtj"] / max(prof["pts_jtj"], 1)},
