@@ -299,6 +299,7 @@ struct Dev {
     double *Hoff;                   // per object edge 6x6 (row = key-frame, col = object)
     double *bp, *bs, *xp;           // reduced rhs / solution
     double *Hs;                     // dense reduced matrix, ld = dimp
+    double *Uf, *Winv, *ych;        // Cholesky: off-diagonal factor blocks, inverse diagonal factors (transposed), L^-1 b
     double *partial;                // block partials for reductions
     double *scal;                   // [0] chi2, [1] scale, [2] maxdiag, [3] chol fail flag (as double)
 };
@@ -681,137 +682,199 @@ __global__ __launch_bounds__(256) void k_schur_points(Dev d, Par par) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// blocked Cholesky A = U^T U on the upper triangle of the dimp x dimp matrix (dimp multiple of NB), right-looking
+// Dense SPD solve of the reduced system  Hs x = bs  (dimp multiple of NB = 64), replacing g2o's LDLT
+// (linear_solver_eigen.h:94-124).  Right-looking blocked Cholesky Hs = L L^T with ONE launch per block step:
+//   * workgroup (i,j), k < i <= j, forms the two panel blocks it needs itself, P_i = L_kk^-1 A_ki and P_j = L_kk^-1 A_kj,
+//     as products with the explicit inverse W_k = L_kk^-1 (no triangular solves anywhere), and updates A_ij -= P_i^T P_j;
+//   * the first row of workgroups (i = k+1) also stores P_j as the factor's block row k and carries the right-hand side
+//     along (forward substitution comes for free: y_k = W_k b_k, b_j -= P_j^T y_k);
+//   * workgroup (k+1,k+1) goes on to factorise its freshly updated diagonal block in registers -- Gauss steps applied
+//     to [S | I] give L^-1 beside the factor -- so the next launch finds W_{k+1} and y_{k+1} ready.
+// Then one workgroup runs the backward substitution x_k = W_k^T (y_k - sum_j U_kj x_j) as matrix-vector products.
 // ---------------------------------------------------------------------------------------------------------------
-// diagonal block: one wave, lane c keeps column c of the 64x64 block in REGISTERS (fully unrolled, static indices);
-// row j of U is broadcast with wave shuffles.  No LDS, no barriers.
-__global__ __launch_bounds__(64) void k_chol_diag(double* A, int ld, int k, double* scal) {
-    const int c = threadIdx.x;
-    double col[NB];
-#pragma unroll
-    for (int r = 0; r < NB; ++r) col[r] = A[(size_t)(k * NB + r) * ld + k * NB + c];
-    bool any_bad = false;
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-        double dd = __shfl(col[j], j, 64);          // A[j][j] lives in lane j, register j
-        const bool bad = !(dd > 0) || !isfinite(dd);
-        any_bad |= bad;
-        if (bad) dd = 1.0;
-        const double piv = sqrt(dd);
-        double ujc = col[j] / piv;                   // U[j][c] for c > j
-        if (c == j) ujc = piv;
-        if (c >= j) col[j] = ujc;
-        if (c <= j) ujc = 0.0;                       // only columns right of the diagonal take part in the update
-#pragma unroll
-        for (int r = j + 1; r < NB; ++r) {
-            const double ujr = __shfl(ujc, r, 64);   // U[j][r]
-            if (c >= r) col[r] -= ujr * ujc;
-        }
-    }
-    if (any_bad && c == 0) scal[3] = 1.0;
-#pragma unroll
-    for (int r = 0; r < NB; ++r) A[(size_t)(k * NB + r) * ld + k * NB + c] = (c >= r) ? col[r] : 0.0;
-}
+constexpr int CHOL_LDS_DOUBLES = 3 * NB * NB + 4 * NB + 2 * NB;
 
-// row-panel: A_kj <- U_kk^-T A_kj for block columns j > k (one workgroup per j)
-__global__ __launch_bounds__(256) void k_chol_panel(double* A, int ld, int k) {
-    __shared__ double U[NB][NB + 1];
-    __shared__ double P[NB][NB + 1];
-    const int j = k + 1 + blockIdx.x;
-    const int t = threadIdx.x;
-    for (int e = t; e < NB * NB; e += 256) {
-        U[e / NB][e % NB] = A[(size_t)(k * NB + e / NB) * ld + k * NB + e % NB];
-        P[e / NB][e % NB] = A[(size_t)(k * NB + e / NB) * ld + j * NB + e % NB];
-    }
-    __syncthreads();
-    // solve U^T X = P column by column of P: forward substitution over rows r; thread t < NB owns column t
-    if (t < NB) {
-        for (int r = 0; r < NB; ++r) {
-            double v = P[r][t];
-            for (int q = 0; q < r; ++q) v -= U[q][r] * P[q][t];
-            P[r][t] = v / U[r][r];
-        }
-    }
-    __syncthreads();
-    for (int e = t; e < NB * NB; e += 256) A[(size_t)(k * NB + e / NB) * ld + j * NB + e % NB] = P[e / NB][e % NB];
-}
-
-// trailing update: A_ij -= A_ki^T A_kj for k < i <= j  (grid: x = j - k - 1, y = i - k - 1, skipping i > j)
-__global__ __launch_bounds__(256) void k_chol_update(double* A, int ld, int k) {
-    const int j = k + 1 + blockIdx.x, i = k + 1 + blockIdx.y;
-    if (i > j) return;
-    __shared__ double Pi[NB][NB + 1];
-    __shared__ double Pj[NB][NB + 1];
-    const int t = threadIdx.x;
-    for (int e = t; e < NB * NB; e += 256) {
-        Pi[e / NB][e % NB] = A[(size_t)(k * NB + e / NB) * ld + i * NB + e % NB];
-        Pj[e / NB][e % NB] = A[(size_t)(k * NB + e / NB) * ld + j * NB + e % NB];
-    }
-    __syncthreads();
-    // each thread: 4x4 micro-tile of the 64x64 block
-    const int r0 = (t / 16) * 4, c0 = (t % 16) * 4;
-    double acc[4][4];
-    for (int a = 0; a < 4; ++a)
-        for (int b = 0; b < 4; ++b) acc[a][b] = 0;
-    for (int q = 0; q < NB; ++q) {
+// acc[a][b] += sum_m X[m][r0+a] * Y[m][c0+b]   (X, Y: 64x64 row-major in LDS)
+__device__ inline void gemm_tn64(const double* X, const double* Y, int r0, int c0, double (&acc)[4][4]) {
+#pragma unroll 4
+    for (int m = 0; m < NB; ++m) {
         double x[4], y[4];
-        for (int a = 0; a < 4; ++a) { x[a] = Pi[q][r0 + a]; y[a] = Pj[q][c0 + a]; }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) { x[a] = X[m * NB + r0 + a]; y[a] = Y[m * NB + c0 + a]; }
+#pragma unroll
         for (int a = 0; a < 4; ++a)
+#pragma unroll
             for (int b = 0; b < 4; ++b) acc[a][b] += x[a] * y[b];
     }
-    for (int a = 0; a < 4; ++a)
-        for (int b = 0; b < 4; ++b) A[(size_t)(i * NB + r0 + a) * ld + j * NB + c0 + b] -= acc[a][b];
 }
 
-// single-workgroup triangular solves with U (upper, ld = n): y = U^-T b, then x = U^-1 y, in place in x.
-// The 64x64 diagonal block of each step is staged in LDS so that the 64 serial steps pay LDS, not L2, latency.
-__global__ __launch_bounds__(256) void k_trsv(const double* __restrict__ U, int n, const double* __restrict__ b,
-                                              double* __restrict__ x) {
-    __shared__ double xs[NB];
-    __shared__ double Dg[NB][NB + 1];
-    const int t = threadIdx.x;
-    for (int i = t; i < n; i += 256) x[i] = b[i];
-    __syncthreads();
-    const int nb = n / NB;
-    for (int k = 0; k < nb; ++k) {      // forward: U^T y = b
-        for (int e = t; e < NB * NB; e += 256) Dg[e / NB][e % NB] = U[(size_t)(k * NB + e / NB) * n + k * NB + e % NB];
-        __syncthreads();
-        if (t < 64) {
-            double v = x[k * NB + t];
-            for (int r = 0; r < NB; ++r) {
-                const double yr = __shfl(v, r, 64) / Dg[r][r];
-                if (t == r) v = yr;
-                if (t > r) v -= Dg[r][t] * yr;
-            }
-            xs[t] = v;
-            x[k * NB + t] = v;
+// In-register factorisation of a 64x64 SPD block spread as 4x4 tiles over 256 threads (thread owns rows r0.., cols c0..).
+// Returns W = L^-1 in the same tiling; S is consumed.  rowbuf: 4*NB doubles of LDS (two buffers of [S row | W row]).
+__device__ inline bool factor_tile64(double (&S)[4][4], double (&W)[4][4], double* rowbuf, int r0, int c0) {
+    bool bad = false;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) W[a][b] = (r0 + a == c0 + b) ? 1.0 : 0.0;
+#pragma nounroll
+    for (int j = 0; j < NB; ++j) {
+        double* rb = rowbuf + (j & 1) * 2 * NB;
+        const int aj = j - r0;
+        if (aj >= 0 && aj < 4) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+                if (a == aj) {
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) { rb[c0 + b] = S[a][b]; rb[NB + c0 + b] = W[a][b]; }
+                }
         }
         __syncthreads();
-        for (int c = (k + 1) * NB + t; c < n; c += 256) {
-            double s = 0;
-            for (int r = 0; r < NB; ++r) s += U[(size_t)(k * NB + r) * n + c] * xs[r];
-            x[c] -= s;
+        double dd = rb[j];
+        const bool isbad = !(dd > 0) || !isfinite(dd);
+        bad |= isbad;
+        if (isbad) dd = 1.0;
+        const double inv = 1.0 / dd;
+        double ur[4], uc[4], wc[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) { ur[a] = (r0 + a > j) ? rb[r0 + a] * inv : 0.0; uc[a] = rb[c0 + a]; wc[a] = rb[NB + c0 + a]; }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) { S[a][b] -= ur[a] * uc[b]; W[a][b] -= ur[a] * wc[b]; }
+        if (aj >= 0 && aj < 4) {
+            const double rs = 1.0 / sqrt(dd);
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+                if (a == aj) {
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) W[a][b] *= rs;
+                }
         }
-        __syncthreads();
     }
-    for (int k = nb - 1; k >= 0; --k) {   // backward: U x = y
-        const int wave = t >> 6, lane = t & 63;
-        for (int e = t; e < NB * NB; e += 256) Dg[e / NB][e % NB] = U[(size_t)(k * NB + e / NB) * n + k * NB + e % NB];
-        for (int r = wave; r < NB; r += 4) {            // wave per row, lanes stride over the columns beyond the block
+    return bad;
+}
+
+// tail shared by the first launch and workgroup (k+1,k+1): factorise block kb, publish W_kb^T and y_kb = W_kb b_kb.
+// bvec (LDS, NB doubles) holds the fully updated right-hand-side block.
+__device__ inline void factor_and_forward(double (&S)[4][4], int kb, double* Winv, double* y, double* lds_mat, double* rowbuf,
+                                          const double* bvec, double* scal, int r0, int c0) {
+    double W[4][4];
+    const bool bad = factor_tile64(S, W, rowbuf, r0, c0);
+    if (bad) scal[3] = 1.0;
+    __syncthreads();
+    // W^T into LDS and global: WT[m][q] = W[q][m]
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) lds_mat[(c0 + b) * NB + r0 + a] = W[a][b];
+    __syncthreads();
+    double* Wg = Winv + (size_t)kb * NB * NB;
+    for (int e = threadIdx.x; e < NB * NB; e += 256) Wg[e] = lds_mat[e];
+    if (threadIdx.x < NB) {
+        double v = 0;
+        for (int m = 0; m < NB; ++m) v += lds_mat[m * NB + threadIdx.x] * bvec[m];
+        y[kb * NB + threadIdx.x] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_chol_first(const double* A, double* Winv, const double* b, double* y, int ld,
+                                                    double* scal) {
+    extern __shared__ __attribute__((aligned(16))) double chol_lds[];
+    double* X = chol_lds;
+    double* rowbuf = chol_lds + 3 * NB * NB;
+    double* bvec = rowbuf + 4 * NB;
+    const int t = threadIdx.x, r0 = (t >> 4) * 4, c0 = (t & 15) * 4;
+    double S[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) S[a][q] = A[(size_t)(r0 + a) * ld + c0 + q];
+    if (t < NB) bvec[t] = b[t];
+    __syncthreads();
+    factor_and_forward(S, 0, Winv, y, X, rowbuf, bvec, scal, r0, c0);
+}
+
+// grid (n, n), n = nb - k - 1: x = j - k - 1, y = i - k - 1; workgroups below the diagonal leave at once
+__global__ __launch_bounds__(256) void k_chol_step(double* A, double* Uf, double* Winv, double* b, double* y, int ld, int k,
+                                                   double* scal) {
+    const int j = k + 1 + blockIdx.x, i = k + 1 + blockIdx.y;
+    if (i > j) return;
+    extern __shared__ __attribute__((aligned(16))) double chol_lds[];
+    double* X = chol_lds;
+    double* Yi = chol_lds + NB * NB;
+    double* Yj = (i == j) ? Yi : chol_lds + 2 * NB * NB;
+    double* rowbuf = chol_lds + 3 * NB * NB;
+    double* bvec = rowbuf + 4 * NB;
+    const int t = threadIdx.x, r0 = (t >> 4) * 4, c0 = (t & 15) * 4;
+    const double* Wg = Winv + (size_t)k * NB * NB;
+    for (int e = t; e < NB * NB; e += 256) {
+        X[e] = Wg[e];
+        Yi[e] = A[(size_t)(k * NB + e / NB) * ld + i * NB + e % NB];
+        if (i != j) Yj[e] = A[(size_t)(k * NB + e / NB) * ld + j * NB + e % NB];
+    }
+    __syncthreads();
+    double pi[4][4] = {}, pj[4][4] = {};
+    gemm_tn64(X, Yi, r0, c0, pi);
+    if (i != j) gemm_tn64(X, Yj, r0, c0, pj);
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            Yi[(r0 + a) * NB + c0 + q] = pi[a][q];
+            if (i != j) Yj[(r0 + a) * NB + c0 + q] = pj[a][q];
+        }
+    __syncthreads();
+    double acc[4][4] = {};
+    gemm_tn64(Yi, Yj, r0, c0, acc);
+    double S[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) S[a][q] = A[(size_t)(i * NB + r0 + a) * ld + j * NB + c0 + q] - acc[a][q];
+    const bool first_row = (i == k + 1);
+    if (first_row) {
+        for (int e = t; e < NB * NB; e += 256) Uf[(size_t)(k * NB + e / NB) * ld + j * NB + e % NB] = Yj[e];
+        if (t < NB) {
+            double v = b[j * NB + t];
+            for (int q = 0; q < NB; ++q) v -= Yj[q * NB + t] * y[k * NB + q];
+            b[j * NB + t] = v;
+            bvec[t] = v;
+        }
+    }
+    if (first_row && i == j) {
+        __syncthreads();
+        factor_and_forward(S, k + 1, Winv, y, X, rowbuf, bvec, scal, r0, c0);
+    } else {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) A[(size_t)(i * NB + r0 + a) * ld + j * NB + c0 + q] = S[a][q];
+    }
+}
+
+// backward substitution, one workgroup of 16 waves: x_k = W_k^T (y_k - sum_{c >= (k+1) NB} U[k-block rows][c] x[c])
+__global__ __launch_bounds__(1024) void k_chol_backsub(const double* __restrict__ Uf, const double* __restrict__ Winv,
+                                                       const double* __restrict__ y, double* x, int n) {
+    __shared__ double sv[NB];
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    const int nb = n / NB;
+    for (int k = nb - 1; k >= 0; --k) {
+        for (int r = wave; r < NB; r += 16) {
+            const double* row = Uf + (size_t)(k * NB + r) * n;
             double s = 0;
-            for (int c = (k + 1) * NB + lane; c < n; c += 64) s += U[(size_t)(k * NB + r) * n + c] * x[c];
+            for (int c = (k + 1) * NB + lane; c < n; c += 64) s += row[c] * x[c];
+#pragma unroll
             for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
-            if (lane == 0) xs[r] = x[k * NB + r] - s;
+            if (lane == 0) sv[r] = y[k * NB + r] - s;
         }
         __syncthreads();
-        if (t < 64) {
-            double v = xs[t];
-            for (int r = NB - 1; r >= 0; --r) {
-                const double xr = __shfl(v, r, 64) / Dg[r][r];
-                if (t == r) v = xr;
-                if (t < r) v -= Dg[t][r] * xr;
-            }
-            x[k * NB + t] = v;
+        const double* WT = Winv + (size_t)k * NB * NB;     // WT[m][q] = W[q][m];  x[m] = sum_q W[q][m] s[q]
+        for (int m = wave; m < NB; m += 16) {
+            double v = WT[m * NB + lane] * sv[lane];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+            if (lane == 0) x[k * NB + m] = v;
         }
         __syncthreads();
     }
@@ -1068,6 +1131,7 @@ extern "C" int qsp_ba_create(const qsp_ba_scene* s, int device, qsp_ba_problem**
     AL(Hoff, 36 * (size_t)d.n_oe);
     AL(bp, p->dimp_max); AL(bs, p->dimp_max); AL(xp, p->dimp_max);
     AL(Hs, (size_t)p->dimp_max * p->dimp_max + p->dimp_max);   // + room for bs right behind the matrix
+    AL(Uf, (size_t)p->dimp_max * p->dimp_max); AL(Winv, (size_t)p->dimp_max * NB); AL(ych, p->dimp_max);
     p->n_partial = 1024;
     AL(partial, p->n_partial);
     AL(scal, 8);
@@ -1079,6 +1143,9 @@ extern "C" int qsp_ba_create(const qsp_ba_scene* s, int device, qsp_ba_problem**
         if (e == hipSuccess) e = hipMemset(d.edge_chi2, 0, sizeof(double) * std::max(d.n_edge, 1));
         if (e == hipSuccess) e = hipMemset(d.oe_chi2, 0, sizeof(double) * std::max(d.n_oe, 1));
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);
+        const int chol_lds = (int)(sizeof(double) * CHOL_LDS_DOUBLES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_chol_first, hipFuncAttributeMaxDynamicSharedMemorySize, chol_lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_chol_step, hipFuncAttributeMaxDynamicSharedMemorySize, chol_lds);
         if (e != hipSuccess) rc = qsp_fail(QSP_ERR_DEVICE, hipGetErrorString(e));
     }
     if (rc) {
@@ -1323,14 +1390,12 @@ extern "C" int qsp_ba_optimize(qsp_ba_problem* p, int32_t n_iter, double delta_m
                 rc = allreduce(p, d.Hs, (int64_t)p->dimp * p->dimp + p->dimp);     // reduced matrix + right-hand side
                 if (rc) return rc;
                 const int nb = p->dimp / NB;
-                for (int k = 0; k < nb; ++k) {
-                    hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(64), 0, s, d.Hs, p->dimp, k, d.scal);
-                    if (k + 1 < nb) {
-                        hipLaunchKernelGGL(k_chol_panel, dim3(nb - k - 1), dim3(256), 0, s, d.Hs, p->dimp, k);
-                        hipLaunchKernelGGL(k_chol_update, dim3(nb - k - 1, nb - k - 1), dim3(256), 0, s, d.Hs, p->dimp, k);
-                    }
-                }
-                hipLaunchKernelGGL(k_trsv, dim3(1), dim3(256), 0, s, d.Hs, p->dimp, d.bs, d.xp);
+                const size_t lds = sizeof(double) * CHOL_LDS_DOUBLES;
+                hipLaunchKernelGGL(k_chol_first, dim3(1), dim3(256), lds, s, d.Hs, d.Winv, d.bs, d.ych, p->dimp, d.scal);
+                for (int k = 0; k + 1 < nb; ++k)
+                    hipLaunchKernelGGL(k_chol_step, dim3(nb - k - 1, nb - k - 1), dim3(256), lds, s, d.Hs, d.Uf, d.Winv, d.bs,
+                                       d.ych, p->dimp, k, d.scal);
+                hipLaunchKernelGGL(k_chol_backsub, dim3(1), dim3(1024), 0, s, d.Uf, d.Winv, d.ych, d.xp, p->dimp);
             } else if (d.n_pt) {
                 hipLaunchKernelGGL(k_schur_points, dim3((d.n_pt + 3) / 4), dim3(256), 0, s, d, par);
             }
