@@ -297,6 +297,7 @@ struct Dev {
     double *Hpl;                    // per edge 6x3
     double *Hdiag;                  // per pose block (hessian index) 6x6
     double *Hoff;                   // per object edge 6x6 (row = key-frame, col = object)
+    double *oe_rec;                 // per object edge: OE_REC doubles (see k_lin_objedges)
     double *bp, *bs, *xp;           // reduced rhs / solution
     double *Hs;                     // dense reduced matrix, ld = dimp
     double *Uf, *Winv, *ych;        // Cholesky: off-diagonal factor blocks, inverse diagonal factors (transposed), L^-1 b
@@ -364,13 +365,13 @@ __global__ __launch_bounds__(256) void k_errors(Dev d, Par par) {
     if (threadIdx.x == 0) d.partial[blockIdx.x] = s;
 }
 
-// sums `n` partials in index order into scal[slot]
-__global__ void k_finish_sum(Dev d, int n, int slot) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        double s = 0;
-        for (int i = 0; i < n; ++i) s += d.partial[i];
-        d.scal[slot] = s;
-    }
+// sums `n` partials in a fixed order into scal[slot]
+__global__ __launch_bounds__(64) void k_finish_sum(Dev d, int n, int slot) {
+    double s = 0;
+    for (int i = threadIdx.x; i < n; i += 64) s += d.partial[i];     // fixed order: lane-strided, then a fixed tree
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (threadIdx.x == 0) d.scal[slot] = s;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -496,67 +497,17 @@ __global__ __launch_bounds__(256) void k_lin_poses(Dev d, Par par) {
         d.kpart[27 * (size_t)sp + threadIdx.x] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
 }
 
-// one 64-thread workgroup per key-frame: ordered sum of its splits + its camera-object edges (vertex 0, Jacobian Ji)
-__global__ __launch_bounds__(64) void k_lin_poses_finish(Dev d, Par par) {
-    const int kf = blockIdx.x;
-    const int h = d.kf_h[kf];
-    if (h < 0) return;
-    __shared__ double acc[27];
-    const int t = threadIdx.x;
-    if (t < 27) {
-        double a = 0;
-        for (int sp = d.ksp_first[kf]; sp < d.ksp_first[kf + 1]; ++sp) a += d.kpart[27 * (size_t)sp + t];
-        acc[t] = a;
-    }
-    __syncthreads();
-    if (t == 0) {
-        double A[21], b[6];
-        for (int i = 0; i < 21; ++i) A[i] = acc[i];
-        for (int i = 0; i < 6; ++i) b[i] = acc[21 + i];
-        for (int q = d.kfo_off[kf]; q < d.kfo_off[kf + 1]; ++q) {
-            const int k = d.kfo_edge[q];
-            if (d.oe_level[k]) continue;
-            double e[6], Zi[7], Ji[36], Jj[36], r0, r1;
-            obj_error(d.kf_pose + 7 * kf, d.obj_pose + 7 * d.oe_obj[k], d.oe_meas + 7 * k, e, Zi);
-            obj_jacobians(e, Zi, Ji, Jj);
-            double c = 0;
-            for (int i = 0; i < 6; ++i) c += e[i] * e[i];
-            c *= d.oe_info;
-            huber(c, par.delta_obj, r0, r1);
-            const double w = r1 * d.oe_info;
-            int tt = 0;
-            for (int i = 0; i < 6; ++i) {
-                double sb = 0;
-                for (int qd = 0; qd < 6; ++qd) sb += Ji[6 * qd + i] * (-d.oe_info * e[qd]) * r1;
-                b[i] += sb;
-                for (int j = i; j < 6; ++j) {
-                    double s = 0;
-                    for (int qd = 0; qd < 6; ++qd) s += Ji[6 * qd + i] * Ji[6 * qd + j];
-                    A[tt++] += w * s;
-                }
-            }
-        }
-        double* Hd = d.Hdiag + 36 * (size_t)h;
-        int tt = 0;
-        for (int i = 0; i < 6; ++i)
-            for (int j = i; j < 6; ++j) { Hd[6 * i + j] = A[tt]; Hd[6 * j + i] = A[tt]; ++tt; }
-        for (int i = 0; i < 6; ++i) d.bp[6 * h + i] = b[i];
-    }
-}
-
-// one 64-thread workgroup per object; lane 0 walks the object's edges in order (few edges per object)
-__global__ void k_lin_objects(Dev d, Par par) {
-    const int ob = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ob >= d.n_obj) return;
-    const int hj = d.obj_h[ob];
-    if (hj < 0) return;
-    double A[36], b[6];
-    for (int i = 0; i < 36; ++i) A[i] = 0;
-    for (int i = 0; i < 6; ++i) b[i] = 0;
-    for (int q = d.obo_off[ob]; q < d.obo_off[ob + 1]; ++q) {
-        const int k = d.obo_edge[q];
-        if (d.oe_level[k]) continue;
-        const int kf = d.oe_kf[k];
+// camera-object edges, one wave per edge: lane 0 evaluates error and Jacobians (ObjectPoseGraph.h:57-89) into LDS, lanes
+// 0..35 form entry (i,j) of w Ji^T Ji, w Jj^T Jj and w Ji^T Jj, lanes 36..47 the two right-hand sides.
+// Record layout (OE_REC doubles per edge): [0,36) key-frame block, [36,72) object block, [72,78) b key-frame, [78,84) b object.
+constexpr int OE_REC = 84;
+__global__ __launch_bounds__(256) void k_lin_objedges(Dev d, Par par) {
+    __shared__ double J[4][80];     // Ji 36 | Jj 36 | -info e r1 (6) | w
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int k = blockIdx.x * 4 + wave;
+    const bool live = k < d.n_oe && !d.oe_level[k];
+    if (live && lane == 0) {
+        const int kf = d.oe_kf[k], ob = d.oe_obj[k];
         double e[6], Zi[7], Ji[36], Jj[36], r0, r1;
         obj_error(d.kf_pose + 7 * kf, d.obj_pose + 7 * ob, d.oe_meas + 7 * k, e, Zi);
         obj_jacobians(e, Zi, Ji, Jj);
@@ -564,37 +515,97 @@ __global__ void k_lin_objects(Dev d, Par par) {
         for (int i = 0; i < 6; ++i) c += e[i] * e[i];
         c *= d.oe_info;
         huber(c, par.delta_obj, r0, r1);
-        const double w = r1 * d.oe_info;
-        for (int i = 0; i < 6; ++i) {
-            double sb = 0;
-            for (int qd = 0; qd < 6; ++qd) sb += Jj[6 * qd + i] * (-d.oe_info * e[qd]) * r1;
-            b[i] += sb;
-            for (int j = 0; j < 6; ++j) {
-                double s = 0, so = 0;
-                for (int qd = 0; qd < 6; ++qd) { s += Jj[6 * qd + i] * Jj[6 * qd + j]; so += Ji[6 * qd + i] * Jj[6 * qd + j]; }
-                A[6 * i + j] += w * s;
-                d.Hoff[36 * (size_t)k + 6 * i + j] = (d.kf_h[kf] >= 0) ? w * so : 0.0;   // Ji^T W Jj at (kf row, obj col)
-            }
-        }
+        for (int i = 0; i < 36; ++i) { J[wave][i] = Ji[i]; J[wave][36 + i] = Jj[i]; }
+        for (int i = 0; i < 6; ++i) J[wave][72 + i] = (-d.oe_info * e[i]);
+        J[wave][78] = r1 * d.oe_info;
+        J[wave][79] = r1;
     }
-    for (int i = 0; i < 36; ++i) d.Hdiag[36 * (size_t)hj + i] = A[i];
-    for (int i = 0; i < 6; ++i) d.bp[6 * hj + i] = b[i];
+    __syncthreads();
+    if (!live) return;
+    const double* Ji = J[wave];
+    const double* Jj = J[wave] + 36;
+    const double w = J[wave][78], r1 = J[wave][79];
+    double* rec = d.oe_rec + (size_t)OE_REC * k;
+    if (lane < 36) {
+        const int i = lane / 6, j = lane % 6;
+        double sii = 0, sjj = 0, sij = 0;
+        for (int q = 0; q < 6; ++q) {
+            sii += Ji[6 * q + i] * Ji[6 * q + j];
+            sjj += Jj[6 * q + i] * Jj[6 * q + j];
+            sij += Ji[6 * q + i] * Jj[6 * q + j];
+        }
+        rec[lane] = w * sii;
+        rec[36 + lane] = w * sjj;
+        d.Hoff[36 * (size_t)k + lane] = (d.kf_h[d.oe_kf[k]] >= 0) ? w * sij : 0.0;   // Ji^T W Jj at (kf row, obj col)
+    } else if (lane < 48) {
+        const int i = (lane - 36) % 6;
+        const double* Jx = (lane < 42) ? Ji : Jj;
+        double sb = 0;
+        for (int q = 0; q < 6; ++q) sb += Jx[6 * q + i] * J[wave][72 + q] * r1;
+        rec[72 + (lane - 36)] = sb;
+    }
+}
+
+// one wave per key-frame: ordered sum of its splits, then of its camera-object edge records (vertex 0 side)
+__global__ __launch_bounds__(64) void k_lin_poses_finish(Dev d, Par par) {
+    const int kf = blockIdx.x;
+    const int h = d.kf_h[kf];
+    if (h < 0) return;
+    const int t = threadIdx.x;
+    if (t >= 42) return;
+    int src, roff;          // index into a split's 27-vector / into an edge record
+    if (t < 36) {
+        const int i = t / 6, j = t % 6, lo = i < j ? i : j, hi = i < j ? j : i;
+        src = lo * 6 - lo * (lo - 1) / 2 + (hi - lo);      // upper-triangle packing of k_lin_poses
+        roff = t;
+    } else {
+        src = 21 + (t - 36);
+        roff = 72 + (t - 36);
+    }
+    double a = 0;
+    for (int sp = d.ksp_first[kf]; sp < d.ksp_first[kf + 1]; ++sp) a += d.kpart[27 * (size_t)sp + src];
+    for (int q = d.kfo_off[kf]; q < d.kfo_off[kf + 1]; ++q) {
+        const int k = d.kfo_edge[q];
+        if (!d.oe_level[k]) a += d.oe_rec[(size_t)OE_REC * k + roff];
+    }
+    if (t < 36) d.Hdiag[36 * (size_t)h + t] = a;
+    else d.bp[6 * h + (t - 36)] = a;
+}
+
+// one wave per object: ordered sum of its edge records (vertex 1 side)
+__global__ __launch_bounds__(64) void k_lin_objects(Dev d, Par par) {
+    const int ob = blockIdx.x;
+    const int hj = d.obj_h[ob];
+    if (hj < 0) return;
+    const int t = threadIdx.x;
+    if (t >= 42) return;
+    const int roff = (t < 36) ? 36 + t : 78 + (t - 36);
+    double a = 0;
+    for (int q = d.obo_off[ob]; q < d.obo_off[ob + 1]; ++q) {
+        const int k = d.obo_edge[q];
+        if (!d.oe_level[k]) a += d.oe_rec[(size_t)OE_REC * k + roff];
+    }
+    if (t < 36) d.Hdiag[36 * (size_t)hj + t] = a;
+    else d.bp[6 * hj + (t - 36)] = a;
 }
 
 // max |diagonal| over all active vertices (computeLambdaInit, optimization_algorithm_levenberg.cpp:166-180)
 __global__ __launch_bounds__(256) void k_maxdiag(Dev d, Par par) {
-    __shared__ double sh[256];
+    // scal[2] is zeroed before the launch; |x| >= 0, so the bit patterns of the doubles order like unsigned integers
+    __shared__ double sh[4];
     double m = 0;
-    for (int i = threadIdx.x; i < par.n_pose * 6; i += 256) m = fmax(m, fabs(d.Hdiag[36 * (size_t)(i / 6) + 7 * (i % 6)]));
-    for (int i = threadIdx.x; i < d.n_pt * 3; i += 256)
+    const int tid = blockIdx.x * 256 + threadIdx.x, nt = gridDim.x * 256;
+    for (int i = tid; i < par.n_pose * 6; i += nt) m = fmax(m, fabs(d.Hdiag[36 * (size_t)(i / 6) + 7 * (i % 6)]));
+    for (int i = tid; i < d.n_pt * 3; i += nt)
         if (d.pt_h[i / 3] >= 0) m = fmax(m, fabs(d.Hll[9 * (size_t)(i / 3) + 4 * (i % 3)]));
-    sh[threadIdx.x] = m;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (threadIdx.x < o) sh[threadIdx.x] = fmax(sh[threadIdx.x], sh[threadIdx.x + o]);
-        __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmax(fmax(sh[0], sh[1]), fmax(sh[2], sh[3]));
+        atomicMax(reinterpret_cast<unsigned long long*>(&d.scal[2]), (unsigned long long)__double_as_longlong(m));
     }
-    if (threadIdx.x == 0) d.scal[2] = sh[0];
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -634,27 +645,62 @@ __device__ inline bool inv3(const double* m, double* o) {
     return true;
 }
 
-// one 64-lane wave per landmark: D^-1 (lane 0), then every (i1 <= i2) pair of its free observing poses with lane q < 36
-// owning entry (q/6, q%6) of the 6x6 update and lanes 36..41 the right-hand side   (block_solver.hpp:381-432)
+// one 64-lane wave per landmark   (block_solver.hpp:381-432).  D^-1 by lane 0; the landmark's hessian indices and
+// 6x3 blocks are staged in LDS (one coalesced pass), then the k*k*36 (pair, entry) items are spread over the lanes so
+// that no lane waits on a dependent global load; landmarks with more than SCH_K observations read from global memory.
+constexpr int SCH_K = 48;
 __global__ __launch_bounds__(256) void k_schur_points(Dev d, Par par) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int pt = blockIdx.x * 4 + wave;
     const bool live = pt < d.n_pt && d.pt_h[pt] >= 0;
     __shared__ double Dsh[4][12];
-    if (live && lane == 0) {
-        double Dm[9], Di[9];
-        for (int i = 0; i < 9; ++i) Dm[i] = d.Hll[9 * (size_t)pt + i];
-        Dm[0] += par.lambda; Dm[4] += par.lambda; Dm[8] += par.lambda;
-        inv3(Dm, Di);
-        const double* bl = d.bl + 3 * (size_t)pt;
-        for (int i = 0; i < 9; ++i) { d.Dinv[9 * (size_t)pt + i] = Di[i]; Dsh[wave][i] = Di[i]; }
-        for (int i = 0; i < 3; ++i) Dsh[wave][9 + i] = Di[3 * i] * bl[0] + Di[3 * i + 1] * bl[1] + Di[3 * i + 2] * bl[2];
+    __shared__ double Bsh[4][SCH_K * 18];
+    __shared__ int hsh[4][SCH_K];
+    const int e0 = live ? d.pt_off[pt] : 0, e1 = live ? d.pt_off[pt + 1] : 0;
+    const int k = e1 - e0;
+    const bool staged = k <= SCH_K;
+    if (live) {
+        if (lane == 0) {
+            double Dm[9], Di[9];
+            for (int i = 0; i < 9; ++i) Dm[i] = d.Hll[9 * (size_t)pt + i];
+            Dm[0] += par.lambda; Dm[4] += par.lambda; Dm[8] += par.lambda;
+            inv3(Dm, Di);
+            const double* bl = d.bl + 3 * (size_t)pt;
+            for (int i = 0; i < 9; ++i) { d.Dinv[9 * (size_t)pt + i] = Di[i]; Dsh[wave][i] = Di[i]; }
+            for (int i = 0; i < 3; ++i) Dsh[wave][9 + i] = Di[3 * i] * bl[0] + Di[3 * i + 1] * bl[1] + Di[3 * i + 2] * bl[2];
+        }
+        if (staged) {
+            for (int a = lane; a < k; a += 64) hsh[wave][a] = d.edge_level[e0 + a] ? -1 : d.kf_h[d.edge[e0 + a].kf];
+            for (int q = lane; q < 18 * k; q += 64) Bsh[wave][q] = d.Hpl[18 * (size_t)e0 + q];
+        }
     }
     __syncthreads();
     if (!live) return;
     const double* Di = Dsh[wave];
     const double* db = Dsh[wave] + 9;
-    const int e0 = d.pt_off[pt], e1 = d.pt_off[pt + 1];
+    if (staged) {
+        for (int q = lane; q < 6 * k; q += 64) {
+            const int a = q / 6, r = q % 6, ha = hsh[wave][a];
+            if (ha < 0) continue;
+            const double* Ba = Bsh[wave] + 18 * a;
+            atomicAdd(&d.bs[6 * ha + r], -(Ba[3 * r] * db[0] + Ba[3 * r + 1] * db[1] + Ba[3 * r + 2] * db[2]));
+        }
+        const int items = k * k * 36;
+        for (int w = lane; w < items; w += 64) {
+            const int en = w % 36, pr = w / 36, a = pr / k, b = pr % k;
+            const int ha = hsh[wave][a], hb = hsh[wave][b];
+            if (ha < 0 || hb < ha || (hb == ha && b != a)) continue;
+            const int i = en / 6, j = en % 6;
+            const double* Ba = Bsh[wave] + 18 * a;
+            const double* Bb = Bsh[wave] + 18 * b;
+            const double bd0 = Ba[3 * i] * Di[0] + Ba[3 * i + 1] * Di[3] + Ba[3 * i + 2] * Di[6];   // row i of B_a D^-1
+            const double bd1 = Ba[3 * i] * Di[1] + Ba[3 * i + 1] * Di[4] + Ba[3 * i + 2] * Di[7];
+            const double bd2 = Ba[3 * i] * Di[2] + Ba[3 * i + 1] * Di[5] + Ba[3 * i + 2] * Di[8];
+            atomicAdd(&d.Hs[(size_t)(6 * ha + i) * par.dimp + 6 * hb + j],
+                      -(bd0 * Bb[3 * j] + bd1 * Bb[3 * j + 1] + bd2 * Bb[3 * j + 2]));
+        }
+        return;
+    }
     const int i = lane / 6, j = lane % 6;      // entry of the 6x6 block (lanes < 36)
     for (int a = e0; a < e1; ++a) {
         if (d.edge_level[a]) continue;
@@ -666,7 +712,7 @@ __global__ __launch_bounds__(256) void k_schur_points(Dev d, Par par) {
             atomicAdd(&d.bs[6 * ha + r], -(Ba[3 * r] * db[0] + Ba[3 * r + 1] * db[1] + Ba[3 * r + 2] * db[2]));
         }
         if (lane < 36) {
-            const double bd0 = Ba[3 * i] * Di[0] + Ba[3 * i + 1] * Di[3] + Ba[3 * i + 2] * Di[6];   // row i of B_a D^-1
+            const double bd0 = Ba[3 * i] * Di[0] + Ba[3 * i + 1] * Di[3] + Ba[3 * i + 2] * Di[6];
             const double bd1 = Ba[3 * i] * Di[1] + Ba[3 * i + 1] * Di[4] + Ba[3 * i + 2] * Di[7];
             const double bd2 = Ba[3 * i] * Di[2] + Ba[3 * i + 1] * Di[5] + Ba[3 * i + 2] * Di[8];
             for (int b = e0; b < e1; ++b) {
@@ -690,9 +736,10 @@ __global__ __launch_bounds__(256) void k_schur_points(Dev d, Par par) {
 //     along (forward substitution comes for free: y_k = W_k b_k, b_j -= P_j^T y_k);
 //   * workgroup (k+1,k+1) goes on to factorise its freshly updated diagonal block in registers -- Gauss steps applied
 //     to [S | I] give L^-1 beside the factor -- so the next launch finds W_{k+1} and y_{k+1} ready.
-// Then one workgroup runs the backward substitution x_k = W_k^T (y_k - sum_j U_kj x_j) as matrix-vector products.
+// The backward substitution x_k = W_k^T (y_k - sum_j U_kj x_j) is nb small launches of matrix-vector products.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int CHOL_LDS_DOUBLES = 3 * NB * NB + 4 * NB + 2 * NB;
+constexpr int CHOL_ROWBUF = 2 * 8 * NB;
+constexpr int CHOL_LDS_DOUBLES = 3 * NB * NB + CHOL_ROWBUF + NB;
 
 // acc[a][b] += sum_m X[m][r0+a] * Y[m][c0+b]   (X, Y: 64x64 row-major in LDS)
 __device__ inline void gemm_tn64(const double* X, const double* Y, int r0, int c0, double (&acc)[4][4]) {
@@ -708,47 +755,76 @@ __device__ inline void gemm_tn64(const double* X, const double* Y, int r0, int c
     }
 }
 
-// In-register factorisation of a 64x64 SPD block spread as 4x4 tiles over 256 threads (thread owns rows r0.., cols c0..).
-// Returns W = L^-1 in the same tiling; S is consumed.  rowbuf: 4*NB doubles of LDS (two buffers of [S row | W row]).
+// 1/sqrt(d): hardware estimate + two Newton steps (full double precision to an ulp or two; keeps the f64 divide and
+// square-root sequences off the factorisation's serial chain)
+__device__ inline double rsqrt_nr(double d) {
+    double r = __builtin_amdgcn_rsq(d);
+    r = r * (1.5 - 0.5 * d * r * r);
+    r = r * (1.5 - 0.5 * d * r * r);
+    return r;
+}
+
+// In-register factorisation of a 64x64 SPD block spread as 4x4 tiles over 256 threads (thread owns rows r0.., cols c0..),
+// four rows per barrier: the 16 threads owning rows 4jb..4jb+3 (16 adjacent lanes of one wave) fetch the diagonal tile by
+// wave shuffle, factor it redundantly, finish their columns of the 4 x 64 panel of U and of W = L^-1 (the same row
+// operations applied to the identity) and publish both; after one barrier everybody below applies a rank-4 update.
+// S is consumed; rowbuf: 2 x 8 x NB doubles of LDS.
 __device__ inline bool factor_tile64(double (&S)[4][4], double (&W)[4][4], double* rowbuf, int r0, int c0) {
     bool bad = false;
+    const int t = threadIdx.x, lane = t & 63;
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) W[a][b] = (r0 + a == c0 + b) ? 1.0 : 0.0;
 #pragma nounroll
-    for (int j = 0; j < NB; ++j) {
-        double* rb = rowbuf + (j & 1) * 2 * NB;
-        const int aj = j - r0;
-        if (aj >= 0 && aj < 4) {
+    for (int jb = 0; jb < NB / 4; ++jb) {
+        double* rb = rowbuf + (jb & 1) * 8 * NB;
+        if ((t >> 4) == jb) {
+            const int src = (lane & 48) | jb;
+            double D[4][4], rs[4];
 #pragma unroll
             for (int a = 0; a < 4; ++a)
-                if (a == aj) {
 #pragma unroll
-                    for (int b = 0; b < 4; ++b) { rb[c0 + b] = S[a][b]; rb[NB + c0 + b] = W[a][b]; }
+                for (int b = a; b < 4; ++b) D[a][b] = __shfl(S[a][b], src, 64);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                double dd = D[q][q];
+                const bool isbad = !(dd > 0) || !isfinite(dd);
+                bad |= isbad;
+                if (isbad) dd = 1.0;
+                rs[q] = rsqrt_nr(dd);
+#pragma unroll
+                for (int b = q + 1; b < 4; ++b) D[q][b] *= rs[q];
+#pragma unroll
+                for (int a = q + 1; a < 4; ++a)
+#pragma unroll
+                    for (int b = a; b < 4; ++b) D[a][b] -= D[q][a] * D[q][b];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    double sv = S[q][b], wv = W[q][b];
+#pragma unroll
+                    for (int pp = 0; pp < q; ++pp) { sv -= D[pp][q] * S[pp][b]; wv -= D[pp][q] * W[pp][b]; }
+                    S[q][b] = sv * rs[q];
+                    W[q][b] = wv * rs[q];
+                    rb[q * NB + c0 + b] = S[q][b];
+                    rb[(4 + q) * NB + c0 + b] = W[q][b];
                 }
         }
         __syncthreads();
-        double dd = rb[j];
-        const bool isbad = !(dd > 0) || !isfinite(dd);
-        bad |= isbad;
-        if (isbad) dd = 1.0;
-        const double inv = 1.0 / dd;
-        double ur[4], uc[4], wc[4];
+        if (r0 > 4 * jb) {
 #pragma unroll
-        for (int a = 0; a < 4; ++a) { ur[a] = (r0 + a > j) ? rb[r0 + a] * inv : 0.0; uc[a] = rb[c0 + a]; wc[a] = rb[NB + c0 + a]; }
+            for (int q = 0; q < 4; ++q) {
+                double ur[4], uc[4], wc[4];
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+                for (int a = 0; a < 4; ++a) { ur[a] = rb[q * NB + r0 + a]; uc[a] = rb[q * NB + c0 + a]; wc[a] = rb[(4 + q) * NB + c0 + a]; }
 #pragma unroll
-            for (int b = 0; b < 4; ++b) { S[a][b] -= ur[a] * uc[b]; W[a][b] -= ur[a] * wc[b]; }
-        if (aj >= 0 && aj < 4) {
-            const double rs = 1.0 / sqrt(dd);
+                for (int a = 0; a < 4; ++a)
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
-                if (a == aj) {
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) W[a][b] *= rs;
-                }
+                    for (int b = 0; b < 4; ++b) { S[a][b] -= ur[a] * uc[b]; W[a][b] -= ur[a] * wc[b]; }
+            }
         }
     }
     return bad;
@@ -782,7 +858,7 @@ __global__ __launch_bounds__(256) void k_chol_first(const double* A, double* Win
     extern __shared__ __attribute__((aligned(16))) double chol_lds[];
     double* X = chol_lds;
     double* rowbuf = chol_lds + 3 * NB * NB;
-    double* bvec = rowbuf + 4 * NB;
+    double* bvec = rowbuf + CHOL_ROWBUF;
     const int t = threadIdx.x, r0 = (t >> 4) * 4, c0 = (t & 15) * 4;
     double S[4][4];
 #pragma unroll
@@ -804,7 +880,7 @@ __global__ __launch_bounds__(256) void k_chol_step(double* A, double* Uf, double
     double* Yi = chol_lds + NB * NB;
     double* Yj = (i == j) ? Yi : chol_lds + 2 * NB * NB;
     double* rowbuf = chol_lds + 3 * NB * NB;
-    double* bvec = rowbuf + 4 * NB;
+    double* bvec = rowbuf + CHOL_ROWBUF;
     const int t = threadIdx.x, r0 = (t >> 4) * 4, c0 = (t & 15) * 4;
     const double* Wg = Winv + (size_t)k * NB * NB;
     for (int e = t; e < NB * NB; e += 256) {
@@ -853,30 +929,46 @@ __global__ __launch_bounds__(256) void k_chol_step(double* A, double* Uf, double
     }
 }
 
-// backward substitution, one workgroup of 16 waves: x_k = W_k^T (y_k - sum_{c >= (k+1) NB} U[k-block rows][c] x[c])
-__global__ __launch_bounds__(1024) void k_chol_backsub(const double* __restrict__ Uf, const double* __restrict__ Winv,
-                                                       const double* __restrict__ y, double* x, int n) {
-    __shared__ double sv[NB];
-    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
-    const int nb = n / NB;
-    for (int k = nb - 1; k >= 0; --k) {
-        for (int r = wave; r < NB; r += 16) {
-            const double* row = Uf + (size_t)(k * NB + r) * n;
-            double s = 0;
-            for (int c = (k + 1) * NB + lane; c < n; c += 64) s += row[c] * x[c];
+// backward substitution, one launch per block step k = nb-1 .. 0 with k workgroups (1 for k = 0): every workgroup forms
+// x_k = W_k^T y_k itself (64x64 matrix-vector product), workgroup m < k then takes U_mk x_k off y_m.
+__global__ __launch_bounds__(256) void k_chol_backstep(const double* __restrict__ Uf, const double* __restrict__ Winv,
+                                                       double* y, double* x, int n, int k) {
+    __shared__ double yk[NB], xk[NB];
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63, m = blockIdx.x;
+    if (t < NB) yk[t] = y[k * NB + t];
+    __syncthreads();
+    const double* WT = Winv + (size_t)k * NB * NB;     // WT[r][q] = W[q][r];  x[r] = sum_q W[q][r] y[q]
+    double v[NB / 4];
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
-            if (lane == 0) sv[r] = y[k * NB + r] - s;
+    for (int q = 0; q < NB / 4; ++q) v[q] = WT[(wave + 4 * q) * NB + lane];          // all 16 loads in flight together
+    if (m < k) {
+        double u[NB / 4];
+#pragma unroll
+        for (int q = 0; q < NB / 4; ++q) u[q] = Uf[(size_t)(m * NB + wave + 4 * q) * n + k * NB + lane];
+#pragma unroll
+        for (int q = 0; q < NB / 4; ++q) {
+            double w = v[q] * yk[lane];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) w += __shfl_xor(w, o, 64);
+            if (lane == 0) xk[wave + 4 * q] = w;
         }
         __syncthreads();
-        const double* WT = Winv + (size_t)k * NB * NB;     // WT[m][q] = W[q][m];  x[m] = sum_q W[q][m] s[q]
-        for (int m = wave; m < NB; m += 16) {
-            double v = WT[m * NB + lane] * sv[lane];
+        if (m == 0 && t < NB) x[k * NB + t] = xk[t];
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-            if (lane == 0) x[k * NB + m] = v;
+        for (int q = 0; q < NB / 4; ++q) {
+            double w = u[q] * xk[lane];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) w += __shfl_xor(w, o, 64);
+            if (lane == 0) y[m * NB + wave + 4 * q] -= w;
         }
-        __syncthreads();
+    } else {   // k == 0: only x_0 is left
+#pragma unroll
+        for (int q = 0; q < NB / 4; ++q) {
+            double w = v[q] * yk[lane];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) w += __shfl_xor(w, o, 64);
+            if (lane == 0) x[k * NB + wave + 4 * q] = w;
+        }
     }
 }
 
@@ -1129,6 +1221,7 @@ extern "C" int qsp_ba_create(const qsp_ba_scene* s, int device, qsp_ba_problem**
     AL(Hpl, 18 * (size_t)d.n_edge);
     AL(Hdiag, 36 * (size_t)(d.n_kf + d.n_obj));
     AL(Hoff, 36 * (size_t)d.n_oe);
+    AL(oe_rec, 84 * (size_t)d.n_oe);
     AL(bp, p->dimp_max); AL(bs, p->dimp_max); AL(xp, p->dimp_max);
     AL(Hs, (size_t)p->dimp_max * p->dimp_max + p->dimp_max);   // + room for bs right behind the matrix
     AL(Uf, (size_t)p->dimp_max * p->dimp_max); AL(Winv, (size_t)p->dimp_max * NB); AL(ych, p->dimp_max);
@@ -1345,12 +1438,17 @@ extern "C" int qsp_ba_optimize(qsp_ba_problem* p, int32_t n_iter, double delta_m
         QSP_HIP(hipMemsetAsync(d.bp, 0, sizeof(double) * std::max(p->dimp, 1), s));
         if (d.n_chunk) hipLaunchKernelGGL(k_lin_points, dim3(d.n_chunk), dim3(256), 0, s, d, par);
         if (d.n_ksplit) hipLaunchKernelGGL(k_lin_poses, dim3(d.n_ksplit), dim3(256), 0, s, d, par);
+        if (d.n_oe) hipLaunchKernelGGL(k_lin_objedges, dim3((d.n_oe + 3) / 4), dim3(256), 0, s, d, par);
         hipLaunchKernelGGL(k_lin_poses_finish, dim3(d.n_kf), dim3(64), 0, s, d, par);
-        if (d.n_obj) hipLaunchKernelGGL(k_lin_objects, dim3((d.n_obj + 63) / 64), dim3(64), 0, s, d, par);
+        if (d.n_obj) hipLaunchKernelGGL(k_lin_objects, dim3(d.n_obj), dim3(64), 0, s, d, par);
         if (p->profiling) hipEventRecord(evB, s);
         int rc = allreduce_gather(p, d.Hdiag, (size_t)36 * p->n_pose, d.bp, (size_t)p->dim, d.scal, 1);   // pose blocks, b_p, chi2
         if (rc) return rc;
-        if (it == 0) hipLaunchKernelGGL(k_maxdiag, dim3(1), dim3(256), 0, s, d, par);
+        if (it == 0) {
+            QSP_HIP(hipMemsetAsync(d.scal + 2, 0, sizeof(double), s));
+            const int gm = std::max(1, std::min(256, (d.n_pt * 3 + p->n_pose * 6 + 255) / 256));
+            hipLaunchKernelGGL(k_maxdiag, dim3(gm), dim3(256), 0, s, d, par);
+        }
         rc = read_scal(p, sc);
         if (rc) return rc;
         if (it == 0 && p->world > 1) {   // max over ranks of the local maxima, as a SUM over one-hot slots
@@ -1395,7 +1493,8 @@ extern "C" int qsp_ba_optimize(qsp_ba_problem* p, int32_t n_iter, double delta_m
                 for (int k = 0; k + 1 < nb; ++k)
                     hipLaunchKernelGGL(k_chol_step, dim3(nb - k - 1, nb - k - 1), dim3(256), lds, s, d.Hs, d.Uf, d.Winv, d.bs,
                                        d.ych, p->dimp, k, d.scal);
-                hipLaunchKernelGGL(k_chol_backsub, dim3(1), dim3(1024), 0, s, d.Uf, d.Winv, d.ych, d.xp, p->dimp);
+                for (int k = nb - 1; k >= 0; --k)
+                    hipLaunchKernelGGL(k_chol_backstep, dim3(k > 0 ? k : 1), dim3(256), 0, s, d.Uf, d.Winv, d.ych, d.xp, p->dimp, k);
             } else if (d.n_pt) {
                 hipLaunchKernelGGL(k_schur_points, dim3((d.n_pt + 3) / 4), dim3(256), 0, s, d, par);
             }
