@@ -155,6 +155,28 @@ int qsp_estimate_pose(qsp_decoder* dec, int32_t n, const float* t_co_se3, const 
                       const float* const* pts, const int32_t* n_pts, const float* code, int32_t n_iter,
                       float* t_co_out);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Mesh extraction: MeshExtractor.extract_mesh_from_code, reconstruct/optimizer.py:284-304
+ * = decode_sdf over the voxel grid of create_voxel_grid (reconstruct/utils.py:98-117) + marching cubes at level 0
+ * (convert_sdf_voxels_to_mesh, reconstruct/utils.py:120-141, skimage.measure.marching_cubes_lewiner there).
+ * Both stages run on the device; only vertices and faces come back.
+ *   voxel_points (dim^3, 3): the grid in the reference's order, point index = i0*dim^2 + i1*dim + i2 (host pointer, copied).
+ *   vertices (V,3) float32 = (index coordinates along axes 0,1,2) * 2/(dim-1) - 1, one vertex per sign-changing grid
+ *   edge at the linear zero crossing, ordered by owning grid point then axis; faces (F,3) int32 ordered by cell, right-hand
+ *   normal towards increasing sdf.  Triangulation rule: csrc/mesh_extract.hpp (not Lewiner's tables: skimage is absent
+ *   from the build image; same vertex set, may differ in ambiguous cells). */
+typedef struct qsp_mesh_extractor qsp_mesh_extractor;
+int qsp_mesh_extractor_create(qsp_decoder* dec, int32_t voxels_dim, const float* voxel_points, qsp_mesh_extractor** out);
+void qsp_mesh_extractor_destroy(qsp_mesh_extractor* m);
+/* decode the volume for `code` (64 floats) and run marching cubes; results stay on the device, counts are returned */
+int qsp_mesh_extract(qsp_mesh_extractor* m, const float* code, int64_t* n_verts, int64_t* n_faces);
+/* marching cubes on a caller-supplied (dim,dim,dim) volume (convert_sdf_voxels_to_mesh alone) */
+int qsp_mesh_from_volume(qsp_mesh_extractor* m, const float* sdf_volume, int64_t* n_verts, int64_t* n_faces);
+/* copy the last result out: verts (n_verts,3), faces (n_faces,3), optionally the (dim^3) volume; any pointer may be NULL */
+int qsp_mesh_fetch(qsp_mesh_extractor* m, float* verts, int32_t* faces, float* sdf_volume);
+/* the generated case table: ntri[256], tri[256][24] cube-edge ids (edge = 4*axis + u + 2v), -1 padded */
+int qsp_mc_tables(int8_t* ntri, int8_t* tri);
+
 /* ===============================================================================================================
  * Path B -- joint bundle adjustment (camera poses, map points, object poses)
  * ============================================================================================================ */

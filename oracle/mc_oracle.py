@@ -1,0 +1,200 @@
+"""TEST INFRASTRUCTURE ONLY -- CPU restatement (numpy) of the mesh-extraction step, the checker for qsp_mesh_extract /
+qsp_mesh_from_volume.  Never imported by the product path.
+
+What it restates: convert_sdf_voxels_to_mesh (reference reconstruct/utils.py:120-141): marching cubes at level 0 on the
+(n,n,n) SDF volume with spacing 2/(n-1), then `+ voxel_grid_origin` (-1,-1,-1) -- vertices are in INDEX coordinates of the
+volume axes (0,1,2), not in the skewed coordinates create_voxel_grid hands to the decoder (utils.py:98-117).
+
+PARITY UNPINNED against the reference's third-party algorithm: the reference calls skimage.measure.marching_cubes_lewiner
+(scikit-image, version unpinned in environment.yml; the function exists in 0.14-0.18), which is not installed in the build
+image and whose 33-case tables are not in /root/reference.  What IS common to every marching-cubes variant, and checked:
+one vertex per sign-changing grid edge at the linear zero crossing.  The triangulation rule restated here is the one
+documented in qsp_slam_amd/csrc/mesh_extract.hpp (face-consistent segments, loops, fans, outward orientation); this file
+derives its case table independently from that description, and tests/test_oracle_mesh.py checks the table for all 256
+cases plus closedness / orientation / volume of whole meshes.
+"""
+import numpy as np
+
+TMAX = 8
+
+
+def _edge_ends(e):
+    a, u, v = e >> 2, e & 1, (e >> 1) & 1
+    others = [x for x in range(3) if x != a]
+    base = (u << others[0]) | (v << others[1])
+    return base, base | (1 << a)
+
+
+_EDGE_OF = {}
+for _e in range(12):
+    _c0, _c1 = _edge_ends(_e)
+    _EDGE_OF[(_c0, _c1)] = _e
+    _EDGE_OF[(_c1, _c0)] = _e
+
+
+def _faces_of(e):
+    c0, c1 = _edge_ends(e)
+    return frozenset((a, sd) for a in range(3) for sd in (0, 1) if ((c0 >> a) & 1) == sd and ((c1 >> a) & 1) == sd)
+
+
+def _corner_pos(c):
+    return np.array([(c >> ax) & 1 for ax in range(3)], float)
+
+
+def case_polygons(case):
+    """Oriented loops of cube-edge ids for one corner-sign configuration (bit c set = corner c inside)."""
+    inside = [(case >> c) & 1 for c in range(8)]
+    adj = {}
+    for a in range(3):
+        b, c = (a + 1) % 3, (a + 2) % 3
+        for side in (0, 1):
+            ring = [(side << a) | (ob << b) | (oc << c) for ob, oc in ((0, 0), (1, 0), (1, 1), (0, 1))]
+            fedge = [_EDGE_OF[(ring[k], ring[(k + 1) % 4])] for k in range(4)]
+            crossing = [k for k in range(4) if inside[ring[k]] != inside[ring[(k + 1) % 4]]]
+            if len(crossing) == 2:
+                pairs = [(fedge[crossing[0]], fedge[crossing[1]])]
+            elif len(crossing) == 4:        # ambiguous face: cut each inside corner off on its own
+                pairs = [(fedge[(k + 3) % 4], fedge[k]) for k in range(4) if inside[ring[k]]]
+            else:
+                pairs = []
+            for x, y in pairs:
+                adj.setdefault(x, []).append(y)
+                adj.setdefault(y, []).append(x)
+    loops, seen = [], set()
+    for start in sorted(adj):
+        if start in seen:
+            continue
+        assert len(adj[start]) == 2
+        loop, prev, cur = [], None, start
+        while True:
+            loop.append(cur)
+            seen.add(cur)
+            n0, n1 = adj[cur]
+            nxt = min(n0, n1) if prev is None else (n1 if n0 == prev else n0)
+            prev, cur = cur, nxt
+            if cur == start:
+                break
+        pts, grad = [], np.zeros(3)
+        for e in loop:
+            c0, c1 = _edge_ends(e)
+            p0, p1 = _corner_pos(c0), _corner_pos(c1)
+            pts.append(0.5 * (p0 + p1))
+            grad += (p1 - p0) if inside[c0] else (p0 - p1)
+        nrm = np.zeros(3)
+        for k in range(len(pts)):
+            p, q = pts[k], pts[(k + 1) % len(pts)]
+            nrm += np.array([(p[1] - q[1]) * (p[2] + q[2]), (p[2] - q[2]) * (p[0] + q[0]), (p[0] - q[0]) * (p[1] + q[1])])
+        s = float(nrm @ grad)
+        assert s != 0
+        if s < 0:
+            loop = [loop[0]] + loop[:0:-1]
+        # rotate to the fan apex: first vertex whose fan diagonals never join two edges of one cube face
+        m = len(loop)
+        for s0 in range(m):
+            if not any(_faces_of(loop[s0]) & _faces_of(loop[(s0 + k) % m]) for k in range(2, m - 1)):
+                loop = loop[s0:] + loop[:s0]
+                break
+        else:
+            raise AssertionError("no admissible fan for case %d" % case)
+        loops.append(loop)
+    return loops
+
+
+def build_tables():
+    ntri = np.zeros(256, np.int8)
+    tri = -np.ones((256, TMAX * 3), np.int8)
+    for case in range(256):
+        k = 0
+        for loop in case_polygons(case):
+            for j in range(1, len(loop) - 1):
+                tri[case, 3 * k:3 * k + 3] = (loop[0], loop[j], loop[j + 1])
+                k += 1
+        ntri[case] = k
+    return ntri, tri
+
+
+_TABLES = None
+
+
+def tables():
+    global _TABLES
+    if _TABLES is None:
+        _TABLES = build_tables()
+    return _TABLES
+
+
+def marching_cubes(volume):
+    """volume (d,d,d) float32 -> verts (V,3) float32, faces (F,3) int32 in the device kernel's order:
+    vertices by owning grid point (C order) then axis; faces by cell (C order of the lowest corner) then table order."""
+    vol = np.ascontiguousarray(volume, np.float32)
+    d = vol.shape[0]
+    assert vol.shape == (d, d, d)
+    n = d ** 3
+    inside = vol < 0
+    flag = np.zeros((3, d, d, d), bool)
+    flag[0, :-1] = inside[:-1] != inside[1:]
+    flag[1, :, :-1] = inside[:, :-1] != inside[:, 1:]
+    flag[2, :, :, :-1] = inside[:, :, :-1] != inside[:, :, 1:]
+    fl = flag.reshape(3, n)
+    cnt = fl.sum(0)
+    off = np.concatenate([[0], np.cumsum(cnt)[:-1]]).astype(np.int64)
+    rank = np.stack([np.zeros(n, np.int64), fl[0].astype(np.int64), fl[0].astype(np.int64) + fl[1]])
+    vid = off[None, :] + rank                                # vertex id of edge (axis, point) where flagged
+    stride = (d * d, d, 1)
+    flat = vol.reshape(-1)
+    # vertices: point-major, axis-minor
+    pa = np.argwhere(fl.T)                                    # rows (point, axis) sorted by point then axis
+    p, a = pa[:, 0], pa[:, 1]
+    v0 = flat[p]
+    v1 = flat[p + np.array(stride)[a]]
+    t = (v0 / (v0 - v1)).astype(np.float32)
+    idx = np.stack([p // (d * d), (p // d) % d, p % d], 1).astype(np.float32)
+    idx[np.arange(len(p)), a] = idx[np.arange(len(p)), a] + t
+    vs = np.float32(2.0 / (d - 1))
+    verts = (idx * vs).astype(np.float32) + np.float32(-1.0)
+    # faces
+    ntri, tri = tables()
+    case = np.zeros((d - 1, d - 1, d - 1), np.int64)
+    for c in range(8):
+        o = [(c >> ax) & 1 for ax in range(3)]
+        case |= inside[o[0]:d - 1 + o[0], o[1]:d - 1 + o[1], o[2]:d - 1 + o[2]].astype(np.int64) << c
+    i0, i1, i2 = np.meshgrid(np.arange(d - 1), np.arange(d - 1), np.arange(d - 1), indexing="ij")
+    cell_p = (i0 * d * d + i1 * d + i2).reshape(-1)
+    case = case.reshape(-1)
+    nt = ntri[case].astype(np.int64)
+    act = nt > 0
+    cell_p, case, nt = cell_p[act], case[act], nt[act]
+    faces = np.zeros((len(cell_p), TMAX, 3), np.int64)
+    for k in range(TMAX * 3):
+        e = tri[case, k].astype(np.int64)
+        valid = e >= 0
+        e = np.where(valid, e, 0)
+        ax, u, v = e >> 2, e & 1, (e >> 1) & 1
+        o = np.zeros((len(e), 3), np.int64)
+        oth = np.array([[1, 2], [0, 2], [0, 1]])[ax]
+        o[np.arange(len(e)), oth[:, 0]] = u
+        o[np.arange(len(e)), oth[:, 1]] = v
+        q = cell_p + o[:, 0] * d * d + o[:, 1] * d + o[:, 2]
+        faces[:, k // 3, k % 3] = np.where(valid, vid[ax, q], -1)
+    keep = np.arange(TMAX)[None, :] < nt[:, None]
+    return verts, faces[keep].astype(np.int32)
+
+
+# ---- mesh checks shared by the tests ---------------------------------------------------------------------------------
+def directed_edge_defects(faces):
+    """(#directed edges used more than once, #directed edges without their reverse)"""
+    f = np.asarray(faces, np.int64)
+    e = np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]])
+    m = int(f.max()) + 1 if len(f) else 1
+    key = e[:, 0] * m + e[:, 1]
+    rkey = e[:, 1] * m + e[:, 0]
+    uniq, counts = np.unique(key, return_counts=True)
+    dup = int((counts > 1).sum())
+    missing = int((~np.isin(rkey, uniq)).sum())
+    return dup, missing
+
+
+def signed_volume(verts, faces):
+    v = np.asarray(verts, np.float64)
+    a, b, c = v[faces[:, 0]], v[faces[:, 1]], v[faces[:, 2]]
+    return float(np.einsum("ij,ij->i", a, np.cross(b, c)).sum() / 6.0)

@@ -78,6 +78,8 @@ SYMBOLS = [
     "qsp_refine_batch_create", "qsp_refine_batch_destroy", "qsp_refine_batch_set_state", "qsp_refine_batch_run",
     "qsp_refine_batch_get", "qsp_refine_batch_trace", "qsp_refine_batch_profile", "qsp_refine_batch_rows",
     "qsp_reconstruct_objects", "qsp_estimate_pose",
+    "qsp_mesh_extractor_create", "qsp_mesh_extractor_destroy", "qsp_mesh_extract", "qsp_mesh_from_volume", "qsp_mesh_fetch",
+    "qsp_mc_tables",
     "qsp_ba_create", "qsp_ba_destroy", "qsp_ba_set_levels", "qsp_ba_optimize", "qsp_ba_local_joint",
     "qsp_ba_set_state", "qsp_ba_get_state", "qsp_ba_get_edges", "qsp_ba_get_index", "qsp_ba_profile", "qsp_ba_set_shard",
 ]
@@ -117,6 +119,13 @@ def lib():
                                           c_float_p, c_uint8_p]
     L.qsp_estimate_pose.argtypes = [vp, C.c_int32, c_float_p, c_float_p, pp_f, c_int32_p, c_float_p, C.c_int32,
                                     c_float_p]
+    L.qsp_mesh_extractor_create.argtypes = [vp, C.c_int32, c_float_p, C.POINTER(vp)]
+    L.qsp_mesh_extractor_destroy.argtypes = [vp]
+    L.qsp_mesh_extractor_destroy.restype = None
+    L.qsp_mesh_extract.argtypes = [vp, c_float_p, c_int64_p, c_int64_p]
+    L.qsp_mesh_from_volume.argtypes = [vp, c_float_p, c_int64_p, c_int64_p]
+    L.qsp_mesh_fetch.argtypes = [vp, c_float_p, c_int32_p, c_float_p]
+    L.qsp_mc_tables.argtypes = [C.POINTER(C.c_int8), C.POINTER(C.c_int8)]
     L.qsp_ba_create.argtypes = [C.POINTER(BaScene), C.c_int, C.POINTER(vp)]
     L.qsp_ba_destroy.argtypes = [vp]
     L.qsp_ba_destroy.restype = None

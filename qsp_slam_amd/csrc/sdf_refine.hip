@@ -1395,3 +1395,5 @@ extern "C" int qsp_estimate_pose(qsp_decoder* dec, int32_t n, const float* t_co_
     qsp_refine_batch_destroy(b);
     return rc;
 }
+
+#include "mesh_extract.hpp"

@@ -215,30 +215,58 @@ def create_voxel_grid(vol_dim=128):
 
 
 class MeshExtractor(object):
-    """reconstruct/optimizer.py:284-304.  The SDF grid is decoded on the GPU; marching cubes stays with the caller's
-    implementation (skimage in the reference, reconstruct/utils.py:120-141) and is out of scope of this round --
-    `extract_sdf_grid` returns the (dim,dim,dim) tensor the reference hands to convert_sdf_voxels_to_mesh."""
+    """reconstruct/optimizer.py:284-304.  The SDF volume over create_voxel_grid(voxels_dim) is decoded and triangulated on
+    the GPU (qsp_mesh_extract: MLP tile kernel + marching cubes, include/qsp_hip.h); only vertices (V,3) float32 and faces
+    (F,3) int32 come back, as in the reference's result object."""
 
     def __init__(self, decoder, code_len=64, voxels_dim=64):
         self.decoder = decoder
         self.code_len = code_len
         self.voxels_dim = voxels_dim
         self.voxel_points = create_voxel_grid(vol_dim=self.voxels_dim)
+        self.handle = C.c_void_p()
+        pts = _lib.f32c(self.voxel_points)
+        _lib.check(_lib.lib().qsp_mesh_extractor_create(decoder.handle, voxels_dim, _lib.fptr(pts), C.byref(self.handle)))
+
+    def __del__(self):
+        h = getattr(self, "handle", None)
+        if h is not None and h.value:
+            _lib.lib().qsp_mesh_extractor_destroy(h)
+            self.handle = C.c_void_p()
+
+    def _fetch(self, nv, nf, volume=False):
+        verts = np.empty((nv.value, 3), np.float32)
+        faces = np.empty((nf.value, 3), np.int32)
+        vol = np.empty((self.voxels_dim,) * 3, np.float32) if volume else None
+        _lib.check(_lib.lib().qsp_mesh_fetch(self.handle, _lib.fptr(verts), _lib.i32ptr(faces),
+                                             _lib.fptr(vol) if volume else None))
+        return verts, faces, vol
 
     def extract_sdf_grid(self, code):
+        """(dim,dim,dim) SDF volume the reference hands to convert_sdf_voxels_to_mesh (optimizer.py:296-297)."""
         sdf = self.decoder.decode_sdf(np.asarray(code, np.float32)[: self.code_len], self.voxel_points)
         return sdf.reshape(self.voxels_dim, self.voxels_dim, self.voxels_dim)
 
-    def extract_mesh_from_code(self, code):
+    def mesh_from_volume(self, sdf_volume):
+        """convert_sdf_voxels_to_mesh (reconstruct/utils.py:120-141) on a given (dim,dim,dim) volume."""
+        vol = _lib.f32c(np.asarray(sdf_volume, np.float32).reshape(-1))
+        if vol.size != self.voxels_dim ** 3:
+            raise ValueError("volume must be (%d,)*3" % self.voxels_dim)
+        nv, nf = C.c_int64(), C.c_int64()
+        _lib.check(_lib.lib().qsp_mesh_from_volume(self.handle, _lib.fptr(vol), C.byref(nv), C.byref(nf)))
+        verts, faces, _ = self._fetch(nv, nf)
+        return verts, faces
+
+    def extract_mesh_from_code(self, code, return_volume=False):
         start = time.time()
-        grid = self.extract_sdf_grid(code)
-        try:
-            import skimage.measure as measure
-        except ImportError:
-            raise NotImplementedError("marching cubes needs skimage (as in the reference); extract_sdf_grid() returns "
-                                      "the decoded SDF volume")
-        voxel_size = 2.0 / (self.voxels_dim - 1)
-        verts, faces, _, _ = measure.marching_cubes(grid, level=0.0, spacing=[voxel_size] * 3)
-        verts = verts + np.array([-1.0, -1.0, -1.0])
+        code = _lib.f32c(np.asarray(code, np.float32)[: self.code_len])
+        if code.size < 64:
+            code = np.concatenate([code, np.zeros(64 - code.size, np.float32)])
+        nv, nf = C.c_int64(), C.c_int64()
+        _lib.check(_lib.lib().qsp_mesh_extract(self.handle, _lib.fptr(code), C.byref(nv), C.byref(nf)))
+        verts, faces, vol = self._fetch(nv, nf, return_volume)
         print("Extract mesh takes %f seconds" % (time.time() - start))
-        return ForceKeyErrorDict(vertices=verts.astype("float32"), faces=faces.astype("int32"))
+        out = ForceKeyErrorDict(vertices=verts, faces=faces)
+        if return_volume:
+            out["sdf_volume"] = vol
+        return out

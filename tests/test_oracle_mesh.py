@@ -1,0 +1,118 @@
+"""CPU tests of the mesh-extraction oracle (oracle/mc_oracle.py) and of the library's generated case table.
+The reference step: convert_sdf_voxels_to_mesh, reconstruct/utils.py:120-141 (skimage absent -> properties, see the
+oracle's header)."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import mc_oracle as mo  # noqa: E402
+
+
+def sphere_volume(d, r=0.5, c=(0.05, -0.1, 0.02)):
+    g = np.linspace(-1, 1, d, dtype=np.float32)
+    x, y, z = np.meshgrid(g, g, g, indexing="ij")
+    return (np.sqrt((x - c[0]) ** 2 + (y - c[1]) ** 2 + (z - c[2]) ** 2) - r).astype(np.float32)
+
+
+def noise_volume(d, seed):
+    v = np.random.default_rng(seed).standard_normal((d, d, d)).astype(np.float32)
+    v[0], v[-1], v[:, 0], v[:, -1], v[:, :, 0], v[:, :, -1] = 1, 1, 1, 1, 1, 1      # keep the surface closed
+    return v
+
+
+def test_table_all_cases():
+    ntri, tri = mo.tables()
+    assert ntri[0] == 0 and ntri[255] == 0 and ntri.max() <= 5
+    for case in range(256):
+        crossed = set()
+        for e in range(12):
+            c0, c1 = mo._edge_ends(e)
+            if ((case >> c0) & 1) != ((case >> c1) & 1):
+                crossed.add(e)
+        used = set(int(x) for x in tri[case, :3 * ntri[case]])
+        assert used == crossed, case                         # every crossing is a mesh vertex and nothing else is
+        loops = mo.case_polygons(case)
+        assert sum(len(l) for l in loops) == len(crossed)    # loops partition the crossings
+        assert sum(len(l) - 2 for l in loops) == ntri[case]
+        # the complement crosses the same edges (its loops may differ: ambiguous faces cut off INSIDE corners)
+        assert set(e for l in mo.case_polygons(255 - case) for e in l) == crossed
+
+
+def test_library_table_matches_oracle():
+    from qsp_slam_amd import _lib
+    L = _lib.lib()
+    nt = np.zeros(256, np.int8)
+    tri = np.zeros((256, 24), np.int8)
+    assert L.qsp_mc_tables(nt.ctypes.data_as(C.POINTER(C.c_int8)), tri.ctypes.data_as(C.POINTER(C.c_int8))) == 0
+    ont, otri = mo.tables()
+    assert np.array_equal(nt, ont) and np.array_equal(tri, otri)
+
+
+@pytest.mark.parametrize("d", [16, 32])
+def test_sphere_mesh(d):
+    vol = sphere_volume(d)
+    v, f = mo.marching_cubes(vol)
+    inside = vol < 0
+    n_cross = sum(int((np.take(inside, range(d - 1), ax) != np.take(inside, range(1, d), ax)).sum()) for ax in range(3))
+    assert len(v) == n_cross and v.dtype == np.float32 and f.dtype == np.int32
+    assert mo.directed_edge_defects(f) == (0, 0)             # closed, consistently oriented
+    E = 3 * len(f) // 2
+    assert len(v) - E + len(f) == 2                           # a sphere
+    vol_mesh = mo.signed_volume(v, f)
+    assert vol_mesh > 0                                       # outward normals
+    assert abs(vol_mesh - 4 / 3 * np.pi * 0.5 ** 3) < 0.03 * (32 / d) ** 2
+    r = np.linalg.norm(v - np.array([0.05, -0.1, 0.02], np.float32), axis=1)
+    assert np.abs(r - 0.5).max() < (2.0 / (d - 1)) ** 2       # linear interpolation of a smooth field
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_noise_volume_is_closed_and_oriented(seed):
+    # white noise exercises every ambiguous configuration; the surface must stay edge-manifold and oriented
+    vol = noise_volume(12, seed)
+    v, f = mo.marching_cubes(vol)
+    assert len(f) > 1000
+    assert mo.directed_edge_defects(f) == (0, 0)
+    cases = set()
+    ins = vol < 0
+    d = vol.shape[0]
+    cs = np.zeros((d - 1,) * 3, int)
+    for c in range(8):
+        o = [(c >> a) & 1 for a in range(3)]
+        cs |= ins[o[0]:d - 1 + o[0], o[1]:d - 1 + o[1], o[2]:d - 1 + o[2]].astype(int) << c
+    cases.update(cs.reshape(-1).tolist())
+    assert len(cases) > 200                                   # nearly all 256 configurations occur
+    # enclosed volume = volume of the inside region up to discretisation: positive and bounded by the box
+    assert 0 < mo.signed_volume(v, f) < 8.0
+
+
+def test_vertices_lie_on_their_grid_edges():
+    d = 10
+    vol = noise_volume(d, 5)
+    v, f = mo.marching_cubes(vol)
+    g = (v + 1.0) / np.float32(2.0 / (d - 1))                  # back to index coordinates
+    frac = np.abs(g - np.round(g))
+    assert ((frac > 1e-4).sum(1) <= 1).all()                  # at most one non-integer coordinate
+    assert g.min() >= 0 and g.max() <= d - 1
+
+
+def test_empty_and_full_volumes():
+    for val in (1.0, -1.0):
+        v, f = mo.marching_cubes(np.full((8, 8, 8), val, np.float32))
+        assert v.shape == (0, 3) and f.shape == (0, 3)
+
+
+def test_zero_is_outside():
+    vol = np.ones((4, 4, 4), np.float32)
+    vol[1, 1, 1] = -1.0
+    vol[2, 1, 1] = 0.0                                        # exact zero: outside, crossing at the zero itself
+    v, f = mo.marching_cubes(vol)
+    assert len(v) == 6 and len(f) == 8                        # an octahedron around the single inside sample
+    assert mo.directed_edge_defects(f) == (0, 0)
+    d = 4
+    hit = np.isclose(v, np.array([2, 1, 1], np.float32) * np.float32(2.0 / (d - 1)) - 1).all(1)
+    assert hit.sum() == 1
