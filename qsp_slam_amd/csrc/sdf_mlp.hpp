@@ -32,7 +32,22 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #ifndef QSP_EXP_VARIANT
 #define QSP_EXP_VARIANT 0   // timing experiments only (tools/exp_variants.sh): bit 0 = no weight loads in the k-loop,
-#endif                      // bit 1 = no LDS operand reads in the k-loop.  Non-zero variants compute garbage.
+#endif                      // bit 1 = no LDS operand reads in the k-loop (bits 0-3 compute garbage); bit 4 (16) = correct
+                            // results + shader-clock stamps at every phase boundary of a tile (tools/phase_times.py)
+#if (QSP_EXP_VARIANT & 16)
+// wave 0 of workgroup (0,0) stamps the shader clock (and the constant 100 MHz counter) at every phase boundary of a tile
+__device__ unsigned long long qsp_dbg_ts[96];
+__device__ unsigned long long qsp_dbg_rt[96];
+__device__ int qsp_dbg_n;
+#define QSP_TS()                                                                        \
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && ts_n < 96) {          \
+        qsp_dbg_rt[ts_n] = __builtin_amdgcn_s_memrealtime();                            \
+        qsp_dbg_ts[ts_n++] = __builtin_readcyclecounter();                              \
+        qsp_dbg_n = ts_n;                                                               \
+    }
+#else
+#define QSP_TS()
+#endif
 
 constexpr int TILE_P = 64;      // points per tile
 constexpr int HID = 512;        // hidden width
@@ -343,6 +358,9 @@ constexpr int LDG = 72;
 template <bool BWD, int PF>
 __device__ __forceinline__ void mlp_tile(MlpSmem& s, const MlpParams* __restrict__ Pm) {
     const int tid = threadIdx.x;
+    int ts_n = 0;
+    (void)ts_n;
+    QSP_TS()
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     // The parameter table is read through an index the compiler cannot see through, once per tile: otherwise every
@@ -367,7 +385,9 @@ __device__ __forceinline__ void mlp_tile(MlpSmem& s, const MlpParams* __restrict
             s.act[row * LDA + c] = v;
         }
     }
+    QSP_TS()
     __syncthreads();
+    QSP_TS()
 
     const int cb0 = 2 * wave;   // this wave's first column block
     constexpr int KG0 = K0_PAD / 8, KGH = HID / 8;
@@ -387,36 +407,54 @@ __device__ __forceinline__ void mlp_tile(MlpSmem& s, const MlpParams* __restrict
     zero_acc(acc);
     BiasQuads bq;
     gemm_2x2<KG0, PF, true>(s.act, QSP_WF(0), QSP_WF1(0), QSP_WF(1), QSP_WF1(1), ring, acc, lane, P.bias[0] + 64 * wave, bq);
+    QSP_TS()
     __syncthreads();
+    QSP_TS()
     fwd_writeout<0>(s, bq, acc, wave, lane, mlo[0], mhi[0]);
+    QSP_TS()
     __syncthreads();
+    QSP_TS()
 
     // ---- layers 1..7 (K = 512) ---------------------------------------------------------------------------------
 #define QSP_FWD_LAYER(L)                                                                                      \
     zero_acc(acc);                                                                                            \
     gemm_2x2<KGH, PF, true>(s.act, QSP_WF(L), QSP_WF1(L), QSP_WF((L) + 1), QSP_WF1((L) + 1), ring, acc, lane,  \
                             P.bias[L] + 64 * wave, bq);                                                       \
+    QSP_TS()                                                                                                  \
     __syncthreads();                                                                                          \
+    QSP_TS()                                                                                                  \
     fwd_writeout<L>(s, bq, acc, wave, lane, mlo[L], mhi[L]);                                                  \
-    __syncthreads();
+    QSP_TS()                                                                                                  \
+    __syncthreads();                                                                                          \
+    QSP_TS()
     QSP_FWD_LAYER(1)
     QSP_FWD_LAYER(2)
     zero_acc(acc);
     gemm_2x2<KGH, PF, true>(s.act, QSP_WF(3), QSP_WF1(3), QSP_WF(4), QSP_WF1(4), ring, acc, lane, P.bias[3] + 64 * wave, bq);
+    QSP_TS()
     __syncthreads();
+    QSP_TS()
     fwd_writeout<3>(s, bq, acc, wave, lane, mlo[3], mhi[3]);
+    QSP_TS()
     __syncthreads();
+    QSP_TS()
     pass_through(s);
+    QSP_TS()
     __syncthreads();
+    QSP_TS()
     QSP_FWD_LAYER(4)
     QSP_FWD_LAYER(5)
     QSP_FWD_LAYER(6)
     zero_acc(acc);
     if (BWD) gemm_2x2<KGH, PF, true>(s.act, QSP_WF(7), QSP_WF1(7), QSP_WB(7), QSP_WB1(7), ring, acc, lane, P.bias[7] + 64 * wave, bq);
     else gemm_2x2<KGH, PF, true>(s.act, QSP_WF(7), QSP_WF1(7), QSP_WF(0), QSP_WF1(0), ring, acc, lane, P.bias[7] + 64 * wave, bq);
+    QSP_TS()
     __syncthreads();
+    QSP_TS()
     fwd_writeout<7>(s, bq, acc, wave, lane, mlo[7], mhi[7]);
+    QSP_TS()
     __syncthreads();
+    QSP_TS()
 #undef QSP_FWD_LAYER
 
     // ---- layer 8: 512 -> 1, tanh ---------------------------------------------------------------------------------
@@ -436,14 +474,18 @@ __device__ __forceinline__ void mlp_tile(MlpSmem& s, const MlpParams* __restrict
         }
         s.red[wave * TILE_P + lane] = part;
     }
+    QSP_TS()
     __syncthreads();
+    QSP_TS()
     if (tid < TILE_P) {
         float t = P.b8;
 #pragma unroll
         for (int q = 0; q < 8; ++q) t += s.red[q * TILE_P + tid];
         s.y[tid] = tanhf(t);
     }
+    QSP_TS()
     __syncthreads();
+    QSP_TS()
     if (!BWD) return;
 
     // ---- backward seed: d y / d a7 = (1 - y^2) * w8[unit] * [a7 > 0] ---------------------------------------------
@@ -467,22 +509,30 @@ __device__ __forceinline__ void mlp_tile(MlpSmem& s, const MlpParams* __restrict
                 }
         }
     }
+    QSP_TS()
     __syncthreads();
+    QSP_TS()
 
     // ---- backward through layers 7..1: g_in = g_a . W_L, masked by layer L-1 ------------------------------------
 #define QSP_BWD_LAYER(L)                                                                                      \
     zero_acc(acc);                                                                                            \
     gemm_2x2<KGH, PF, false>(s.act, QSP_WB(L), QSP_WB1(L), (L) > 1 ? QSP_WB((L) - 1) : wb0,                   \
                              (L) > 1 ? QSP_WB1((L) - 1) : wb0, ring, acc, lane, nullptr, bq);                 \
+    QSP_TS()                                                                                                  \
     __syncthreads();                                                                                          \
+    QSP_TS()                                                                                                  \
     bwd_writeout<L>(s, acc, wave, lane, mlo[L - 1], mhi[L - 1]);                                              \
-    __syncthreads();
+    QSP_TS()                                                                                                  \
+    __syncthreads();                                                                                          \
+    QSP_TS()
     QSP_BWD_LAYER(7)
     QSP_BWD_LAYER(6)
     QSP_BWD_LAYER(5)
     QSP_BWD_LAYER(4)
     stash_extract(s);
+    QSP_TS()
     __syncthreads();
+    QSP_TS()
     QSP_BWD_LAYER(3)
     QSP_BWD_LAYER(2)
     QSP_BWD_LAYER(1)
@@ -497,7 +547,9 @@ __device__ __forceinline__ void mlp_tile(MlpSmem& s, const MlpParams* __restrict
 #undef QSP_WF1
 #undef QSP_WB
 #undef QSP_WB1
+    QSP_TS()
     __syncthreads();
+    QSP_TS()
     if (wave < 6) {
         // D[i = input column within block c0][j = point]: four consecutive input columns per register quad
         const int p = 32 * r0 + (lane & 31);
@@ -513,7 +565,9 @@ __device__ __forceinline__ void mlp_tile(MlpSmem& s, const MlpParams* __restrict
             }
         }
     }
+    QSP_TS()
     __syncthreads();
+    QSP_TS()
 }
 
 }  // namespace qsp

@@ -1396,4 +1396,15 @@ extern "C" int qsp_estimate_pose(qsp_decoder* dec, int32_t n, const float* t_co_
     return rc;
 }
 
+#if (QSP_EXP_VARIANT & 16)
+// timing experiment only (tools/phase_times.py): the stamps of the last launch
+extern "C" int qsp_debug_timestamps(unsigned long long* out /*96*/, int* n, unsigned long long* rt /*96*/) {
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(qsp::qsp_dbg_ts), sizeof(unsigned long long) * 96);
+    if (rt) hipMemcpyFromSymbol(rt, HIP_SYMBOL(qsp::qsp_dbg_rt), sizeof(unsigned long long) * 96);
+    hipMemcpyFromSymbol(n, HIP_SYMBOL(qsp::qsp_dbg_n), sizeof(int));
+    return 0;
+}
+#endif
+
 #include "mesh_extract.hpp"
