@@ -63,11 +63,13 @@ constexpr int MLP_THREADS = 512;
 constexpr int HT_TILES = 6;     // upper-triangular 32x32 tiles of the 96x96 padded J~^T J~
 
 struct MlpParams {
-    const float4* wf[8];    // forward-packed weights of layers 0..7
+    const float4* wf[8];    // forward-packed weights of layers 1..7 (wf[0] unused: layer 0 is evaluated directly)
     const float4* wb[8];    // backward-packed weights of layers 0..7
     const float* bias[8];   // [512] zero-padded
     const float* w8;        // [512] last layer row
     float b8;
+    const float* w0c;       // [512][64] layer-0 weights of the latent code (row-major)
+    const float4* w0x;      // [128 unit quads][3] layer-0 weights of x, y, z for four consecutive units
 };
 
 // LDS carve (bytes): act 132096 | stash 17408 | inp 64*4*4 | code 256 | y 256 | red 2048 | row scale/res 512
@@ -76,6 +78,7 @@ struct __attribute__((aligned(16))) MlpSmem {
     float stash[TILE_P * LDST];
     float xin[TILE_P * 4];      // object-frame xyz per row (4th = 0)
     float code[CODE_LEN];
+    float c0[HID];              // layer-0 pre-activation without the xyz part: b0 + W0[:, :64] code (mlp_prepare)
     float y[TILE_P];            // tanh output
     float red[8 * TILE_P];      // layer-8 partial sums
     float rscale[TILE_P];       // row scale of the Jacobian (1 for SDF rows, de/ds for render rows, 0 for padding)
@@ -350,6 +353,18 @@ __device__ __forceinline__ void stash_extract(MlpSmem& s) {
     }
 }
 
+// Once per workgroup, after s.code is written (all threads): the code part of layer 0 is the same for every point,
+// c0[u] = b0[u] + sum_k W0[u][k] code[k].  The caller's next barrier (top of its tile loop) publishes c0.
+__device__ __forceinline__ void mlp_prepare(MlpSmem& s, const MlpParams* __restrict__ Pm) {
+    __syncthreads();
+    const int u = threadIdx.x;
+    const float* w = Pm->w0c + (size_t)u * CODE_LEN;
+    float a = Pm->bias[0][u];
+#pragma unroll 8
+    for (int k = 0; k < CODE_LEN; ++k) a += w[k] * s.code[k];
+    s.c0[u] = a;
+}
+
 // Whole network for the tile whose inputs are staged in s.code / s.xin.
 // On return (all threads, after a barrier):
 //   s.y[row]                         = sdf value
@@ -371,46 +386,61 @@ __device__ __forceinline__ void mlp_tile(MlpSmem& s, const MlpParams* __restrict
     uint32_t mlo[8], mhi[8];
     f32x16 acc[2][2];
 
-    // ---- stage the layer-0 input: [code(64) | xyz(3) | 0 pad] into act[:, 0:96) -------------------------------
-    // (and the last layer's row: read from LDS later so that no vector-memory wait has to drain the weight ring)
+    // the last layer's row is read from LDS later so that no vector-memory wait has to drain the weight ring
     s.w8[tid] = P.w8[tid];
-    {
-        const int row = tid >> 3, sub = tid & 7;
-#pragma unroll
-        for (int q = 0; q < 12; ++q) {
-            const int c = sub * 12 + q;
-            float v = 0.f;
-            if (c < CODE_LEN) v = s.code[c];
-            else if (c < NIN) v = s.xin[row * 4 + (c - CODE_LEN)];
-            s.act[row * LDA + c] = v;
-        }
-    }
-    QSP_TS()
-    __syncthreads();
-    QSP_TS()
 
     const int cb0 = 2 * wave;   // this wave's first column block
-    constexpr int KG0 = K0_PAD / 8, KGH = HID / 8;
+    constexpr int KGH = HID / 8;
     // column-block bases of this wave in every packed matrix
-#define QSP_WF(L) (P.wf[L] + (cb0 * ((L) == 0 ? KG0 : KGH)) * 64)
-#define QSP_WF1(L) (P.wf[L] + ((cb0 + 1) * ((L) == 0 ? KG0 : KGH)) * 64)
+#define QSP_WF(L) (P.wf[L] + (cb0 * KGH) * 64)
+#define QSP_WF1(L) (P.wf[L] + ((cb0 + 1) * KGH) * 64)
 #define QSP_WB(L) (P.wb[L] + (cb0 * KGH) * 64)
 #define QSP_WB1(L) (P.wb[L] + ((cb0 + 1) * KGH) * 64)
     // layer-0 backward: waves 0..5 own one of 3 column blocks; the others prefetch block 0 (never used)
     const int r0 = wave / 3, c0 = wave % 3;
     const float4* wb0 = P.wb[0] + ((wave < 6 ? c0 : 0) * KGH) * 64;
 
-    // ---- layer 0 (K = 96) --------------------------------------------------------------------------------------
-    static_assert(PF == 4, "the ring depth is shared by all layers; layer 0 has only 12 k-groups");
+    // ---- layer 0: a0 = relu(c0 + W0[:, 64:67] xyz), written in the MFMA write-out's lane/register pattern ------------
+    // The 64 code columns of layer 0 are the same for every point of the workgroup: folded into c0 by mlp_prepare().
+    static_assert(PF == 4, "ring depth");
     WRing<PF> ring;
-    ring_prime(ring, QSP_WF(0), QSP_WF1(0), lane);
-    zero_acc(acc);
+    ring_prime(ring, QSP_WF(1), QSP_WF1(1), lane);
     BiasQuads bq;
-    gemm_2x2<KG0, PF, true>(s.act, QSP_WF(0), QSP_WF1(0), QSP_WF(1), QSP_WF1(1), ring, acc, lane, P.bias[0] + 64 * wave, bq);
-    QSP_TS()
-    __syncthreads();
-    QSP_TS()
-    fwd_writeout<0>(s, bq, acc, wave, lane, mlo[0], mhi[0]);
+    {
+        const int h = lane >> 5;
+        const f32x4 x0 = lds4(s.xin + 4 * (lane & 31)), x1 = lds4(s.xin + 4 * (32 + (lane & 31)));
+        uint32_t lo = 0, hi = 0;
+        typedef const __attribute__((address_space(1))) f32x4* gq;
+        gq wx = (gq)P.w0x;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int u0 = 64 * wave + 32 * c + 8 * g + 4 * h;
+                const f32x4 cq = lds4(s.c0 + u0);
+                const f32x4 w0 = wx[3 * (u0 >> 2)], w1 = wx[3 * (u0 >> 2) + 1], w2 = wx[3 * (u0 >> 2) + 2];
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const f32x4 xp = r == 0 ? x0 : x1;
+                    const int p = 32 * r + (lane & 31);
+                    f32x4 v;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int i = 4 * g + q;
+                        const float x = cq[q] + w0[q] * xp.x + w1[q] * xp.y + w2[q] * xp.z;
+                        const bool pos = x > 0.f;
+                        const uint32_t bit = pos ? 1u : 0u;
+                        if (r == 0) lo |= bit << (c * 16 + i);
+                        else hi |= bit << (c * 16 + i);
+                        v[q] = pos ? x : 0.f;
+                    }
+                    *reinterpret_cast<f32x4*>(s.act + p * LDA + u0) = v;
+                }
+            }
+        asm volatile("" : "+v"(lo), "+v"(hi));
+        mlo[0] = lo;
+        mhi[0] = hi;
+    }
     QSP_TS()
     __syncthreads();
     QSP_TS()
@@ -447,7 +477,7 @@ __device__ __forceinline__ void mlp_tile(MlpSmem& s, const MlpParams* __restrict
     QSP_FWD_LAYER(6)
     zero_acc(acc);
     if (BWD) gemm_2x2<KGH, PF, true>(s.act, QSP_WF(7), QSP_WF1(7), QSP_WB(7), QSP_WB1(7), ring, acc, lane, P.bias[7] + 64 * wave, bq);
-    else gemm_2x2<KGH, PF, true>(s.act, QSP_WF(7), QSP_WF1(7), QSP_WF(0), QSP_WF1(0), ring, acc, lane, P.bias[7] + 64 * wave, bq);
+    else gemm_2x2<KGH, PF, true>(s.act, QSP_WF(7), QSP_WF1(7), QSP_WF(1), QSP_WF1(1), ring, acc, lane, P.bias[7] + 64 * wave, bq);
     QSP_TS()
     __syncthreads();
     QSP_TS()

@@ -231,6 +231,7 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void k_mlp_fwd(const HypState* __re
     const int32_t* rk = valid_rk + h * rk_stride;
     float* out = sdf_valid + h * rk_stride;
     stage_code_T(s, S, Tsh);
+    mlp_prepare(s, P);
     const float d_min = S.d_min, d_max = S.d_max;
     for (int t = blockIdx.x; t * TILE_P < n; t += gridDim.x) {
         __syncthreads();
@@ -392,6 +393,7 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void k_mlp_jtj(const HypState* __re
     const int tb = (wave < 3) ? wave : (wave < 5 ? wave - 2 : 2);
 
     stage_code_T(s, S, Tsh);
+    mlp_prepare(s, P);
     const float* Pc = pts + 3 * ov.pts_off;
     const float* R = rays + 3 * ov.ray_off;
     const int32_t* rk = rend_rk + h * rk_stride;
@@ -773,6 +775,7 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void k_decode(const float* __restri
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     MlpSmem& s = *reinterpret_cast<MlpSmem*>(smem_raw);
     if (threadIdx.x < CODE_LEN) s.code[threadIdx.x] = code[threadIdx.x];
+    mlp_prepare(s, P);
     for (int64_t t = blockIdx.x; t * TILE_P < n; t += gridDim.x) {
         __syncthreads();
         if (threadIdx.x < TILE_P) {
@@ -854,21 +857,34 @@ static int pack_weights(qsp_decoder* d, const qsp_decoder_desc* desc) {
     };
     for (int l = 0; l < 8; ++l) {
         const int in = desc->in_dim[l], out = desc->out_dim[l];
-        // forward: B[k][o]; column blocks over o (16 blocks of 32), k-groups of 8 over the padded K
-        const int Kp = (l == 0) ? K0_PAD : HID;
-        const int KG = Kp / 8;
-        std::vector<float> pf((size_t)16 * KG * 64 * 4, 0.f);
-        for (int cb = 0; cb < 16; ++cb)
-            for (int kg = 0; kg < KG; ++kg)
-                for (int lane = 0; lane < 64; ++lane)
-                    for (int e = 0; e < 4; ++e) {
-                        const int o = 32 * cb + (lane & 31);
-                        const int k = 8 * kg + 4 * (lane >> 5) + e;
-                        float v = 0.f;
-                        if (o < out && k < in) v = W[l][(size_t)o * in + k];
-                        pf[(((size_t)cb * KG + kg) * 64 + lane) * 4 + e] = v;
-                    }
-        int rc = upload(pf, (const void**)&d->P.wf[l]);
+        int rc = QSP_OK;
+        if (l == 0) {
+            // layer 0 is evaluated directly (mlp_prepare + mlp_tile): code columns row-major, xyz columns per unit quad
+            std::vector<float> wc((size_t)HID * CODE_LEN), wx((size_t)(HID / 4) * 3 * 4);
+            for (int o = 0; o < HID; ++o)
+                for (int k = 0; k < CODE_LEN; ++k) wc[(size_t)o * CODE_LEN + k] = W[0][(size_t)o * in + k];
+            for (int q = 0; q < HID / 4; ++q)
+                for (int a = 0; a < 3; ++a)
+                    for (int e = 0; e < 4; ++e) wx[((size_t)q * 3 + a) * 4 + e] = W[0][(size_t)(4 * q + e) * in + CODE_LEN + a];
+            rc = upload(wc, (const void**)&d->P.w0c);
+            if (!rc) rc = upload(wx, (const void**)&d->P.w0x);
+            d->P.wf[0] = nullptr;
+        } else {
+            // forward: B[k][o]; column blocks over o (16 blocks of 32), k-groups of 8 over K = 512
+            const int KG = HID / 8;
+            std::vector<float> pf((size_t)16 * KG * 64 * 4, 0.f);
+            for (int cb = 0; cb < 16; ++cb)
+                for (int kg = 0; kg < KG; ++kg)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int e = 0; e < 4; ++e) {
+                            const int o = 32 * cb + (lane & 31);
+                            const int k = 8 * kg + 4 * (lane >> 5) + e;
+                            float v = 0.f;
+                            if (o < out && k < in) v = W[l][(size_t)o * in + k];
+                            pf[(((size_t)cb * KG + kg) * 64 + lane) * 4 + e] = v;
+                        }
+            rc = upload(pf, (const void**)&d->P.wf[l]);
+        }
         if (rc) return rc;
         // backward: B[o][k]; column blocks over the layer's inputs k, groups of 8 over o (padded to 512)
         const int NCB = (l == 0) ? 3 : 16;

@@ -49,7 +49,60 @@ void run(int threads, int blocks, const char* name) {
     hipFree(out); hipFree(cyc);
 }
 
+// the same loop with 16 different random operand pairs per lane (realistic toggling), long enough to reach steady state
+__global__ void k_rate_random(float* out, unsigned long long* cyc, unsigned long long* rt, int iters, const float* rnd) {
+    f32x16 acc[4];
+    for (int a = 0; a < 4; ++a)
+        for (int i = 0; i < 16; ++i) acc[a][i] = 0.f;
+    float x[16], y[16];
+    for (int i = 0; i < 16; ++i) { x[i] = rnd[(threadIdx.x * 16 + i) % 4096]; y[i] = rnd[(threadIdx.x * 16 + i + 1777) % 4096]; }
+    __syncthreads();
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int a = 0; a < 4; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(x[4 * u + a], y[4 * a + u], acc[a], 0, 0, 0);
+    }
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+    float s = 0;
+    for (int a = 0; a < 4; ++a)
+        for (int i = 0; i < 16; ++i) s += acc[a][i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (threadIdx.x == 0) { cyc[blockIdx.x] = t1 - t0; rt[blockIdx.x] = r1 - r0; }
+}
+
+void run_random(int threads, int iters) {
+    const int blocks = 256;
+    float *out, *rnd; unsigned long long *cyc, *rt;
+    hipMalloc(&out, sizeof(float) * threads * blocks);
+    hipMalloc(&cyc, sizeof(unsigned long long) * blocks);
+    hipMalloc(&rt, sizeof(unsigned long long) * blocks);
+    hipMalloc(&rnd, sizeof(float) * 4096);
+    float h[4096];
+    unsigned s = 12345;
+    for (int i = 0; i < 4096; ++i) { s = s * 1664525u + 1013904223u; h[i] = ((int)(s >> 8) - (1 << 23)) * (1.0f / (1 << 23)); }
+    hipMemcpy(rnd, h, sizeof(h), hipMemcpyHostToDevice);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int rep = 0; rep < 3; ++rep) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(k_rate_random, dim3(blocks), dim3(threads), 0, 0, out, cyc, rt, iters, rnd);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        unsigned long long hc, hr;
+        hipMemcpy(&hc, cyc, 8, hipMemcpyDeviceToHost);
+        hipMemcpy(&hr, rt, 8, hipMemcpyDeviceToHost);
+        const double tf = 4096.0 * 16.0 * iters * (threads / 64) * blocks / (ms * 1e-3) / 1e12;
+        printf("random operands, %d waves/SIMD, %.1f ms: %.2f cycles/MFMA/SIMD, %.1f TFLOP/s, shader clock %.3f GHz\n", threads / 256, ms,
+               (double)hc / (16.0 * iters * (threads / 256)), tf, (double)hc / (double)hr * 0.1);
+    }
+}
+
 int main() {
+    run_random(512, 200000);
+    run_random(256, 400000);
     for (int rep = 0; rep < 2; ++rep) {
         run<4>(256, 256, "4 acc, 1 wave/SIMD, 1 WG/CU");
         run<4>(512, 256, "4 acc, 2 waves/SIMD, 1 WG/CU");
