@@ -727,6 +727,82 @@ __global__ __launch_bounds__(256) void k_schur_points(Dev d, Par par) {
     }
 }
 
+// The same Schur complement by BLOCK ROW (the default): one workgroup per (key-frame, split of <= KSPLIT of its edges)
+// keeps the key-frame's 6 x dimp row block and its 6 right-hand-side entries in LDS, accumulates
+// -B_a D^-1 B_b^T for every other observation b of the landmark of each of its edges a (h_b >= h_a) with LDS atomics,
+// and adds the non-zero part to Hs once at the end.  Global atomics drop from 36 per (a,b) pair to at most 6*dimp per
+// workgroup: with few poses and many landmarks (64 key-frames, 2 M edges) the per-landmark kernel above spends 5.4 ms
+// fighting over 147 k addresses.  D^-1 and D^-1 b_l come from k_schur_dinv.
+constexpr size_t SCHUR_ROW_LDS_MAX = 160 * 1024;
+constexpr int SCHUR_ROWS_MIN_EDGES = 65536;
+__global__ __launch_bounds__(256) void k_schur_dinv(Dev d, Par par) {
+    const int pt = blockIdx.x * 256 + threadIdx.x;
+    if (pt >= d.n_pt || d.pt_h[pt] < 0) return;
+    double Dm[9], Di[9];
+    for (int i = 0; i < 9; ++i) Dm[i] = d.Hll[9 * (size_t)pt + i];
+    Dm[0] += par.lambda; Dm[4] += par.lambda; Dm[8] += par.lambda;
+    inv3(Dm, Di);
+    const double* bl = d.bl + 3 * (size_t)pt;
+    for (int i = 0; i < 9; ++i) d.Dinv[9 * (size_t)pt + i] = Di[i];
+    for (int i = 0; i < 3; ++i) d.xl[3 * (size_t)pt + i] = Di[3 * i] * bl[0] + Di[3 * i + 1] * bl[1] + Di[3 * i + 2] * bl[2];
+}
+
+__global__ __launch_bounds__(256) void k_schur_rows(Dev d, Par par) {
+    extern __shared__ __attribute__((aligned(16))) double srow[];     // [6][dimp] row block, then 6 rhs entries
+    const int sp = blockIdx.x, t = threadIdx.x;
+    const int ha = d.kf_h[d.ksp_kf[sp]];
+    if (ha < 0) return;
+    const int dimp = par.dimp;
+    for (int i = t; i < 6 * dimp + 6; i += 256) srow[i] = 0.0;
+    __syncthreads();
+    for (int q = d.ksp_begin[sp] + t; q < d.ksp_end[sp]; q += 256) {
+        const int a = d.kf_edge[q];
+        if (d.edge_level[a]) continue;
+        const int pt = d.edge[a].pt;
+        if (d.pt_h[pt] < 0) continue;
+        double Ba[18], BD[18];
+        {
+            const double* Bg = d.Hpl + 18 * (size_t)a;
+            const double* Di = d.Dinv + 9 * (size_t)pt;
+            double Dl[9];
+#pragma unroll
+            for (int i = 0; i < 18; ++i) Ba[i] = Bg[i];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) Dl[i] = Di[i];
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) BD[3 * i + c] = Ba[3 * i] * Dl[c] + Ba[3 * i + 1] * Dl[3 + c] + Ba[3 * i + 2] * Dl[6 + c];
+            const double* db = d.xl + 3 * (size_t)pt;
+            const double d0 = db[0], d1 = db[1], d2 = db[2];
+#pragma unroll
+            for (int r = 0; r < 6; ++r) atomicAdd(&srow[6 * dimp + r], -(Ba[3 * r] * d0 + Ba[3 * r + 1] * d1 + Ba[3 * r + 2] * d2));
+        }
+        const int e0 = d.pt_off[pt], e1 = d.pt_off[pt + 1];
+        for (int b = e0; b < e1; ++b) {
+            if (d.edge_level[b]) continue;
+            const int hb = d.kf_h[d.edge[b].kf];
+            if (hb < ha || (hb == ha && b != a)) continue;
+            const double* Bg = d.Hpl + 18 * (size_t)b;
+            double Bb[18];
+#pragma unroll
+            for (int i = 0; i < 18; ++i) Bb[i] = Bg[i];
+            double* dst = srow + 6 * hb;
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int j = 0; j < 6; ++j)
+                    atomicAdd(&dst[i * dimp + j], -(BD[3 * i] * Bb[3 * j] + BD[3 * i + 1] * Bb[3 * j + 1] + BD[3 * i + 2] * Bb[3 * j + 2]));
+        }
+    }
+    __syncthreads();
+    for (int i = t; i < 6 * dimp; i += 256) {
+        const double v = srow[i];
+        if (v != 0.0) atomicAdd(&d.Hs[(size_t)(6 * ha + i / dimp) * dimp + i % dimp], v);
+    }
+    if (t < 6) atomicAdd(&d.bs[6 * ha + t], srow[6 * dimp + t]);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Dense SPD solve of the reduced system  Hs x = bs  (dimp multiple of NB = 64), replacing g2o's LDLT
 // (linear_solver_eigen.h:94-124).  Right-looking blocked Cholesky Hs = L L^T with ONE launch per block step:
@@ -1239,6 +1315,7 @@ extern "C" int qsp_ba_create(const qsp_ba_scene* s, int device, qsp_ba_problem**
         const int chol_lds = (int)(sizeof(double) * CHOL_LDS_DOUBLES);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_chol_first, hipFuncAttributeMaxDynamicSharedMemorySize, chol_lds);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_chol_step, hipFuncAttributeMaxDynamicSharedMemorySize, chol_lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_schur_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCHUR_ROW_LDS_MAX);
         if (e != hipSuccess) rc = qsp_fail(QSP_ERR_DEVICE, hipGetErrorString(e));
     }
     if (rc) {
@@ -1484,7 +1561,15 @@ extern "C" int qsp_ba_optimize(qsp_ba_problem* p, int32_t n_iter, double delta_m
                 QSP_HIP(hipMemsetAsync(d.Hs, 0, sizeof(double) * (size_t)p->dimp * p->dimp, s));
                 const int nprep = p->n_pose * 36 + d.n_oe * 36 + (p->dimp - p->dim);
                 hipLaunchKernelGGL(k_schur_prepare, dim3((std::max(nprep, p->dimp) + 255) / 256), dim3(256), 0, s, d, par);
-                if (d.n_pt) hipLaunchKernelGGL(k_schur_points, dim3((d.n_pt + 3) / 4), dim3(256), 0, s, d, par);
+                const size_t row_lds = sizeof(double) * ((size_t)6 * p->dimp + 6);
+                // block rows pay off once the per-landmark kernel's global atomics collide or scatter (measured: C5 435 ->
+                // 157 us, 2 M edges 5.4 -> 0.8 ms); below ~64 k edges both are latency-bound and the single launch wins
+                if (d.n_pt && row_lds <= SCHUR_ROW_LDS_MAX && d.n_ksplit && d.n_edge >= SCHUR_ROWS_MIN_EDGES) {
+                    hipLaunchKernelGGL(k_schur_dinv, dim3((d.n_pt + 255) / 256), dim3(256), 0, s, d, par);
+                    hipLaunchKernelGGL(k_schur_rows, dim3(d.n_ksplit), dim3(256), row_lds, s, d, par);
+                } else if (d.n_pt) {
+                    hipLaunchKernelGGL(k_schur_points, dim3((d.n_pt + 3) / 4), dim3(256), 0, s, d, par);
+                }
                 rc = allreduce(p, d.Hs, (int64_t)p->dimp * p->dimp + p->dimp);     // reduced matrix + right-hand side
                 if (rc) return rc;
                 const int nb = p->dimp / NB;
@@ -1496,7 +1581,7 @@ extern "C" int qsp_ba_optimize(qsp_ba_problem* p, int32_t n_iter, double delta_m
                 for (int k = nb - 1; k >= 0; --k)
                     hipLaunchKernelGGL(k_chol_backstep, dim3(k > 0 ? k : 1), dim3(256), 0, s, d.Uf, d.Winv, d.ych, d.xp, p->dimp, k);
             } else if (d.n_pt) {
-                hipLaunchKernelGGL(k_schur_points, dim3((d.n_pt + 3) / 4), dim3(256), 0, s, d, par);
+                hipLaunchKernelGGL(k_schur_dinv, dim3((d.n_pt + 255) / 256), dim3(256), 0, s, d, par);   // only D^-1 is needed
             }
             // update (oplus) + rho denominator
             hipLaunchKernelGGL(k_update_points, dim3(gp), dim3(256), 0, s, d, par);

@@ -196,3 +196,23 @@ def test_sharded_ba_with_rccl_world_of_one():
         p.close()
     finally:
         dist.destroy_process_group()
+
+
+def test_block_row_schur_path_on_a_large_graph():
+    """>= 65536 edges switches the Schur complement to k_schur_rows (LDS row blocks per key-frame split); same bars as
+    the small scenes, against the C oracle on the same graph (12 key-frames, 10 000 landmarks x 8 observations, 2 objects)."""
+    from qsp_slam_amd.ba import BaProblem
+    sc = synth.make_ba_scene_large(11, 12, 10000, obs_per_pt=8, n_obj=2)
+    assert len(sc["mono_pt"]) >= 65536
+    ref = bo.BaProblem(sc)
+    tr = ref.optimize(4, DM, DS, DO)
+    gpu = BaProblem(sc)
+    tg = gpu.optimize(4, DM, DS, DO)
+    assert np.array_equal(tg["kf_hidx"], tr["kf_hidx"]) and np.array_equal(tg["pt_hidx"], tr["pt_hidx"])
+    assert list(tg["trials"]) == list(tr["trials"]) and list(tg["accepted"]) == list(tr["accepted"])
+    assert close(tg["chi2"], tr["chi2"]) and close(tg["lam"], tr["lam"])
+    kf, pt, ob = gpu.state()
+    rkf, rpt, rob = ref.state()
+    assert close(kf, rkf, rtol=1e-8, atol=1e-10) and close(pt, rpt, rtol=1e-8, atol=1e-10)
+    assert close(ob, rob, rtol=1e-8, atol=1e-10)
+    gpu.close()
