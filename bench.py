@@ -247,6 +247,24 @@ def main():
                         "ba_linearize_GBps": ba_stat["bytes_lin"] / max(1e-3 * ba_stat["ms_lin"] / max(ba_stat["n_lin"], 1), 1e-12) / 1e9,
                         "ba_linearize_frac_of_8TBps": ba_stat["bytes_lin"] / max(1e-3 * ba_stat["ms_lin"] / max(ba_stat["n_lin"], 1), 1e-12) / 8e12},
         }
+        if world == 1:
+            # the boundary as the reference calls it: host buffers in, host results out (upload + allocation inside the
+            # step); reported beside `value`, never as `value`
+            th = time.perf_counter()
+            b2 = RefineBatch(dec, _joint_cfg(opt), [o["pts"] for o in objs], [o["rays"] for o in objs],
+                             [o["depth"] for o in objs], hyp)
+            b2.set_state(T0, None)
+            b2.run(0)
+            b2.get()
+            ba2 = BaProblem(scene, device=dev)
+            ba2.local_joint_ba()
+            ba2.state()
+            th = time.perf_counter() - th
+            out["host_buffers"] = {"ms_per_step": 1e3 * th, "value": iters_total / args.steps / th, "unit": "iters/s",
+                                   "note": "one step with observations, graph and results crossing PCIe and device "
+                                           "buffers allocated inside the step"}
+            b2.close()
+            ba2.close()
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w, objs, scene, n_hyp)
         print(json.dumps(out))
