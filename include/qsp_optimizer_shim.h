@@ -110,9 +110,13 @@ struct Flat {   // the flattened graph + back-references for the write-back
         return i;
     }
 
-    // one map point: vertex + one edge per observing key-frame that is in the graph (src/Optimizer_util.cc:454-541)
-    void add_point(MapPoint* pMP) {
+    // one map point: vertex + one edge per observing key-frame that is in the graph (src/Optimizer_util.cc:454-541).
+    // global_rules (Optimizer::BundleAdjustment / JointBundleAdjustment, src/Optimizer.cc:93-191, Optimizer_util.cc:87-173):
+    // maxMPid counts every point offered, and a point without any edge is removed again (vbNotIncludedMP) -> false.
+    bool add_point(MapPoint* pMP, bool global_rules = false) {
         const int ip = (int)pts.size();
+        const size_t nm0 = mono_pt.size(), ns0 = st_pt.size();
+        if (global_rules && pMP->mnId > maxMPid) maxMPid = pMP->mnId;
         pts.push_back(pMP);
         const cv::Mat X = pMP->GetWorldPos();
         for (int i = 0; i < 3; ++i) pt_xyz.push_back((double)X.at<float>(i));
@@ -138,12 +142,20 @@ struct Flat {   // the flattened graph + back-references for the write-back
             }
             if (pMP->mnId > maxMPid) maxMPid = pMP->mnId;
         }
+        if (global_rules && mono_pt.size() == nm0 && st_pt.size() == ns0) {
+            pts.pop_back();
+            pt_xyz.resize(pt_xyz.size() - 3);
+            pt_id.pop_back();
+            return false;
+        }
+        return true;
     }
 
     // one static object: SE3 vertex (estimate SE3Tow) + one EdgeSE3LieAlgebra per observing key-frame in the graph
     // (src/Optimizer_util.cc:544-586)
-    void add_object(MapObject* pMO) {
+    bool add_object(MapObject* pMO, bool global_rules = false) {
         const int io = (int)objs.size();
+        const size_t ne0 = oe_kf.size();
         objs.push_back(pMO);
         double p[7];
         pose7_from_rt([&](int r, int c) { return (double)pMO->SE3Tow(r, c); }, p);
@@ -161,6 +173,13 @@ struct Flat {   // the flattened graph + back-references for the write-back
             oe_kf.push_back(f->second); oe_obj.push_back(io);
             oe_kfp.push_back(pKFi); oe_mo.push_back(pMO);
         }
+        if (global_rules && oe_kf.size() == ne0) {      // vbNotIncludedMO, src/Optimizer_util.cc:229-233
+            objs.pop_back();
+            obj_pose.resize(obj_pose.size() - 7);
+            obj_id.pop_back();
+            return false;
+        }
+        return true;
     }
 
     void finish(qsp_ba_scene* s) {
@@ -296,22 +315,21 @@ public:
         LocalJointBundleAdjustment(pKF, pbStopFlag, pMap, false);
     }
 
-    // Optimizer::JointBundleAdjustment / GlobalJointBundleAdjustemnt, src/Optimizer_util.cc:36-307: every key-frame, point
-    // and object; one optimize(nIterations); Huber sqrt(5.99)/sqrt(7.815)/sqrt(0.1*1e3) only if bRobust; results go to the
-    // *GBA members when nLoopKF != 0.
-    static void GlobalJointBundleAdjustemnt(Map* pMap, int nIterations = 5, bool* pbStopFlag = nullptr,
-                                            const unsigned long nLoopKF = 0, const bool bRobust = true) {
+    // Optimizer::JointBundleAdjustment, src/Optimizer_util.cc:44-307 (and, with no objects, Optimizer::BundleAdjustment,
+    // src/Optimizer.cc:54-242): the given key-frames (mnId 0 fixed), points and static objects; one optimize(nIterations);
+    // Huber sqrt(5.99) / sqrt(7.815) / sqrt(0.1*1e3) only if bRobust; vertices left without an edge are dropped and not
+    // written back; results go to the *GBA members when nLoopKF != 0.
+    static void JointBundleAdjustment(const std::vector<KeyFrame*>& vpKFs, const std::vector<MapPoint*>& vpMP,
+                                      const std::vector<MapObject*>& vpMO, int nIterations = 5, bool* pbStopFlag = nullptr,
+                                      const unsigned long nLoopKF = 0, const bool bRobust = true) {
         using namespace qsp_shim;
-        std::vector<KeyFrame*> vpKFs = pMap->GetAllKeyFrames();
-        std::vector<MapPoint*> vpMP = pMap->GetAllMapPoints();
-        std::vector<MapObject*> vpMO = pMap->GetAllMapObjects();
         Flat F;
         for (KeyFrame* k : vpKFs)
             if (!k->isBad()) F.add_kf(k, k->mnId == 0);
         for (MapPoint* pMP : vpMP)
-            if (!pMP->isBad()) F.add_point(pMP);
+            if (!pMP->isBad()) F.add_point(pMP, true);
         for (MapObject* pMO : vpMO)
-            if (pMO && !pMO->isDynamic() && !pMO->isBad()) F.add_object(pMO);
+            if (pMO && !pMO->isDynamic() && !pMO->isBad()) F.add_object(pMO, true);
         qsp_ba_scene scene;
         F.finish(&scene);
         qsp_ba_problem* prob = nullptr;
@@ -349,6 +367,25 @@ public:
             if (nLoopKF == 0) F.objs[i]->SetObjectPoseSE3(Tow.inverse());
             else { F.objs[i]->mTwoGBA = Tow.inverse(); F.objs[i]->mnBAGlobalForKF = nLoopKF; }
         }
+    }
+
+    // src/Optimizer.cc:54-242
+    static void BundleAdjustment(const std::vector<KeyFrame*>& vpKFs, const std::vector<MapPoint*>& vpMP, int nIterations = 5,
+                                 bool* pbStopFlag = nullptr, const unsigned long nLoopKF = 0, const bool bRobust = true) {
+        JointBundleAdjustment(vpKFs, vpMP, std::vector<MapObject*>(), nIterations, pbStopFlag, nLoopKF, bRobust);
+    }
+
+    // src/Optimizer.cc:46-51
+    static void GlobalBundleAdjustemnt(Map* pMap, int nIterations = 5, bool* pbStopFlag = nullptr,
+                                       const unsigned long nLoopKF = 0, const bool bRobust = true) {
+        BundleAdjustment(pMap->GetAllKeyFrames(), pMap->GetAllMapPoints(), nIterations, pbStopFlag, nLoopKF, bRobust);
+    }
+
+    // src/Optimizer_util.cc:36-42
+    static void GlobalJointBundleAdjustemnt(Map* pMap, int nIterations = 5, bool* pbStopFlag = nullptr,
+                                            const unsigned long nLoopKF = 0, const bool bRobust = true) {
+        JointBundleAdjustment(pMap->GetAllKeyFrames(), pMap->GetAllMapPoints(), pMap->GetAllMapObjects(), nIterations,
+                              pbStopFlag, nLoopKF, bRobust);
     }
 };
 

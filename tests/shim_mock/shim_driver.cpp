@@ -89,7 +89,20 @@ int main(int argc, char** argv) {
         if (!have) k.mos.push_back(&objs[oe_obj[e]]);
     }
     bool stop = false;
-    OptimizerHip::LocalJointBundleAdjustment(&kfs[0], &stop, &map);
+    const std::string mode = argc > 3 ? argv[3] : "local";
+    const unsigned long nLoopKF = argc > 4 ? (unsigned long)atol(argv[4]) : 0;
+    if (mode == "local") OptimizerHip::LocalJointBundleAdjustment(&kfs[0], &stop, &map);
+    else if (mode == "global_joint") OptimizerHip::GlobalJointBundleAdjustemnt(&map, 10, &stop, nLoopKF, true);
+    else if (mode == "global_points") OptimizerHip::GlobalBundleAdjustemnt(&map, 20, &stop, nLoopKF, false);
+    else return 2;
+    if (nLoopKF != 0) {   // loop-closing mode: results are parked in the *GBA members; move them over for the output
+        for (int i = 0; i < n_kf; ++i)
+            if (kfs[i].mnBAGlobalForKF == nLoopKF) kfs[i].Tcw = kfs[i].mTcwGBA.clone();
+        for (int i = 0; i < n_pt; ++i)
+            if (pts[i].mnBAGlobalForKF == nLoopKF) pts[i].pos = pts[i].mPosGBA.clone();
+        for (int i = 0; i < n_obj; ++i)
+            if (objs[i].mnBAGlobalForKF == nLoopKF) objs[i].SE3Tow = objs[i].mTwoGBA.inverse();
+    }
 
     FILE* o = fopen(argv[2], "wb");
     for (int i = 0; i < n_kf; ++i) fwrite(kfs[i].Tcw.d->data(), sizeof(float), 16, o);

@@ -45,7 +45,16 @@ int qsp_ba_local_joint(qsp_ba_problem* p, const volatile uint8_t* stop, qsp_ba_t
     return QSP_OK;
 }
 int qsp_ba_optimize(qsp_ba_problem* p, int32_t n, double a, double b, double c, const volatile uint8_t* s, qsp_ba_trace* t) {
-    (void)n; (void)a; (void)b; (void)c; return qsp_ba_local_joint(p, s, t, t);
+    const char* path = getenv("QSP_STUB_DUMP");
+    if (path) {                       /* the call's arguments beside the scene dump: <dump>.args */
+        char name[4096];
+        snprintf(name, sizeof(name), "%s.args", path);
+        FILE* f = fopen(name, "wb");
+        double v[4] = {(double)n, a, b, c};
+        wr(f, v, sizeof(v));
+        fclose(f);
+    }
+    return qsp_ba_local_joint(p, s, t, t);
 }
 int qsp_ba_set_levels(qsp_ba_problem* p, const uint8_t* a, const uint8_t* b, const uint8_t* c) { (void)p; (void)a; (void)b; (void)c; return QSP_OK; }
 int qsp_ba_get_state(qsp_ba_problem* p, double* kf, double* pt, double* ob) {

@@ -191,3 +191,73 @@ def test_shim_end_to_end_equals_python_binding_on_the_same_graph():
         assert np.abs(kf_o[id2idx[int(vid)]] - T).max() < 2e-6
         n_checked += 1
     assert n_checked >= 5 and nba == 1
+
+
+def _with_unobserved_extras(m):
+    """the same map + 3 map points nobody observes + 1 object nobody observes (dropped by the global BA, never written)"""
+    sc = dict(m["sc"])
+    m2 = dict(m, sc=sc)
+    sc["pt_xyz"] = np.concatenate([sc["pt_xyz"], np.array([[9.0, 9.0, 9.0], [8.0, 8.0, 8.0], [7.0, 7.0, 7.0]])])
+    m2["pt_mn"] = np.concatenate([m["pt_mn"], m["pt_mn"].max() + 1 + np.arange(3)]).astype(np.int64)
+    sc["obj_pose"] = np.concatenate([sc["obj_pose"], sc["obj_pose"][:1]])
+    m2["objT"] = np.concatenate([m["objT"], m["objT"][:1]])
+    m2["obj_mn"] = np.concatenate([m["obj_mn"], [m["obj_mn"].max() + 5]]).astype(np.int64)
+    return m2
+
+
+def _run_stub(m, mode, loop_kf=0):
+    sc = m["sc"]
+    with tempfile.TemporaryDirectory() as tmp:
+        drv = build_driver(tmp, real=False)
+        write_scene(m, os.path.join(tmp, "scene.bin"))
+        env = dict(os.environ, QSP_STUB_DUMP=os.path.join(tmp, "dump.bin"))
+        subprocess.check_call([drv, os.path.join(tmp, "scene.bin"), os.path.join(tmp, "out.bin"), mode, str(loop_kf)], env=env)
+        d = read_dump(os.path.join(tmp, "dump.bin"))
+        args = np.fromfile(os.path.join(tmp, "dump.bin.args"), np.float64)
+        out = read_out(os.path.join(tmp, "out.bin"), len(sc["kf_pose"]), len(sc["pt_xyz"]), len(sc["obj_pose"]))
+    return d, args, out
+
+
+@pytest.mark.parametrize("loop_kf", [0, 7])
+def test_global_joint_ba_flattening_and_write_back(loop_kf):
+    """Optimizer::GlobalJointBundleAdjustemnt -> JointBundleAdjustment (src/Optimizer_util.cc:36-307): every key-frame
+    (only mnId 0 fixed), every point WITH an edge, every static object WITH an observation; optimize(nIterations) with the
+    robust deltas; write-back to the map (nLoopKF == 0) or to the *GBA members (loop closing)."""
+    m = _with_unobserved_extras(make_map(seed=9, n_kf=7, n_pt=60, n_obj=2))
+    sc = m["sc"]
+    d, args, (kf_o, pt_o, ob_o, nobs, nba) = _run_stub(m, "global_joint", loop_kf)
+    n_kf, n_pt_all, n_obj_all = len(sc["kf_pose"]), len(sc["pt_xyz"]), len(sc["obj_pose"])
+    assert len(d["kf_pose"]) == n_kf and list(d["kf_fixed"]) == [1 if i == 0 else 0 for i in sc["kf_id"]]
+    observed = sorted(set(sc["mono_pt"].tolist()) | set(sc["st_pt"].tolist()))
+    unobserved = sorted(set(range(n_pt_all)) - set(observed))
+    assert len(d["pt_xyz"]) == len(observed) and set(range(n_pt_all - 3, n_pt_all)) <= set(unobserved)
+    assert len(d["obj_pose"]) == n_obj_all - 1 and len(d["oe_kf"]) == len(sc["oe_kf"])
+    assert len(d["mono_pt"]) + len(d["st_pt"]) == len(sc["mono_pt"]) + len(sc["st_pt"])
+    max_kf = int(sc["kf_id"].max())
+    max_mp = int(m["pt_mn"].max())                      # every point offered counts, also the dropped ones (:97-98)
+    assert np.array_equal(d["pt_id"], m["pt_mn"][observed] + max_kf + 1)
+    assert np.array_equal(d["obj_id"], m["obj_mn"][: n_obj_all - 1] + max_kf + max_mp + 2)
+    assert args[0] == 10 and np.allclose(args[1:], [np.float32(np.sqrt(5.99)), np.float32(np.sqrt(7.815)),
+                                                    np.float32(np.sqrt(np.float32(0.1) * np.float32(1e3)))])
+    # write-back: the stub shifts free key-frames by +0.5 in x, points by +0.25 in y, objects by +0.125 in z (of T_ow)
+    for i in range(n_kf):
+        shift = 0.0 if sc["kf_id"][i] == 0 else 0.5
+        assert abs(kf_o[i][0, 3] - (m["kfT"][i][0, 3] + shift)) < 1e-5
+    moved = np.abs(pt_o[:, 1] - sc["pt_xyz"][:, 1].astype(np.float32)) > 0.2
+    assert moved[observed].all() and not moved[unobserved].any()
+    Tow_in = m["objT"]
+    assert np.abs(ob_o[-1] - Tow_in[-1]).max() < 1e-6           # the unobserved object is untouched
+    assert all(abs(ob_o[i][2, 3] - (Tow_in[i][2, 3] + 0.125)) < 1e-4 for i in range(n_obj_all - 1))
+
+
+def test_global_points_only_ba():
+    """Optimizer::GlobalBundleAdjustemnt -> BundleAdjustment (src/Optimizer.cc:46-242): no objects in the graph, no robust
+    kernel when bRobust is false, nIterations passed through."""
+    m = _with_unobserved_extras(make_map(seed=10, n_kf=6, n_pt=40, n_obj=2))
+    sc = m["sc"]
+    d, args, (kf_o, pt_o, ob_o, nobs, nba) = _run_stub(m, "global_points")
+    assert len(d["obj_pose"]) == 0 and len(d["oe_kf"]) == 0
+    n_observed = len(set(sc["mono_pt"].tolist()) | set(sc["st_pt"].tolist()))
+    assert len(d["kf_pose"]) == len(sc["kf_pose"]) and len(d["pt_xyz"]) == n_observed <= len(sc["pt_xyz"]) - 3
+    assert args[0] == 20 and not args[1:].any()
+    assert np.abs(ob_o - m["objT"]).max() < 1e-6                # objects are not part of this call
