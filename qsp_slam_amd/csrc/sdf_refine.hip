@@ -31,9 +31,18 @@
 namespace qsp {
 
 constexpr int MAX_DEPTH = 64;
-constexpr int NW_REND = 16;     // workgroups per hypothesis looping over render-row tiles
-constexpr int NW_VALID = 32;    // workgroups per hypothesis looping over valid-sample tiles
-constexpr int NW_SDF_MAX = 64;  // workgroups per hypothesis looping over surface-point tiles
+#ifndef QSP_NW_REND
+#define QSP_NW_REND 16
+#endif
+#ifndef QSP_NW_SDF_MAX
+#define QSP_NW_SDF_MAX 256      // one 64-point tile per workgroup up to 16 k surface points (uniform workgroups balance best)
+#endif
+constexpr int NW_REND = QSP_NW_REND;     // workgroups per hypothesis looping over render-row tiles
+#ifndef QSP_NW_VALID
+#define QSP_NW_VALID 32
+#endif
+constexpr int NW_VALID = QSP_NW_VALID;    // workgroups per hypothesis looping over valid-sample tiles
+constexpr int NW_SDF_MAX = QSP_NW_SDF_MAX;  // workgroups per hypothesis looping over surface-point tiles
 constexpr int NH = 71;          // 7 pose + 64 code unknowns
 constexpr int PART_FLOATS = HT_TILES * 1024;
 
@@ -225,7 +234,8 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void k_mlp_fwd(const HypState* __re
     const HypState& S = st[h];
     if (!S.alive) return;
     const int n = S.n_valid;
-    if ((int)blockIdx.x * TILE_P >= n) return;
+    const int t0 = ((int)blockIdx.x + ((gridDim.x & 1) ? 0 : h)) % (int)gridDim.x;     // XCD-aware rotation: see k_mlp_jtj
+    if (t0 * TILE_P >= n) return;
     const ObjView ov = objs[S.obj];
     const float* R = rays + 3 * ov.ray_off;
     const int32_t* rk = valid_rk + h * rk_stride;
@@ -233,7 +243,7 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void k_mlp_fwd(const HypState* __re
     stage_code_T(s, S, Tsh);
     mlp_prepare(s, P);
     const float d_min = S.d_min, d_max = S.d_max;
-    for (int t = blockIdx.x; t * TILE_P < n; t += gridDim.x) {
+    for (int t = t0; t * TILE_P < n; t += gridDim.x) {
         __syncthreads();
         if (threadIdx.x < TILE_P) {
             const int v = t * TILE_P + threadIdx.x;
@@ -379,9 +389,17 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void k_mlp_jtj(const HypState* __re
     if (!S.alive) return;
     const ObjView ov = objs[S.obj];
     const bool is_sdf = (int)blockIdx.x < nw_sdf;
-    const int slot = blockIdx.x;
-    const int j0 = is_sdf ? blockIdx.x : blockIdx.x - nw_sdf;
     const int stride = is_sdf ? nw_sdf : (int)gridDim.x - nw_sdf;
+    // Consecutive workgroup ids go round-robin over the 8 XCDs: slot x of hypothesis h runs on XCD (h * gridDim.x + x) % 8.
+    // With an even row length the slots that carry work (the first few render slots, the surface slots with one tile
+    // more) would sit on the same XCDs for every hypothesis -- measured: 6 % of the step lost to idle XCDs.  The logical
+    // position of a slot is therefore rotated by the hypothesis index whenever gridDim.x is even, which makes the XCD of
+    // logical slot j advance by an odd amount per hypothesis and visit all eight.
+    const int rot = (gridDim.x & 1) ? 0 : 1;
+    const int x_in = is_sdf ? (int)blockIdx.x : (int)blockIdx.x - nw_sdf;
+    const int j0 = (x_in + rot * h) % stride;
+    const int slot = is_sdf ? j0 : nw_sdf + j0;     // partials are stored by LOGICAL position: the sum order in k_solve
+                                                    // (and with it every bit of the result) does not depend on the rotation
     const int n = is_sdf ? ov.n_pts : S.n_render;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
 
