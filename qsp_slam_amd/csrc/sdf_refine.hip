@@ -623,7 +623,10 @@ __global__ __launch_bounds__(256) void k_solve(HypState* __restrict__ st, const 
         if (a > b) continue;
         const int off = tri_tile(a >> 5, b >> 5) * 1024 + (a & 31) * 32 + (b & 31);
         float ss = 0.f, sr = 0.f;
+        // same left-to-right order as ever; unrolled so that 16 of the (24 KiB-strided) loads are in flight at a time
+#pragma unroll 16
         for (int j = 0; j < n_sdf_slots; ++j) ss += base[(int64_t)j * PART_FLOATS + off];
+#pragma unroll 4
         for (int j = 0; j < n_rend_slots; ++j) sr += base[(int64_t)(nw_sdf + j) * PART_FLOATS + off];
         if (b < NH) {                      // normal-matrix entry
             if (a >= N || b >= N) continue;
