@@ -259,6 +259,21 @@ def main():
                         "ba_linearize_frac_of_8TBps": ba_stat["bytes_lin"] / max(1e-3 * ba_stat["ms_lin"] / max(ba_stat["n_lin"], 1), 1e-12) / 8e12},
         }
         if world == 1:
+            # the BA linearisation kernels are launch-bound at the BASELINE sizes (7.5 MB per build); their bandwidth is
+            # measured on a graph large enough to stream: 64 key-frames x 250 000 landmarks x 8 observations
+            big = synth.make_ba_scene_large(7, 64, 250000)
+            bb = BaProblem(big, device=dev)
+            bb.profile(True)
+            for _ in range(2):
+                bb.set_state(big["kf_pose"], big["pt_xyz"], big["obj_pose"])
+                bb.optimize(2, 0, 0, 0)
+                st = bb.profile(True)
+            us = 1e3 * st.ms_linearize / max(st.n_linearize, 1)
+            out["kernels"]["ba_linearize_large"] = {
+                "graph": "64 KF / 250000 landmarks / %d mono edges" % len(big["mono_pt"]), "us": us,
+                "algorithmic_bytes": int(st.bytes_linearize), "GBps": st.bytes_linearize / us / 1e3,
+                "frac_of_8TBps": st.bytes_linearize / us / 1e3 / 8000.0}
+            bb.close()
             # the boundary as the reference calls it: host buffers in, host results out (upload + allocation inside the
             # step); reported beside `value`, never as `value`
             th = time.perf_counter()
