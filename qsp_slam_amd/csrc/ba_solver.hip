@@ -5,7 +5,7 @@
 // LinearSolverEigen, single-threaded, heap-allocated edges walked through pointers):
 //
 //   k_errors          computeActiveErrors + activeRobustChi2            (sparse_optimizer.cpp:61-114)
-//   k_lin_points      per landmark: Jacobians of its edges, Hll, b_l, one 6x3 Hpl block per edge
+//   k_lin_points      per landmark: Jacobians of its edges, Hll, b_l (the 6x3 Hpl blocks are recomputed where needed)
 //   k_lin_poses       per key-frame: segmented reduction of J^T W J / J^T W e over its edges (Hpp diagonal, b_p)
 //   k_lin_objects     per object: its camera-object edges (Hpp diagonal, off-diagonal blocks, b_p)
 //                                                                       (block_solver.hpp:502-560, base_binary_edge.hpp:55-120)
@@ -294,7 +294,6 @@ struct Dev {
     int32_t *kf_h, *obj_h, *pt_h;
     // system
     double *Hll, *bl, *Dinv, *xl;   // per landmark (indexed by landmark, not by hessian index)
-    double *Hpl;                    // per edge 6x3
     double *Hdiag;                  // per pose block (hessian index) 6x6
     double *Hoff;                   // per object edge 6x6 (row = key-frame, col = object)
     double *oe_rec;                 // per object edge: OE_REC doubles (see k_lin_objedges)
@@ -376,7 +375,7 @@ __global__ __launch_bounds__(64) void k_finish_sum(Dev d, int n, int slot) {
 
 // ---------------------------------------------------------------------------------------------------------------
 // k_lin_points: edge-parallel.  A workgroup owns a chunk of consecutive landmarks whose edges (contiguous, landmark-
-// major) number at most 256: thread = edge.  Each thread writes its 6x3 Hpl block and parks its J_p^T W J_p (6 unique)
+// major) number at most 256: thread = edge.  Each thread parks its J_p^T W J_p (6 unique)
 // and J_p^T W e (3) in LDS; the first `n landmarks` threads then sum their landmark's segment in edge order.
 // ---------------------------------------------------------------------------------------------------------------
 template <int D>
@@ -402,7 +401,22 @@ __device__ inline void lin_point_edge(const Dev& d, const Edge& E, int ei, doubl
         for (int q = 0; q < D; ++q) sb += Jp[3 * q + i] * (-E.info * e[q]) * r1;
         out9[6 + i] = sb;
     }
-    double* B = d.Hpl + 18 * (size_t)ei;
+}
+
+// The 6x3 block  w J_x^T J_p  of one edge (block_solver.hpp's Hpl) at the current estimates, zero for a fixed pose.
+// It is NOT stored: the Schur complement and the back-substitution recompute it from the edge (56 B) instead of reading
+// 144 B per edge per use -- the same code and inputs everywhere, so every consumer sees the same bits.
+template <int D>
+__device__ inline void edge_hpl_t(const Dev& d, const Edge& E, double delta, double* B /*18*/) {
+    double e[3], p[3], Jp[9], Jx[18], r0, r1;
+    const double* pose = d.kf_pose + 7 * E.kf;
+    proj_error<D>(pose, d.pt_xyz + 3 * E.pt, d.kf_K + 5 * E.kf, E.obs, e, p);
+    proj_jacobians<D>(pose, p, d.kf_K + 5 * E.kf, Jp, Jx);
+    double c = 0;
+    for (int q = 0; q < D; ++q) c += e[q] * e[q];
+    c *= E.info;
+    huber(c, delta, r0, r1);
+    const double w = r1 * E.info;
     const bool free_pose = d.kf_h[E.kf] >= 0;
     for (int i = 0; i < 6; ++i)
         for (int j = 0; j < 3; ++j) {
@@ -410,6 +424,10 @@ __device__ inline void lin_point_edge(const Dev& d, const Edge& E, int ei, doubl
             for (int q = 0; q < D; ++q) s += Jx[6 * q + i] * Jp[3 * q + j];
             B[3 * i + j] = free_pose ? w * s : 0.0;
         }
+}
+__device__ inline void edge_hpl(const Dev& d, const Edge& E, const Par& par, double* B) {
+    if (E.stereo) edge_hpl_t<3>(d, E, par.delta_stereo, B);
+    else edge_hpl_t<2>(d, E, par.delta_mono, B);
 }
 
 __global__ __launch_bounds__(256) void k_lin_points(Dev d, Par par) {
@@ -671,7 +689,7 @@ __global__ __launch_bounds__(256) void k_schur_points(Dev d, Par par) {
         }
         if (staged) {
             for (int a = lane; a < k; a += 64) hsh[wave][a] = d.edge_level[e0 + a] ? -1 : d.kf_h[d.edge[e0 + a].kf];
-            for (int q = lane; q < 18 * k; q += 64) Bsh[wave][q] = d.Hpl[18 * (size_t)e0 + q];
+            if (lane < k) edge_hpl(d, d.edge[e0 + lane], par, Bsh[wave] + 18 * lane);      // level-masked edges are never read
         }
     }
     __syncthreads();
@@ -706,7 +724,8 @@ __global__ __launch_bounds__(256) void k_schur_points(Dev d, Par par) {
         if (d.edge_level[a]) continue;
         const int ha = d.kf_h[d.edge[a].kf];
         if (ha < 0) continue;
-        const double* Ba = d.Hpl + 18 * (size_t)a;
+        double Ba[18];
+        edge_hpl(d, d.edge[a], par, Ba);
         if (lane >= 36 && lane < 42) {
             const int r = lane - 36;
             atomicAdd(&d.bs[6 * ha + r], -(Ba[3 * r] * db[0] + Ba[3 * r + 1] * db[1] + Ba[3 * r + 2] * db[2]));
@@ -719,7 +738,8 @@ __global__ __launch_bounds__(256) void k_schur_points(Dev d, Par par) {
                 if (d.edge_level[b]) continue;
                 const int hb = d.kf_h[d.edge[b].kf];
                 if (hb < ha || (hb == ha && b != a)) continue;
-                const double* Bb = d.Hpl + 18 * (size_t)b;
+                double Bb[18];
+                edge_hpl(d, d.edge[b], par, Bb);
                 atomicAdd(&d.Hs[(size_t)(6 * ha + i) * par.dimp + 6 * hb + j],
                           -(bd0 * Bb[3 * j] + bd1 * Bb[3 * j + 1] + bd2 * Bb[3 * j + 2]));
             }
@@ -762,11 +782,9 @@ __global__ __launch_bounds__(256) void k_schur_rows(Dev d, Par par) {
         if (d.pt_h[pt] < 0) continue;
         double Ba[18], BD[18];
         {
-            const double* Bg = d.Hpl + 18 * (size_t)a;
             const double* Di = d.Dinv + 9 * (size_t)pt;
             double Dl[9];
-#pragma unroll
-            for (int i = 0; i < 18; ++i) Ba[i] = Bg[i];
+            edge_hpl(d, d.edge[a], par, Ba);
 #pragma unroll
             for (int i = 0; i < 9; ++i) Dl[i] = Di[i];
 #pragma unroll
@@ -783,10 +801,8 @@ __global__ __launch_bounds__(256) void k_schur_rows(Dev d, Par par) {
             if (d.edge_level[b]) continue;
             const int hb = d.kf_h[d.edge[b].kf];
             if (hb < ha || (hb == ha && b != a)) continue;
-            const double* Bg = d.Hpl + 18 * (size_t)b;
             double Bb[18];
-#pragma unroll
-            for (int i = 0; i < 18; ++i) Bb[i] = Bg[i];
+            edge_hpl(d, d.edge[b], par, Bb);
             double* dst = srow + 6 * hb;
 #pragma unroll
             for (int i = 0; i < 6; ++i)
@@ -1062,7 +1078,8 @@ __global__ __launch_bounds__(256) void k_update_points(Dev d, Par par) {
             if (d.edge_level[a]) continue;
             const int ha = d.kf_h[d.edge[a].kf];
             if (ha < 0) continue;
-            const double* B = d.Hpl + 18 * (size_t)a;
+            double B[18];
+            edge_hpl(d, d.edge[a], par, B);
             for (int j = 0; j < 3; ++j)
                 for (int i = 0; i < 6; ++i) c[j] -= B[3 * i + j] * d.xp[6 * ha + i];
         }
@@ -1294,7 +1311,6 @@ extern "C" int qsp_ba_create(const qsp_ba_scene* s, int device, qsp_ba_problem**
     UP(obo_edge, obo_edge.data(), d.n_oe);
     AL(kf_h, d.n_kf); AL(obj_h, d.n_obj); AL(pt_h, d.n_pt);
     AL(Hll, 9 * (size_t)d.n_pt); AL(bl, 3 * (size_t)d.n_pt); AL(Dinv, 9 * (size_t)d.n_pt); AL(xl, 3 * (size_t)d.n_pt);
-    AL(Hpl, 18 * (size_t)d.n_edge);
     AL(Hdiag, 36 * (size_t)(d.n_kf + d.n_obj));
     AL(Hoff, 36 * (size_t)d.n_oe);
     AL(oe_rec, 84 * (size_t)d.n_oe);

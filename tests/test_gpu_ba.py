@@ -2,8 +2,10 @@
 itself pinned by an independent dense formulation in tests/test_oracle_ba.py) run live on the same seeded scenes, and
 against committed fixtures of the oracle's output (tests/golden/ba_*.npz).
 
-Bars: hessian indices, trial counts, accept flags and outlier levels bit-exact; chi2 / lambda / estimates to 1e-9 relative
-(FP64 on both sides; differences come only from summation order and the Cholesky variant) -- far inside the 1e-4 pose bar."""
+Bars: hessian indices, trial counts, accept flags and outlier levels bit-exact; chi2 / lambda / estimates to 1e-8 relative
+(FP64 on both sides; differences come only from summation order and the Cholesky variant; the Schur complement's f64
+atomics make the GPU's own run-to-run spread up to 4e-10 relative on the ill-conditioned 4-key-frame scene, measured with
+tools/ba_repeat.py) -- far inside the 1e-4 pose bar."""
 import os
 
 import numpy as np
@@ -28,7 +30,7 @@ SCENES = {
 }
 
 
-def close(a, b, rtol=1e-9, atol=1e-12):
+def close(a, b, rtol=1e-8, atol=1e-12):
     return np.allclose(a, b, rtol=rtol, atol=atol)
 
 
