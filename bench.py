@@ -142,11 +142,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     dist = None
+    # QSP_BENCH_REHEARSAL=1: rehearse the N > 1 control flow on a one-GPU box -- all ranks share device 0 and the two
+    # scalar reductions go over gloo.  Never set by the driver; the numbers of such a run mean nothing.
+    rehearsal = os.environ.get("QSP_BENCH_REHEARSAL") == "1"
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = local_rank if world > 1 else 0
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = local_rank if (world > 1 and not rehearsal) else 0
+    red_dev = "cpu" if rehearsal else "cuda:%d" % dev
 
     from qsp_slam_amd import DeepSdfDecoder, synth
     from qsp_slam_amd.ba import BaProblem
@@ -209,7 +216,7 @@ def main():
     sync_all()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], device="cuda:%d" % dev, dtype=torch.float64)
+        t = torch.tensor([dt], device=red_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     _, _, loss, good = batch.get()
@@ -217,7 +224,7 @@ def main():
     n_hyp = len(hyp)
     iters_total = n_hyp * w["n_iter"] * args.steps + ba_stat["iters"]
     if dist is not None:
-        t = torch.tensor([float(iters_total)], device="cuda:%d" % dev, dtype=torch.float64)
+        t = torch.tensor([float(iters_total)], device=red_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         iters_total_all = float(t.item())
     else:
