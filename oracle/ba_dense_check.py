@@ -270,3 +270,115 @@ class DenseBA(object):
             if n_bad >= 3:
                 break
         return {k: np.array(v) for k, v in tr.items()}
+
+
+def pose_optimization_dense(K, pose7_in, X, obs, info, stereo):
+    """Independent formulation of Optimizer::PoseOptimization (reference src/Optimizer.cc:244-456) for pinning
+    ba_oracle_pose_optimization: 4x4 poses, Taylor-series exponential, central-difference Jacobians of the residuals with
+    respect to the left perturbation exp(d) T, scipy solve of the 6x6 system.  Shared with the oracle only as
+    specification: residuals (types_six_dof_expmap.cpp:290-306, float 1/z and DOUBLE bf in the stereo only-pose edge),
+    Huber re-weighting, the LM schedule and the four-round inlier/outlier logic.
+    Returns dict(T (4,4), outlier (n,), n_inliers, iters (4,), trace (4,10,3))."""
+    n = len(info)
+    T0 = T_from_pose7(np.asarray(pose7_in, float))
+    dM, dS = float(np.float32(np.sqrt(5.991))), float(np.float32(np.sqrt(7.815)))
+
+    def res(T, k, exact=False):
+        if not stereo[k]:
+            return res_mono(T, X[k], K, obs[k])
+        p = T[:3, :3] @ X[k] + T[:3, 3]
+        invz = 1.0 / p[2] if exact else float(np.float32(1.0) / np.float32(p[2]))
+        u = p[0] * invz * K[0] + K[2]
+        v = p[1] * invz * K[1] + K[3]
+        return np.array([obs[k][0] - u, obs[k][1] - v, obs[k][2] - (u - K[4] * invz)])
+
+    def errors(T, level, robust):
+        chi, c2 = 0.0, np.zeros(n)
+        for k in range(n):
+            if level[k]:
+                continue
+            e = res(T, k)
+            c2[k] = info[k] * float(e @ e)
+            chi += huber(c2[k], (dS if stereo[k] else dM) if robust else 0.0)[0]
+        return chi, c2
+
+    outlier = np.zeros(n, np.uint8)
+    level = np.zeros(n, np.uint8)
+    trace = np.full((4, 10, 3), np.nan)
+    iters = np.zeros(4, np.int32)
+    if n < 3:
+        return dict(T=T0, outlier=outlier, n_inliers=0, iters=iters, trace=trace)
+    chi2_last = np.zeros(n)
+    robust = True
+    T = T0.copy()
+    n_bad_edges = 0
+    h = 1e-6
+    for rnd in range(4):
+        T = T0.copy()
+        lam, ni, n_bad = 0.0, 2.0, 0
+        for it in range(10):
+            cur, c2 = errors(T, level, robust)
+            chi2_last[level == 0] = c2[level == 0]
+            ini = cur
+            H, b = np.zeros((6, 6)), np.zeros(6)
+            for k in range(n):
+                if level[k]:
+                    continue
+                e = res(T, k)
+                J = np.zeros((len(e), 6))
+                for a in range(6):
+                    d = np.zeros(6)
+                    d[a] = h
+                    J[:, a] = (res(exp_series(d) @ T, k, exact=True) - res(exp_series(-d) @ T, k, exact=True)) / (2 * h)
+                _, r1 = huber(info[k] * float(e @ e), (dS if stereo[k] else dM) if robust else 0.0)
+                H += r1 * info[k] * (J.T @ J)
+                b += J.T @ (-info[k] * e) * r1
+            if it == 0:
+                lam, ni, n_bad = 1e-5 * np.abs(np.diag(H)).max(), 2.0, 0
+            rho, qmax = 0.0, 0
+            while True:
+                Tb = T.copy()
+                try:
+                    x = sla.cho_solve(sla.cho_factor(H + lam * np.eye(6)), b)
+                    T = exp_series(x) @ T
+                    tmp, c2 = errors(T, level, robust)
+                    chi2_last[level == 0] = c2[level == 0]
+                except sla.LinAlgError:
+                    x = np.zeros(6)
+                    tmp = np.inf
+                rho = (cur - tmp) / (float(x @ (lam * x + b)) + 1e-3)
+                if rho > 0 and np.isfinite(tmp):
+                    alpha = min(1.0 - (2 * rho - 1) ** 3, 2.0 / 3.0)
+                    lam *= max(1.0 / 3.0, alpha)
+                    ni = 2.0
+                    cur = tmp
+                else:
+                    lam *= ni
+                    ni *= 2
+                    T = Tb
+                qmax += 1
+                if not (rho < 0 and qmax < 10):
+                    break
+            trace[rnd, it] = (cur, lam, qmax)
+            iters[rnd] += 1
+            if qmax == 10 or rho == 0:
+                break
+            n_bad = n_bad + 1 if (ini - cur) * 1e3 < ini else 0
+            if n_bad >= 3:
+                break
+        n_bad_edges = 0
+        for k in range(n):
+            if outlier[k]:
+                e = res(T, k)
+                chi2_last[k] = info[k] * float(e @ e)
+            c = np.float32(chi2_last[k])
+            if c > np.float32(7.815 if stereo[k] else 5.991):
+                outlier[k], level[k] = 1, 1
+                n_bad_edges += 1
+            else:
+                outlier[k], level[k] = 0, 0
+        if rnd == 2:
+            robust = False
+        if n < 10:
+            break
+    return dict(T=T, outlier=outlier, n_inliers=n - n_bad_edges, iters=iters, trace=trace)

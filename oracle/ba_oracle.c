@@ -773,3 +773,164 @@ void ba_oracle_depth_positive(const ba_problem* p, unsigned char* mono_pos, unsi
         st_pos[k] = q[2] > 0.0;
     }
 }
+
+/* ------------------------------------------------------------------------------------------------------------ */
+/* Optimizer::PoseOptimization (reference src/Optimizer.cc:244-456): one free SE3 vertex (the frame), unary edges   */
+/* EdgeSE3ProjectXYZOnlyPose / EdgeStereoSE3ProjectXYZOnlyPose with the map point fixed inside the edge            */
+/* (Thirdparty/g2o/g2o/types/types_six_dof_expmap.h:142-214, .cpp:266-358), 4 rounds of optimize(10) with the same  */
+/* Levenberg-Marquardt as above, inlier / outlier classification after every round.                                */
+/* ------------------------------------------------------------------------------------------------------------ */
+static void po_edge(const double* pose, const double* X, const double* K, const double* obs, int stereo, double* e,
+                    double* J /* D x 6, may be NULL */) {
+    double p[3];
+    se3_map(pose, X, p);
+    const double fx = K[0], fy = K[1], cx = K[2], cy = K[3], bf = K[4];
+    if (!stereo) {                       /* project2d then cam_project, .cpp:290-296 */
+        e[0] = obs[0] - (p[0] / p[2] * fx + cx);
+        e[1] = obs[1] - (p[1] / p[2] * fy + cy);
+    } else {                             /* .cpp:299-306: float 1/z, DOUBLE bf (the binary edge casts bf to float) */
+        const float invz = 1.0f / (float)p[2];
+        const double u = p[0] * invz * fx + cx, v = p[1] * invz * fy + cy;
+        e[0] = obs[0] - u; e[1] = obs[1] - v; e[2] = obs[2] - (u - bf * invz);
+    }
+    if (!J) return;
+    const double x = p[0], y = p[1], invz = 1.0 / p[2], invz_2 = invz * invz;   /* .cpp:266-288, 335-358 */
+    J[0] = x * y * invz_2 * fx; J[1] = -(1 + (x * x * invz_2)) * fx; J[2] = y * invz * fx;
+    J[3] = -invz * fx; J[4] = 0; J[5] = x * invz_2 * fx;
+    J[6] = (1 + y * y * invz_2) * fy; J[7] = -x * y * invz_2 * fy; J[8] = -x * invz * fy;
+    J[9] = 0; J[10] = -invz * fy; J[11] = y * invz_2 * fy;
+    if (stereo) {
+        J[12] = J[0] - bf * y * invz_2; J[13] = J[1] + bf * x * invz_2; J[14] = J[2];
+        J[15] = J[3]; J[16] = 0; J[17] = J[5] - bf * invz_2;
+    }
+}
+
+static double po_errors(int n, const double* K, const double* pose, const double* X, const double* obs, const double* info,
+                        const unsigned char* stereo, const unsigned char* level, double dm, double ds, double* chi2) {
+    double chi = 0, e[3], r0, r1;
+    for (int k = 0; k < n; ++k) {
+        if (level[k]) continue;
+        po_edge(pose, X + 3 * k, K, obs + 3 * k, stereo[k], e, NULL);
+        const int D = stereo[k] ? 3 : 2;
+        double c = 0;
+        for (int d = 0; d < D; ++d) c += e[d] * e[d];
+        c *= info[k];
+        chi2[k] = c;
+        huber(c, stereo[k] ? ds : dm, &r0, &r1);
+        chi += r0;
+    }
+    return chi;
+}
+
+/* trace: [4 rounds][10 iterations][3] = chi2, lambda, trials (rows beyond iters[round] untouched) */
+int ba_oracle_pose_optimization(int n, const double* K, const double* pose_in, const double* X, const double* obs,
+                                const double* info, const unsigned char* stereo, double* pose_out, unsigned char* outlier,
+                                double* trace, int* iters) {
+    unsigned char* level = calloc(n + 1, 1);
+    double* chi2 = calloc(n + 1, sizeof(double));
+    double pose[7], bk[7];
+    memset(outlier, 0, n);
+    if (n < 3) { memcpy(pose_out, pose_in, sizeof(pose)); free(level); free(chi2); return 0; }   /* :368-369 */
+    int nBadEdges = 0;
+    int robust = 1;
+    const double dM = (double)(float)sqrt(5.991), dS = (double)(float)sqrt(7.815);          /* :282-283 */
+    const float chi2Mono = 5.991f, chi2Stereo = 7.815f;                                       /* :373-374 */
+    memcpy(pose, pose_in, sizeof(pose));
+    for (int round = 0; round < 4; ++round) {
+        memcpy(pose, pose_in, sizeof(pose));            /* vSE3->setEstimate(pFrame->mTcw), :381 */
+        const double dm = robust ? dM : 0.0, ds = robust ? dS : 0.0;
+        double lambda = 0, ni = 2;
+        int nBad = 0, done = 0;
+        for (int it = 0; it < 10; ++it) {
+            double currentChi = po_errors(n, K, pose, X, obs, info, stereo, level, dm, ds, chi2);
+            double tempChi = currentChi;
+            const double iniChi = currentChi;
+            double H[36], b[6], x[6];
+            memset(H, 0, sizeof(H)); memset(b, 0, sizeof(b));
+            for (int k = 0; k < n; ++k) {
+                if (level[k]) continue;
+                double e[3], J[18], r0, r1;
+                po_edge(pose, X + 3 * k, K, obs + 3 * k, stereo[k], e, J);
+                const int D = stereo[k] ? 3 : 2;
+                double c = 0;
+                for (int d = 0; d < D; ++d) c += e[d] * e[d];
+                c *= info[k];
+                huber(c, stereo[k] ? ds : dm, &r0, &r1);
+                const double w = r1 * info[k];
+                for (int i = 0; i < 6; ++i) {
+                    double sb = 0;
+                    for (int d = 0; d < D; ++d) sb += J[6 * d + i] * (-info[k] * e[d]) * r1;
+                    b[i] += sb;
+                    for (int j = 0; j < 6; ++j) {
+                        double sum = 0;
+                        for (int d = 0; d < D; ++d) sum += J[6 * d + i] * J[6 * d + j];
+                        H[6 * i + j] += w * sum;
+                    }
+                }
+            }
+            if (it == 0) {
+                double md = 0;
+                for (int i = 0; i < 6; ++i) md = fmax(fabs(H[7 * i]), md);
+                lambda = 1e-5 * md; ni = 2; nBad = 0;
+            }
+            double rho = 0;
+            int qmax = 0;
+            do {
+                memcpy(bk, pose, sizeof(pose));
+                double A[36];
+                memcpy(A, H, sizeof(A));
+                for (int i = 0; i < 6; ++i) A[7 * i] += lambda;
+                const int ok2 = chol_solve_upper(A, 6, b, x);
+                if (ok2) {
+                    double dl[7], np[7];
+                    ba_se3_exp(x, dl);
+                    se3_mul(dl, pose, np);
+                    memcpy(pose, np, sizeof(pose));
+                }
+                tempChi = po_errors(n, K, pose, X, obs, info, stereo, level, dm, ds, chi2);
+                if (!ok2) tempChi = DBL_MAX;
+                rho = currentChi - tempChi;
+                double scale = 1e-3;
+                for (int i = 0; i < 6; ++i) scale += x[i] * (lambda * x[i] + b[i]);
+                rho /= scale;
+                if (rho > 0 && isfinite(tempChi)) {
+                    double alpha = 1. - pow(2 * rho - 1, 3);
+                    alpha = fmin(alpha, 2. / 3.);
+                    lambda *= fmax(1. / 3., alpha);
+                    ni = 2;
+                    currentChi = tempChi;
+                } else {
+                    lambda *= ni;
+                    ni *= 2;
+                    memcpy(pose, bk, sizeof(pose));
+                }
+                qmax++;
+            } while (rho < 0 && qmax < 10);
+            if (trace) { double* t = trace + 3 * (10 * round + it); t[0] = currentChi; t[1] = lambda; t[2] = qmax; }
+            done++;
+            if (qmax == 10 || rho == 0) break;
+            if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0;
+            if (nBad >= 3) break;
+        }
+        if (iters) iters[round] = done;
+        nBadEdges = 0;
+        for (int k = 0; k < n; ++k) {                    /* :384-437 */
+            if (outlier[k]) {                            /* e->computeError() at the final pose */
+                double e[3];
+                po_edge(pose, X + 3 * k, K, obs + 3 * k, stereo[k], e, NULL);
+                const int D = stereo[k] ? 3 : 2;
+                double c = 0;
+                for (int d = 0; d < D; ++d) c += e[d] * e[d];
+                chi2[k] = c * info[k];
+            }
+            const float c = (float)chi2[k];              /* const float chi2 = e->chi2(); */
+            if (c > (stereo[k] ? chi2Stereo : chi2Mono)) { outlier[k] = 1; level[k] = 1; nBadEdges++; }
+            else { outlier[k] = 0; level[k] = 0; }
+        }
+        if (round == 2) robust = 0;                      /* e->setRobustKernel(0) */
+        if (n < 10) break;                               /* optimizer.edges().size() < 10 */
+    }
+    memcpy(pose_out, pose, sizeof(pose));
+    free(level); free(chi2);
+    return n - nBadEdges;
+}

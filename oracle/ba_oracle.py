@@ -53,6 +53,8 @@ def lib():
         _LIB.ba_stereo_edge.argtypes = [dp, dp, dp, dp, dp, dp, dp]
         _LIB.ba_stereo_edge.restype = C.c_double
         _LIB.ba_obj_edge.argtypes = [dp, dp, dp, dp, dp, dp]
+        _LIB.ba_oracle_pose_optimization.argtypes = [C.c_int, dp, dp, dp, dp, dp, up, dp, up, dp, ip]
+        _LIB.ba_oracle_pose_optimization.restype = C.c_int
     return _LIB
 
 
@@ -124,3 +126,23 @@ class BaProblem(object):
 
     def state(self):
         return self.s["kf_pose"].copy(), self.s["pt_xyz"].copy(), self.s["obj_pose"].copy()
+
+
+def pose_optimization(K, pose, X, obs, info, stereo):
+    """Optimizer::PoseOptimization (src/Optimizer.cc:244-456) on flattened inputs: K (5,) fx fy cx cy bf, pose (7,) T_cw,
+    X (n,3) world points, obs (n,3) u v u_right (u_right ignored for mono rows), info (n,) invSigma2, stereo (n,) 0/1.
+    Returns dict(pose (7,), outlier (n,) uint8, n_inliers, iters (4,), trace (4,10,3): chi2, lambda, trials)."""
+    n = len(info)
+    K = np.ascontiguousarray(K, np.float64)
+    pose = np.ascontiguousarray(pose, np.float64)
+    X = np.ascontiguousarray(X, np.float64).reshape(-1, 3)
+    obs = np.ascontiguousarray(obs, np.float64).reshape(-1, 3)
+    info = np.ascontiguousarray(info, np.float64)
+    stereo = np.ascontiguousarray(stereo, np.uint8)
+    out = np.zeros(7)
+    outlier = np.zeros(max(n, 1), np.uint8)
+    trace = np.full((4, 10, 3), np.nan)
+    iters = np.zeros(4, np.int32)
+    r = lib().ba_oracle_pose_optimization(n, _p(K, dp), _p(pose, dp), _p(X, dp), _p(obs, dp), _p(info, dp), _p(stereo, up),
+                                          _p(out, dp), _p(outlier, up), _p(trace, dp), _p(iters, ip))
+    return dict(pose=out, outlier=outlier[:n], n_inliers=int(r), iters=iters, trace=trace)

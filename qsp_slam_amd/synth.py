@@ -320,3 +320,32 @@ def make_ba_scene_large(seed, n_kf, n_pt, obs_per_pt=8, n_obj=0):
     if n_obj:
         out["obj_id"] = np.arange(n_obj, dtype=np.int64) + int(out["pt_id"].max()) + 2
     return out
+
+
+def make_pose_problem(seed, n=400, stereo_frac=0.3, outlier_frac=0.1, pose_noise=(0.03, 0.02)):
+    """One frame for Optimizer::PoseOptimization (reference src/Optimizer.cc:244-456): n map points in front of a camera,
+    pixel noise 1 px, `outlier_frac` gross outliers (30-80 px), initial pose = truth * exp(noise).
+    Returns dict(K (5,), pose (7,) initial T_cw, X (n,3), obs (n,3) u v u_right, info (n,), stereo (n,) uint8, gt_pose)."""
+    rng = np.random.default_rng(seed)
+    fx, fy, cx, cy, bf = 535.4, 539.2, 320.1, 247.6, 40.0
+    T_gt = se3(rot_y(rng.uniform(-0.2, 0.2)) @ np.diag([1.0, 1.0, 1.0]), rng.uniform(-0.3, 0.3, 3))
+    Xc = np.stack([rng.uniform(-1.5, 1.5, n), rng.uniform(-1.0, 1.0, n), rng.uniform(1.5, 8.0, n)], 1)
+    Xw = (np.linalg.inv(T_gt) @ np.concatenate([Xc, np.ones((n, 1))], 1).T).T[:, :3]
+    u = fx * Xc[:, 0] / Xc[:, 2] + cx
+    v = fy * Xc[:, 1] / Xc[:, 2] + cy
+    ur = u - bf / Xc[:, 2]
+    obs = np.stack([u, v, ur], 1) + rng.normal(size=(n, 3))
+    bad = rng.random(n) < outlier_frac
+    obs[bad, :2] += rng.uniform(30, 80, size=(bad.sum(), 2)) * rng.choice([-1, 1], size=(bad.sum(), 2))
+    stereo = (rng.random(n) < stereo_frac).astype(np.uint8)
+    obs[stereo == 0, 2] = -1.0
+    octave = rng.integers(0, 8, n)
+    info = 1.2 ** (-2.0 * octave)
+    w = rng.normal(scale=pose_noise[1], size=3)
+    th = np.linalg.norm(w)
+    Kx = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+    dR = np.eye(3) + np.sin(th) / max(th, 1e-12) * Kx + (1 - np.cos(th)) / max(th * th, 1e-12) * Kx @ Kx
+    T0 = se3(dR, rng.normal(scale=pose_noise[0], size=3)) @ T_gt
+    f32 = lambda a: np.asarray(a, np.float32).astype(np.float64)      # the map holds float32 pixels / poses
+    return dict(K=np.array([fx, fy, cx, cy, bf]), pose=pose7(f32(T0)), X=f32(Xw), obs=f32(obs), info=f32(info),
+                stereo=stereo, gt_pose=pose7(T_gt), gross=bad)
