@@ -281,6 +281,26 @@ int qsp_ba_profile(qsp_ba_problem* p, int enable, qsp_ba_stats* out);
 typedef int (*qsp_allreduce_fn)(void* ctx, double* device_buf, int64_t count, void* hip_stream);
 int qsp_ba_set_shard(qsp_ba_problem* p, int32_t rank, int32_t world, qsp_allreduce_fn fn, void* ctx);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Pose-only optimisation: Optimizer::PoseOptimization(Frame*), src/Optimizer.cc:244-456 --
+ * one free SE3 vertex, one unary edge per matched map point (EdgeSE3ProjectXYZOnlyPose / EdgeStereoSE3ProjectXYZOnlyPose),
+ * 4 rounds of optimize(10) with inlier / outlier re-classification (chi2 5.991 / 7.815), robust kernel off from round 3.
+ * The whole procedure is one kernel launch.  Host pointers.
+ *   K (5) fx fy cx cy bf; pose (7) tx ty tz qx qy qz qw of T_cw = Converter::toSE3Quat(pFrame->mTcw);
+ *   X (n,3) world points; obs (n,3) u v u_right (third entry ignored where stereo[i] == 0); info (n) invSigma2;
+ *   outlier (n) out = pFrame->mvbOutlier of the matched points; *n_inliers = nInitialCorrespondences - nBad (0 and the
+ *   pose unchanged when n < 3, :368-369). */
+typedef struct qsp_pose_optimizer qsp_pose_optimizer;
+typedef struct {
+    int32_t iters[4];          /* LM iterations run in each round                       */
+    double trace[4][10][3];    /* chi2, lambda, trials after each (round, iteration)    */
+} qsp_pose_trace;
+int qsp_pose_optimizer_create(int device, int32_t max_points, qsp_pose_optimizer** out);
+void qsp_pose_optimizer_destroy(qsp_pose_optimizer* h);
+int qsp_pose_optimize(qsp_pose_optimizer* h, int32_t n, const double* K, const double* pose_in, const double* X,
+                      const double* obs, const double* info, const uint8_t* stereo, double* pose_out, uint8_t* outlier,
+                      int32_t* n_inliers, qsp_pose_trace* trace);
+
 #ifdef __cplusplus
 }
 #endif

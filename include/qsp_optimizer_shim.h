@@ -26,6 +26,7 @@
 
 #ifndef QSP_SHIM_MOCK_TYPES      // the real tree
 #include "Converter.h"
+#include "Frame.h"
 #include "KeyFrame.h"
 #include "Map.h"
 #include "MapObject.h"
@@ -367,6 +368,60 @@ public:
             if (nLoopKF == 0) F.objs[i]->SetObjectPoseSE3(Tow.inverse());
             else { F.objs[i]->mTwoGBA = Tow.inverse(); F.objs[i]->mnBAGlobalForKF = nLoopKF; }
         }
+    }
+
+    // Optimizer::PoseOptimization, src/Optimizer.cc:244-456: the frame's pose against its matched map points (fixed),
+    // 4 x optimize(10) with inlier / outlier re-classification; sets pFrame->mvbOutlier and the pose, returns the number
+    // of inliers.  One kernel launch (qsp_pose_optimize); the optimiser object is created once per thread.
+    static int PoseOptimization(Frame* pFrame) {
+        using namespace qsp_shim;
+        const int N = pFrame->N;
+        std::vector<double> X, obs, info;
+        std::vector<uint8_t> stereo;
+        std::vector<int> index;
+        {
+            std::unique_lock<std::mutex> lock(MapPoint::mGlobalMutex);
+            for (int i = 0; i < N; ++i) {
+                MapPoint* pMP = pFrame->mvpMapPoints[i];
+                if (!pMP) continue;
+                pFrame->mvbOutlier[i] = false;
+                const cv::KeyPoint& kpUn = pFrame->mvKeysUn[i];
+                const bool st = !(pFrame->mvuRight[i] < 0);
+                obs.push_back(kpUn.pt.x); obs.push_back(kpUn.pt.y); obs.push_back(st ? pFrame->mvuRight[i] : -1.0);
+                info.push_back(pFrame->mvInvLevelSigma2[kpUn.octave]);
+                stereo.push_back(st ? 1 : 0);
+                const cv::Mat Xw = pMP->GetWorldPos();
+                for (int r = 0; r < 3; ++r) X.push_back((double)Xw.at<float>(r));
+                index.push_back(i);
+            }
+        }
+        const int n = (int)index.size();
+        if (n < 3) return 0;                                                     // :368-369
+        static thread_local qsp_pose_optimizer* ctx = nullptr;
+        static thread_local int ctx_cap = 0;
+        if (!ctx || n > ctx_cap) {
+            if (ctx) qsp_pose_optimizer_destroy(ctx);
+            ctx = nullptr;
+            ctx_cap = n > 4096 ? 2 * n : 4096;
+            if (qsp_pose_optimizer_create(device(), ctx_cap, &ctx) != QSP_OK) { ctx = nullptr; return 0; }
+        }
+        double pose[7], pose_out[7];
+        const cv::Mat Tcw = pFrame->mTcw;
+        pose7_from_rt([&](int r, int c) { return (double)Tcw.at<float>(r, c); }, pose);
+        const double K[5] = {pFrame->fx, pFrame->fy, pFrame->cx, pFrame->cy, pFrame->mbf};
+        std::vector<uint8_t> outlier(n, 0);
+        int32_t n_inliers = 0;
+        if (qsp_pose_optimize(ctx, n, K, pose, X.data(), obs.data(), info.data(), stereo.data(), pose_out, outlier.data(),
+                              &n_inliers, nullptr) != QSP_OK)
+            return 0;
+        for (int e = 0; e < n; ++e) pFrame->mvbOutlier[index[e]] = outlier[e] != 0;
+        float T[16];
+        pose7_to_mat(pose_out, T);
+        cv::Mat M(4, 4, CV_32F);
+        for (int r = 0; r < 4; ++r)
+            for (int c = 0; c < 4; ++c) M.at<float>(r, c) = T[4 * r + c];
+        pFrame->SetPose(M);
+        return n_inliers;
     }
 
     // src/Optimizer.cc:54-242

@@ -845,7 +845,7 @@ int ba_oracle_pose_optimization(int n, const double* K, const double* pose_in, c
             double currentChi = po_errors(n, K, pose, X, obs, info, stereo, level, dm, ds, chi2);
             double tempChi = currentChi;
             const double iniChi = currentChi;
-            double H[36], b[6], x[6];
+            double H[36], b[6], x[6] = {0, 0, 0, 0, 0, 0};
             memset(H, 0, sizeof(H)); memset(b, 0, sizeof(b));
             for (int k = 0; k < n; ++k) {
                 if (level[k]) continue;

@@ -72,6 +72,10 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_
 _lib = None
 
 # every symbol include/qsp_hip.h declares; tests/test_abi.py checks the list against the header
+class PoseTrace(C.Structure):
+    _fields_ = [("iters", C.c_int32 * 4), ("trace", C.c_double * 120)]
+
+
 SYMBOLS = [
     "qsp_last_error", "qsp_version", "qsp_device_count",
     "qsp_decoder_create", "qsp_decoder_destroy", "qsp_decode_sdf", "qsp_sdf_value_grad",
@@ -80,6 +84,7 @@ SYMBOLS = [
     "qsp_reconstruct_objects", "qsp_estimate_pose",
     "qsp_mesh_extractor_create", "qsp_mesh_extractor_destroy", "qsp_mesh_extract", "qsp_mesh_from_volume", "qsp_mesh_fetch",
     "qsp_mc_tables",
+    "qsp_pose_optimizer_create", "qsp_pose_optimizer_destroy", "qsp_pose_optimize",
     "qsp_ba_create", "qsp_ba_destroy", "qsp_ba_set_levels", "qsp_ba_optimize", "qsp_ba_local_joint",
     "qsp_ba_set_state", "qsp_ba_get_state", "qsp_ba_get_edges", "qsp_ba_get_index", "qsp_ba_profile", "qsp_ba_set_shard",
 ]
@@ -126,6 +131,11 @@ def lib():
     L.qsp_mesh_from_volume.argtypes = [vp, c_float_p, c_int64_p, c_int64_p]
     L.qsp_mesh_fetch.argtypes = [vp, c_float_p, c_int32_p, c_float_p]
     L.qsp_mc_tables.argtypes = [C.POINTER(C.c_int8), C.POINTER(C.c_int8)]
+    L.qsp_pose_optimizer_create.argtypes = [C.c_int, C.c_int32, C.POINTER(vp)]
+    L.qsp_pose_optimizer_destroy.argtypes = [vp]
+    L.qsp_pose_optimizer_destroy.restype = None
+    L.qsp_pose_optimize.argtypes = [vp, C.c_int32, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, c_uint8_p,
+                                    c_double_p, c_uint8_p, c_int32_p, C.POINTER(PoseTrace)]
     L.qsp_ba_create.argtypes = [C.POINTER(BaScene), C.c_int, C.POINTER(vp)]
     L.qsp_ba_destroy.argtypes = [vp]
     L.qsp_ba_destroy.restype = None

@@ -135,3 +135,41 @@ class BaProblem(object):
         p = _lib.BaProfile()
         _lib.check(_lib.lib().qsp_ba_profile(self.handle, 1 if enable else 0, C.byref(p)))
         return p
+
+
+class PoseOptimizer(object):
+    """Optimizer::PoseOptimization (reference src/Optimizer.cc:244-456) on flattened inputs, one kernel launch per call
+    (qsp_pose_optimize, include/qsp_hip.h)."""
+
+    def __init__(self, max_points=4096, device=0):
+        self.handle = C.c_void_p()
+        _lib.check(_lib.lib().qsp_pose_optimizer_create(int(device), int(max_points), C.byref(self.handle)))
+
+    def close(self):
+        if self.handle is not None and self.handle.value:
+            _lib.lib().qsp_pose_optimizer_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def optimize(self, K, pose, X, obs, info, stereo):
+        """K (5,) fx fy cx cy bf; pose (7,) T_cw; X (n,3); obs (n,3) u v u_right; info (n,); stereo (n,) 0/1.
+        Returns dict(pose (7,), outlier (n,) uint8, n_inliers, iters (4,), trace (4,10,3) chi2 / lambda / trials)."""
+        n = int(np.size(info))                 # (_arr pads empty arrays so that their pointers stay valid)
+        info = _arr(info, np.float64)
+        K, pose = _arr(K, np.float64), _arr(pose, np.float64)
+        X, obs = _arr(np.reshape(X, (-1, 3)), np.float64), _arr(np.reshape(obs, (-1, 3)), np.float64)
+        stereo = _arr(stereo, np.uint8)
+        out = np.zeros(7)
+        outlier = np.zeros(max(n, 1), np.uint8)
+        ninl = C.c_int32()
+        tr = _lib.PoseTrace()
+        _lib.check(_lib.lib().qsp_pose_optimize(self.handle, n, _lib.dptr(K), _lib.dptr(pose), _lib.dptr(X), _lib.dptr(obs),
+                                                _lib.dptr(info), _lib.u8ptr(stereo), _lib.dptr(out), _lib.u8ptr(outlier),
+                                                C.byref(ninl), C.byref(tr)))
+        trace = np.array(tr.trace[:], np.float64).reshape(4, 10, 3)
+        return dict(pose=out, outlier=outlier[:n], n_inliers=int(ninl.value), iters=np.array(tr.iters[:], np.int32), trace=trace)

@@ -1126,6 +1126,276 @@ __global__ void k_depth_positive(Dev d, uint8_t* pos) {
     pos[i] = p[2] > 0.0;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Optimizer::PoseOptimization (reference src/Optimizer.cc:244-456) as ONE launch of ONE workgroup: a single free SE3
+// vertex, unary only-pose edges (Thirdparty/g2o/g2o/types/types_six_dof_expmap.cpp:266-358), 4 rounds of optimize(10)
+// with g2o's Levenberg-Marquardt and the inlier / outlier classification after every round -- everything, including
+// the LM control flow, stays on the device: the problem is a few hundred edges and 6 unknowns, so what matters is that
+// no host round trip sits between its ~100 dependent steps.  Thread = edges k, k+256, ...; sums in a fixed tree.
+// ---------------------------------------------------------------------------------------------------------------
+struct PoseOptIn {
+    int n;
+    const double *X, *obs, *info;     // [n][3], [n][3] (u v u_right), [n]
+    const uint8_t* stereo;            // [n]
+    double K[5], pose0[7];
+};
+struct PoseOptOut {
+    double pose[7];
+    double trace[4][10][3];           // chi2, lambda, trials per (round, iteration)
+    int iters[4];
+    int n_inliers;
+};
+
+__device__ inline void po_residual(const double* pose, const double* X, const double* K, const double* obs, bool stereo,
+                                   double* e, double* p) {
+    se3_map(pose, X, p);
+    if (!stereo) {                                   // project2d + cam_project, .cpp:290-296
+        e[0] = obs[0] - (p[0] / p[2] * K[0] + K[2]);
+        e[1] = obs[1] - (p[1] / p[2] * K[1] + K[3]);
+        e[2] = 0.0;
+    } else {                                         // .cpp:299-306: float 1/z, double bf
+        const float invz = 1.0f / (float)p[2];
+        const double u = p[0] * invz * K[0] + K[2], v = p[1] * invz * K[1] + K[3];
+        e[0] = obs[0] - u;
+        e[1] = obs[1] - v;
+        e[2] = obs[2] - (u - K[4] * invz);
+    }
+}
+
+__device__ inline void po_jacobian(const double* p, const double* K, bool stereo, double* J /*3x6*/) {   // .cpp:266-288,335-358
+    const double x = p[0], y = p[1], invz = 1.0 / p[2], invz_2 = invz * invz, fx = K[0], fy = K[1], bf = K[4];
+    J[0] = x * y * invz_2 * fx; J[1] = -(1 + (x * x * invz_2)) * fx; J[2] = y * invz * fx;
+    J[3] = -invz * fx; J[4] = 0; J[5] = x * invz_2 * fx;
+    J[6] = (1 + y * y * invz_2) * fy; J[7] = -x * y * invz_2 * fy; J[8] = -x * invz * fy;
+    J[9] = 0; J[10] = -invz * fy; J[11] = y * invz_2 * fy;
+    if (stereo) {
+        J[12] = J[0] - bf * y * invz_2; J[13] = J[1] + bf * x * invz_2; J[14] = J[2];
+        J[15] = J[3]; J[16] = 0; J[17] = J[5] - bf * invz_2;
+    } else {
+        for (int i = 12; i < 18; ++i) J[i] = 0;
+    }
+}
+
+// sums v[0..N) over the 256 threads in a fixed tree; the totals are in tot[] for every thread after the call
+template <int N>
+__device__ inline void po_block_sum(double* v, double (*sh)[N], double* tot) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        double a = v[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+        if (lane == 0) sh[wave][i] = a;
+    }
+    __syncthreads();
+    if (threadIdx.x < N) tot[threadIdx.x] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void k_pose_opt(PoseOptIn in, uint8_t* outlier, uint8_t* level, double* chi2, PoseOptOut* out) {
+    __shared__ double sh[4][28];
+    __shared__ double tot[28];
+    __shared__ double pose[7], bk[7], x[6];
+    __shared__ double s_lambda, s_ni, s_cur, s_ini, s_rho;
+    __shared__ int s_qmax, s_nbad, s_again, s_stop, s_ok;
+    const int t = threadIdx.x, n = in.n;
+    const double dM = (double)(float)sqrt(5.991), dS = (double)(float)sqrt(7.815);
+    for (int k = t; k < n; k += 256) { outlier[k] = 0; level[k] = 0; chi2[k] = 0.0; }
+    if (t < 6) x[t] = 0.0;
+    if (t == 0) {
+        for (int r = 0; r < 4; ++r) out->iters[r] = 0;
+        out->n_inliers = 0;
+        for (int i = 0; i < 7; ++i) { pose[i] = in.pose0[i]; out->pose[i] = in.pose0[i]; }
+    }
+    __syncthreads();
+    if (n < 3) return;                                               // :368-369
+    bool robust = true;
+    int n_bad_edges = 0;
+
+    // robust chi2 of the active edges at `pose`; raw chi2 per edge kept (computeActiveErrors + activeRobustChi2)
+    auto errors = [&](double* v /*[1]*/) {
+        double a = 0;
+        for (int k = t; k < n; k += 256) {
+            if (level[k]) continue;
+            double e[3], p[3], r0, r1;
+            const bool st = in.stereo[k] != 0;
+            po_residual(pose, in.X + 3 * k, in.K, in.obs + 3 * k, st, e, p);
+            const double c = in.info[k] * (e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
+            chi2[k] = c;
+            huber(c, robust ? (st ? dS : dM) : 0.0, r0, r1);
+            a += r0;
+        }
+        v[0] = a;
+    };
+
+    for (int round = 0; round < 4; ++round) {
+        if (t < 7) pose[t] = in.pose0[t];                            // vSE3->setEstimate(pFrame->mTcw), :381
+        if (t == 0) { s_lambda = 0; s_ni = 2; s_nbad = 0; }
+        __syncthreads();
+        int done = 0;
+        for (int it = 0; it < 10; ++it) {
+            double v[28];
+            errors(v + 27);
+            // buildSystem: H (upper triangle, 21) and b (6)
+            for (int i = 0; i < 27; ++i) v[i] = 0;
+            for (int k = t; k < n; k += 256) {
+                if (level[k]) continue;
+                double e[3], p[3], J[18], r0, r1;
+                const bool st = in.stereo[k] != 0;
+                po_residual(pose, in.X + 3 * k, in.K, in.obs + 3 * k, st, e, p);
+                po_jacobian(p, in.K, st, J);
+                const double info = in.info[k];
+                const double c = info * (e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
+                huber(c, robust ? (st ? dS : dM) : 0.0, r0, r1);
+                const double w = r1 * info;
+                int q = 0;
+                for (int i = 0; i < 6; ++i) {
+                    double sb = 0;
+                    for (int d = 0; d < 3; ++d) sb += J[6 * d + i] * (-info * e[d]) * r1;
+                    v[21 + i] += sb;
+                    for (int j = i; j < 6; ++j) {
+                        double sum = 0;
+                        for (int d = 0; d < 3; ++d) sum += J[6 * d + i] * J[6 * d + j];
+                        v[q++] += w * sum;
+                    }
+                }
+            }
+            po_block_sum<28>(v, sh, tot);
+            if (t == 0) {
+                s_cur = tot[27];
+                s_ini = tot[27];
+                if (it == 0) {                                      // computeLambdaInit
+                    double md = 0;
+                    int q = 0;
+                    for (int i = 0; i < 6; ++i) { md = fmax(fabs(tot[q]), md); q += 6 - i; }
+                    s_lambda = 1e-5 * md; s_ni = 2; s_nbad = 0;
+                }
+                s_qmax = 0;
+                s_rho = 0;
+            }
+            __syncthreads();
+            while (true) {                                           // LM trials
+                if (t == 0) {
+                    for (int i = 0; i < 7; ++i) bk[i] = pose[i];
+                    // (H + lambda I) x = b by Cholesky (upper-triangle storage, row i starts at 6i - i(i-1)/2)
+                    double A[6][6];
+                    int q = 0;
+                    for (int i = 0; i < 6; ++i)
+                        for (int j = i; j < 6; ++j) { A[i][j] = tot[q]; A[j][i] = tot[q]; ++q; }
+                    for (int i = 0; i < 6; ++i) A[i][i] += s_lambda;
+                    bool ok = true;
+                    for (int j = 0; j < 6 && ok; ++j) {
+                        double dd = A[j][j];
+                        for (int q2 = 0; q2 < j; ++q2) dd -= A[j][q2] * A[j][q2];
+                        if (!(dd > 0) || !isfinite(dd)) { ok = false; break; }
+                        const double l = sqrt(dd);
+                        A[j][j] = l;
+                        for (int i = j + 1; i < 6; ++i) {
+                            double s2 = A[i][j];
+                            for (int q2 = 0; q2 < j; ++q2) s2 -= A[i][q2] * A[j][q2];
+                            A[i][j] = s2 / l;
+                        }
+                    }
+                    if (ok) {
+                        double y[6];
+                        for (int i = 0; i < 6; ++i) {
+                            double s2 = tot[21 + i];
+                            for (int q2 = 0; q2 < i; ++q2) s2 -= A[i][q2] * y[q2];
+                            y[i] = s2 / A[i][i];
+                        }
+                        for (int i = 5; i >= 0; --i) {
+                            double s2 = y[i];
+                            for (int q2 = i + 1; q2 < 6; ++q2) s2 -= A[q2][i] * x[q2];
+                            x[i] = s2 / A[i][i];
+                        }
+                        double dl[7], np[7];
+                        se3_exp(x, dl);
+                        se3_mul(dl, pose, np);
+                        for (int i = 0; i < 7; ++i) pose[i] = np[i];
+                    }
+                    s_ok = ok ? 1 : 0;
+                }
+                __syncthreads();
+                double tv[28];
+                for (int i = 0; i < 28; ++i) tv[i] = 0;
+                errors(tv);
+                double* tsum = tot;                                   // keep H and b: reduce into a scratch row
+                {
+                    double a = tv[0];
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+                    if ((t & 63) == 0) sh[t >> 6][0] = a;
+                    __syncthreads();
+                }
+                if (t == 0) {
+                    double tempChi = (sh[0][0] + sh[1][0]) + (sh[2][0] + sh[3][0]);
+                    if (!s_ok) tempChi = DBL_MAX;
+                    double rho = s_cur - tempChi;
+                    double scale = 1e-3;
+                    for (int i = 0; i < 6; ++i) scale += x[i] * (s_lambda * x[i] + tsum[21 + i]);
+                    rho /= scale;
+                    if (rho > 0 && isfinite(tempChi)) {
+                        double alpha = 1. - pow(2 * rho - 1, 3);
+                        alpha = fmin(alpha, 2. / 3.);
+                        s_lambda *= fmax(1. / 3., alpha);
+                        s_ni = 2;
+                        s_cur = tempChi;
+                    } else {
+                        s_lambda *= s_ni;
+                        s_ni *= 2;
+                        for (int i = 0; i < 7; ++i) pose[i] = bk[i];
+                    }
+                    s_qmax++;
+                    s_rho = rho;
+                    s_again = (rho < 0 && s_qmax < 10) ? 1 : 0;
+                }
+                __syncthreads();
+                if (!s_again) break;
+            }
+            ++done;
+            if (t == 0) {
+                out->trace[round][it][0] = s_cur;
+                out->trace[round][it][1] = s_lambda;
+                out->trace[round][it][2] = (double)s_qmax;
+                int stop = 0;
+                if (s_qmax == 10 || s_rho == 0) stop = 1;
+                else {
+                    if ((s_ini - s_cur) * 1e3 < s_ini) s_nbad++; else s_nbad = 0;
+                    if (s_nbad >= 3) stop = 1;
+                }
+                s_stop = stop;
+            }
+            __syncthreads();
+            if (s_stop) break;
+        }
+        // classification, :384-437
+        double nb[28];
+        for (int i = 0; i < 28; ++i) nb[i] = 0;
+        for (int k = t; k < n; k += 256) {
+            const bool st = in.stereo[k] != 0;
+            if (outlier[k]) {                                        // e->computeError() at the final pose
+                double e[3], p[3];
+                po_residual(pose, in.X + 3 * k, in.K, in.obs + 3 * k, st, e, p);
+                chi2[k] = in.info[k] * (e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
+            }
+            const float c = (float)chi2[k];
+            if (c > (st ? 7.815f : 5.991f)) { outlier[k] = 1; level[k] = 1; nb[0] += 1.0; }
+            else { outlier[k] = 0; level[k] = 0; }
+        }
+        po_block_sum<28>(nb, sh, tot);
+        n_bad_edges = (int)tot[0];
+        if (t == 0) out->iters[round] = done;
+        if (round == 2) robust = false;                              // e->setRobustKernel(0)
+        __syncthreads();
+        if (n < 10) break;                                           // optimizer.edges().size() < 10
+    }
+    if (t == 0) {
+        for (int i = 0; i < 7; ++i) out->pose[i] = pose[i];
+        out->n_inliers = n - n_bad_edges;
+    }
+}
+
 }  // namespace ba
 }  // namespace qsp
 
@@ -1747,4 +2017,87 @@ extern "C" int qsp_ba_local_joint(qsp_ba_problem* p, const volatile uint8_t* sto
     rc = qsp_ba_set_levels(p, lm.data(), ls.data(), lo.data());
     if (!rc) rc = qsp_ba_optimize(p, 10, 0.0, 0.0, 0.0, stop_flag, t2);              // robust kernels dropped, :628,643,655
     return rc;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// pose-only optimisation (Optimizer::PoseOptimization)
+// ---------------------------------------------------------------------------------------------------------------
+struct qsp_pose_optimizer {
+    int device = 0;
+    int cap = 0;
+    hipStream_t stream = nullptr;
+    double *X = nullptr, *obs = nullptr, *info = nullptr, *chi2 = nullptr;
+    uint8_t *stereo = nullptr, *outlier = nullptr, *level = nullptr;
+    PoseOptOut* out = nullptr;
+};
+
+extern "C" void qsp_pose_optimizer_destroy(qsp_pose_optimizer* h) {
+    if (!h) return;
+    hipSetDevice(h->device);
+    void* ptrs[] = {h->X, h->obs, h->info, h->chi2, h->stereo, h->outlier, h->level, h->out};
+    for (void* p : ptrs)
+        if (p) hipFree(p);
+    if (h->stream) hipStreamDestroy(h->stream);
+    delete h;
+}
+
+extern "C" int qsp_pose_optimizer_create(int device, int32_t max_points, qsp_pose_optimizer** out) {
+    if (!out || max_points < 1) return qsp_fail(QSP_ERR_INVALID, "qsp_pose_optimizer_create: bad argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return qsp_fail(QSP_ERR_NO_DEVICE, "no HIP device");
+    if (device < 0 || device >= ndev) return qsp_fail(QSP_ERR_INVALID, "qsp_pose_optimizer_create: device out of range");
+    QSP_HIP(hipSetDevice(device));
+    qsp_pose_optimizer* h = new qsp_pose_optimizer();
+    h->device = device;
+    h->cap = max_points;
+    hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    const size_t n = (size_t)max_points;
+    if (e == hipSuccess) e = hipMalloc((void**)&h->X, 24 * n);
+    if (e == hipSuccess) e = hipMalloc((void**)&h->obs, 24 * n);
+    if (e == hipSuccess) e = hipMalloc((void**)&h->info, 8 * n);
+    if (e == hipSuccess) e = hipMalloc((void**)&h->chi2, 8 * n);
+    if (e == hipSuccess) e = hipMalloc((void**)&h->stereo, n);
+    if (e == hipSuccess) e = hipMalloc((void**)&h->outlier, n);
+    if (e == hipSuccess) e = hipMalloc((void**)&h->level, n);
+    if (e == hipSuccess) e = hipMalloc((void**)&h->out, sizeof(PoseOptOut));
+    if (e != hipSuccess) {
+        qsp_pose_optimizer_destroy(h);
+        return qsp_fail(QSP_ERR_DEVICE, hipGetErrorString(e));
+    }
+    *out = h;
+    return QSP_OK;
+}
+
+extern "C" int qsp_pose_optimize(qsp_pose_optimizer* h, int32_t n, const double* K, const double* pose_in, const double* X,
+                                 const double* obs, const double* info, const uint8_t* stereo, double* pose_out,
+                                 uint8_t* outlier, int32_t* n_inliers, qsp_pose_trace* trace) {
+    if (!h || !K || !pose_in || !pose_out || n < 0) return qsp_fail(QSP_ERR_INVALID, "qsp_pose_optimize: bad argument");
+    if (n > h->cap) return qsp_fail(QSP_ERR_INVALID, "qsp_pose_optimize: more correspondences than the optimiser was created for");
+    if (n > 0 && (!X || !obs || !info || !stereo)) return qsp_fail(QSP_ERR_INVALID, "qsp_pose_optimize: null edge array");
+    QSP_HIP(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    PoseOptIn in;
+    in.n = n; in.X = h->X; in.obs = h->obs; in.info = h->info; in.stereo = h->stereo;
+    for (int i = 0; i < 5; ++i) in.K[i] = K[i];
+    for (int i = 0; i < 7; ++i) in.pose0[i] = pose_in[i];
+    if (n) {
+        QSP_HIP(hipMemcpyAsync(h->X, X, 24 * (size_t)n, hipMemcpyHostToDevice, s));
+        QSP_HIP(hipMemcpyAsync(h->obs, obs, 24 * (size_t)n, hipMemcpyHostToDevice, s));
+        QSP_HIP(hipMemcpyAsync(h->info, info, 8 * (size_t)n, hipMemcpyHostToDevice, s));
+        QSP_HIP(hipMemcpyAsync(h->stereo, stereo, (size_t)n, hipMemcpyHostToDevice, s));
+    }
+    hipLaunchKernelGGL(k_pose_opt, dim3(1), dim3(256), 0, s, in, h->outlier, h->level, h->chi2, h->out);
+    QSP_HIP(hipGetLastError());
+    PoseOptOut o;
+    QSP_HIP(hipMemcpyAsync(&o, h->out, sizeof(o), hipMemcpyDeviceToHost, s));
+    if (outlier && n) QSP_HIP(hipMemcpyAsync(outlier, h->outlier, (size_t)n, hipMemcpyDeviceToHost, s));
+    QSP_HIP(hipStreamSynchronize(s));
+    for (int i = 0; i < 7; ++i) pose_out[i] = o.pose[i];
+    if (n_inliers) *n_inliers = o.n_inliers;
+    if (trace) {
+        for (int r = 0; r < 4; ++r) trace->iters[r] = o.iters[r];
+        memcpy(trace->trace, o.trace, sizeof(o.trace));
+    }
+    return QSP_OK;
 }

@@ -58,6 +58,21 @@ public:
     bool isBad() { return bad; }
     std::map<KeyFrame*, size_t> GetObservations() { return obs; }
     void EraseObservation(KeyFrame* k) { obs.erase(k); }
+    static std::mutex mGlobalMutex;
+};
+inline std::mutex MapPoint::mGlobalMutex;
+
+class Frame {     // include/Frame.h of the reference: what Optimizer::PoseOptimization reads and writes
+public:
+    int N = 0;
+    float fx = 0, fy = 0, cx = 0, cy = 0, mbf = 0;
+    cv::Mat mTcw;
+    std::vector<cv::KeyPoint> mvKeysUn;
+    std::vector<float> mvuRight;
+    std::vector<float> mvInvLevelSigma2;
+    std::vector<MapPoint*> mvpMapPoints;
+    std::vector<bool> mvbOutlier;
+    void SetPose(const cv::Mat& T) { mTcw = T.clone(); }
 };
 
 class MapObject {

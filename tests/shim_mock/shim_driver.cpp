@@ -94,6 +94,29 @@ int main(int argc, char** argv) {
     if (mode == "local") OptimizerHip::LocalJointBundleAdjustment(&kfs[0], &stop, &map);
     else if (mode == "global_joint") OptimizerHip::GlobalJointBundleAdjustemnt(&map, 10, &stop, nLoopKF, true);
     else if (mode == "global_points") OptimizerHip::GlobalBundleAdjustemnt(&map, 20, &stop, nLoopKF, false);
+    else if (mode == "pose") {
+        // a Frame made of key-frame 0's observations: slots in key-point order, every 5th slot without a map point
+        KeyFrame& k = kfs[0];
+        Frame fr;
+        fr.fx = k.fx; fr.fy = k.fy; fr.cx = k.cx; fr.cy = k.cy; fr.mbf = k.mbf;
+        fr.mTcw = k.Tcw.clone();
+        fr.mvInvLevelSigma2 = sig;
+        for (size_t i = 0; i < k.mvKeysUn.size(); ++i) {
+            fr.mvKeysUn.push_back(k.mvKeysUn[i]);
+            fr.mvuRight.push_back(k.mvuRight[i]);
+            fr.mvpMapPoints.push_back(i % 5 == 4 ? nullptr : k.mps[i]);
+            fr.mvbOutlier.push_back(true);                 // stale flags must be cleared for matched slots only
+        }
+        fr.N = (int)fr.mvKeysUn.size();
+        const int ninl = OptimizerHip::PoseOptimization(&fr);
+        FILE* o = fopen(argv[2], "wb");
+        fwrite(fr.mTcw.d->data(), sizeof(float), 16, o);
+        int32_t hdr[2] = {ninl, fr.N};
+        fwrite(hdr, sizeof(hdr), 1, o);
+        for (int i = 0; i < fr.N; ++i) { unsigned char b = fr.mvbOutlier[i] ? 1 : 0; fwrite(&b, 1, 1, o); }
+        fclose(o);
+        return 0;
+    }
     else return 2;
     if (nLoopKF != 0) {   // loop-closing mode: results are parked in the *GBA members; move them over for the output
         for (int i = 0; i < n_kf; ++i)

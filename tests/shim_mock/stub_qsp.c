@@ -68,3 +68,33 @@ int qsp_ba_get_edges(qsp_ba_problem* p, double* cm, double* cs, double* co, uint
     for (int i = 0; i < p->s.n_objedge; ++i) co[i] = 0.0;
     return QSP_OK;
 }
+
+/* pose-only optimisation: dump the flattened correspondences to <dump>.pose, return a visible fake result */
+struct qsp_pose_optimizer { int cap; };
+int qsp_pose_optimizer_create(int device, int32_t max_points, qsp_pose_optimizer** out) {
+    (void)device;
+    *out = calloc(1, sizeof(**out));
+    (*out)->cap = max_points;
+    return QSP_OK;
+}
+void qsp_pose_optimizer_destroy(qsp_pose_optimizer* h) { free(h); }
+int qsp_pose_optimize(qsp_pose_optimizer* h, int32_t n, const double* K, const double* pose_in, const double* X,
+                      const double* obs, const double* info, const uint8_t* stereo, double* pose_out, uint8_t* outlier,
+                      int32_t* n_inliers, qsp_pose_trace* trace) {
+    (void)trace;
+    if (n > h->cap) return QSP_ERR_INVALID;
+    const char* path = getenv("QSP_STUB_DUMP");
+    if (path) {
+        char name[4096];
+        snprintf(name, sizeof(name), "%s.pose", path);
+        FILE* f = fopen(name, "wb");
+        wr(f, &n, 4); wr(f, K, 40); wr(f, pose_in, 56); wr(f, X, 24 * (size_t)n); wr(f, obs, 24 * (size_t)n);
+        wr(f, info, 8 * (size_t)n); wr(f, stereo, (size_t)n);
+        fclose(f);
+    }
+    memcpy(pose_out, pose_in, 56);
+    pose_out[1] += 0.75;                                  /* visible fake update */
+    for (int i = 0; i < n; ++i) outlier[i] = (uint8_t)(i % 3 == 0);
+    *n_inliers = n - (n + 2) / 3;
+    return QSP_OK;
+}

@@ -261,3 +261,84 @@ def test_global_points_only_ba():
     assert len(d["kf_pose"]) == len(sc["kf_pose"]) and len(d["pt_xyz"]) == n_observed <= len(sc["pt_xyz"]) - 3
     assert args[0] == 20 and not args[1:].any()
     assert np.abs(ob_o - m["objT"]).max() < 1e-6                # objects are not part of this call
+
+
+def _frame_of_kf0(m):
+    """what the driver's "pose" mode builds: key-frame 0's observations in key-point order (mono edges first, then stereo)"""
+    sc = m["sc"]
+    rows = [(int(p), sc["mono_obs"][e][0], sc["mono_obs"][e][1], -1.0, int(m["mono_oct"][e]))
+            for e, (p, k) in enumerate(zip(sc["mono_pt"], sc["mono_kf"])) if k == 0]
+    rows += [(int(p), sc["st_obs"][e][0], sc["st_obs"][e][1], sc["st_obs"][e][2], int(m["st_oct"][e]))
+             for e, (p, k) in enumerate(zip(sc["st_pt"], sc["st_kf"])) if k == 0]
+    return rows
+
+
+def test_pose_optimization_flattening_and_write_back():
+    """Optimizer::PoseOptimization (src/Optimizer.cc:244-456) through the shim with the stub library: matched slots only,
+    mono / stereo split by mvuRight < 0, float32 pixels and world points, K and the pose of the frame; write-back of the
+    outlier flags to the matched slots, of the pose, and the inlier count as return value."""
+    m = make_map(seed=12, n_kf=5, n_pt=200, n_obj=0)
+    sc = m["sc"]
+    with tempfile.TemporaryDirectory() as tmp:
+        drv = build_driver(tmp, real=False)
+        write_scene(m, os.path.join(tmp, "scene.bin"))
+        env = dict(os.environ, QSP_STUB_DUMP=os.path.join(tmp, "dump.bin"))
+        subprocess.check_call([drv, os.path.join(tmp, "scene.bin"), os.path.join(tmp, "out.bin"), "pose"], env=env)
+        raw = open(os.path.join(tmp, "dump.bin.pose"), "rb").read()
+        out = open(os.path.join(tmp, "out.bin"), "rb").read()
+    rows = _frame_of_kf0(m)
+    matched = [i for i in range(len(rows)) if i % 5 != 4]
+    n = struct.unpack_from("<i", raw, 0)[0]
+    assert n == len(matched) >= 20
+    off = 4
+    K = np.frombuffer(raw, np.float64, 5, off); off += 40
+    pose = np.frombuffer(raw, np.float64, 7, off); off += 56
+    X = np.frombuffer(raw, np.float64, 3 * n, off).reshape(n, 3); off += 24 * n
+    obs = np.frombuffer(raw, np.float64, 3 * n, off).reshape(n, 3); off += 24 * n
+    info = np.frombuffer(raw, np.float64, n, off); off += 8 * n
+    stereo = np.frombuffer(raw, np.uint8, n, off)
+    assert np.allclose(K, sc["kf_K"][0].astype(np.float32))
+    assert np.abs(pose - synth.pose7(m["kfT"][0].astype(np.float64))).max() < 1e-6
+    for e, i in enumerate(matched):
+        p, u, v, ur, octv = rows[i]
+        st = not (np.float32(ur) < 0)
+        assert stereo[e] == (1 if st else 0)
+        assert obs[e][0] == np.float32(u) and obs[e][1] == np.float32(v) and obs[e][2] == (np.float32(ur) if st else -1.0)
+        assert np.array_equal(X[e], sc["pt_xyz"][p].astype(np.float32).astype(np.float64))
+        assert np.isclose(info[e], np.float32(1.0) / np.float32(1.2) ** np.float32(2.0 * octv), rtol=1e-6)
+    T = np.frombuffer(out, np.float32, 16).reshape(4, 4)
+    ninl, N = struct.unpack_from("<2i", out, 64)
+    flags = np.frombuffer(out, np.uint8, N, 72)
+    assert N == len(rows) and ninl == n - (n + 2) // 3
+    assert abs(T[1, 3] - (m["kfT"][0][1, 3] + 0.75)) < 1e-5                 # the stub's fake update reached SetPose
+    for e, i in enumerate(matched):
+        assert flags[i] == (1 if e % 3 == 0 else 0)
+    assert all(flags[i] == 1 for i in range(len(rows)) if i % 5 == 4)       # unmatched slots keep their stale flag
+
+
+@pytest.mark.gpu
+def test_pose_optimization_shim_equals_python_binding():
+    from qsp_slam_amd.ba import PoseOptimizer
+    m = make_map(seed=13, n_kf=5, n_pt=300, n_obj=0)
+    sc = m["sc"]
+    with tempfile.TemporaryDirectory() as tmp:
+        write_scene(m, os.path.join(tmp, "scene.bin"))
+        real = build_driver(tmp, real=True)
+        subprocess.check_call([real, os.path.join(tmp, "scene.bin"), os.path.join(tmp, "out.bin"), "pose"])
+        out = open(os.path.join(tmp, "out.bin"), "rb").read()
+    rows = _frame_of_kf0(m)
+    matched = [i for i in range(len(rows)) if i % 5 != 4]
+    f32 = lambda a: np.asarray(a, np.float32).astype(np.float64)
+    X = f32([sc["pt_xyz"][rows[i][0]] for i in matched])
+    obs = f32([[rows[i][1], rows[i][2], rows[i][3] if not (np.float32(rows[i][3]) < 0) else -1.0] for i in matched])
+    stereo = np.array([0 if np.float32(rows[i][3]) < 0 else 1 for i in matched], np.uint8)
+    info = f32([np.float32(1.0) / np.float32(1.2) ** np.float32(2.0 * rows[i][4]) for i in matched])
+    po = PoseOptimizer(4096)
+    g = po.optimize(f32(sc["kf_K"][0]), synth.pose7(m["kfT"][0].astype(np.float64)), X, obs, info, stereo)
+    po.close()
+    T = np.frombuffer(out, np.float32, 16).reshape(4, 4)
+    ninl, N = struct.unpack_from("<2i", out, 64)
+    flags = np.frombuffer(out, np.uint8, N, 72)
+    assert ninl == g["n_inliers"]
+    assert np.array_equal(flags[matched], g["outlier"])
+    assert np.abs(T - synth.pose7_to_T(g["pose"]).astype(np.float32)).max() < 2e-6

@@ -7,7 +7,7 @@ from qsp_slam_amd.ba import BaProblem
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from test_gpu_ba import SCENES
 for name in ("tiny", "mono", "two_fixed"):
-    sc = synth.make_ba_scene(**SCENES[name])
+    sc = synth.make_ba_scene(**dict(SCENES[name], outlier_frac=0.08))
     out = collections.Counter()
     chis = []
     for rep in range(30):
@@ -15,6 +15,6 @@ for name in ("tiny", "mono", "two_fixed"):
         t1, t2 = p.local_joint_ba()
         key = (tuple(t1["trials"]), tuple(t1["accepted"]), tuple(t2["trials"]), tuple(t2["accepted"]))
         out[key] += 1
-        chis.append(t2["chi2"][-1])
+        chis.append(t2["chi2"][-1]); last = t2["chi2"]
         p.close()
-    print(os.environ.get("QSP_HIP_LIB", "default")[-16:], name, "distinct outcomes:", len(out), "chi2 spread %.3e" % (max(chis) - min(chis)), list(out.values()))
+    print(os.environ.get("QSP_HIP_LIB", "default")[-16:], name, "distinct outcomes:", len(out), "chi2 spread %.3e" % (max(chis) - min(chis)), list(out.values()), "rel %.2e" % ((max(chis) - min(chis)) / max(chis)))
