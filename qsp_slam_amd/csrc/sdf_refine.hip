@@ -35,14 +35,10 @@ constexpr int MAX_DEPTH = 64;
 #define QSP_NW_REND 16
 #endif
 #ifndef QSP_NW_SDF_MAX
-#define QSP_NW_SDF_MAX 256      // one 64-point tile per workgroup up to 16 k surface points (uniform workgroups balance best)
+#define QSP_NW_SDF_MAX 256      // surface slots per hypothesis: one 64-point tile per work item up to 16 k surface points
 #endif
-constexpr int NW_REND = QSP_NW_REND;     // workgroups per hypothesis looping over render-row tiles
-#ifndef QSP_NW_VALID
-#define QSP_NW_VALID 32
-#endif
-constexpr int NW_VALID = QSP_NW_VALID;    // workgroups per hypothesis looping over valid-sample tiles
-constexpr int NW_SDF_MAX = QSP_NW_SDF_MAX;  // workgroups per hypothesis looping over surface-point tiles
+constexpr int NW_REND = QSP_NW_REND;     // render slots per hypothesis (work items looping over render-row tiles beyond 16 x 64 rows)
+constexpr int NW_SDF_MAX = QSP_NW_SDF_MAX;  // work items per hypothesis looping over surface-point tiles
 constexpr int NH = 71;          // 7 pose + 64 code unknowns
 constexpr int PART_FLOATS = HT_TILES * 1024;
 
@@ -220,30 +216,105 @@ __device__ __forceinline__ void stage_code_T(MlpSmem& s, const HypState& S, floa
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Work queues of the two MLP kernels.
+// Both kernels are launched as ONE workgroup per CU and pull (hypothesis, slot) items from a list through an atomic
+// counter until it is exhausted.  Why not a (slots, hypotheses) grid: workgroup ids are dealt round-robin to the 8 XCDs, a
+// grid row holds slots with and without work (render slots beyond K, the ragged last surface slot), and for most row
+// lengths the working slots of every hypothesis fall on the same XCDs -- measured 6-40 % of the chip idle depending on
+// (slots mod 8).  A compacted list has no empty items, so whichever CU is free takes the next one.
+// Partial sums stay addressed by the LOGICAL (hypothesis, slot), so results do not depend on who processed what.
+//   qctl[0] = #items forward, qctl[1] = next forward item, qctl[2] = #items jtj, qctl[3] = next jtj item
+// ---------------------------------------------------------------------------------------------------------------
+// c0[h][u] = b0[u] + sum_k W0[u][k] code_h[k]: layer 0 without its xyz columns (see mlp_prepare), once per hypothesis
+__global__ __launch_bounds__(MLP_THREADS) void k_c0(const HypState* __restrict__ st, const MlpParams* __restrict__ Pm,
+                                                    float* __restrict__ c0_all) {
+    __shared__ float code[CODE_LEN];
+    const HypState& S = st[blockIdx.x];
+    if (!S.alive) return;
+    if (threadIdx.x < CODE_LEN) code[threadIdx.x] = S.code[threadIdx.x];
+    __syncthreads();
+    const int u = threadIdx.x;
+    const float* w = Pm->w0c + (size_t)u * CODE_LEN;
+    float a = Pm->bias[0][u];
+#pragma unroll 8
+    for (int k = 0; k < CODE_LEN; ++k) a += w[k] * code[k];
+    c0_all[(size_t)blockIdx.x * HID + u] = a;
+}
+
+// mode 0: forward items (h, tile) over the valid ray samples; mode 1: jtj items (h, slot), surface slots then render slots
+__global__ __launch_bounds__(1024) void k_plan(int mode, const HypState* __restrict__ st, const ObjView* __restrict__ objs,
+                                               int n_hyp, int nw_sdf, int nw_rend, int2* __restrict__ work, int* __restrict__ qctl) {
+    __shared__ int wsum[16];
+    __shared__ int carry_sh;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (t == 0) carry_sh = 0;
+    __syncthreads();
+    for (int base = 0; base < n_hyp; base += 1024) {
+        const int h = base + t;
+        int n_a = 0, n_b = 0;
+        if (h < n_hyp && st[h].alive) {
+            if (mode == 0) n_a = (st[h].n_valid + TILE_P - 1) / TILE_P;
+            else {
+                n_a = min(nw_sdf, (objs[st[h].obj].n_pts + TILE_P - 1) / TILE_P);
+                n_b = min(nw_rend, (st[h].n_render + TILE_P - 1) / TILE_P);
+            }
+        }
+        const int cnt = n_a + n_b;
+        int inc = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int up = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += up;
+        }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        int off = carry_sh + inc - cnt;
+        for (int w = 0; w < wave; ++w) off += wsum[w];
+        for (int j = 0; j < n_a; ++j) work[off + j] = make_int2(h, j);
+        for (int j = 0; j < n_b; ++j) work[off + n_a + j] = make_int2(h, nw_sdf + j);
+        __syncthreads();
+        if (t == 1023) carry_sh = off + cnt;
+        __syncthreads();
+    }
+    if (t == 0) {
+        qctl[2 * mode] = carry_sh;
+        qctl[2 * mode + 1] = 0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // k_mlp_fwd: decoder forward on the valid ray samples (loss.py:78)
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(MLP_THREADS, 2) void k_mlp_fwd(const HypState* __restrict__ st,
                                                             const ObjView* __restrict__ objs,
                                                             const float* __restrict__ rays, RefineCfg cfg, const MlpParams* __restrict__ P,
                                                             const int32_t* __restrict__ valid_rk, int64_t rk_stride,
-                                                            float* __restrict__ sdf_valid) {
+                                                            float* __restrict__ sdf_valid, const int2* __restrict__ work,
+                                                            int* __restrict__ qctl, const float* __restrict__ c0_all) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     MlpSmem& s = *reinterpret_cast<MlpSmem*>(smem_raw);
     __shared__ float Tsh[16];
-    const int h = blockIdx.y;
-    const HypState& S = st[h];
-    if (!S.alive) return;
-    const int n = S.n_valid;
-    const int t0 = ((int)blockIdx.x + ((gridDim.x & 1) ? 0 : h)) % (int)gridDim.x;     // XCD-aware rotation: see k_mlp_jtj
-    if (t0 * TILE_P >= n) return;
-    const ObjView ov = objs[S.obj];
-    const float* R = rays + 3 * ov.ray_off;
-    const int32_t* rk = valid_rk + h * rk_stride;
-    float* out = sdf_valid + h * rk_stride;
-    stage_code_T(s, S, Tsh);
-    mlp_prepare(s, P);
-    const float d_min = S.d_min, d_max = S.d_max;
-    for (int t = t0; t * TILE_P < n; t += gridDim.x) {
+    __shared__ int s_item;
+    const int n_items = qctl[0];
+    int h_cached = -1;
+    for (;;) {
+        if (threadIdx.x == 0) s_item = atomicAdd(&qctl[1], 1);
+        __syncthreads();                       // also: everybody is done with the previous item's LDS
+        const int item = s_item;
+        if (item >= n_items) break;            // the queue only grows towards n_items: every workgroup gets here
+        const int h = work[item].x, t = work[item].y;
+        const HypState& S = st[h];
+        const int n = S.n_valid;
+        const ObjView ov = objs[S.obj];
+        const float* R = rays + 3 * ov.ray_off;
+        const int32_t* rk = valid_rk + h * rk_stride;
+        float* out = sdf_valid + h * rk_stride;
+        if (h != h_cached) {                   // per-hypothesis staging: code, pose, layer-0 code part
+            stage_code_T(s, S, Tsh);
+            s.c0[threadIdx.x] = c0_all[(size_t)h * HID + threadIdx.x];
+            h_cached = h;
+        }
+        const float d_min = S.d_min, d_max = S.d_max;
         __syncthreads();
         if (threadIdx.x < TILE_P) {
             const int v = t * TILE_P + threadIdx.x;
@@ -380,26 +451,25 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void k_mlp_jtj(const HypState* __re
                                                             const float* __restrict__ rend_res, int64_t rk_stride,
                                                             const uint8_t* __restrict__ pt_active, int64_t act_stride,
                                                             float* __restrict__ res_out, float* __restrict__ rows_out, int64_t rows_stride,
-                                                            float* __restrict__ partials) {
+                                                            float* __restrict__ partials, int nw_total,
+                                                            const int2* __restrict__ work, int* __restrict__ qctl,
+                                                            const float* __restrict__ c0_all) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     MlpSmem& s = *reinterpret_cast<MlpSmem*>(smem_raw);
     __shared__ float Tsh[16];
-    const int h = blockIdx.y;
+    __shared__ int s_item;
+    const int n_items = qctl[2];
+  for (;;) {                                   // work queue, see k_plan
+    if (threadIdx.x == 0) s_item = atomicAdd(&qctl[3], 1);
+    __syncthreads();                           // also: everybody is done with the previous item's LDS
+    const int item = s_item;
+    if (item >= n_items) break;                // the queue only grows towards n_items: every workgroup gets here
+    const int h = work[item].x, slot = work[item].y;
     const HypState& S = st[h];
-    if (!S.alive) return;
     const ObjView ov = objs[S.obj];
-    const bool is_sdf = (int)blockIdx.x < nw_sdf;
-    const int stride = is_sdf ? nw_sdf : (int)gridDim.x - nw_sdf;
-    // Consecutive workgroup ids go round-robin over the 8 XCDs: slot x of hypothesis h runs on XCD (h * gridDim.x + x) % 8.
-    // With an even row length the slots that carry work (the first few render slots, the surface slots with one tile
-    // more) would sit on the same XCDs for every hypothesis -- measured: 6 % of the step lost to idle XCDs.  The logical
-    // position of a slot is therefore rotated by the hypothesis index whenever gridDim.x is even, which makes the XCD of
-    // logical slot j advance by an odd amount per hypothesis and visit all eight.
-    const int rot = (gridDim.x & 1) ? 0 : 1;
-    const int x_in = is_sdf ? (int)blockIdx.x : (int)blockIdx.x - nw_sdf;
-    const int j0 = (x_in + rot * h) % stride;
-    const int slot = is_sdf ? j0 : nw_sdf + j0;     // partials are stored by LOGICAL position: the sum order in k_solve
-                                                    // (and with it every bit of the result) does not depend on the rotation
+    const bool is_sdf = slot < nw_sdf;
+    const int stride = is_sdf ? nw_sdf : nw_total - nw_sdf;
+    const int j0 = is_sdf ? slot : slot - nw_sdf;
     const int n = is_sdf ? ov.n_pts : S.n_render;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
 
@@ -411,7 +481,7 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void k_mlp_jtj(const HypState* __re
     const int tb = (wave < 3) ? wave : (wave < 5 ? wave - 2 : 2);
 
     stage_code_T(s, S, Tsh);
-    mlp_prepare(s, P);
+    s.c0[threadIdx.x] = c0_all[(size_t)h * HID + threadIdx.x];
     const float* Pc = pts + 3 * ov.pts_off;
     const float* R = rays + 3 * ov.ray_off;
     const int32_t* rk = rend_rk + h * rk_stride;
@@ -501,10 +571,11 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void k_mlp_jtj(const HypState* __re
     }
     // partial slot [h][slot][tile][32][32]
     if (wave < 6) {
-        float* out = partials + ((int64_t)h * gridDim.x + slot) * PART_FLOATS + wave * 1024;
+        float* out = partials + ((int64_t)h * nw_total + slot) * PART_FLOATS + wave * 1024;
 #pragma unroll
         for (int i = 0; i < 16; ++i) out[acc_row(i, lane) * 32 + (lane & 31)] = hacc[i];
     }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1044,6 +1115,10 @@ struct qsp_refine_batch {
     uint8_t* pt_active = nullptr;   // pose-only mode
     float* res_buf = nullptr;       // pose-only mode: per-point residual of the current iteration
     unsigned long long* counters = nullptr;   // [4] points/tiles processed (fwd+bwd, fwd-only)
+    int2 *work_fwd = nullptr, *work_jtj = nullptr;   // work-queue items (k_plan)
+    int* qctl = nullptr;            // [4] item counts / next-item counters
+    float* c0_all = nullptr;        // [n_hyp][512] layer-0 code part per hypothesis (k_c0)
+    int n_cu = 256;
     float* rows = nullptr;          // optional tap of the Jacobian rows (qsp_refine_batch_rows)
     int64_t rows_stride = 0;
     // profiling
@@ -1056,7 +1131,8 @@ static void batch_free(qsp_refine_batch* b) {
     if (!b) return;
     hipSetDevice(b->dec->device);
     void* ptrs[] = {b->st, b->objs, b->pts, b->rays, b->depth, b->valid_rk, b->ray_voff, b->rend_rk, b->sdf_valid,
-                    b->rend_deds, b->rend_res, b->partials, b->trH, b->trb, b->trdx, b->pt_active, b->res_buf, b->rows, b->counters};
+                    b->rend_deds, b->rend_res, b->partials, b->trH, b->trb, b->trdx, b->pt_active, b->res_buf, b->rows, b->counters,
+                    b->work_fwd, b->work_jtj, b->qctl, b->c0_all};
     for (void* p : ptrs)
         if (p) hipFree(p);
     for (hipEvent_t e : b->ev) hipEventDestroy(e);
@@ -1128,6 +1204,14 @@ static int batch_create(qsp_decoder* dec, const RefineCfg& cfg, int n_iter, int3
     QSP_ALLOC(b->trb, sizeof(float) * (size_t)n_hyp * NH);
     QSP_ALLOC(b->trdx, sizeof(float) * (size_t)n_hyp * NH);
     QSP_ALLOC(b->counters, sizeof(unsigned long long) * 4);
+    QSP_ALLOC(b->qctl, sizeof(int) * 4);
+    QSP_ALLOC(b->c0_all, sizeof(float) * (size_t)n_hyp * HID);
+    QSP_ALLOC(b->work_jtj, sizeof(int2) * (size_t)n_hyp * nw_total);
+    if (!cfg.pose_only) QSP_ALLOC(b->work_fwd, sizeof(int2) * (size_t)n_hyp * ((b->rk_stride + TILE_P - 1) / TILE_P));
+    {
+        int ncu = 0;
+        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dec->device) == hipSuccess && ncu > 0) b->n_cu = ncu;
+    }
     if (!cfg.pose_only) {
         QSP_ALLOC(b->valid_rk, sizeof(int32_t) * (size_t)n_hyp * b->rk_stride);
         QSP_ALLOC(b->ray_voff, sizeof(int32_t) * (size_t)n_hyp * b->ray_stride);
@@ -1237,14 +1321,17 @@ extern "C" int qsp_refine_batch_run(qsp_refine_batch* b, int32_t n_iter) {
         RefineCfg cfg = b->cfg;
         cfg.iter = it;
         hipEvent_t a = nullptr;
+        hipLaunchKernelGGL(k_c0, dim3(nH), dim3(MLP_THREADS), 0, s, b->st, b->dec->Pd, b->c0_all);
         if (!cfg.pose_only) {
             if (b->prof) a = next_event(b, cur);
             hipLaunchKernelGGL(k_sample, dim3(nH), dim3(256), 0, s, b->st, b->objs, b->rays, cfg, b->valid_rk, b->rk_stride,
                                b->ray_voff, b->ray_stride);
             if (b->prof) spans.push_back({a, next_event(b, cur), 2});
             if (b->prof) a = next_event(b, cur);
-            hipLaunchKernelGGL(k_mlp_fwd, dim3(NW_VALID, nH), dim3(MLP_THREADS), sizeof(MlpSmem), s, b->st, b->objs, b->rays,
-                               cfg, b->dec->Pd, b->valid_rk, b->rk_stride, b->sdf_valid);
+            hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, s, 0, b->st, b->objs, nH, b->nw_sdf, nw_total - b->nw_sdf,
+                               b->work_fwd, b->qctl);
+            hipLaunchKernelGGL(k_mlp_fwd, dim3(b->n_cu), dim3(MLP_THREADS), sizeof(MlpSmem), s, b->st, b->objs, b->rays,
+                               cfg, b->dec->Pd, b->valid_rk, b->rk_stride, b->sdf_valid, b->work_fwd, b->qctl, b->c0_all);
             if (b->prof) spans.push_back({a, next_event(b, cur), 1});
             if (b->prof) a = next_event(b, cur);
             hipLaunchKernelGGL(k_scan, dim3(nH), dim3(256), 0, s, b->st, b->objs, b->depth, cfg, b->valid_rk, b->rk_stride,
@@ -1252,9 +1339,12 @@ extern "C" int qsp_refine_batch_run(qsp_refine_batch* b, int32_t n_iter) {
             if (b->prof) spans.push_back({a, next_event(b, cur), 2});
         }
         if (b->prof) a = next_event(b, cur);
-        hipLaunchKernelGGL(k_mlp_jtj, dim3(nw_total, nH), dim3(MLP_THREADS), sizeof(MlpSmem), s, b->st, b->objs, b->pts,
+        hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, s, 1, b->st, b->objs, nH, b->nw_sdf, nw_total - b->nw_sdf,
+                           b->work_jtj, b->qctl);
+        hipLaunchKernelGGL(k_mlp_jtj, dim3(b->n_cu), dim3(MLP_THREADS), sizeof(MlpSmem), s, b->st, b->objs, b->pts,
                            b->rays, cfg, b->dec->Pd, b->nw_sdf, b->rend_rk, b->rend_deds, b->rend_res, b->rk_stride,
-                           b->pt_active, b->act_stride, b->res_buf, b->rows, b->rows_stride, b->partials);
+                           b->pt_active, b->act_stride, b->res_buf, b->rows, b->rows_stride, b->partials, nw_total,
+                           b->work_jtj, b->qctl, b->c0_all);
         if (b->prof) spans.push_back({a, next_event(b, cur), 0});
         if (b->prof) a = next_event(b, cur);
         hipLaunchKernelGGL(k_solve, dim3(nH), dim3(256), 0, s, b->st, b->objs, cfg, b->partials, b->nw_sdf, nw_total,
