@@ -132,3 +132,30 @@ def test_full_size_ba_properties(name):
     assert np.allclose(u2["chi2"], t2["chi2"], rtol=1e-9)
     assert np.allclose(kf1, kf2, rtol=1e-8, atol=1e-10) and np.allclose(ob1, ob2, rtol=1e-8, atol=1e-10)
     assert np.allclose(pt1, pt2, rtol=1e-8, atol=1e-10)
+
+
+def test_more_than_1024_hypotheses_in_one_batch(gpu_decoder):
+    """k_plan builds the work list in chunks of 1024 hypotheses: 1280 hypotheses with small inputs, spot-checked against
+    single-hypothesis runs (bit-exact), including the last one."""
+    from qsp_slam_amd.reconstruct.optimizer import Optimizer, RefineBatch, _joint_cfg
+    objs = synth.make_object_views(77, 320, 200, n_fg=40, n_bg=20)
+    opt = Optimizer(gpu_decoder, bench.joint_cfg(2))
+    T0, hyp = bench.flip_states(objs, 4)
+    assert len(hyp) == 1280
+    batch = RefineBatch(gpu_decoder, _joint_cfg(opt), [o["pts"] for o in objs], [o["rays"] for o in objs],
+                        [o["depth"] for o in objs], hyp)
+    batch.set_state(T0, None)
+    batch.run(0)
+    T, code, loss, good = batch.get()
+    batch.close()
+    assert np.isfinite(T[good]).all() and good.sum() > 1000
+    for h in (0, 1023, 1024, 1279):
+        o = objs[hyp[h]]
+        single = RefineBatch(gpu_decoder, _joint_cfg(opt), [o["pts"]], [o["rays"]], [o["depth"]], [0])
+        single.set_state(T0[h:h + 1], None)
+        single.run(0)
+        Ts, cs, ls, gs = single.get()
+        single.close()
+        assert bool(gs[0]) == bool(good[h])
+        if good[h]:
+            assert np.array_equal(Ts[0], T[h]) and np.array_equal(cs[0], code[h]) and ls[0] == loss[h]
