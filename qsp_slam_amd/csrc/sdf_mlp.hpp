@@ -45,8 +45,15 @@ __device__ int qsp_dbg_n;
         qsp_dbg_ts[ts_n++] = __builtin_readcyclecounter();                              \
         qsp_dbg_n = ts_n;                                                               \
     }
+// kernel-level stamps of k_mlp_jtj's item loop go to slots 80..95 (first item of workgroup 0)
+#define QSP_TSK(i)                                                                      \
+    if (blockIdx.x == 0 && threadIdx.x == 0 && tsk_first) {                             \
+        qsp_dbg_rt[80 + (i)] = __builtin_amdgcn_s_memrealtime();                        \
+        qsp_dbg_ts[80 + (i)] = __builtin_readcyclecounter();                            \
+    }
 #else
 #define QSP_TS()
+#define QSP_TSK(i)
 #endif
 
 constexpr int TILE_P = 64;      // points per tile
@@ -396,9 +403,13 @@ __device__ __forceinline__ void mlp_tile(MlpSmem& s, const MlpParams* __restrict
 #define QSP_WF1(L) (P.wf[L] + ((cb0 + 1) * KGH) * 64)
 #define QSP_WB(L) (P.wb[L] + (cb0 * KGH) * 64)
 #define QSP_WB1(L) (P.wb[L] + ((cb0 + 1) * KGH) * 64)
-    // layer-0 backward: waves 0..5 own one of 3 column blocks; the others prefetch block 0 (never used)
-    const int r0 = wave / 3, c0 = wave % 3;
-    const float4* wb0 = P.wb[0] + ((wave < 6 ? c0 : 0) * KGH) * 64;
+    // layer-0 backward: six 32x32 output tiles (2 point blocks x 3 column blocks of the 96 padded inputs) on four SIMDs:
+    // waves 0..3 (one per SIMD) take tiles 0..3 over the whole K; tiles 4 and 5 are split in K between the two waves of
+    // SIMDs 0/2 (waves 4, 6) and 1/3 (waves 5, 7) -- 1.5 tiles of MFMA work on every SIMD instead of 2/2/1/1
+    const int l0_tile = wave < 4 ? wave : 4 + (wave & 1);
+    const int l0_half = wave < 4 ? 0 : (wave >> 1) - 2;          // 0 = first (or whole) K range, 1 = second half
+    const int r0 = l0_tile / 3, c0 = l0_tile % 3;
+    const float4* wb0 = P.wb[0] + (c0 * KGH + l0_half * (KGH / 2)) * 64;
 
     // ---- layer 0: a0 = relu(c0 + W0[:, 64:67] xyz), written in the MFMA write-out's lane/register pattern ------------
     // The 64 code columns of layer 0 are the same for every point of the workgroup: folded into c0 by mlp_prepare().
@@ -568,11 +579,12 @@ __device__ __forceinline__ void mlp_tile(MlpSmem& s, const MlpParams* __restrict
     QSP_BWD_LAYER(1)
 #undef QSP_BWD_LAYER
 
-    // ---- backward through layer 0: 67 (padded 96) input columns; waves 0..5 take one 32x32 tile each -------------
+    // ---- backward through layer 0: 67 (padded 96) input columns ----------------------------------------------------
     f32x16 g0;
 #pragma unroll
     for (int i = 0; i < 16; ++i) g0[i] = 0.f;
-    if (wave < 6) gemm_1x1<KGH, PF>(s.act + 32 * r0 * LDA, wb0, ring, g0, lane);
+    if (wave < 4) gemm_1x1<KGH, PF>(s.act + 32 * r0 * LDA, wb0, ring, g0, lane);
+    else gemm_1x1<KGH / 2, PF>(s.act + 32 * r0 * LDA + l0_half * (HID / 2), wb0, ring, g0, lane);
 #undef QSP_WF
 #undef QSP_WF1
 #undef QSP_WB
@@ -580,7 +592,17 @@ __device__ __forceinline__ void mlp_tile(MlpSmem& s, const MlpParams* __restrict
     QSP_TS()
     __syncthreads();
     QSP_TS()
+    float* l0_scr = s.act + TILE_P * LDG;             // behind the G image; free now that every GEMM read is done
+    if (wave >= 6) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) l0_scr[((wave - 6) * 16 + i) * 64 + lane] = g0[i];
+    }
+    __syncthreads();
     if (wave < 6) {
+        if (wave >= 4) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) g0[i] += l0_scr[((wave - 4) * 16 + i) * 64 + lane];
+        }
         // D[i = input column within block c0][j = point]: four consecutive input columns per register quad
         const int p = 32 * r0 + (lane & 31);
 #pragma unroll

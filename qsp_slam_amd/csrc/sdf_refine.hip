@@ -459,11 +459,15 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void k_mlp_jtj(const HypState* __re
     __shared__ float Tsh[16];
     __shared__ int s_item;
     const int n_items = qctl[2];
+    bool tsk_first = true;
+    (void)tsk_first;
   for (;;) {                                   // work queue, see k_plan
+    QSP_TSK(0)
     if (threadIdx.x == 0) s_item = atomicAdd(&qctl[3], 1);
     __syncthreads();                           // also: everybody is done with the previous item's LDS
     const int item = s_item;
     if (item >= n_items) break;                // the queue only grows towards n_items: every workgroup gets here
+    QSP_TSK(1)
     const int h = work[item].x, slot = work[item].y;
     const HypState& S = st[h];
     const ObjView ov = objs[S.obj];
@@ -517,7 +521,9 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void k_mlp_jtj(const HypState* __re
             s.rres[tid] = rr;
         }
         __syncthreads();
+        QSP_TSK(2)
         mlp_tile<true, 4>(s, P);
+        QSP_TSK(3)
         // ---- Jacobian rows: J~[p] = [ s*(g_x . [I | -x^ | x]) (7) | s*g_z (64) | r~ ] -------------------------------
         // G (gradient w.r.t. [code | xyz]) sits in s.act with row stride LDG; J~ goes behind it.
         float* G = s.act;
@@ -568,6 +574,7 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void k_mlp_jtj(const HypState* __re
 #pragma unroll 8
             for (int ks = 0; ks < TILE_P / 2; ++ks) hacc = mfma32(A[2 * ks * LDJ], B[2 * ks * LDJ], hacc);
         }
+        QSP_TSK(4)
     }
     // partial slot [h][slot][tile][32][32]
     if (wave < 6) {
@@ -575,6 +582,8 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void k_mlp_jtj(const HypState* __re
 #pragma unroll
         for (int i = 0; i < 16; ++i) out[acc_row(i, lane) * 32 + (lane & 31)] = hacc[i];
     }
+    QSP_TSK(5)
+    tsk_first = false;
   }
 }
 
