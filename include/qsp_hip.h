@@ -281,6 +281,12 @@ int qsp_ba_profile(qsp_ba_problem* p, int enable, qsp_ba_stats* out);
 typedef int (*qsp_allreduce_fn)(void* ctx, double* device_buf, int64_t count, void* hip_stream);
 int qsp_ba_set_shard(qsp_ba_problem* p, int32_t rank, int32_t world, qsp_allreduce_fn fn, void* ctx);
 
+/* Reproducible mode: the Schur complement is accumulated without atomics, every sum in a fixed order (per pair of
+ * key-frames over their common landmarks in landmark order), so repeated runs give the same bits.  Builds the pair lists on
+ * the host at the first call (sum_l k_l (k_l+1)/2 entries) and keeps 144 B per edge of extra device storage.  Default off:
+ * the default kernels use FP64 atomics (run-to-run spread of the final chi2 3e-15 .. 8e-9 relative). */
+int qsp_ba_set_deterministic(qsp_ba_problem* p, int on);
+
 /* ---------------------------------------------------------------------------------------------------------------
  * Pose-only optimisation: Optimizer::PoseOptimization(Frame*), src/Optimizer.cc:244-456 --
  * one free SE3 vertex, one unary edge per matched map point (EdgeSE3ProjectXYZOnlyPose / EdgeStereoSE3ProjectXYZOnlyPose),

@@ -86,7 +86,7 @@ SYMBOLS = [
     "qsp_mc_tables",
     "qsp_pose_optimizer_create", "qsp_pose_optimizer_destroy", "qsp_pose_optimize",
     "qsp_ba_create", "qsp_ba_destroy", "qsp_ba_set_levels", "qsp_ba_optimize", "qsp_ba_local_joint",
-    "qsp_ba_set_state", "qsp_ba_get_state", "qsp_ba_get_edges", "qsp_ba_get_index", "qsp_ba_profile", "qsp_ba_set_shard",
+    "qsp_ba_set_state", "qsp_ba_get_state", "qsp_ba_get_edges", "qsp_ba_get_index", "qsp_ba_profile", "qsp_ba_set_shard", "qsp_ba_set_deterministic",
 ]
 
 
@@ -148,6 +148,7 @@ def lib():
     L.qsp_ba_get_index.argtypes = [vp, c_int32_p, c_int32_p, c_int32_p]
     L.qsp_ba_profile.argtypes = [vp, C.c_int, C.POINTER(BaProfile)]
     L.qsp_ba_set_shard.argtypes = [vp, C.c_int32, C.c_int32, ALLREDUCE_FN, C.c_void_p]
+    L.qsp_ba_set_deterministic.argtypes = [vp, C.c_int]
     _lib = L
     return L
 

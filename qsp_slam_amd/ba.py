@@ -81,6 +81,10 @@ class BaProblem(object):
         self._cb = _lib.ALLREDUCE_FN(_cb) if world > 1 else _lib.ALLREDUCE_FN(0)
         _lib.check(_lib.lib().qsp_ba_set_shard(self.handle, int(rank), int(world), self._cb, None))
 
+    def set_deterministic(self, on=True):
+        """no atomics in the Schur complement: repeated runs give the same bits (qsp_ba_set_deterministic)"""
+        _lib.check(_lib.lib().qsp_ba_set_deterministic(self.handle, 1 if on else 0))
+
     def set_levels(self, mono=None, stereo=None, obj=None):
         def p(a):
             return _lib.c_uint8_p() if a is None else _lib.u8ptr(_arr(a, np.uint8))

@@ -299,6 +299,10 @@ struct Dev {
     double *oe_rec;                 // per object edge: OE_REC doubles (see k_lin_objedges)
     double *bp, *bs, *xp;           // reduced rhs / solution
     double *Hs;                     // dense reduced matrix, ld = dimp
+    double *Hpl;                    // deterministic mode only: materialised 6x3 blocks (k_hpl_fill)
+    int32_t *pk_ka, *pk_kb, *pk_off; // deterministic mode: key-frame pairs with common landmarks, CSR into pk_ent
+    int2* pk_ent;                    //   (edge in ka, edge in kb) per common landmark, in landmark order
+    int32_t n_pk;
     double *Uf, *Winv, *ych;        // Cholesky: off-diagonal factor blocks, inverse diagonal factors (transposed), L^-1 b
     double *partial;                // block partials for reductions
     double *scal;                   // [0] chi2, [1] scale, [2] maxdiag, [3] chol fail flag (as double)
@@ -817,6 +821,68 @@ __global__ __launch_bounds__(256) void k_schur_rows(Dev d, Par par) {
         if (v != 0.0) atomicAdd(&d.Hs[(size_t)(6 * ha + i / dimp) * dimp + i % dimp], v);
     }
     if (t < 6) atomicAdd(&d.bs[6 * ha + t], srow[6 * dimp + t]);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Deterministic Schur complement (qsp_ba_set_deterministic): no atomics, every sum in a fixed order.
+//   k_hpl_fill    materialises the 6x3 blocks once per build (edge-parallel);
+//   k_schur_pairs one wave per pair of key-frames that share landmarks (list built on the host, in landmark order):
+//                 lane (i,j) accumulates entry (i,j) of  sum_l B_a D_l^-1 B_b^T  and is the only writer of that entry;
+//   k_schur_rhs   one wave per key-frame: sum over its edges of B_a D^-1 b_l.
+// Costs one sort-free pass over sum_l k_l (k_l+1)/2 pairs on the host at creation and 144 B per edge of extra storage;
+// meant for reproducible runs and for the parity tests, not for the largest graphs.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_hpl_fill(Dev d, Par par) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= d.n_edge) return;
+    double B[18];
+    if (d.edge_level[e]) {
+        for (int i = 0; i < 18; ++i) B[i] = 0.0;
+    } else {
+        edge_hpl(d, d.edge[e], par, B);
+    }
+    for (int i = 0; i < 18; ++i) d.Hpl[18 * (size_t)e + i] = B[i];
+}
+
+__global__ __launch_bounds__(64) void k_schur_pairs(Dev d, Par par) {
+    const int q = blockIdx.x, lane = threadIdx.x;
+    const int ha = d.kf_h[d.pk_ka[q]], hb = d.kf_h[d.pk_kb[q]];
+    if (ha < 0 || hb < 0 || lane >= 36) return;
+    const int i = lane / 6, j = lane % 6;
+    double acc = 0;
+    for (int t = d.pk_off[q]; t < d.pk_off[q + 1]; ++t) {
+        const int2 en = d.pk_ent[t];
+        if (d.edge_level[en.x] || d.edge_level[en.y]) continue;
+        const int pt = d.edge[en.x].pt;
+        if (d.pt_h[pt] < 0) continue;
+        const double* Ba = d.Hpl + 18 * (size_t)en.x + 3 * i;
+        const double* Bb = d.Hpl + 18 * (size_t)en.y + 3 * j;
+        const double* Di = d.Dinv + 9 * (size_t)pt;
+        const double bd0 = Ba[0] * Di[0] + Ba[1] * Di[3] + Ba[2] * Di[6];
+        const double bd1 = Ba[0] * Di[1] + Ba[1] * Di[4] + Ba[2] * Di[7];
+        const double bd2 = Ba[0] * Di[2] + Ba[1] * Di[5] + Ba[2] * Di[8];
+        acc += bd0 * Bb[0] + bd1 * Bb[1] + bd2 * Bb[2];
+    }
+    // T = sum B_a D^-1 B_b^T belongs at (ha, hb); only the upper block triangle of Hs is used: transpose if ha > hb
+    if (ha <= hb) d.Hs[(size_t)(6 * ha + i) * par.dimp + 6 * hb + j] -= acc;
+    else d.Hs[(size_t)(6 * hb + j) * par.dimp + 6 * ha + i] -= acc;
+}
+
+__global__ __launch_bounds__(64) void k_schur_rhs(Dev d, Par par) {
+    const int kf = blockIdx.x, r = threadIdx.x;
+    const int ha = d.kf_h[kf];
+    if (ha < 0 || r >= 6) return;
+    double acc = 0;
+    for (int q = d.kf_off[kf]; q < d.kf_off[kf + 1]; ++q) {
+        const int a = d.kf_edge[q];
+        if (d.edge_level[a]) continue;
+        const int pt = d.edge[a].pt;
+        if (d.pt_h[pt] < 0) continue;
+        const double* Ba = d.Hpl + 18 * (size_t)a + 3 * r;
+        const double* db = d.xl + 3 * (size_t)pt;
+        acc += Ba[0] * db[0] + Ba[1] * db[1] + Ba[2] * db[2];
+    }
+    d.bs[6 * ha + r] -= acc;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1423,6 +1489,7 @@ struct qsp_ba_problem {
     // LM state that persists inside one optimize call only
     qsp_ba_stats prof{};
     bool profiling = false;
+    bool deterministic = false;   // qsp_ba_set_deterministic
     // landmark sharding across ranks: this rank linearises and marginalises the landmarks with
     // pt_id % world == rank (and the camera-object edges of objects with obj_id % world == rank); one SUM all-reduce of
     // the reduced system per LM trial
@@ -1850,7 +1917,12 @@ extern "C" int qsp_ba_optimize(qsp_ba_problem* p, int32_t n_iter, double delta_m
                 const size_t row_lds = sizeof(double) * ((size_t)6 * p->dimp + 6);
                 // block rows pay off once the per-landmark kernel's global atomics collide or scatter (measured: C5 435 ->
                 // 157 us, 2 M edges 5.4 -> 0.8 ms); below ~64 k edges both are latency-bound and the single launch wins
-                if (d.n_pt && row_lds <= SCHUR_ROW_LDS_MAX && d.n_ksplit && d.n_edge >= SCHUR_ROWS_MIN_EDGES) {
+                if (d.n_pt && p->deterministic) {
+                    hipLaunchKernelGGL(k_schur_dinv, dim3((d.n_pt + 255) / 256), dim3(256), 0, s, d, par);
+                    hipLaunchKernelGGL(k_hpl_fill, dim3((d.n_edge + 255) / 256), dim3(256), 0, s, d, par);
+                    if (d.n_pk) hipLaunchKernelGGL(k_schur_pairs, dim3(d.n_pk), dim3(64), 0, s, d, par);
+                    hipLaunchKernelGGL(k_schur_rhs, dim3(d.n_kf), dim3(64), 0, s, d, par);
+                } else if (d.n_pt && row_lds <= SCHUR_ROW_LDS_MAX && d.n_ksplit && d.n_edge >= SCHUR_ROWS_MIN_EDGES) {
                     hipLaunchKernelGGL(k_schur_dinv, dim3((d.n_pt + 255) / 256), dim3(256), 0, s, d, par);
                     hipLaunchKernelGGL(k_schur_rows, dim3(d.n_ksplit), dim3(256), row_lds, s, d, par);
                 } else if (d.n_pt) {
@@ -2099,5 +2171,56 @@ extern "C" int qsp_pose_optimize(qsp_pose_optimizer* h, int32_t n, const double*
         for (int r = 0; r < 4; ++r) trace->iters[r] = o.iters[r];
         memcpy(trace->trace, o.trace, sizeof(o.trace));
     }
+    return QSP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// deterministic mode
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" int qsp_ba_set_deterministic(qsp_ba_problem* p, int on) {
+    if (!p) return qsp_fail(QSP_ERR_INVALID, "qsp_ba_set_deterministic: null problem");
+    QSP_HIP(hipSetDevice(p->device));
+    Dev& d = p->d;
+    if (on && !d.pk_off) {
+        // pairs of key-frames (by scene index, ka <= kb) that observe a common landmark, and per pair the (edge in ka,
+        // edge in kb) entries in landmark order: counting sort over the keys ka * n_kf + kb
+        const int nk = d.n_kf;
+        const std::vector<Edge>& E = p->edge_h;
+        const std::vector<int32_t>& off = p->pt_off_h;
+        std::vector<int64_t> cnt((size_t)nk * nk + 1, 0);
+        auto for_pairs = [&](auto&& fn) {
+            for (int l = 0; l < d.n_pt; ++l)
+                for (int a = off[l]; a < off[l + 1]; ++a)
+                    for (int b = a; b < off[l + 1]; ++b) {
+                        const int ka = E[a].kf, kb = E[b].kf;
+                        if (ka == kb && a != b) continue;          // (two edges of one landmark in one key-frame: skipped
+                        if (ka <= kb) fn(ka, kb, a, b);            //  like in the atomic kernels)
+                        else fn(kb, ka, b, a);
+                    }
+        };
+        for_pairs([&](int ka, int kb, int, int) { cnt[(size_t)ka * nk + kb + 1]++; });
+        std::vector<int32_t> pk_ka, pk_kb, pk_off(1, 0);
+        std::vector<int64_t> start((size_t)nk * nk, -1);
+        int64_t tot = 0;
+        for (int ka = 0; ka < nk; ++ka)
+            for (int kb = ka; kb < nk; ++kb) {
+                const int64_t c = cnt[(size_t)ka * nk + kb + 1];
+                if (!c) continue;
+                start[(size_t)ka * nk + kb] = tot;
+                tot += c;
+                pk_ka.push_back(ka); pk_kb.push_back(kb); pk_off.push_back((int32_t)tot);
+            }
+        if (tot > (int64_t)1 << 30) return qsp_fail(QSP_ERR_UNSUPPORTED, "qsp_ba_set_deterministic: graph too large for the pair lists");
+        std::vector<int2> ent((size_t)std::max<int64_t>(tot, 1));
+        for_pairs([&](int ka, int kb, int a, int b) { ent[(size_t)start[(size_t)ka * nk + kb]++] = make_int2(a, b); });
+        d.n_pk = (int32_t)pk_ka.size();
+        int rc = dupload(p, &d.pk_ka, pk_ka.data(), pk_ka.size());
+        if (!rc) rc = dupload(p, &d.pk_kb, pk_kb.data(), pk_kb.size());
+        if (!rc) rc = dupload(p, &d.pk_off, pk_off.data(), pk_off.size());
+        if (!rc) rc = dupload(p, &d.pk_ent, ent.data(), ent.size());
+        if (!rc) rc = dalloc(p, &d.Hpl, 18 * (size_t)std::max(d.n_edge, 1));
+        if (rc) return rc;
+    }
+    p->deterministic = on != 0;
     return QSP_OK;
 }

@@ -223,3 +223,54 @@ def test_block_row_schur_path_on_a_large_graph():
     assert close(kf, rkf, rtol=1e-8, atol=1e-10) and close(pt, rpt, rtol=1e-8, atol=1e-10)
     assert close(ob, rob, rtol=1e-8, atol=1e-10)
     gpu.close()
+
+
+@pytest.mark.parametrize("name", ["tiny", "mono", "c2", "two_fixed"])
+def test_deterministic_mode_is_bit_reproducible_and_matches_oracle(name):
+    """qsp_ba_set_deterministic: the Schur complement without atomics.  Five runs give the same bits; against the oracle
+    the well-posed scenes hold 1e-9 (the ill-conditioned 4-key-frame scene 1e-6: there any re-association of the sums --
+    oracle vs GPU -- is amplified the same way as the atomics' run-to-run noise)."""
+    from qsp_slam_amd.ba import BaProblem
+    sc = synth.make_ba_scene(**dict(SCENES[name], outlier_frac=0.08))
+    ref = bo.BaProblem(sc)
+    r1, r2 = ref.local_joint_ba()
+    runs = []
+    for _ in range(5):
+        gpu = BaProblem(sc)
+        gpu.set_deterministic(True)
+        g1, g2 = gpu.local_joint_ba()
+        runs.append((np.array(g1["chi2"]), np.array(g2["chi2"]), np.array(g2["lam"]), *gpu.state()))
+        gpu.close()
+    for other in runs[1:]:
+        for a, b in zip(runs[0], other):
+            assert np.array_equal(a, b)
+    tol = 1e-6 if name == "tiny" else 1e-9
+    assert list(g1["trials"]) == list(r1["trials"]) and list(g2["trials"]) == list(r2["trials"])
+    assert close(g1["chi2"], r1["chi2"], rtol=tol) and close(g2["chi2"], r2["chi2"], rtol=tol)
+    rkf, rpt, rob = ref.state()
+    etol = 1e-5 if name == "tiny" else 1e-8
+    assert close(runs[0][3], rkf, rtol=etol, atol=1e-10) and close(runs[0][4], rpt, rtol=etol, atol=1e-10)
+
+
+def test_deterministic_mode_full_size_c4_and_sharded_consistency():
+    """C4-size graph: deterministic and default modes agree (1e-8), and the deterministic mode repeats bit-exactly"""
+    import bench
+    from qsp_slam_amd.ba import BaProblem
+    w = bench.WORKLOADS["c4"]
+    sc = synth.make_ba_scene(2000, w["n_kf"], w["n_map"], w["n_obj"], stereo_frac=0.2)
+    a = BaProblem(sc)
+    a1, a2 = a.local_joint_ba()
+    ka, pa, oa = a.state()
+    a.close()
+    outs = []
+    for _ in range(2):
+        b = BaProblem(sc)
+        b.set_deterministic(True)
+        b1, b2 = b.local_joint_ba()
+        outs.append((np.array(b2["chi2"]), *b.state()))
+        b.close()
+    for x, y in zip(outs[0], outs[1]):
+        assert np.array_equal(x, y)
+    assert list(b2["trials"]) == list(a2["trials"])
+    assert np.allclose(outs[0][0], a2["chi2"], rtol=1e-8)
+    assert np.allclose(outs[0][1], ka, rtol=1e-7, atol=1e-10) and np.allclose(outs[0][2], pa, rtol=1e-7, atol=1e-10)
