@@ -282,9 +282,11 @@ typedef int (*qsp_allreduce_fn)(void* ctx, double* device_buf, int64_t count, vo
 int qsp_ba_set_shard(qsp_ba_problem* p, int32_t rank, int32_t world, qsp_allreduce_fn fn, void* ctx);
 
 /* Reproducible mode: the Schur complement is accumulated without atomics, every sum in a fixed order (per pair of
- * key-frames over their common landmarks in landmark order), so repeated runs give the same bits.  Builds the pair lists on
- * the host at the first call (sum_l k_l (k_l+1)/2 entries) and keeps 144 B per edge of extra device storage.  Default off:
- * the default kernels use FP64 atomics (run-to-run spread of the final chi2 3e-15 .. 8e-9 relative). */
+ * key-frames over their common landmarks in landmark order, pair lists built on the host from sum_l k_l (k_l+1)/2 entries,
+ * 144 B per edge of extra device storage), so repeated runs give the same bits.  It is the DEFAULT whenever the lists stay
+ * below 4 M entries (C2, C4, C5 of BASELINE.json all do; as fast as the atomic kernels there); larger graphs fall back to
+ * FP64 atomics (run-to-run spread of the final chi2 3e-15 .. 8e-9 relative).  on = 1 forces it
+ * (QSP_ERR_UNSUPPORTED when the graph is too large), on = 0 selects the atomic kernels. */
 int qsp_ba_set_deterministic(qsp_ba_problem* p, int on);
 
 /* ---------------------------------------------------------------------------------------------------------------

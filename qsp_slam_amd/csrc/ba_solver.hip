@@ -301,7 +301,7 @@ struct Dev {
     double *Hs;                     // dense reduced matrix, ld = dimp
     double *Hpl;                    // deterministic mode only: materialised 6x3 blocks (k_hpl_fill)
     int32_t *pk_ka, *pk_kb, *pk_off; // deterministic mode: key-frame pairs with common landmarks, CSR into pk_ent
-    int2* pk_ent;                    //   (edge in ka, edge in kb) per common landmark, in landmark order
+    int4* pk_ent;                    //   (edge in ka, edge in kb, landmark, 0) per common landmark, in landmark order
     int32_t n_pk;
     double *Uf, *Winv, *ych;        // Cholesky: off-diagonal factor blocks, inverse diagonal factors (transposed), L^-1 b
     double *partial;                // block partials for reductions
@@ -845,44 +845,77 @@ __global__ __launch_bounds__(256) void k_hpl_fill(Dev d, Par par) {
 }
 
 __global__ __launch_bounds__(64) void k_schur_pairs(Dev d, Par par) {
+    // lane = list entry (strided by 64): every lane accumulates the whole 6x6 of its entries, then a fixed butterfly over
+    // the lanes adds the 64 partial blocks -- the loads of 64 entries are in flight together and the order of every
+    // addition depends on list positions only
     const int q = blockIdx.x, lane = threadIdx.x;
     const int ha = d.kf_h[d.pk_ka[q]], hb = d.kf_h[d.pk_kb[q]];
-    if (ha < 0 || hb < 0 || lane >= 36) return;
-    const int i = lane / 6, j = lane % 6;
-    double acc = 0;
-    for (int t = d.pk_off[q]; t < d.pk_off[q + 1]; ++t) {
-        const int2 en = d.pk_ent[t];
-        if (d.edge_level[en.x] || d.edge_level[en.y]) continue;
-        const int pt = d.edge[en.x].pt;
-        if (d.pt_h[pt] < 0) continue;
-        const double* Ba = d.Hpl + 18 * (size_t)en.x + 3 * i;
-        const double* Bb = d.Hpl + 18 * (size_t)en.y + 3 * j;
-        const double* Di = d.Dinv + 9 * (size_t)pt;
-        const double bd0 = Ba[0] * Di[0] + Ba[1] * Di[3] + Ba[2] * Di[6];
-        const double bd1 = Ba[0] * Di[1] + Ba[1] * Di[4] + Ba[2] * Di[7];
-        const double bd2 = Ba[0] * Di[2] + Ba[1] * Di[5] + Ba[2] * Di[8];
-        acc += bd0 * Bb[0] + bd1 * Bb[1] + bd2 * Bb[2];
+    if (ha < 0 || hb < 0) return;
+    double acc[36];
+#pragma unroll
+    for (int i = 0; i < 36; ++i) acc[i] = 0.0;
+    for (int t = d.pk_off[q] + lane; t < d.pk_off[q + 1]; t += 64) {
+        const int4 en = d.pk_ent[t];                      // edge in ka, edge in kb, landmark
+        if (d.edge_level[en.x] || d.edge_level[en.y] || d.pt_h[en.z] < 0) continue;
+        double Ba[18], Bb[18], Di[9];
+        const double* pa = d.Hpl + 18 * (size_t)en.x;
+        const double* pb = d.Hpl + 18 * (size_t)en.y;
+        const double* pd = d.Dinv + 9 * (size_t)en.z;
+#pragma unroll
+        for (int i = 0; i < 18; ++i) { Ba[i] = pa[i]; Bb[i] = pb[i]; }
+#pragma unroll
+        for (int i = 0; i < 9; ++i) Di[i] = pd[i];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const double bd0 = Ba[3 * i] * Di[0] + Ba[3 * i + 1] * Di[3] + Ba[3 * i + 2] * Di[6];
+            const double bd1 = Ba[3 * i] * Di[1] + Ba[3 * i + 1] * Di[4] + Ba[3 * i + 2] * Di[7];
+            const double bd2 = Ba[3 * i] * Di[2] + Ba[3 * i + 1] * Di[5] + Ba[3 * i + 2] * Di[8];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) acc[6 * i + j] += bd0 * Bb[3 * j] + bd1 * Bb[3 * j + 1] + bd2 * Bb[3 * j + 2];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 36; ++i) {
+        double v = acc[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        acc[i] = v;
     }
     // T = sum B_a D^-1 B_b^T belongs at (ha, hb); only the upper block triangle of Hs is used: transpose if ha > hb
-    if (ha <= hb) d.Hs[(size_t)(6 * ha + i) * par.dimp + 6 * hb + j] -= acc;
-    else d.Hs[(size_t)(6 * hb + j) * par.dimp + 6 * ha + i] -= acc;
+    if (lane < 36) {
+        const int i = lane / 6, j = lane % 6;
+        double v = 0;
+#pragma unroll
+        for (int e = 0; e < 36; ++e) v = (e == lane) ? acc[e] : v;
+        if (ha <= hb) d.Hs[(size_t)(6 * ha + i) * par.dimp + 6 * hb + j] -= v;
+        else d.Hs[(size_t)(6 * hb + j) * par.dimp + 6 * ha + i] -= v;
+    }
 }
 
 __global__ __launch_bounds__(64) void k_schur_rhs(Dev d, Par par) {
-    const int kf = blockIdx.x, r = threadIdx.x;
+    // lane = edge of the key-frame (strided by 64), then a fixed butterfly over the lanes, as in k_schur_pairs
+    const int kf = blockIdx.x, lane = threadIdx.x;
     const int ha = d.kf_h[kf];
-    if (ha < 0 || r >= 6) return;
-    double acc = 0;
-    for (int q = d.kf_off[kf]; q < d.kf_off[kf + 1]; ++q) {
+    if (ha < 0) return;
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    for (int q = d.kf_off[kf] + lane; q < d.kf_off[kf + 1]; q += 64) {
         const int a = d.kf_edge[q];
         if (d.edge_level[a]) continue;
         const int pt = d.edge[a].pt;
         if (d.pt_h[pt] < 0) continue;
-        const double* Ba = d.Hpl + 18 * (size_t)a + 3 * r;
+        const double* Ba = d.Hpl + 18 * (size_t)a;
         const double* db = d.xl + 3 * (size_t)pt;
-        acc += Ba[0] * db[0] + Ba[1] * db[1] + Ba[2] * db[2];
+        const double d0 = db[0], d1 = db[1], d2 = db[2];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) acc[r] += Ba[3 * r] * d0 + Ba[3 * r + 1] * d1 + Ba[3 * r + 2] * d2;
     }
-    d.bs[6 * ha + r] -= acc;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        double v = acc[r];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == r) d.bs[6 * ha + r] -= v;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1528,6 +1561,63 @@ static void csr_build(int n_rows, const std::vector<int32_t>& row_of, std::vecto
     for (size_t e = 0; e < row_of.size(); ++e) idx[cur[row_of[e]]++] = (int32_t)e;
 }
 
+// pairs of key-frames (by scene index, ka <= kb) that observe a common landmark, and per pair the (edge in ka, edge in kb,
+// landmark) entries in landmark order: counting sort over the keys ka * n_kf + kb.  Returns QSP_ERR_UNSUPPORTED when the
+// lists would exceed PAIR_CAP entries.
+constexpr int64_t PAIR_CAP = (int64_t)4 << 20;
+static int64_t count_pairs(const qsp_ba_problem* p) {
+    int64_t n = 0;
+    for (int l = 0; l < p->d.n_pt; ++l) {
+        const int64_t k = p->pt_off_h[l + 1] - p->pt_off_h[l];
+        n += k * (k + 1) / 2;
+    }
+    return n;
+}
+static int build_pair_lists(qsp_ba_problem* p) {
+    Dev& d = p->d;
+    if (d.pk_off) return QSP_OK;
+    if (count_pairs(p) > PAIR_CAP || (int64_t)d.n_kf * d.n_kf > ((int64_t)1 << 24))
+        return qsp_fail(QSP_ERR_UNSUPPORTED, "deterministic mode: graph too large for the pair lists");
+    {
+        const int nk = d.n_kf;
+        const std::vector<Edge>& E = p->edge_h;
+        const std::vector<int32_t>& off = p->pt_off_h;
+        std::vector<int64_t> cnt((size_t)nk * nk + 1, 0);
+        auto for_pairs = [&](auto&& fn) {
+            for (int l = 0; l < d.n_pt; ++l)
+                for (int a = off[l]; a < off[l + 1]; ++a)
+                    for (int b = a; b < off[l + 1]; ++b) {
+                        const int ka = E[a].kf, kb = E[b].kf;
+                        if (ka == kb && a != b) continue;          // (two edges of one landmark in one key-frame: skipped
+                        if (ka <= kb) fn(ka, kb, a, b);            //  like in the atomic kernels)
+                        else fn(kb, ka, b, a);
+                    }
+        };
+        for_pairs([&](int ka, int kb, int, int) { cnt[(size_t)ka * nk + kb + 1]++; });
+        std::vector<int32_t> pk_ka, pk_kb, pk_off(1, 0);
+        std::vector<int64_t> start((size_t)nk * nk, -1);
+        int64_t tot = 0;
+        for (int ka = 0; ka < nk; ++ka)
+            for (int kb = ka; kb < nk; ++kb) {
+                const int64_t c = cnt[(size_t)ka * nk + kb + 1];
+                if (!c) continue;
+                start[(size_t)ka * nk + kb] = tot;
+                tot += c;
+                pk_ka.push_back(ka); pk_kb.push_back(kb); pk_off.push_back((int32_t)tot);
+            }
+        std::vector<int4> ent((size_t)std::max<int64_t>(tot, 1));
+        for_pairs([&](int ka, int kb, int a, int b) { ent[(size_t)start[(size_t)ka * nk + kb]++] = make_int4(a, b, E[a].pt, 0); });
+        d.n_pk = (int32_t)pk_ka.size();
+        int rc = dupload(p, &d.pk_ka, pk_ka.data(), pk_ka.size());
+        if (!rc) rc = dupload(p, &d.pk_kb, pk_kb.data(), pk_kb.size());
+        if (!rc) rc = dupload(p, &d.pk_off, pk_off.data(), pk_off.size());
+        if (!rc) rc = dupload(p, &d.pk_ent, ent.data(), ent.size());
+        if (!rc) rc = dalloc(p, &d.Hpl, 18 * (size_t)std::max(d.n_edge, 1));
+        if (rc) return rc;
+    }
+    return QSP_OK;
+}
+
 extern "C" int qsp_ba_create(const qsp_ba_scene* s, int device, qsp_ba_problem** out) {
     if (!s || !out) return qsp_fail(QSP_ERR_INVALID, "qsp_ba_create: null argument");
     if (s->n_kf <= 0 || s->n_pt < 0 || s->n_obj < 0 || s->n_mono < 0 || s->n_stereo < 0 || s->n_objedge < 0)
@@ -1674,6 +1764,16 @@ extern "C" int qsp_ba_create(const qsp_ba_scene* s, int device, qsp_ba_problem**
     if (rc) {
         qsp_ba_destroy(p);
         return rc;
+    }
+    // default: the atomic-free Schur complement whenever its pair lists stay small (measured as fast as the atomic kernels
+    // at C2 / C4 / C5); larger graphs use the block-row kernel with LDS atomics.  qsp_ba_set_deterministic overrides.
+    if (count_pairs(p) <= PAIR_CAP && (int64_t)d.n_kf * d.n_kf <= ((int64_t)1 << 24)) {
+        rc = build_pair_lists(p);
+        if (rc) {
+            qsp_ba_destroy(p);
+            return rc;
+        }
+        p->deterministic = true;
     }
     *out = p;
     return QSP_OK;
@@ -2180,45 +2280,8 @@ extern "C" int qsp_pose_optimize(qsp_pose_optimizer* h, int32_t n, const double*
 extern "C" int qsp_ba_set_deterministic(qsp_ba_problem* p, int on) {
     if (!p) return qsp_fail(QSP_ERR_INVALID, "qsp_ba_set_deterministic: null problem");
     QSP_HIP(hipSetDevice(p->device));
-    Dev& d = p->d;
-    if (on && !d.pk_off) {
-        // pairs of key-frames (by scene index, ka <= kb) that observe a common landmark, and per pair the (edge in ka,
-        // edge in kb) entries in landmark order: counting sort over the keys ka * n_kf + kb
-        const int nk = d.n_kf;
-        const std::vector<Edge>& E = p->edge_h;
-        const std::vector<int32_t>& off = p->pt_off_h;
-        std::vector<int64_t> cnt((size_t)nk * nk + 1, 0);
-        auto for_pairs = [&](auto&& fn) {
-            for (int l = 0; l < d.n_pt; ++l)
-                for (int a = off[l]; a < off[l + 1]; ++a)
-                    for (int b = a; b < off[l + 1]; ++b) {
-                        const int ka = E[a].kf, kb = E[b].kf;
-                        if (ka == kb && a != b) continue;          // (two edges of one landmark in one key-frame: skipped
-                        if (ka <= kb) fn(ka, kb, a, b);            //  like in the atomic kernels)
-                        else fn(kb, ka, b, a);
-                    }
-        };
-        for_pairs([&](int ka, int kb, int, int) { cnt[(size_t)ka * nk + kb + 1]++; });
-        std::vector<int32_t> pk_ka, pk_kb, pk_off(1, 0);
-        std::vector<int64_t> start((size_t)nk * nk, -1);
-        int64_t tot = 0;
-        for (int ka = 0; ka < nk; ++ka)
-            for (int kb = ka; kb < nk; ++kb) {
-                const int64_t c = cnt[(size_t)ka * nk + kb + 1];
-                if (!c) continue;
-                start[(size_t)ka * nk + kb] = tot;
-                tot += c;
-                pk_ka.push_back(ka); pk_kb.push_back(kb); pk_off.push_back((int32_t)tot);
-            }
-        if (tot > (int64_t)1 << 30) return qsp_fail(QSP_ERR_UNSUPPORTED, "qsp_ba_set_deterministic: graph too large for the pair lists");
-        std::vector<int2> ent((size_t)std::max<int64_t>(tot, 1));
-        for_pairs([&](int ka, int kb, int a, int b) { ent[(size_t)start[(size_t)ka * nk + kb]++] = make_int2(a, b); });
-        d.n_pk = (int32_t)pk_ka.size();
-        int rc = dupload(p, &d.pk_ka, pk_ka.data(), pk_ka.size());
-        if (!rc) rc = dupload(p, &d.pk_kb, pk_kb.data(), pk_kb.size());
-        if (!rc) rc = dupload(p, &d.pk_off, pk_off.data(), pk_off.size());
-        if (!rc) rc = dupload(p, &d.pk_ent, ent.data(), ent.size());
-        if (!rc) rc = dalloc(p, &d.Hpl, 18 * (size_t)std::max(d.n_edge, 1));
+    if (on) {
+        const int rc = build_pair_lists(p);
         if (rc) return rc;
     }
     p->deterministic = on != 0;

@@ -12,6 +12,8 @@ for name in ("tiny", "mono", "two_fixed"):
     chis = []
     for rep in range(30):
         p = BaProblem(sc)
+        if os.environ.get("QSP_BA_DET") == "0":
+            p.set_deterministic(False)
         t1, t2 = p.local_joint_ba()
         key = (tuple(t1["trials"]), tuple(t1["accepted"]), tuple(t2["trials"]), tuple(t2["accepted"]))
         out[key] += 1
