@@ -1510,6 +1510,8 @@ struct qsp_ba_problem {
     Dev d{};
     int n_mono = 0, n_stereo = 0;
     std::vector<void*> allocs;
+    char* pool_cur = nullptr;     // bump allocator over the chunks in `allocs`
+    size_t pool_left = 0;
     // host mirrors needed for index building
     std::vector<Edge> edge_h;
     std::vector<int32_t> pt_off_h, oe_kf_h, oe_obj_h;
@@ -1536,12 +1538,26 @@ struct qsp_ba_problem {
 
 static int upload_levels(qsp_ba_problem* p);
 
+// device buffers come out of a few large chunks (a problem has ~50 of them; one hipMalloc each costs more than the
+// uploads at the BASELINE sizes)
 template <typename T>
 static int dalloc(qsp_ba_problem* p, T** ptr, size_t n) {
-    void* q = nullptr;
-    QSP_HIP(hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T)));
-    p->allocs.push_back(q);
-    *ptr = (T*)q;
+    const size_t bytes = (std::max<size_t>(n, 1) * sizeof(T) + 255) & ~(size_t)255;
+    if (bytes > p->pool_left) {
+        const size_t chunk = std::max<size_t>(bytes, (size_t)8 << 20);
+        void* q = nullptr;
+        QSP_HIP(hipMalloc(&q, chunk));
+        p->allocs.push_back(q);
+        if (chunk - bytes > p->pool_left) {          // keep whichever tail is larger for the next requests
+            p->pool_cur = (char*)q + bytes;
+            p->pool_left = chunk - bytes;
+        }
+        *ptr = (T*)q;
+        return QSP_OK;
+    }
+    *ptr = (T*)p->pool_cur;
+    p->pool_cur += bytes;
+    p->pool_left -= bytes;
     return QSP_OK;
 }
 template <typename T>
