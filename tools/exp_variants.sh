@@ -1,5 +1,5 @@
 #!/bin/bash
-# Builds timing-only variants of the library (QSP_EXP_VARIANT) into gpurun_out/exp/ -- run here, then time on the GPU box
+# Builds timing-only variants of the library (QSP_EXP_VARIANT) into build/exp/ (travels to the GPU box; gpurun_out/ does not) -- run here, then time with QSP_HIP_LIB=build/exp/libqsp_vN.so
 set -e
 cd "$(dirname "$0")/../qsp_slam_amd/csrc"
 mkdir -p ../../build/exp
