@@ -1980,8 +1980,7 @@ extern "C" int qsp_ba_optimize(qsp_ba_problem* p, int32_t n_iter, double delta_m
         launch_errors(p, par);
         // buildSystem
         if (p->profiling) hipEventRecord(evA, s);
-        QSP_HIP(hipMemsetAsync(d.Hdiag, 0, sizeof(double) * 36 * (size_t)std::max(p->n_pose, 1), s));
-        QSP_HIP(hipMemsetAsync(d.bp, 0, sizeof(double) * std::max(p->dimp, 1), s));
+        // (every entry of Hdiag and bp that is read is written by k_lin_poses_finish / k_lin_objects: no memsets)
         if (d.n_chunk) hipLaunchKernelGGL(k_lin_points, dim3(d.n_chunk), dim3(256), 0, s, d, par);
         if (d.n_ksplit) hipLaunchKernelGGL(k_lin_poses, dim3(d.n_ksplit), dim3(256), 0, s, d, par);
         if (d.n_oe) hipLaunchKernelGGL(k_lin_objedges, dim3((d.n_oe + 3) / 4), dim3(256), 0, s, d, par);
