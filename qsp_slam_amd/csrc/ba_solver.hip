@@ -313,6 +313,7 @@ struct Par {
     double lambda;
     int dim, dimp, n_pose;
     int is_root;   // landmark-sharded runs: only rank 0 contributes the (already all-reduced) pose blocks and padding
+    int have_hpl;  // d.Hpl holds this build's 6x3 blocks (atomic-free Schur mode)
 };
 
 // block-wide sum of one double per thread (256 threads), fixed tree -> thread 0 holds the result
@@ -1178,7 +1179,12 @@ __global__ __launch_bounds__(256) void k_update_points(Dev d, Par par) {
             const int ha = d.kf_h[d.edge[a].kf];
             if (ha < 0) continue;
             double B[18];
-            edge_hpl(d, d.edge[a], par, B);
+            if (par.have_hpl) {                      // atomic-free mode keeps the blocks of this build (k_hpl_fill)
+                const double* Bg = d.Hpl + 18 * (size_t)a;
+                for (int i = 0; i < 18; ++i) B[i] = Bg[i];
+            } else {
+                edge_hpl(d, d.edge[a], par, B);
+            }
             for (int j = 0; j < 3; ++j)
                 for (int i = 0; i < 6; ++i) c[j] -= B[3 * i + j] * d.xp[6 * ha + i];
         }
@@ -1961,7 +1967,8 @@ extern "C" int qsp_ba_optimize(qsp_ba_problem* p, int32_t n_iter, double delta_m
     QSP_HIP(hipMemcpyAsync(d.kf_h, p->kf_h.data(), sizeof(int32_t) * d.n_kf, hipMemcpyHostToDevice, s));
     if (d.n_obj) QSP_HIP(hipMemcpyAsync(d.obj_h, p->obj_h.data(), sizeof(int32_t) * d.n_obj, hipMemcpyHostToDevice, s));
     if (d.n_pt) QSP_HIP(hipMemcpyAsync(d.pt_h, p->pt_h.data(), sizeof(int32_t) * d.n_pt, hipMemcpyHostToDevice, s));
-    Par par{delta_mono, delta_stereo, delta_obj, 0.0, p->dim, p->dimp, p->n_pose, p->rank == 0 ? 1 : 0};
+    Par par{delta_mono, delta_stereo, delta_obj, 0.0, p->dim, p->dimp, p->n_pose, p->rank == 0 ? 1 : 0,
+            (p->deterministic && p->dimp > 0) ? 1 : 0};
     if (tr) { tr->n = 0; tr->result = 0; tr->n_pose_blocks = p->n_pose; tr->n_landmarks = p->n_land; }
     hipEvent_t ev0 = nullptr, ev1 = nullptr, evA = nullptr, evB = nullptr;
     if (p->profiling) {
