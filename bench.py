@@ -52,16 +52,12 @@ def joint_cfg(n_iter):
 
 
 def flip_states(objs, flips):
+    from qsp_slam_amd.reconstruct.optimizer import _flip_rotation
     T0, hyp = [], []
     for i, o in enumerate(objs):
         T = o["t_cam_obj"]
         for k in range(flips):
-            Tk = T.copy()
-            if k:
-                a = k * 2.0 * np.pi / flips
-                Ry = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]], np.float32)
-                Tk[:3, :3] = T[:3, :3] @ Ry
-            T0.append(Tk)
+            T0.append(_flip_rotation(T, k, 2.0 * np.pi / flips))     # src/LocalMapping_util.cc:722-726
             hyp.append(i)
     return np.stack(T0), hyp
 

@@ -309,6 +309,54 @@ int qsp_pose_optimize(qsp_pose_optimizer* h, int32_t n, const double* K, const d
                       const double* obs, const double* info, const uint8_t* stereo, double* pose_out, uint8_t* outlier,
                       int32_t* n_inliers, qsp_pose_trace* trace);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Caller-side marshalling on the device: what LocalMapping::ProcessDetectedObjects does
+ * around Optimizer.reconstruct_object for every detection of a key frame, src/LocalMapping_util.cc:585-760 --
+ *   surface_points_cam = Rcw * x3Dw + tcw over the object's map points                               (:610-628)
+ *   depth_obs = z of the same transform over the detection's feature points, ray = invK * (u, v, 1)  (:634-669)
+ *   rays = [fg_rays ; background_rays]                                                               (:671-672)
+ *   hypothesis k: t_cam_obj = SE3Tcw * Sim3Two with the rotation block of Sim3Two right-multiplied by
+ *   AngleAxisf(k * flip_sample_angle, e_y); k = 0 only when the object already has a good orientation (:706-733)
+ *   keep the first result, replace it when it is not good or when the new one is good with a smaller loss (:748-752)
+ * -- for ALL detections in one call: world-frame inputs go up once, three small kernels assemble the resident batch and
+ * the initial states, the Gauss-Newton iterations run as in qsp_refine_batch_run, one kernel applies the selection rule, and
+ * only the kept pose / code / loss per detection come back.  The filters on MapPoint flags (isBad, isOutlier, object_id:
+ * :612-617,640-647) are pointer chasing over the map and stay with the caller: the arrays hold the points that passed.
+ * Host pointers; ragged arrays are concatenated, *_off has n_det + 1 entries. */
+typedef struct {
+    int32_t n_det;
+    const float* T_cw;         /* (n_det,4,4) row-major SE3 pose of the detection's key frame (KeyFrame::GetPose)        */
+    const float* K;            /* (n_det,4) fx fy cx cy (Tracking::GetCameraIntrinsics)                                  */
+    const float* T_wo;         /* (n_det,4,4) MapObject::Sim3Two                                                         */
+    const float* code;         /* (n_det,code_len) MapObject::vShapeCode, or NULL for zero codes                         */
+    const int32_t* n_flip;     /* (n_det) 1 if MapObject::findGoodOrientation else flip_sample_num; NULL = all 1         */
+    double flip_angle;         /* flip_sample_angle = 2 pi / flip_sample_num (src/LocalMapping.cc:76)                    */
+    const int32_t* pts_off;    /* map points on the object, world frame                                                  */
+    const float* pts_world;    /* (pts_off[n_det],3)                                                                     */
+    const int32_t* fg_off;     /* feature points of the detection that lie on the object                                 */
+    const float* fg_px;        /* (fg_off[n_det],2) undistorted key-point pixel (mvKeysUn[idx].pt)                       */
+    const float* fg_world;     /* (fg_off[n_det],3) world position of the matched map point                              */
+    const int32_t* bg_off;     /* background rays of the detection (ObjectDetection::background_rays)                    */
+    const float* bg_rays;      /* (bg_off[n_det],3)                                                                      */
+} qsp_detections;
+
+typedef struct {               /* any pointer may be NULL */
+    float* t_cam_obj;          /* (n_det,4,4) Sim3Tco of the kept result (unspecified where is_good == 0)                */
+    float* code;               /* (n_det,code_len)                                                                       */
+    float* loss;               /* (n_det) loss of the kept result                                                        */
+    uint8_t* is_good;          /* (n_det) 0: the reference's t_cam_obj would be None                                     */
+    int32_t* kept_flip;        /* (n_det) index k of the kept hypothesis                                                 */
+    float* losses;             /* (sum n_flip) loss of every hypothesis, detection-major (the "# Losses" line, :755-759) */
+    /* parity taps: the assembled inputs as reconstruct_object would have received them */
+    float* pts_cam;            /* (pts_off[n_det],3)                                                                     */
+    float* rays;               /* (fg_off[n_det] + bg_off[n_det], 3), per detection foreground then background           */
+    float* depth_obs;          /* (fg_off[n_det])                                                                        */
+    float* t_cam_obj_init;     /* (sum n_flip,4,4)                                                                       */
+} qsp_detection_results;
+
+int qsp_refine_detections(qsp_decoder* dec, const qsp_joint_cfg* cfg, const qsp_detections* det,
+                          qsp_detection_results* out);
+
 #ifdef __cplusplus
 }
 #endif

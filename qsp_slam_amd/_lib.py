@@ -76,12 +76,25 @@ class PoseTrace(C.Structure):
     _fields_ = [("iters", C.c_int32 * 4), ("trace", C.c_double * 120)]
 
 
+class Detections(C.Structure):
+    _fields_ = [("n_det", C.c_int32), ("T_cw", c_float_p), ("K", c_float_p), ("T_wo", c_float_p), ("code", c_float_p),
+                ("n_flip", c_int32_p), ("flip_angle", C.c_double), ("pts_off", c_int32_p), ("pts_world", c_float_p),
+                ("fg_off", c_int32_p), ("fg_px", c_float_p), ("fg_world", c_float_p), ("bg_off", c_int32_p),
+                ("bg_rays", c_float_p)]
+
+
+class DetectionResults(C.Structure):
+    _fields_ = [("t_cam_obj", c_float_p), ("code", c_float_p), ("loss", c_float_p), ("is_good", c_uint8_p),
+                ("kept_flip", c_int32_p), ("losses", c_float_p), ("pts_cam", c_float_p), ("rays", c_float_p),
+                ("depth_obs", c_float_p), ("t_cam_obj_init", c_float_p)]
+
+
 SYMBOLS = [
     "qsp_last_error", "qsp_version", "qsp_device_count",
     "qsp_decoder_create", "qsp_decoder_destroy", "qsp_decode_sdf", "qsp_sdf_value_grad",
     "qsp_refine_batch_create", "qsp_refine_batch_destroy", "qsp_refine_batch_set_state", "qsp_refine_batch_run",
     "qsp_refine_batch_get", "qsp_refine_batch_trace", "qsp_refine_batch_profile", "qsp_refine_batch_rows",
-    "qsp_reconstruct_objects", "qsp_estimate_pose",
+    "qsp_reconstruct_objects", "qsp_estimate_pose", "qsp_refine_detections",
     "qsp_mesh_extractor_create", "qsp_mesh_extractor_destroy", "qsp_mesh_extract", "qsp_mesh_from_volume", "qsp_mesh_fetch",
     "qsp_mc_tables",
     "qsp_pose_optimizer_create", "qsp_pose_optimizer_destroy", "qsp_pose_optimize",
@@ -124,6 +137,7 @@ def lib():
                                           c_float_p, c_uint8_p]
     L.qsp_estimate_pose.argtypes = [vp, C.c_int32, c_float_p, c_float_p, pp_f, c_int32_p, c_float_p, C.c_int32,
                                     c_float_p]
+    L.qsp_refine_detections.argtypes = [vp, C.POINTER(JointCfg), C.POINTER(Detections), C.POINTER(DetectionResults)]
     L.qsp_mesh_extractor_create.argtypes = [vp, C.c_int32, c_float_p, C.POINTER(vp)]
     L.qsp_mesh_extractor_destroy.argtypes = [vp]
     L.qsp_mesh_extractor_destroy.restype = None

@@ -904,6 +904,39 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void k_decode(const float* __restri
     }
 }
 
+// 4x4 inverse as the reference's torch.inverse calls need it (optimizer.py:123,273): Gauss-Jordan with partial pivoting in
+// double, rounded to f32.  One definition for host (set_state / get) and device (detections.hpp), no contraction, so both
+// give the same bits.
+__host__ __device__ inline void inv4_gj(const float* in, float* out) {
+#pragma clang fp contract(off)
+    double a[4][8];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            a[i][j] = in[4 * i + j];
+            a[i][4 + j] = i == j;
+        }
+    for (int c = 0; c < 4; ++c) {
+        int p = c;
+        for (int r = c + 1; r < 4; ++r)
+            if (fabs(a[r][c]) > fabs(a[p][c])) p = r;
+        if (p != c)
+            for (int j = 0; j < 8; ++j) {
+                const double t = a[c][j];
+                a[c][j] = a[p][j];
+                a[p][j] = t;
+            }
+        const double inv = 1.0 / a[c][c];
+        for (int j = 0; j < 8; ++j) a[c][j] *= inv;
+        for (int r = 0; r < 4; ++r)
+            if (r != c) {
+                const double f = a[r][c];
+                for (int j = 0; j < 8; ++j) a[r][j] -= f * a[c][j];
+            }
+    }
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) out[4 * i + j] = (float)a[i][4 + j];
+}
+
 }  // namespace qsp
 
 // =================================================================================================================
@@ -1151,10 +1184,12 @@ static void batch_free(qsp_refine_batch* b) {
 static int batch_create(qsp_decoder* dec, const RefineCfg& cfg, int n_iter, int32_t n_obj, const float* const* pts,
                         const int32_t* n_pts, const float* const* rays, const int32_t* n_rays,
                         const float* const* depth, const int32_t* n_fg, int32_t n_hyp, const int32_t* hyp_obj,
-                        qsp_refine_batch** out) {
-    if (!dec || !out || n_obj <= 0 || n_hyp <= 0 || !pts || !n_pts || !hyp_obj)
+                        qsp_refine_batch** out, bool device_fill = false) {
+    // device_fill: only the extents are given, the observation arrays are written by a kernel (detections.hpp)
+    if (!dec || !out || n_obj <= 0 || n_hyp <= 0 || (!pts && !device_fill) || !n_pts || !hyp_obj)
         return qsp_fail(QSP_ERR_INVALID, "refine batch: bad argument");
-    if (!cfg.pose_only && (!rays || !n_rays || !depth || !n_fg)) return qsp_fail(QSP_ERR_INVALID, "refine batch: rays missing");
+    if (!cfg.pose_only && ((!device_fill && (!rays || !depth)) || !n_rays || !n_fg))
+        return qsp_fail(QSP_ERR_INVALID, "refine batch: rays missing");
     if (cfg.n_depth < 2 || cfg.n_depth > MAX_DEPTH) return qsp_fail(QSP_ERR_INVALID, "n_depth must be in [2, 64]");
     QSP_HIP(hipSetDevice(dec->device));
     qsp_refine_batch* b = new qsp_refine_batch();
@@ -1186,7 +1221,7 @@ static int batch_create(qsp_decoder* dec, const RefineCfg& cfg, int n_iter, int3
         }
     std::vector<float> hp((size_t)std::max<int64_t>(po, 1) * 3), hr((size_t)std::max<int64_t>(ro, 1) * 3),
         hd((size_t)std::max<int64_t>(ro, 1), 0.f);
-    for (int o = 0; o < n_obj; ++o) {
+    for (int o = 0; o < n_obj && !device_fill; ++o) {
         const ObjView& v = b->objs_h[o];
         if (v.n_pts) memcpy(&hp[3 * v.pts_off], pts[o], sizeof(float) * 3 * v.n_pts);
         if (v.n_rays) memcpy(&hr[3 * v.ray_off], rays[o], sizeof(float) * 3 * v.n_rays);
@@ -1235,9 +1270,10 @@ static int batch_create(qsp_decoder* dec, const RefineCfg& cfg, int n_iter, int3
 #undef QSP_ALLOC
     if (!rc) {
         hipError_t e = hipMemcpy(b->objs, b->objs_h.data(), sizeof(ObjView) * n_obj, hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(b->pts, hp.data(), hp.size() * sizeof(float), hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(b->rays, hr.data(), hr.size() * sizeof(float), hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(b->depth, hd.data(), hd.size() * sizeof(float), hipMemcpyHostToDevice);
+        if (e == hipSuccess && !device_fill) e = hipMemcpy(b->pts, hp.data(), hp.size() * sizeof(float), hipMemcpyHostToDevice);
+        if (e == hipSuccess && !device_fill) e = hipMemcpy(b->rays, hr.data(), hr.size() * sizeof(float), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = device_fill ? hipMemset(b->depth, 0, hd.size() * sizeof(float))
+                                             : hipMemcpy(b->depth, hd.data(), hd.size() * sizeof(float), hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemset(b->trH, 0, sizeof(float) * (size_t)n_hyp * NH * NH);
         if (e == hipSuccess) e = hipMemset(b->trb, 0, sizeof(float) * (size_t)n_hyp * NH);
         if (e == hipSuccess) e = hipMemset(b->trdx, 0, sizeof(float) * (size_t)n_hyp * NH);
@@ -1270,29 +1306,7 @@ extern "C" int qsp_refine_batch_set_state(qsp_refine_batch* b, const float* t_ca
     for (int h = 0; h < b->n_hyp; ++h) {
         HypState& S = hs[h];
         memset(&S, 0, sizeof(S));
-        // t_obj_cam = inverse(t_cam_obj)  (optimizer.py:123): Gauss-Jordan in double, rounded to f32
-        double a[4][8];
-        for (int i = 0; i < 4; ++i)
-            for (int j = 0; j < 4; ++j) {
-                a[i][j] = t_cam_obj[16 * h + 4 * i + j];
-                a[i][4 + j] = i == j;
-            }
-        for (int c = 0; c < 4; ++c) {
-            int p = c;
-            for (int r = c + 1; r < 4; ++r)
-                if (fabs(a[r][c]) > fabs(a[p][c])) p = r;
-            if (p != c)
-                for (int j = 0; j < 8; ++j) std::swap(a[c][j], a[p][j]);
-            const double inv = 1.0 / a[c][c];
-            for (int j = 0; j < 8; ++j) a[c][j] *= inv;
-            for (int r = 0; r < 4; ++r)
-                if (r != c) {
-                    const double f = a[r][c];
-                    for (int j = 0; j < 8; ++j) a[r][j] -= f * a[c][j];
-                }
-        }
-        for (int i = 0; i < 4; ++i)
-            for (int j = 0; j < 4; ++j) S.T_oc[4 * i + j] = (float)a[i][4 + j];
+        inv4_gj(t_cam_obj + 16 * h, S.T_oc);   // t_obj_cam = inverse(t_cam_obj)  (optimizer.py:123)
         if (code) memcpy(S.code, code + (size_t)h * CODE_LEN, sizeof(float) * CODE_LEN);
         S.alive = 1;
         S.obj = b->hyp_obj[h];
@@ -1403,29 +1417,7 @@ extern "C" int qsp_refine_batch_get(qsp_refine_batch* b, float* t_cam_obj_out, f
     for (int h = 0; h < b->n_hyp; ++h) {
         const HypState& S = hs[h];
         if (t_cam_obj_out) {
-            // t_cam_obj = inverse(t_obj_cam)  (optimizer.py:273)
-            double a[4][8];
-            for (int i = 0; i < 4; ++i)
-                for (int j = 0; j < 4; ++j) {
-                    a[i][j] = S.T_oc[4 * i + j];
-                    a[i][4 + j] = i == j;
-                }
-            for (int c = 0; c < 4; ++c) {
-                int p = c;
-                for (int r = c + 1; r < 4; ++r)
-                    if (fabs(a[r][c]) > fabs(a[p][c])) p = r;
-                if (p != c)
-                    for (int j = 0; j < 8; ++j) std::swap(a[c][j], a[p][j]);
-                const double inv = 1.0 / a[c][c];
-                for (int j = 0; j < 8; ++j) a[c][j] *= inv;
-                for (int r = 0; r < 4; ++r)
-                    if (r != c) {
-                        const double f = a[r][c];
-                        for (int j = 0; j < 8; ++j) a[r][j] -= f * a[c][j];
-                    }
-            }
-            for (int i = 0; i < 4; ++i)
-                for (int j = 0; j < 4; ++j) t_cam_obj_out[16 * h + 4 * i + j] = (float)a[i][4 + j];
+            inv4_gj(S.T_oc, t_cam_obj_out + 16 * h);   // t_cam_obj = inverse(t_obj_cam)  (optimizer.py:273)
         }
         if (code_out) memcpy(code_out + (size_t)h * CODE_LEN, S.code, sizeof(float) * CODE_LEN);
         if (loss_out) loss_out[h] = S.loss;
@@ -1544,3 +1536,4 @@ extern "C" int qsp_debug_timestamps(unsigned long long* out /*96*/, int* n, unsi
 #endif
 
 #include "mesh_extract.hpp"
+#include "detections.hpp"

@@ -19,6 +19,23 @@ def _joint_cfg(o):
                          int(o.num_depth_samples), int(o.code_len))
 
 
+def _flip_rotation(T, k, flip_angle):
+    """T with its rotation block right-multiplied by Eigen::AngleAxisf(double(k) * flip_sample_angle, e_y).matrix()
+    (src/LocalMapping_util.cc:722-726): the angle is narrowed to float before cos / sin, the (1,1) entry is (1-c)+c, and
+    the 3x3 product sums over k in increasing order in float."""
+    Tk = np.array(T, dtype=np.float32).reshape(4, 4).copy()
+    if k == 0:
+        return Tk
+    f = np.float32
+    a = float(f(float(k) * flip_angle))
+    c, s = f(math.cos(a)), f(math.sin(a))
+    Ry = np.array([[c, 0, s], [0, f(f(1) - c) + c, 0], [f(0) - s, 0, c]], dtype=np.float32)
+    R = Tk[:3, :3].copy()
+    for j in range(3):
+        Tk[:3, j] = (R[:, 0] * Ry[0, j] + R[:, 1] * Ry[1, j]) + R[:, 2] * Ry[2, j]
+    return Tk
+
+
 class RefineBatch(object):
     """Thin owner of a qsp_refine_batch* (resident device batch)."""
 
@@ -147,12 +164,7 @@ class Optimizer(object):
         for i, o in enumerate(objects):
             T = np.asarray(o["t_cam_obj"], dtype=np.float32).reshape(4, 4)
             for k in range(flip_sample_num):
-                Tk = T.copy()
-                if k:
-                    a = k * 2.0 * math.pi / flip_sample_num
-                    c, s = math.cos(a), math.sin(a)
-                    Ry = np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]], dtype=np.float32)
-                    Tk[:3, :3] = T[:3, :3] @ Ry
+                Tk = _flip_rotation(T, k, 2.0 * math.pi / flip_sample_num)
                 hyp_obj.append(i)
                 T0.append(Tk)
                 c0 = o.get("code")
@@ -184,6 +196,77 @@ class Optimizer(object):
                 out.append(best)
             else:
                 out.append(res)
+        return out
+
+    # ---- the caller's loop around reconstruct_object, on the device ---------------------------------
+    def refine_detections(self, detections, flip_sample_num=4, taps=False):
+        """LocalMapping::ProcessDetectedObjects' marshalling + flip loop + keep rule (src/LocalMapping_util.cc:585-760) for a
+        list of detections in ONE call (qsp_refine_detections, include/qsp_hip.h).  Each detection is a dict of WORLD-frame
+        inputs, as the caller holds them:
+            T_cw (4,4) key-frame pose, K (4,) fx fy cx cy, T_wo (4,4) Sim3Two of the map object, code (64,) | None,
+            pts_world (M,3) map points on the object, fg_px (F,2) key-point pixels, fg_world (F,3) their map points,
+            bg_rays (B,3), found_good_orientation (bool, default False -> flip_sample_num hypotheses, else one).
+        Returns per detection the object the reference keeps in pyMapObjectLeastLoss (t_cam_obj None when not good), with
+        the extra keys kept_flip and losses; taps=True adds the assembled pts / rays / depth / initial poses."""
+        n = len(detections)
+        f = _lib.f32c
+
+        def cat(key, width):
+            arrs = [f(d[key]).reshape(-1, width) for d in detections]
+            off = np.zeros(n + 1, np.int32)
+            off[1:] = np.cumsum([a.shape[0] for a in arrs])
+            flat = np.concatenate(arrs, axis=0) if off[-1] else np.zeros((1, width), np.float32)
+            return off, np.ascontiguousarray(flat)
+
+        pts_off, pts_world = cat("pts_world", 3)
+        fg_off, fg_px = cat("fg_px", 2)
+        fg_off2, fg_world = cat("fg_world", 3)
+        if not np.array_equal(fg_off, fg_off2):
+            raise ValueError("fg_px and fg_world must have one row per feature point")
+        bg_off, bg_rays = cat("bg_rays", 3)
+        T_cw = f(np.stack([np.asarray(d["T_cw"], np.float32).reshape(4, 4) for d in detections]))
+        T_wo = f(np.stack([np.asarray(d["T_wo"], np.float32).reshape(4, 4) for d in detections]))
+        K = f(np.stack([np.asarray(d["K"], np.float32).reshape(4) for d in detections]))
+        any_code = any(d.get("code") is not None for d in detections)
+        code = f(np.stack([np.zeros(self.code_len, np.float32) if d.get("code") is None
+                           else np.asarray(d["code"], np.float32)[: self.code_len] for d in detections]))
+        n_flip = np.array([1 if d.get("found_good_orientation") else int(flip_sample_num) for d in detections], np.int32)
+        n_hyp = int(n_flip.sum())
+        inp = _lib.Detections(n, _lib.fptr(T_cw), _lib.fptr(K), _lib.fptr(T_wo),
+                              _lib.fptr(code) if any_code else _lib.c_float_p(), _lib.i32ptr(n_flip),
+                              2.0 * math.pi / float(flip_sample_num), _lib.i32ptr(pts_off), _lib.fptr(pts_world),
+                              _lib.i32ptr(fg_off), _lib.fptr(fg_px), _lib.fptr(fg_world), _lib.i32ptr(bg_off),
+                              _lib.fptr(bg_rays))
+        T = np.empty((n, 4, 4), np.float32)
+        c_out = np.empty((n, self.code_len), np.float32)
+        loss = np.empty(n, np.float32)
+        good = np.empty(n, np.uint8)
+        kept = np.empty(n, np.int32)
+        losses = np.empty(n_hyp, np.float32)
+        res = _lib.DetectionResults(_lib.fptr(T), _lib.fptr(c_out), _lib.fptr(loss), _lib.u8ptr(good), _lib.i32ptr(kept),
+                                    _lib.fptr(losses))
+        if taps:
+            t_pts = np.empty((max(int(pts_off[-1]), 1), 3), np.float32)
+            t_rays = np.empty((max(int(fg_off[-1] + bg_off[-1]), 1), 3), np.float32)
+            t_depth = np.empty(max(int(fg_off[-1]), 1), np.float32)
+            t_init = np.empty((n_hyp, 4, 4), np.float32)
+            res.pts_cam, res.rays, res.depth_obs, res.t_cam_obj_init = (_lib.fptr(t_pts), _lib.fptr(t_rays),
+                                                                        _lib.fptr(t_depth), _lib.fptr(t_init))
+        _lib.check(_lib.lib().qsp_refine_detections(self.decoder.handle, C.byref(_joint_cfg(self)), C.byref(inp),
+                                                    C.byref(res)))
+        out = []
+        hyp_off = np.concatenate([[0], np.cumsum(n_flip)])
+        ray_off = fg_off + bg_off
+        for i in range(n):
+            r = ForceKeyErrorDict(t_cam_obj=T[i].copy() if good[i] else None, code=c_out[i].copy() if good[i] else None,
+                                  is_good=bool(good[i]), loss=float(loss[i]), kept_flip=int(kept[i]),
+                                  losses=losses[hyp_off[i]:hyp_off[i + 1]].copy())
+            if taps:
+                r["pts"] = t_pts[pts_off[i]:pts_off[i + 1]].copy()
+                r["rays"] = t_rays[ray_off[i]:ray_off[i + 1]].copy()
+                r["depth"] = t_depth[fg_off[i]:fg_off[i + 1]].copy()
+                r["t_cam_obj_init"] = t_init[hyp_off[i]:hyp_off[i + 1]].copy()
+            out.append(r)
         return out
 
     def estimate_pose_cam_obj(self, t_co_se3, scale, pts, code):

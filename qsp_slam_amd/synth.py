@@ -158,6 +158,38 @@ def make_object_views(seed, n_obj, n_pts, n_fg=256, n_bg=200, code_scale=0.0, pe
     return objs
 
 
+def make_detections(seed, n_det, n_pts, n_fg=256, n_bg=200, n_kf=3, code_scale=0.0):
+    """World-frame inputs of LocalMapping::ProcessDetectedObjects' reconstruction block (src/LocalMapping_util.cc:585-706)
+    for `n_det` detections spread over `n_kf` key frames: the object views of make_object_views moved into a world frame.
+
+    returns a list of dicts: T_cw (4,4), K (4,) fx fy cx cy, T_wo (4,4) Sim3Two, code (64,), pts_world (M,3),
+    fg_px (F,2), fg_world (F,3), bg_rays (B,3) -- float32 -- plus gt_t_cam_obj / gt_code."""
+    rng = np.random.default_rng(seed + 7919)
+    views = make_object_views(seed, n_det, n_pts, n_fg=n_fg, n_bg=n_bg, code_scale=code_scale)
+    K = np.array([535.4, 539.2, 320.1, 247.6])         # configs/tum_fr1_desk.yaml
+    kfs = []
+    for _ in range(n_kf):
+        w = rng.normal(scale=0.4, size=3)
+        kfs.append(se3(rodrigues(w), rng.uniform(-2.0, 2.0, size=3)))
+    dets = []
+    for i, v in enumerate(views):
+        T_cw = kfs[i % n_kf]
+        T_wc = np.linalg.inv(T_cw)
+
+        def to_world(x):
+            return (T_wc[:3, :3] @ np.asarray(x, np.float64).T).T + T_wc[:3, 3]
+
+        n_f = len(v["depth"])
+        fg_cam = v["rays"][:n_f].astype(np.float64) * v["depth"][:, None].astype(np.float64)
+        px = np.stack([K[0] * v["rays"][:n_f, 0] + K[2], K[1] * v["rays"][:n_f, 1] + K[3]], axis=1)
+        dets.append(dict(T_cw=T_cw.astype(np.float32), K=K.astype(np.float32),
+                         T_wo=(T_wc @ v["t_cam_obj"].astype(np.float64)).astype(np.float32),
+                         code=np.zeros(64, np.float32), pts_world=to_world(v["pts"]).astype(np.float32),
+                         fg_px=px.astype(np.float32), fg_world=to_world(fg_cam).astype(np.float32),
+                         bg_rays=v["rays"][n_f:].copy(), gt_t_cam_obj=v["gt_t_cam_obj"], gt_code=v["gt_code"]))
+    return dets
+
+
 # ----------------------------------------------------------------------------------------------------------
 # path B: joint bundle-adjustment scenes (flattened graph of src/Optimizer_util.cc:309-771)
 # ----------------------------------------------------------------------------------------------------------

@@ -129,6 +129,7 @@ def test_pose_only_vs_reference(gpu_decoder, golden_dir):
 def test_batched_flips_match_single_calls_and_selection_rule(gpu_decoder):
     """objects x 4 yaw flips in one batch == the same hypotheses run one at a time (bit-exact: fixed-order reductions),
     and the kept result follows src/LocalMapping_util.cc:748-752."""
+    from oracle import detections_oracle as DO
     from qsp_slam_amd import synth
     from qsp_slam_amd.reconstruct.optimizer import Optimizer
     objs = synth.make_object_views(5, 3, 500, n_fg=96, n_bg=48)
@@ -139,11 +140,9 @@ def test_batched_flips_match_single_calls_and_selection_rule(gpu_decoder):
     for i, o in enumerate(objs):
         best = None
         for k in range(4):
-            a = k * 2.0 * np.pi / 4
             T = o["t_cam_obj"].copy()
-            if k:
-                Ry = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]], np.float32)
-                T[:3, :3] = o["t_cam_obj"][:3, :3] @ Ry
+            if k:   # Eigen's AngleAxisf(k * flip_sample_angle, e_y) in float, as oracle/detections_oracle.py restates it
+                T[:3, :3] = DO._matmul_f32(o["t_cam_obj"][:3, :3], DO.rot_y(k, 2.0 * np.pi / 4))
             single = opt.reconstruct_object(T, o["pts"], o["rays"], o["depth"])
             b = allr[i][k]
             assert single.is_good == b.is_good
