@@ -357,6 +357,21 @@ typedef struct {               /* any pointer may be NULL */
 int qsp_refine_detections(qsp_decoder* dec, const qsp_joint_cfg* cfg, const qsp_detections* det,
                           qsp_detection_results* out);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Single-ellipsoid fits, batched: EllipsoidExtractor::OptimizeEllipsoidUsingPlanes,
+ * src/pca/EllipsoidExtractorLocalOptimization.cpp:16-85 -- per ellipsoid one VertexEllipsoidXYZABC (translation and half-axes
+ * free, rotation fixed) and one unary EdgeEllipsoidPlane per plane (error = distance from the plane to the nearest tangent
+ * point, src/pca/EllipsoidExtractorEdges.cpp:35-175; information 1; g2o's numeric Jacobian, delta 1e-9), dense
+ * Levenberg-Marquardt, optimize(n_iter) (reference: 10).  One wave per ellipsoid, all ellipsoids in one launch.
+ *   ellipsoid_in/out (n,10): translation (3), quaternion x y z w (4), half-axes (3) = g2o::ellipsoid::toVector()
+ *   planes (plane_off[n],4): A B C D of the planes of ellipsoid i at [plane_off[i], plane_off[i+1]); no planes: unchanged
+ *   normal_direction != 0: the residual of EdgeSE3EllipsoidPlane with setNormalDirection(true) and an identity camera
+ *   (GetDistanceWithDirection + its NaN -> 0 rule, EllipsoidExtractorEdges.cpp:151-226) instead of EdgeEllipsoidPlane's
+ *   chi2_out (n), iters_out (n), trace (n,n_iter,3) chi2 / lambda / trials per iteration: optional.  Host pointers. */
+int qsp_ellipsoid_fit_planes(int device, int32_t n, const double* ellipsoid_in, const int32_t* plane_off,
+                             const double* planes, int32_t n_iter, int32_t normal_direction, double* ellipsoid_out,
+                             double* chi2_out, int32_t* iters_out, double* trace);
+
 #ifdef __cplusplus
 }
 #endif

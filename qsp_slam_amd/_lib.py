@@ -97,7 +97,7 @@ SYMBOLS = [
     "qsp_reconstruct_objects", "qsp_estimate_pose", "qsp_refine_detections",
     "qsp_mesh_extractor_create", "qsp_mesh_extractor_destroy", "qsp_mesh_extract", "qsp_mesh_from_volume", "qsp_mesh_fetch",
     "qsp_mc_tables",
-    "qsp_pose_optimizer_create", "qsp_pose_optimizer_destroy", "qsp_pose_optimize",
+    "qsp_pose_optimizer_create", "qsp_pose_optimizer_destroy", "qsp_pose_optimize", "qsp_ellipsoid_fit_planes",
     "qsp_ba_create", "qsp_ba_destroy", "qsp_ba_set_levels", "qsp_ba_optimize", "qsp_ba_local_joint",
     "qsp_ba_set_state", "qsp_ba_get_state", "qsp_ba_get_edges", "qsp_ba_get_index", "qsp_ba_profile", "qsp_ba_set_shard", "qsp_ba_set_deterministic",
 ]
@@ -150,6 +150,8 @@ def lib():
     L.qsp_pose_optimizer_destroy.restype = None
     L.qsp_pose_optimize.argtypes = [vp, C.c_int32, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, c_uint8_p,
                                     c_double_p, c_uint8_p, c_int32_p, C.POINTER(PoseTrace)]
+    L.qsp_ellipsoid_fit_planes.argtypes = [C.c_int, C.c_int32, c_double_p, c_int32_p, c_double_p, C.c_int32, C.c_int32,
+                                           c_double_p, c_double_p, c_int32_p, c_double_p]
     L.qsp_ba_create.argtypes = [C.POINTER(BaScene), C.c_int, C.POINTER(vp)]
     L.qsp_ba_destroy.argtypes = [vp]
     L.qsp_ba_destroy.restype = None

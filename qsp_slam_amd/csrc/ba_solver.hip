@@ -2309,3 +2309,5 @@ extern "C" int qsp_ba_set_deterministic(qsp_ba_problem* p, int on) {
     p->deterministic = on != 0;
     return QSP_OK;
 }
+
+#include "ellipsoid_fit.hpp"
