@@ -19,15 +19,18 @@ def owner_of(obj, world):
     return obj % world
 
 
-def pack_results(results):
-    """list of reconstruct_object results (attr-dicts) -> (n, 82) float32 table"""
-    out = np.zeros((len(results), RESULT_WIDTH), np.float32)
+def pack_results(results, with_flip=False):
+    """list of reconstruct_object results (attr-dicts) -> (n, 82) float32 table (83 with the kept flip index of
+    Optimizer.refine_detections)"""
+    out = np.zeros((len(results), RESULT_WIDTH + (1 if with_flip else 0)), np.float32)
     for i, r in enumerate(results):
         if r.is_good:
             out[i, :16] = np.asarray(r.t_cam_obj, np.float32).reshape(-1)
             out[i, 16:80] = np.asarray(r.code, np.float32)[:64]
         out[i, 80] = r.loss
         out[i, 81] = 1.0 if r.is_good else 0.0
+        if with_flip:
+            out[i, 82] = float(r.kept_flip)
     return out
 
 
@@ -40,6 +43,8 @@ def unpack_results(table):
                                          loss=float(row[80])))
         else:
             res.append(ForceKeyErrorDict(t_cam_obj=None, code=None, is_good=False, loss=float(row[80])))
+        if len(row) > RESULT_WIDTH:
+            res[-1]["kept_flip"] = int(row[82])
     return res
 
 
@@ -50,13 +55,14 @@ def gather_object_results(local_table, n_obj, rank, world, device=None):
     import torch.distributed as dist
     if world == 1:
         return np.asarray(local_table, np.float32)
+    width = int(np.shape(local_table)[1])
     per = (n_obj + world - 1) // world                      # padded shard size
-    buf = torch.zeros(per, RESULT_WIDTH, dtype=torch.float32, device=device)
+    buf = torch.zeros(per, width, dtype=torch.float32, device=device)
     if len(local_table):
         buf[: len(local_table)] = torch.from_numpy(np.ascontiguousarray(local_table, np.float32)).to(buf.device)
     parts = [torch.zeros_like(buf) for _ in range(world)]
     dist.all_gather(parts, buf)
-    full = np.zeros((n_obj, RESULT_WIDTH), np.float32)
+    full = np.zeros((n_obj, width), np.float32)
     for r in range(world):
         idx = shard_objects(n_obj, r, world)
         full[idx] = parts[r][: len(idx)].cpu().numpy()
@@ -70,6 +76,15 @@ def refine_objects_sharded(optimizer, objects, flip_sample_num, rank, world, dev
     local = optimizer.reconstruct_objects_batched([objects[i] for i in mine], flip_sample_num=flip_sample_num,
                                                   select=True) if mine else []
     table = gather_object_results(pack_results(local), len(objects), rank, world, device=device)
+    return unpack_results(table)
+
+
+def refine_detections_sharded(optimizer, detections, flip_sample_num, rank, world, device=None):
+    """As refine_objects_sharded for the world-frame entry point (Optimizer.refine_detections): detection
+    d is marshalled, refined over its yaw flips and selected on rank d % world; one all_gather of 83 floats per detection."""
+    mine = shard_objects(len(detections), rank, world)
+    local = optimizer.refine_detections([detections[i] for i in mine], flip_sample_num=flip_sample_num) if mine else []
+    table = gather_object_results(pack_results(local, with_flip=True), len(detections), rank, world, device=device)
     return unpack_results(table)
 
 

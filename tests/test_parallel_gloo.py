@@ -28,6 +28,12 @@ class FakeOptimizer(object):
                                              code=np.arange(64, dtype=np.float32) + tag, is_good=True, loss=0.5 * tag))
         return out
 
+    def refine_detections(self, detections, flip_sample_num=4):
+        out = self.reconstruct_objects_batched(detections, flip_sample_num)
+        for d, r in zip(detections, out):
+            r["kept_flip"] = int(d["tag"]) % flip_sample_num
+        return out
+
 
 def _worker(rank, world, port, n_obj, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -41,6 +47,13 @@ def _worker(rank, world, port, n_obj, q):
             ok &= (not r.is_good) and r.t_cam_obj is None and r.loss == float(i)
         else:
             ok &= r.is_good and float(r.t_cam_obj[2, 1]) == float(i) and float(r.code[7]) == 7.0 + i and r.loss == 0.5 * i
+    # the world-frame entry point shards the same way and carries the kept flip index
+    res = parallel.refine_detections_sharded(FakeOptimizer(), objs, 4, rank, world)
+    ok &= len(res) == n_obj
+    for i, r in enumerate(res):
+        ok &= r.kept_flip == i % 4 and r.is_good == (i % 5 != 3)
+        if r.is_good:
+            ok &= float(r.t_cam_obj[1, 3]) == float(i)
     q.put((rank, bool(ok)))
     dist.barrier()
     dist.destroy_process_group()
