@@ -61,6 +61,8 @@ constexpr int HID = 512;        // hidden width
 constexpr int CODE_LEN = 64;    // latent code length
 constexpr int NIN = CODE_LEN + 3;
 constexpr int SKIP_COL = HID - NIN;   // 445: first pass-through column of the latent_in layer's input
+constexpr int K4 = SKIP_COL + 3;      // forward K of the latent_in layer: [h3 (445) | xyz (3)]; its 64 code columns are folded
+constexpr int KG4 = K4 / 8;           // into the per-hypothesis bias c4 (mlp_prepare / k_c0), like layer 0's
 constexpr int K0_PAD = 96;      // layer-0 K (67) padded to a multiple of 8*PF
 constexpr int LDA = HID + 4;    // activation row stride (floats)
 constexpr int LDST = 68;        // stash row stride
@@ -76,6 +78,7 @@ struct MlpParams {
     const float* w8;        // [512] last layer row
     float b8;
     const float* w0c;       // [512][64] layer-0 weights of the latent code (row-major)
+    const float* w4c;       // [512][64] layer-4 weights of the latent code (input columns 445..508)
     const float4* w0x;      // [128 unit quads][3] layer-0 weights of x, y, z for four consecutive units
 };
 
@@ -86,6 +89,7 @@ struct __attribute__((aligned(16))) MlpSmem {
     float xin[TILE_P * 4];      // object-frame xyz per row (4th = 0)
     float code[CODE_LEN];
     float c0[HID];              // layer-0 pre-activation without the xyz part: b0 + W0[:, :64] code (mlp_prepare)
+    float c4[HID];              // layer-4 bias with the code part of the skip connection: b4 + W4[:, 445:509] code
     float y[TILE_P];            // tanh output
     float red[8 * TILE_P];      // layer-8 partial sums
     float rscale[TILE_P];       // row scale of the Jacobian (1 for SDF rows, de/ds for render rows, 0 for padding)
@@ -313,12 +317,13 @@ __device__ __forceinline__ void fwd_writeout(MlpSmem& s, const BiasQuads& bq, co
     m_hi = hi;
 }
 
-// Layer 4 consumes [h3(445) | code(64) | xyz(3)]: fill columns 445..511 of every row (all 512 threads; runs after a
-// barrier behind fwd_writeout<3>, whose 16-byte stores cover those columns with zeros).
+// Layer 4 consumes [h3(445) | code(64) | xyz(3)].  The code columns are the same for every point of a hypothesis and live in
+// the bias c4; the forward GEMM runs over K4 = 448 columns [h3 | xyz]: put xyz into columns 445..447 of every row (runs after
+// a barrier behind fwd_writeout<3>, whose 16-byte stores cover those columns with zeros).
 __device__ __forceinline__ void pass_through(MlpSmem& s) {
-    for (int e = threadIdx.x; e < TILE_P * NIN; e += MLP_THREADS) {
-        const int row = e / NIN, ci = e - row * NIN;
-        s.act[row * LDA + SKIP_COL + ci] = ci < CODE_LEN ? s.code[ci] : s.xin[row * 4 + (ci - CODE_LEN)];
+    if (threadIdx.x < TILE_P * 3) {
+        const int row = threadIdx.x / 3, ci = threadIdx.x - row * 3;
+        s.act[row * LDA + SKIP_COL + ci] = s.xin[row * 4 + ci];
     }
 }
 
@@ -366,10 +371,15 @@ __device__ __forceinline__ void mlp_prepare(MlpSmem& s, const MlpParams* __restr
     __syncthreads();
     const int u = threadIdx.x;
     const float* w = Pm->w0c + (size_t)u * CODE_LEN;
-    float a = Pm->bias[0][u];
+    const float* w4 = Pm->w4c + (size_t)u * CODE_LEN;
+    float a = Pm->bias[0][u], a4 = Pm->bias[4][u];
 #pragma unroll 8
-    for (int k = 0; k < CODE_LEN; ++k) a += w[k] * s.code[k];
+    for (int k = 0; k < CODE_LEN; ++k) {
+        a += w[k] * s.code[k];
+        a4 += w4[k] * s.code[k];
+    }
     s.c0[u] = a;
+    s.c4[u] = a4;
 }
 
 // Whole network for the tile whose inputs are staged in s.code / s.xin.
@@ -401,6 +411,8 @@ __device__ __forceinline__ void mlp_tile(MlpSmem& s, const MlpParams* __restrict
     // column-block bases of this wave in every packed matrix
 #define QSP_WF(L) (P.wf[L] + (cb0 * KGH) * 64)
 #define QSP_WF1(L) (P.wf[L] + ((cb0 + 1) * KGH) * 64)
+#define QSP_WF4 (P.wf[4] + (cb0 * KG4) * 64)
+#define QSP_WF41 (P.wf[4] + ((cb0 + 1) * KG4) * 64)
 #define QSP_WB(L) (P.wb[L] + (cb0 * KGH) * 64)
 #define QSP_WB1(L) (P.wb[L] + ((cb0 + 1) * KGH) * 64)
     // layer-0 backward: six 32x32 output tiles (2 point blocks x 3 column blocks of the 96 padded inputs) on four SIMDs:
@@ -471,7 +483,7 @@ __device__ __forceinline__ void mlp_tile(MlpSmem& s, const MlpParams* __restrict
     QSP_FWD_LAYER(1)
     QSP_FWD_LAYER(2)
     zero_acc(acc);
-    gemm_2x2<KGH, PF, true>(s.act, QSP_WF(3), QSP_WF1(3), QSP_WF(4), QSP_WF1(4), ring, acc, lane, P.bias[3] + 64 * wave, bq);
+    gemm_2x2<KGH, PF, true>(s.act, QSP_WF(3), QSP_WF1(3), QSP_WF4, QSP_WF41, ring, acc, lane, P.bias[3] + 64 * wave, bq);
     QSP_TS()
     __syncthreads();
     QSP_TS()
@@ -483,7 +495,20 @@ __device__ __forceinline__ void mlp_tile(MlpSmem& s, const MlpParams* __restrict
     QSP_TS()
     __syncthreads();
     QSP_TS()
-    QSP_FWD_LAYER(4)
+    // layer 4: K = 448, bias = c4 of this hypothesis (LDS)
+    zero_acc(acc);
+    gemm_2x2<KG4, PF, false>(s.act, QSP_WF4, QSP_WF41, QSP_WF(5), QSP_WF1(5), ring, acc, lane, nullptr, bq);
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bq.v[c][g] = lds4(s.c4 + 64 * wave + 32 * c + 8 * g + 4 * (lane >> 5));
+    QSP_TS()
+    __syncthreads();
+    QSP_TS()
+    fwd_writeout<4>(s, bq, acc, wave, lane, mlo[4], mhi[4]);
+    QSP_TS()
+    __syncthreads();
+    QSP_TS()
     QSP_FWD_LAYER(5)
     QSP_FWD_LAYER(6)
     zero_acc(acc);
@@ -587,6 +612,8 @@ __device__ __forceinline__ void mlp_tile(MlpSmem& s, const MlpParams* __restrict
     else gemm_1x1<KGH / 2, PF>(s.act + 32 * r0 * LDA + l0_half * (HID / 2), wb0, ring, g0, lane);
 #undef QSP_WF
 #undef QSP_WF1
+#undef QSP_WF4
+#undef QSP_WF41
 #undef QSP_WB
 #undef QSP_WB1
     QSP_TS()

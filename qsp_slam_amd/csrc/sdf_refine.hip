@@ -235,10 +235,15 @@ __global__ __launch_bounds__(MLP_THREADS) void k_c0(const HypState* __restrict__
     __syncthreads();
     const int u = threadIdx.x;
     const float* w = Pm->w0c + (size_t)u * CODE_LEN;
-    float a = Pm->bias[0][u];
+    const float* w4 = Pm->w4c + (size_t)u * CODE_LEN;
+    float a = Pm->bias[0][u], a4 = Pm->bias[4][u];
 #pragma unroll 8
-    for (int k = 0; k < CODE_LEN; ++k) a += w[k] * code[k];
-    c0_all[(size_t)blockIdx.x * HID + u] = a;
+    for (int k = 0; k < CODE_LEN; ++k) {
+        a += w[k] * code[k];
+        a4 += w4[k] * code[k];
+    }
+    c0_all[(size_t)blockIdx.x * 2 * HID + u] = a;
+    c0_all[(size_t)blockIdx.x * 2 * HID + HID + u] = a4;     // layer 4's bias with the skip connection's code part
 }
 
 // mode 0: forward items (h, tile) over the valid ray samples; mode 1: jtj items (h, slot), surface slots then render slots
@@ -311,7 +316,8 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void k_mlp_fwd(const HypState* __re
         float* out = sdf_valid + h * rk_stride;
         if (h != h_cached) {                   // per-hypothesis staging: code, pose, layer-0 code part
             stage_code_T(s, S, Tsh);
-            s.c0[threadIdx.x] = c0_all[(size_t)h * HID + threadIdx.x];
+            s.c0[threadIdx.x] = c0_all[(size_t)h * 2 * HID + threadIdx.x];
+            s.c4[threadIdx.x] = c0_all[(size_t)h * 2 * HID + HID + threadIdx.x];
             h_cached = h;
         }
         const float d_min = S.d_min, d_max = S.d_max;
@@ -485,7 +491,8 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void k_mlp_jtj(const HypState* __re
     const int tb = (wave < 3) ? wave : (wave < 5 ? wave - 2 : 2);
 
     stage_code_T(s, S, Tsh);
-    s.c0[threadIdx.x] = c0_all[(size_t)h * HID + threadIdx.x];
+    s.c0[threadIdx.x] = c0_all[(size_t)h * 2 * HID + threadIdx.x];
+    s.c4[threadIdx.x] = c0_all[(size_t)h * 2 * HID + HID + threadIdx.x];
     const float* Pc = pts + 3 * ov.pts_off;
     const float* R = rays + 3 * ov.ray_off;
     const int32_t* rk = rend_rk + h * rk_stride;
@@ -1004,20 +1011,29 @@ static int pack_weights(qsp_decoder* d, const qsp_decoder_desc* desc) {
             if (!rc) rc = upload(wx, (const void**)&d->P.w0x);
             d->P.wf[0] = nullptr;
         } else {
-            // forward: B[k][o]; column blocks over o (16 blocks of 32), k-groups of 8 over K = 512
-            const int KG = HID / 8;
+            // forward: B[k][o]; column blocks over o (16 blocks of 32), k-groups of 8 over K = 512.
+            // Layer 4 (latent_in): K = 448 = [h3 (445) | xyz (3)]; its 64 code columns go to w4c (folded into a bias per
+            // hypothesis by k_c0 / mlp_prepare).
+            const int KG = (l == 4) ? KG4 : HID / 8;
             std::vector<float> pf((size_t)16 * KG * 64 * 4, 0.f);
             for (int cb = 0; cb < 16; ++cb)
                 for (int kg = 0; kg < KG; ++kg)
                     for (int lane = 0; lane < 64; ++lane)
                         for (int e = 0; e < 4; ++e) {
                             const int o = 32 * cb + (lane & 31);
-                            const int k = 8 * kg + 4 * (lane >> 5) + e;
+                            int k = 8 * kg + 4 * (lane >> 5) + e;
+                            if (l == 4 && k >= SKIP_COL) k += CODE_LEN;      // xyz columns 509..511
                             float v = 0.f;
                             if (o < out && k < in) v = W[l][(size_t)o * in + k];
                             pf[(((size_t)cb * KG + kg) * 64 + lane) * 4 + e] = v;
                         }
             rc = upload(pf, (const void**)&d->P.wf[l]);
+            if (!rc && l == 4) {
+                std::vector<float> wc((size_t)HID * CODE_LEN);
+                for (int o = 0; o < HID; ++o)
+                    for (int k = 0; k < CODE_LEN; ++k) wc[(size_t)o * CODE_LEN + k] = W[4][(size_t)o * in + SKIP_COL + k];
+                rc = upload(wc, (const void**)&d->P.w4c);
+            }
         }
         if (rc) return rc;
         // backward: B[o][k]; column blocks over the layer's inputs k, groups of 8 over o (padded to 512)
@@ -1159,7 +1175,7 @@ struct qsp_refine_batch {
     unsigned long long* counters = nullptr;   // [4] points/tiles processed (fwd+bwd, fwd-only)
     int2 *work_fwd = nullptr, *work_jtj = nullptr;   // work-queue items (k_plan)
     int* qctl = nullptr;            // [4] item counts / next-item counters
-    float* c0_all = nullptr;        // [n_hyp][512] layer-0 code part per hypothesis (k_c0)
+    float* c0_all = nullptr;        // [n_hyp][2][512] code part of layers 0 and 4 (bias included) per hypothesis (k_c0)
     int n_cu = 256;
     float* rows = nullptr;          // optional tap of the Jacobian rows (qsp_refine_batch_rows)
     int64_t rows_stride = 0;
@@ -1249,7 +1265,7 @@ static int batch_create(qsp_decoder* dec, const RefineCfg& cfg, int n_iter, int3
     QSP_ALLOC(b->trdx, sizeof(float) * (size_t)n_hyp * NH);
     QSP_ALLOC(b->counters, sizeof(unsigned long long) * 4);
     QSP_ALLOC(b->qctl, sizeof(int) * 4);
-    QSP_ALLOC(b->c0_all, sizeof(float) * (size_t)n_hyp * HID);
+    QSP_ALLOC(b->c0_all, sizeof(float) * (size_t)n_hyp * 2 * HID);
     QSP_ALLOC(b->work_jtj, sizeof(int2) * (size_t)n_hyp * nw_total);
     if (!cfg.pose_only) QSP_ALLOC(b->work_fwd, sizeof(int2) * (size_t)n_hyp * ((b->rk_stride + TILE_P - 1) / TILE_P));
     {
