@@ -599,7 +599,17 @@ __device__ __forceinline__ void mlp_tile(MlpSmem& s, const MlpParams* __restrict
     QSP_TS()
     __syncthreads();
     QSP_TS()
-    QSP_BWD_LAYER(3)
+    // layer 3 has 445 outputs: its backward contraction runs over K4 = 448 gradient columns (445..447 were zeroed by
+    // stash_extract, the packed rows 445..511 are zero)
+    zero_acc(acc);
+    gemm_2x2<KG4, PF, false>(s.act, QSP_WB(3), QSP_WB1(3), QSP_WB(2), QSP_WB1(2), ring, acc, lane, nullptr, bq);
+    QSP_TS()
+    __syncthreads();
+    QSP_TS()
+    bwd_writeout<3>(s, acc, wave, lane, mlo[2], mhi[2]);
+    QSP_TS()
+    __syncthreads();
+    QSP_TS()
     QSP_BWD_LAYER(2)
     QSP_BWD_LAYER(1)
 #undef QSP_BWD_LAYER
