@@ -294,7 +294,7 @@ def main():
                                            "buffers allocated inside the step"}
             b2.close()
             ba2.close()
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(w, objs, scene, n_hyp)
         print(json.dumps(out))
     batch.close()
