@@ -801,36 +801,16 @@ __global__ __launch_bounds__(256) void k_solve(HypState* __restrict__ st, const 
         for (int a = tid; a < N; a += 256) trb[(int64_t)h * NH + a] = (float)Hd[a * (N + 1) + N];
     }
     __syncthreads();
-    // Gaussian elimination with partial pivoting in f64 on the augmented system (reference: torch.inverse(H) @ b, f32)
-    __shared__ int piv_sh;
+    // Gauss-Jordan elimination in f64 on the augmented system (reference: torch.inverse(H) @ b, f32).  H is symmetric
+    // positive definite by construction (Gram matrices plus the identity damping of optimizer.py:240-252 / :75), so no
+    // pivot search is needed: one barrier per column, every (row, column strip) pair on its own thread.
+    const int STR = 256 / N;                   // 3 strips for the 71 x 71 system
     for (int c = 0; c < N; ++c) {
-        if (tid == 0) {
-            int p = c;
-            double best = fabs(Hd[c * (N + 1) + c]);
-            for (int r = c + 1; r < N; ++r) {
-                const double v = fabs(Hd[r * (N + 1) + c]);
-                if (v > best) { best = v; p = r; }
-            }
-            piv_sh = p;
-        }
-        __syncthreads();
-        const int p = piv_sh;
-        if (p != c) {
-            for (int j = tid; j <= N; j += 256) {
-                const double t = Hd[c * (N + 1) + j];
-                Hd[c * (N + 1) + j] = Hd[p * (N + 1) + j];
-                Hd[p * (N + 1) + j] = t;
-            }
-            __syncthreads();
-        }
-        const double pv = Hd[c * (N + 1) + c];
-        // eliminate column c from every other row (Gauss-Jordan); thread -> (row, column-strip)
-        for (int e = tid; e < N * 4; e += 256) {
-            const int r = e >> 2, q = e & 3;
-            if (r != c) {
-                const double f = Hd[r * (N + 1) + c] / pv;
-                for (int j = c + 1 + q; j <= N; j += 4) Hd[r * (N + 1) + j] -= f * Hd[c * (N + 1) + j];
-            }
+        const double inv = 1.0 / Hd[c * (N + 1) + c];
+        const int r = tid / STR, q = tid - r * STR;
+        if (r < N && r != c) {
+            const double f = Hd[r * (N + 1) + c] * inv;
+            for (int j = c + 1 + q; j <= N; j += STR) Hd[r * (N + 1) + j] -= f * Hd[c * (N + 1) + j];
         }
         __syncthreads();
     }
