@@ -8,3 +8,7 @@ SRCS="sdf_refine.hip c_abi.cpp"
 [ -f ba_solver.hip ] && SRCS="$SRCS ba_solver.hip"
 $HIPCC $FLAGS -shared -o ../libqsp_hip.so $SRCS "$@"
 echo "built $(cd .. && pwd)/libqsp_hip.so"
+# C++ host layer for Python embedders (pybind11 over the C-ABI; no HIP code in it)
+PYMOD=../reconstruct_hip$(python3-config --extension-suffix)
+g++ -O2 -std=c++17 -fPIC -fvisibility=hidden -shared $(python3 -m pybind11 --includes) reconstruct_hip.cpp -o $PYMOD -L.. -lqsp_hip -Wl,-rpath,'$ORIGIN'
+echo "built $(cd .. && pwd)/$(basename $PYMOD)"
