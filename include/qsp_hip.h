@@ -60,6 +60,8 @@ typedef struct {
 typedef struct qsp_decoder qsp_decoder;
 
 int qsp_decoder_create(const qsp_decoder_desc* desc, int device, qsp_decoder** out);
+/* Batches and mesh extractors created from a decoder use it until they are destroyed: destroy them first.  (Destroying one of
+ * them after its decoder only frees its own memory and is harmless; any other call on it is undefined.) */
 void qsp_decoder_destroy(qsp_decoder* dec);
 
 /* decode_sdf, reconstruct/loss_utils.py:51-79.  Host pointers: code (code_len), xyz (n,3) row-major, sdf_out (n). */

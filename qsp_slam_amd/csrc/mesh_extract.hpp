@@ -292,15 +292,17 @@ struct qsp_mesh_extractor {
     qsp::mc::Tables* tables = nullptr;
     int64_t n_verts = 0, n_faces = 0, cap_verts = 0, cap_faces = 0;
     bool have_volume = false;
+    int device = 0;         // of the decoder, cached: destroy must not touch a decoder that may already be gone
 };
 
 extern "C" void qsp_mesh_extractor_destroy(qsp_mesh_extractor* m) {
     if (!m) return;
-    if (m->dec) hipSetDevice(m->dec->device);
+    hipSetDevice(m->device);
     void* ptrs[] = {m->xyz, m->sdf, m->code, m->verts, m->faces, m->flags, m->cnt, m->bsum, m->total, m->tables};
     for (void* p : ptrs)
         if (p) hipFree(p);
     delete m;
+    (void)hipGetLastError();   // errors are ignored here; do not leave one behind for the next call's launch check
 }
 
 extern "C" int qsp_mesh_extractor_create(qsp_decoder* dec, int32_t voxels_dim, const float* voxel_points,
@@ -314,6 +316,7 @@ extern "C" int qsp_mesh_extractor_create(qsp_decoder* dec, int32_t voxels_dim, c
     QSP_HIP(hipSetDevice(dec->device));
     qsp_mesh_extractor* m = new qsp_mesh_extractor();
     m->dec = dec;
+    m->device = dec->device;
     m->dim = voxels_dim;
     m->n = (int64_t)voxels_dim * voxels_dim * voxels_dim;
     m->nb = (int)((m->n + mc::SCAN_BLOCK - 1) / mc::SCAN_BLOCK);

@@ -117,7 +117,8 @@ __device__ __forceinline__ float det3(const float* T) {   // of the upper-left 3
     return (float)(a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g));
 }
 
-// exclusive scan of one int per thread over a 256-thread block; returns the exclusive prefix, total in *total
+// exclusive scan of one int per thread over the block (a multiple of 64, at most 512 threads); returns the exclusive prefix,
+// total in *total
 __device__ int block_excl_scan_256(int v, int* smem /* >= 8 ints */, int* total) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int x = v;
@@ -128,9 +129,12 @@ __device__ int block_excl_scan_256(int v, int* smem /* >= 8 ints */, int* total)
     }
     if (lane == 63) smem[wave] = x;
     __syncthreads();
-    int base = 0;
-    for (int w = 0; w < wave; ++w) base += smem[w];
-    const int tot = smem[0] + smem[1] + smem[2] + smem[3];
+    int base = 0, tot = 0;
+    const int nw = blockDim.x >> 6;
+    for (int w = 0; w < nw; ++w) {
+        if (w < wave) base += smem[w];
+        tot += smem[w];
+    }
     __syncthreads();
     *total = tot;
     return base + x - v;
@@ -405,7 +409,7 @@ __device__ __forceinline__ int scan_ray(const float* __restrict__ sdf, uint64_t 
     return n;
 }
 
-__global__ __launch_bounds__(256) void k_scan(HypState* __restrict__ st, const ObjView* __restrict__ objs,
+__global__ __launch_bounds__(512) void k_scan(HypState* __restrict__ st, const ObjView* __restrict__ objs,
                                               const float* __restrict__ depth, RefineCfg cfg,
                                               const int32_t* __restrict__ valid_rk, int64_t rk_stride,
                                               const int32_t* __restrict__ ray_voff, int64_t ray_stride,
@@ -426,7 +430,7 @@ __global__ __launch_bounds__(256) void k_scan(HypState* __restrict__ st, const O
     float* e_res = rend_res + h * rk_stride;
     const float d_min = S.d_min, d_max = S.d_max;
     int carry = 0;
-    for (int base = 0; base < ov.n_rays; base += 256) {
+    for (int base = 0; base < ov.n_rays; base += (int)blockDim.x) {      // one ray per thread: 456 rays in one pass
         const int r = base + threadIdx.x;
         int cnt = 0, v0 = 0, n = 0;
         float dobs = 0.f;
@@ -1135,6 +1139,7 @@ extern "C" int qsp_sdf_value_grad(qsp_decoder* d, const float* code, const float
 // ---------------------------------------------------------------------------------------------------------------
 struct qsp_refine_batch {
     qsp_decoder* dec = nullptr;
+    int device = 0;                 // of the decoder, cached: destroy must not touch a decoder that may already be gone
     RefineCfg cfg{};
     int n_iter_cfg = 5;
     int n_obj = 0, n_hyp = 0;
@@ -1167,7 +1172,7 @@ struct qsp_refine_batch {
 
 static void batch_free(qsp_refine_batch* b) {
     if (!b) return;
-    hipSetDevice(b->dec->device);
+    hipSetDevice(b->device);
     void* ptrs[] = {b->st, b->objs, b->pts, b->rays, b->depth, b->valid_rk, b->ray_voff, b->rend_rk, b->sdf_valid,
                     b->rend_deds, b->rend_res, b->partials, b->trH, b->trb, b->trdx, b->pt_active, b->res_buf, b->rows, b->counters,
                     b->work_fwd, b->work_jtj, b->qctl, b->c0_all};
@@ -1175,6 +1180,7 @@ static void batch_free(qsp_refine_batch* b) {
         if (p) hipFree(p);
     for (hipEvent_t e : b->ev) hipEventDestroy(e);
     delete b;
+    (void)hipGetLastError();   // errors are ignored here; do not leave one behind for the next call's launch check
 }
 
 static int batch_create(qsp_decoder* dec, const RefineCfg& cfg, int n_iter, int32_t n_obj, const float* const* pts,
@@ -1190,6 +1196,7 @@ static int batch_create(qsp_decoder* dec, const RefineCfg& cfg, int n_iter, int3
     QSP_HIP(hipSetDevice(dec->device));
     qsp_refine_batch* b = new qsp_refine_batch();
     b->dec = dec;
+    b->device = dec->device;
     b->cfg = cfg;
     b->n_iter_cfg = n_iter;
     b->n_obj = n_obj;
@@ -1353,7 +1360,7 @@ extern "C" int qsp_refine_batch_run(qsp_refine_batch* b, int32_t n_iter) {
                                cfg, b->dec->Pd, b->valid_rk, b->rk_stride, b->sdf_valid, b->work_fwd, b->qctl, b->c0_all);
             if (b->prof) spans.push_back({a, next_event(b, cur), 1});
             if (b->prof) a = next_event(b, cur);
-            hipLaunchKernelGGL(k_scan, dim3(nH), dim3(256), 0, s, b->st, b->objs, b->depth, cfg, b->valid_rk, b->rk_stride,
+            hipLaunchKernelGGL(k_scan, dim3(nH), dim3(512), 0, s, b->st, b->objs, b->depth, cfg, b->valid_rk, b->rk_stride,
                                b->ray_voff, b->ray_stride, b->sdf_valid, b->rend_rk, b->rend_deds, b->rend_res);
             if (b->prof) spans.push_back({a, next_event(b, cur), 2});
         }

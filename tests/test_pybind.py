@@ -65,4 +65,14 @@ def test_pybind_layer_gives_the_same_bits_as_the_ctypes_twin(golden_dir):
     ma, mb = rh.MeshExtractor(dec, 64, 32), tw.MeshExtractor(dec, 64, 32)
     xa, xb = ma.extract_mesh_from_code(np.zeros(64, np.float32)), mb.extract_mesh_from_code(np.zeros(64, np.float32))
     assert np.array_equal(xa.vertices, xb.vertices) and np.array_equal(xa.faces, xb.faces) and xa.faces.dtype == np.int32
+    # lifetime: extractors destroyed AFTER their decoder only free their own memory (include/qsp_hip.h) and leave no HIP
+    # error behind for the next call's launch check
+    import gc
+    from qsp_slam_amd.ba import BaProblem
     dec.close()
+    del ma, mb, xa, xb, a, b
+    gc.collect()
+    prob = BaProblem(synth.make_ba_scene(5, 6, 200, 2, stereo_frac=0.2))
+    t1, t2 = prob.local_joint_ba()
+    assert t1["iterations"] >= 1
+    prob.close()
