@@ -97,8 +97,26 @@ struct __attribute__((aligned(16))) MlpSmem {
     float w8[HID];              // last layer's weight row (read by the layer-8 dot product and the backward seed)
 };
 
-__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+// The same instruction with the accumulator tile in AccVGPRs.  A kernel that fits 256 registers gets ArchVGPR accumulators from
+// the compiler (it has no reason to use the second file); the matrix pipe then reads and writes C/D through the same register
+// file that the weight and activation loads are landing in.  With the accumulators in the Acc file `k_mlp_jtj` runs 2.8 %
+// faster (same box: 0.879 -> 0.904 of peak) although the compiler then splits the 256-register budget 128 / 128; the forward
+// kernel, which needs ~166 ArchVGPRs next to its accumulators, loses 0.7 % to the extra copies and keeps the builtin.
+// Written as inline asm because only an operand constraint can name the register file; the compiler therefore does not see an
+// MFMA here and inserts none of the software wait states of the MFMA hazards -- mfma_acc_settle() provides them where a result
+// is read by a non-matrix instruction (dependent MFMAs on the same tile are interlocked by the hardware).
+template <bool AG>
+__device__ __forceinline__ f32x16 mfma32t(float a, float b, f32x16 c) {
+    if (AG) {
+        asm("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+        return c;
+    }
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+// 24 wait states: more than the 18 a 16-pass MFMA result needs before a VALU / accvgpr read (CDNA3 ISA, MFMA dependency table)
+template <bool AG>
+__device__ __forceinline__ void mfma_acc_settle() {
+    if (AG) asm volatile("s_nop 15\n\ts_nop 7");
 }
 
 // D-row of accumulator register i of a 32x32 tile for this lane (C/D map of v_mfma_f32_32x32x2_f32); the D-column is
@@ -119,22 +137,22 @@ __device__ __forceinline__ f32x4 lds4(const float* p) { return *reinterpret_cast
 // consecutive units per register quad -> the write-out is a 16-byte ds_write_b128 per quad into the [point][unit] image
 // (with D = [point][unit] it would be sixteen 4-byte stores per tile).
 #define QSP_MFMA_STEP_2x2(a0, a1, b0, b1)                   \
-    acc[0][0] = mfma32(b0.x, a0.x, acc[0][0]);              \
-    acc[0][1] = mfma32(b1.x, a0.x, acc[0][1]);              \
-    acc[1][0] = mfma32(b0.x, a1.x, acc[1][0]);              \
-    acc[1][1] = mfma32(b1.x, a1.x, acc[1][1]);              \
-    acc[0][0] = mfma32(b0.y, a0.y, acc[0][0]);              \
-    acc[0][1] = mfma32(b1.y, a0.y, acc[0][1]);              \
-    acc[1][0] = mfma32(b0.y, a1.y, acc[1][0]);              \
-    acc[1][1] = mfma32(b1.y, a1.y, acc[1][1]);              \
-    acc[0][0] = mfma32(b0.z, a0.z, acc[0][0]);              \
-    acc[0][1] = mfma32(b1.z, a0.z, acc[0][1]);              \
-    acc[1][0] = mfma32(b0.z, a1.z, acc[1][0]);              \
-    acc[1][1] = mfma32(b1.z, a1.z, acc[1][1]);              \
-    acc[0][0] = mfma32(b0.w, a0.w, acc[0][0]);              \
-    acc[0][1] = mfma32(b1.w, a0.w, acc[0][1]);              \
-    acc[1][0] = mfma32(b0.w, a1.w, acc[1][0]);              \
-    acc[1][1] = mfma32(b1.w, a1.w, acc[1][1]);
+    acc[0][0] = mfma32t<AG>(b0.x, a0.x, acc[0][0]);         \
+    acc[0][1] = mfma32t<AG>(b1.x, a0.x, acc[0][1]);              \
+    acc[1][0] = mfma32t<AG>(b0.x, a1.x, acc[1][0]);              \
+    acc[1][1] = mfma32t<AG>(b1.x, a1.x, acc[1][1]);              \
+    acc[0][0] = mfma32t<AG>(b0.y, a0.y, acc[0][0]);              \
+    acc[0][1] = mfma32t<AG>(b1.y, a0.y, acc[0][1]);              \
+    acc[1][0] = mfma32t<AG>(b0.y, a1.y, acc[1][0]);              \
+    acc[1][1] = mfma32t<AG>(b1.y, a1.y, acc[1][1]);              \
+    acc[0][0] = mfma32t<AG>(b0.z, a0.z, acc[0][0]);              \
+    acc[0][1] = mfma32t<AG>(b1.z, a0.z, acc[0][1]);              \
+    acc[1][0] = mfma32t<AG>(b0.z, a1.z, acc[1][0]);              \
+    acc[1][1] = mfma32t<AG>(b1.z, a1.z, acc[1][1]);              \
+    acc[0][0] = mfma32t<AG>(b0.w, a0.w, acc[0][0]);              \
+    acc[0][1] = mfma32t<AG>(b1.w, a0.w, acc[0][1]);              \
+    acc[1][0] = mfma32t<AG>(b0.w, a1.w, acc[1][0]);              \
+    acc[1][1] = mfma32t<AG>(b1.w, a1.w, acc[1][1]);
 
 // The weight ring: PF k-groups (2 x 1 KiB wave-loads each) in flight per wave, global -> VGPR.  It is owned by mlp_tile
 // and runs ACROSS layers: the last PF steps of a GEMM already fetch the first PF k-groups of the NEXT GEMM, so a layer
@@ -169,7 +187,7 @@ struct BiasQuads {
     f32x4 v[2][4];   // [column block][register quad]
 };
 
-template <int KG, int PF, bool BIAS>
+template <int KG, int PF, bool BIAS, bool AG>
 __device__ __forceinline__ void gemm_2x2(const float* __restrict__ act, const float4* __restrict__ w0_,
                                          const float4* __restrict__ w1_, const float4* __restrict__ n0_,
                                          const float4* __restrict__ n1_, WRing<PF>& R, f32x16 (&acc)[2][2], int lane,
@@ -238,11 +256,12 @@ __device__ __forceinline__ void gemm_2x2(const float* __restrict__ act, const fl
         a0 = a0n;
         a1 = a1n;
     }
+    mfma_acc_settle<AG>();
 }
 
 // one 32x32 tile over K = 8*KG (the 67-column backward of layer 0; waves 0..5).  Uses ring half q0, primed by the
 // preceding GEMM; nothing follows it inside a tile, so it does not refill.
-template <int KG, int PF>
+template <int KG, int PF, bool AG>
 __device__ __forceinline__ void gemm_1x1(const float* __restrict__ act_rows, const float4* __restrict__ w0_, WRing<PF>& R,
                                          f32x16& acc, int lane) {
     gptr4 w0 = (gptr4)w0_;
@@ -256,14 +275,15 @@ __device__ __forceinline__ void gemm_1x1(const float* __restrict__ act_rows, con
             if (kg + PF < KG) R.q0[d] = w0[(kg + d + PF) * 64 + lane];
             const f32x4 a0n = lds4(a_row0 + 8 * (kg + d + 1));
             __builtin_amdgcn_sched_barrier(0);
-            acc = mfma32(b0.x, a0.x, acc);
-            acc = mfma32(b0.y, a0.y, acc);
-            acc = mfma32(b0.z, a0.z, acc);
-            acc = mfma32(b0.w, a0.w, acc);
+            acc = mfma32t<AG>(b0.x, a0.x, acc);
+            acc = mfma32t<AG>(b0.y, a0.y, acc);
+            acc = mfma32t<AG>(b0.z, a0.z, acc);
+            acc = mfma32t<AG>(b0.w, a0.w, acc);
             __builtin_amdgcn_sched_barrier(0);
             a0 = a0n;
         }
     }
+    mfma_acc_settle<AG>();
 }
 
 __device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][2]) {
@@ -471,7 +491,7 @@ __device__ __forceinline__ void mlp_tile(MlpSmem& s, const MlpParams* __restrict
     // ---- layers 1..7 (K = 512) ---------------------------------------------------------------------------------
 #define QSP_FWD_LAYER(L)                                                                                      \
     zero_acc(acc);                                                                                            \
-    gemm_2x2<KGH, PF, true>(s.act, QSP_WF(L), QSP_WF1(L), QSP_WF((L) + 1), QSP_WF1((L) + 1), ring, acc, lane,  \
+    gemm_2x2<KGH, PF, true, BWD>(s.act, QSP_WF(L), QSP_WF1(L), QSP_WF((L) + 1), QSP_WF1((L) + 1), ring, acc, lane,  \
                             P.bias[L] + 64 * wave, bq);                                                       \
     QSP_TS()                                                                                                  \
     __syncthreads();                                                                                          \
@@ -483,7 +503,7 @@ __device__ __forceinline__ void mlp_tile(MlpSmem& s, const MlpParams* __restrict
     QSP_FWD_LAYER(1)
     QSP_FWD_LAYER(2)
     zero_acc(acc);
-    gemm_2x2<KGH, PF, true>(s.act, QSP_WF(3), QSP_WF1(3), QSP_WF4, QSP_WF41, ring, acc, lane, P.bias[3] + 64 * wave, bq);
+    gemm_2x2<KGH, PF, true, BWD>(s.act, QSP_WF(3), QSP_WF1(3), QSP_WF4, QSP_WF41, ring, acc, lane, P.bias[3] + 64 * wave, bq);
     QSP_TS()
     __syncthreads();
     QSP_TS()
@@ -497,7 +517,7 @@ __device__ __forceinline__ void mlp_tile(MlpSmem& s, const MlpParams* __restrict
     QSP_TS()
     // layer 4: K = 448, bias = c4 of this hypothesis (LDS)
     zero_acc(acc);
-    gemm_2x2<KG4, PF, false>(s.act, QSP_WF4, QSP_WF41, QSP_WF(5), QSP_WF1(5), ring, acc, lane, nullptr, bq);
+    gemm_2x2<KG4, PF, false, BWD>(s.act, QSP_WF4, QSP_WF41, QSP_WF(5), QSP_WF1(5), ring, acc, lane, nullptr, bq);
 #pragma unroll
     for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -512,8 +532,8 @@ __device__ __forceinline__ void mlp_tile(MlpSmem& s, const MlpParams* __restrict
     QSP_FWD_LAYER(5)
     QSP_FWD_LAYER(6)
     zero_acc(acc);
-    if (BWD) gemm_2x2<KGH, PF, true>(s.act, QSP_WF(7), QSP_WF1(7), QSP_WB(7), QSP_WB1(7), ring, acc, lane, P.bias[7] + 64 * wave, bq);
-    else gemm_2x2<KGH, PF, true>(s.act, QSP_WF(7), QSP_WF1(7), QSP_WF(1), QSP_WF1(1), ring, acc, lane, P.bias[7] + 64 * wave, bq);
+    if (BWD) gemm_2x2<KGH, PF, true, BWD>(s.act, QSP_WF(7), QSP_WF1(7), QSP_WB(7), QSP_WB1(7), ring, acc, lane, P.bias[7] + 64 * wave, bq);
+    else gemm_2x2<KGH, PF, true, BWD>(s.act, QSP_WF(7), QSP_WF1(7), QSP_WF(1), QSP_WF1(1), ring, acc, lane, P.bias[7] + 64 * wave, bq);
     QSP_TS()
     __syncthreads();
     QSP_TS()
@@ -582,7 +602,7 @@ __device__ __forceinline__ void mlp_tile(MlpSmem& s, const MlpParams* __restrict
     // ---- backward through layers 7..1: g_in = g_a . W_L, masked by layer L-1 ------------------------------------
 #define QSP_BWD_LAYER(L)                                                                                      \
     zero_acc(acc);                                                                                            \
-    gemm_2x2<KGH, PF, false>(s.act, QSP_WB(L), QSP_WB1(L), (L) > 1 ? QSP_WB((L) - 1) : wb0,                   \
+    gemm_2x2<KGH, PF, false, BWD>(s.act, QSP_WB(L), QSP_WB1(L), (L) > 1 ? QSP_WB((L) - 1) : wb0,                   \
                              (L) > 1 ? QSP_WB1((L) - 1) : wb0, ring, acc, lane, nullptr, bq);                 \
     QSP_TS()                                                                                                  \
     __syncthreads();                                                                                          \
@@ -602,7 +622,7 @@ __device__ __forceinline__ void mlp_tile(MlpSmem& s, const MlpParams* __restrict
     // layer 3 has 445 outputs: its backward contraction runs over K4 = 448 gradient columns (445..447 were zeroed by
     // stash_extract, the packed rows 445..511 are zero)
     zero_acc(acc);
-    gemm_2x2<KG4, PF, false>(s.act, QSP_WB(3), QSP_WB1(3), QSP_WB(2), QSP_WB1(2), ring, acc, lane, nullptr, bq);
+    gemm_2x2<KG4, PF, false, BWD>(s.act, QSP_WB(3), QSP_WB1(3), QSP_WB(2), QSP_WB1(2), ring, acc, lane, nullptr, bq);
     QSP_TS()
     __syncthreads();
     QSP_TS()
@@ -618,8 +638,8 @@ __device__ __forceinline__ void mlp_tile(MlpSmem& s, const MlpParams* __restrict
     f32x16 g0;
 #pragma unroll
     for (int i = 0; i < 16; ++i) g0[i] = 0.f;
-    if (wave < 4) gemm_1x1<KGH, PF>(s.act + 32 * r0 * LDA, wb0, ring, g0, lane);
-    else gemm_1x1<KGH / 2, PF>(s.act + 32 * r0 * LDA + l0_half * (HID / 2), wb0, ring, g0, lane);
+    if (wave < 4) gemm_1x1<KGH, PF, BWD>(s.act + 32 * r0 * LDA, wb0, ring, g0, lane);
+    else gemm_1x1<KGH / 2, PF, BWD>(s.act + 32 * r0 * LDA + l0_half * (HID / 2), wb0, ring, g0, lane);
 #undef QSP_WF
 #undef QSP_WF1
 #undef QSP_WF4

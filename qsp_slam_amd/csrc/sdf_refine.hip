@@ -583,7 +583,8 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void k_mlp_jtj(const HypState* __re
             const float* A = Jt + (lane >> 5) * LDJ + 32 * ta + (lane & 31);
             const float* B = Jt + (lane >> 5) * LDJ + 32 * tb + (lane & 31);
 #pragma unroll 8
-            for (int ks = 0; ks < TILE_P / 2; ++ks) hacc = mfma32(A[2 * ks * LDJ], B[2 * ks * LDJ], hacc);
+            for (int ks = 0; ks < TILE_P / 2; ++ks) hacc = mfma32t<true>(A[2 * ks * LDJ], B[2 * ks * LDJ], hacc);
+            mfma_acc_settle<true>();
         }
         QSP_TSK(4)
     }
