@@ -409,6 +409,10 @@ __device__ __forceinline__ void mlp_prepare(MlpSmem& s, const MlpParams* __restr
 constexpr int LDG = 72;
 template <bool BWD, int PF>
 __device__ __forceinline__ void mlp_tile(MlpSmem& s, const MlpParams* __restrict__ Pm) {
+    // AccVGPR accumulators in the forward+backward tile only (see mfma32t): measured on one box, C4 -- forward-only tile with
+    // them 0.908-0.910 of peak against 0.918 with the builtin; with the bias quads parked in AccVGPRs as well 0.910 and
+    // `k_mlp_jtj` 0.895 instead of 0.900; accumulators pinned by an empty asm around the builtin MFMA 0.897 / 0.909.
+    constexpr bool AGT = BWD;
     const int tid = threadIdx.x;
     int ts_n = 0;
     (void)ts_n;
@@ -491,7 +495,7 @@ __device__ __forceinline__ void mlp_tile(MlpSmem& s, const MlpParams* __restrict
     // ---- layers 1..7 (K = 512) ---------------------------------------------------------------------------------
 #define QSP_FWD_LAYER(L)                                                                                      \
     zero_acc(acc);                                                                                            \
-    gemm_2x2<KGH, PF, true, BWD>(s.act, QSP_WF(L), QSP_WF1(L), QSP_WF((L) + 1), QSP_WF1((L) + 1), ring, acc, lane,  \
+    gemm_2x2<KGH, PF, true, AGT>(s.act, QSP_WF(L), QSP_WF1(L), QSP_WF((L) + 1), QSP_WF1((L) + 1), ring, acc, lane,  \
                             P.bias[L] + 64 * wave, bq);                                                       \
     QSP_TS()                                                                                                  \
     __syncthreads();                                                                                          \
@@ -503,7 +507,7 @@ __device__ __forceinline__ void mlp_tile(MlpSmem& s, const MlpParams* __restrict
     QSP_FWD_LAYER(1)
     QSP_FWD_LAYER(2)
     zero_acc(acc);
-    gemm_2x2<KGH, PF, true, BWD>(s.act, QSP_WF(3), QSP_WF1(3), QSP_WF4, QSP_WF41, ring, acc, lane, P.bias[3] + 64 * wave, bq);
+    gemm_2x2<KGH, PF, true, AGT>(s.act, QSP_WF(3), QSP_WF1(3), QSP_WF4, QSP_WF41, ring, acc, lane, P.bias[3] + 64 * wave, bq);
     QSP_TS()
     __syncthreads();
     QSP_TS()
@@ -517,7 +521,7 @@ __device__ __forceinline__ void mlp_tile(MlpSmem& s, const MlpParams* __restrict
     QSP_TS()
     // layer 4: K = 448, bias = c4 of this hypothesis (LDS)
     zero_acc(acc);
-    gemm_2x2<KG4, PF, false, BWD>(s.act, QSP_WF4, QSP_WF41, QSP_WF(5), QSP_WF1(5), ring, acc, lane, nullptr, bq);
+    gemm_2x2<KG4, PF, false, AGT>(s.act, QSP_WF4, QSP_WF41, QSP_WF(5), QSP_WF1(5), ring, acc, lane, nullptr, bq);
 #pragma unroll
     for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -532,8 +536,8 @@ __device__ __forceinline__ void mlp_tile(MlpSmem& s, const MlpParams* __restrict
     QSP_FWD_LAYER(5)
     QSP_FWD_LAYER(6)
     zero_acc(acc);
-    if (BWD) gemm_2x2<KGH, PF, true, BWD>(s.act, QSP_WF(7), QSP_WF1(7), QSP_WB(7), QSP_WB1(7), ring, acc, lane, P.bias[7] + 64 * wave, bq);
-    else gemm_2x2<KGH, PF, true, BWD>(s.act, QSP_WF(7), QSP_WF1(7), QSP_WF(1), QSP_WF1(1), ring, acc, lane, P.bias[7] + 64 * wave, bq);
+    if (BWD) gemm_2x2<KGH, PF, true, AGT>(s.act, QSP_WF(7), QSP_WF1(7), QSP_WB(7), QSP_WB1(7), ring, acc, lane, P.bias[7] + 64 * wave, bq);
+    else gemm_2x2<KGH, PF, true, AGT>(s.act, QSP_WF(7), QSP_WF1(7), QSP_WF(1), QSP_WF1(1), ring, acc, lane, P.bias[7] + 64 * wave, bq);
     QSP_TS()
     __syncthreads();
     QSP_TS()
@@ -602,7 +606,7 @@ __device__ __forceinline__ void mlp_tile(MlpSmem& s, const MlpParams* __restrict
     // ---- backward through layers 7..1: g_in = g_a . W_L, masked by layer L-1 ------------------------------------
 #define QSP_BWD_LAYER(L)                                                                                      \
     zero_acc(acc);                                                                                            \
-    gemm_2x2<KGH, PF, false, BWD>(s.act, QSP_WB(L), QSP_WB1(L), (L) > 1 ? QSP_WB((L) - 1) : wb0,                   \
+    gemm_2x2<KGH, PF, false, AGT>(s.act, QSP_WB(L), QSP_WB1(L), (L) > 1 ? QSP_WB((L) - 1) : wb0,                   \
                              (L) > 1 ? QSP_WB1((L) - 1) : wb0, ring, acc, lane, nullptr, bq);                 \
     QSP_TS()                                                                                                  \
     __syncthreads();                                                                                          \
@@ -622,7 +626,7 @@ __device__ __forceinline__ void mlp_tile(MlpSmem& s, const MlpParams* __restrict
     // layer 3 has 445 outputs: its backward contraction runs over K4 = 448 gradient columns (445..447 were zeroed by
     // stash_extract, the packed rows 445..511 are zero)
     zero_acc(acc);
-    gemm_2x2<KG4, PF, false, BWD>(s.act, QSP_WB(3), QSP_WB1(3), QSP_WB(2), QSP_WB1(2), ring, acc, lane, nullptr, bq);
+    gemm_2x2<KG4, PF, false, AGT>(s.act, QSP_WB(3), QSP_WB1(3), QSP_WB(2), QSP_WB1(2), ring, acc, lane, nullptr, bq);
     QSP_TS()
     __syncthreads();
     QSP_TS()
@@ -638,8 +642,8 @@ __device__ __forceinline__ void mlp_tile(MlpSmem& s, const MlpParams* __restrict
     f32x16 g0;
 #pragma unroll
     for (int i = 0; i < 16; ++i) g0[i] = 0.f;
-    if (wave < 4) gemm_1x1<KGH, PF, BWD>(s.act + 32 * r0 * LDA, wb0, ring, g0, lane);
-    else gemm_1x1<KGH / 2, PF, BWD>(s.act + 32 * r0 * LDA + l0_half * (HID / 2), wb0, ring, g0, lane);
+    if (wave < 4) gemm_1x1<KGH, PF, AGT>(s.act + 32 * r0 * LDA, wb0, ring, g0, lane);
+    else gemm_1x1<KGH / 2, PF, AGT>(s.act + 32 * r0 * LDA + l0_half * (HID / 2), wb0, ring, g0, lane);
 #undef QSP_WF
 #undef QSP_WF1
 #undef QSP_WF4
