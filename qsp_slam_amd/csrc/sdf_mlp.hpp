@@ -407,12 +407,12 @@ __device__ __forceinline__ void mlp_prepare(MlpSmem& s, const MlpParams* __restr
 //   s.y[row]                         = sdf value
 //   BWD: s.act viewed as G[row*LDST_G + c], c < 67 = d sdf / d [code | xyz] (skip gradient already added)
 constexpr int LDG = 72;
-template <bool BWD, int PF>
+template <bool BWD, int PF, bool AGT = false>
 __device__ __forceinline__ void mlp_tile(MlpSmem& s, const MlpParams* __restrict__ Pm) {
-    // AccVGPR accumulators in the forward+backward tile only (see mfma32t): measured on one box, C4 -- forward-only tile with
+    // AGT: AccVGPR accumulators (see mfma32t).  Only `k_mlp_jtj` asks for them.  Measured on one box, C4: forward-only tile with
     // them 0.908-0.910 of peak against 0.918 with the builtin; with the bias quads parked in AccVGPRs as well 0.910 and
-    // `k_mlp_jtj` 0.895 instead of 0.900; accumulators pinned by an empty asm around the builtin MFMA 0.897 / 0.909.
-    constexpr bool AGT = BWD;
+    // `k_mlp_jtj` 0.895 instead of 0.900; accumulators pinned by an empty asm around the builtin MFMA 0.897 / 0.909; the
+    // forward+backward tile inside `k_decode<true>` (no Jacobian rows, no normal equations, 230 registers) 1.3 % slower with them.
     const int tid = threadIdx.x;
     int ts_n = 0;
     (void)ts_n;

@@ -533,7 +533,7 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void k_mlp_jtj(const HypState* __re
         }
         __syncthreads();
         QSP_TSK(2)
-        mlp_tile<true, 4>(s, P);
+        mlp_tile<true, 4, true>(s, P);
         QSP_TSK(3)
         // ---- Jacobian rows: J~[p] = [ s*(g_x . [I | -x^ | x]) (7) | s*g_z (64) | r~ ] -------------------------------
         // G (gradient w.r.t. [code | xyz]) sits in s.act with row stride LDG; J~ goes behind it.
