@@ -113,10 +113,16 @@ __device__ __forceinline__ f32x16 mfma32t(float a, float b, f32x16 c) {
     }
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
-// 24 wait states: more than the 18 a 16-pass MFMA result needs before a VALU / accvgpr read (CDNA3 ISA, MFMA dependency table)
+// 24 wait states: more than the 18-19 a 16-pass MFMA result needs before a VALU / accvgpr read (CDNA3 ISA, MFMA dependency
+// table).  The accumulators are in/out operands of the asm so that every later read of them is ordered behind the wait states
+// (a bare `asm volatile("s_nop")` does not stop the compiler from hoisting a v_accvgpr_read above it -- it did).
 template <bool AG>
-__device__ __forceinline__ void mfma_acc_settle() {
-    if (AG) asm volatile("s_nop 15\n\ts_nop 7");
+__device__ __forceinline__ void mfma_acc_settle(f32x16& c0, f32x16& c1, f32x16& c2, f32x16& c3) {
+    if (AG) asm volatile("s_nop 15\n\ts_nop 7" : "+a"(c0), "+a"(c1), "+a"(c2), "+a"(c3));
+}
+template <bool AG>
+__device__ __forceinline__ void mfma_acc_settle(f32x16& c0) {
+    if (AG) asm volatile("s_nop 15\n\ts_nop 7" : "+a"(c0));
 }
 
 // D-row of accumulator register i of a 32x32 tile for this lane (C/D map of v_mfma_f32_32x32x2_f32); the D-column is
@@ -256,7 +262,7 @@ __device__ __forceinline__ void gemm_2x2(const float* __restrict__ act, const fl
         a0 = a0n;
         a1 = a1n;
     }
-    mfma_acc_settle<AG>();
+    mfma_acc_settle<AG>(acc[0][0], acc[0][1], acc[1][0], acc[1][1]);
 }
 
 // one 32x32 tile over K = 8*KG (the 67-column backward of layer 0; waves 0..5).  Uses ring half q0, primed by the
@@ -283,7 +289,7 @@ __device__ __forceinline__ void gemm_1x1(const float* __restrict__ act_rows, con
             a0 = a0n;
         }
     }
-    mfma_acc_settle<AG>();
+    mfma_acc_settle<AG>(acc);
 }
 
 __device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][2]) {

@@ -584,7 +584,7 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void k_mlp_jtj(const HypState* __re
             const float* B = Jt + (lane >> 5) * LDJ + 32 * tb + (lane & 31);
 #pragma unroll 8
             for (int ks = 0; ks < TILE_P / 2; ++ks) hacc = mfma32t<true>(A[2 * ks * LDJ], B[2 * ks * LDJ], hacc);
-            mfma_acc_settle<true>();
+            mfma_acc_settle<true>(hacc);
         }
         QSP_TSK(4)
     }
