@@ -15,5 +15,7 @@ def test_no_accumulator_is_read_before_its_mfma_wait_states():
         path = os.path.join(tmp, "sdf_refine.s")
         chk.compile_isa(path)
         n, bad = chk.check(path)
+        bad2 = chk.check_valu_def_before_mfma(path)
+    assert not bad2, bad2[:5]
     assert n > 1000, "expected the asm MFMAs of k_mlp_jtj in the ISA, found %d" % n
     assert not bad, bad[:5]
