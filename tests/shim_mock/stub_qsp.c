@@ -30,9 +30,10 @@ int qsp_ba_create(const qsp_ba_scene* s, int device, qsp_ba_problem** out) {
     }
     qsp_ba_problem* p = calloc(1, sizeof(*p));
     p->s = *s;
-    p->kf = malloc(56 * (size_t)s->n_kf + 8); memcpy(p->kf, s->kf_pose, 56 * (size_t)s->n_kf);
-    p->pt = malloc(24 * (size_t)s->n_pt + 8); memcpy(p->pt, s->pt_xyz, 24 * (size_t)s->n_pt);
-    p->ob = malloc(56 * (size_t)s->n_obj + 8); memcpy(p->ob, s->obj_pose, 56 * (size_t)s->n_obj);
+    /* empty vectors arrive as NULL with a zero count (legal on this ABI); memcpy(dst, NULL, 0) is not */
+    p->kf = malloc(56 * (size_t)s->n_kf + 8); if (s->n_kf) memcpy(p->kf, s->kf_pose, 56 * (size_t)s->n_kf);
+    p->pt = malloc(24 * (size_t)s->n_pt + 8); if (s->n_pt) memcpy(p->pt, s->pt_xyz, 24 * (size_t)s->n_pt);
+    p->ob = malloc(56 * (size_t)s->n_obj + 8); if (s->n_obj) memcpy(p->ob, s->obj_pose, 56 * (size_t)s->n_obj);
     *out = p;
     return QSP_OK;
 }

@@ -21,15 +21,18 @@ MOCK = os.path.join(ROOT, "tests", "shim_mock")
 def build_driver(tmp, real):
     out = os.path.join(tmp, "shim_driver_real" if real else "shim_driver_stub")
     inc = ["-I" + MOCK, "-I" + os.path.join(ROOT, "include")]
-    subprocess.check_call(["g++", "-std=c++17", "-O1"] + inc + ["-c", os.path.join(MOCK, "shim_driver.cpp"), "-o",
-                                                                  os.path.join(tmp, "drv.o")])
+    # the stub build (CPU tests) runs the shim's flattening / write-back code under AddressSanitizer + UBSan: any out-of-bounds
+    # index into the map vectors or the flat arrays fails the test.  (Sanitizers are for the CPU build only.)
+    san = [] if real else ["-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer", "-g"]
+    subprocess.check_call(["g++", "-std=c++17", "-O1"] + san + inc + ["-c", os.path.join(MOCK, "shim_driver.cpp"), "-o",
+                                                                        os.path.join(tmp, "drv.o")])
     if real:
         lib = os.path.join(ROOT, "qsp_slam_amd")
         subprocess.check_call(["g++", "-o", out, os.path.join(tmp, "drv.o"), "-L" + lib, "-lqsp_hip", "-Wl,-rpath," + lib])
     else:
-        subprocess.check_call(["gcc", "-std=c11", "-O1"] + inc + ["-c", os.path.join(MOCK, "stub_qsp.c"), "-o",
-                                                                    os.path.join(tmp, "stub.o")])
-        subprocess.check_call(["g++", "-o", out, os.path.join(tmp, "drv.o"), os.path.join(tmp, "stub.o")])
+        subprocess.check_call(["gcc", "-std=c11", "-O1"] + san + inc + ["-c", os.path.join(MOCK, "stub_qsp.c"), "-o",
+                                                                          os.path.join(tmp, "stub.o")])
+        subprocess.check_call(["g++"] + san + ["-o", out, os.path.join(tmp, "drv.o"), os.path.join(tmp, "stub.o")])
     return out
 
 
