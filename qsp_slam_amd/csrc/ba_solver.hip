@@ -1803,9 +1803,9 @@ extern "C" int qsp_ba_create(const qsp_ba_scene* s, int device, qsp_ba_problem**
 
 extern "C" void qsp_ba_destroy(qsp_ba_problem* p) {
     if (!p) return;
-    hipSetDevice(p->device);
-    for (void* q : p->allocs) hipFree(q);
-    if (p->stream) hipStreamDestroy(p->stream);
+    (void)hipSetDevice(p->device);
+    for (void* q : p->allocs) (void)hipFree(q);
+    if (p->stream) (void)hipStreamDestroy(p->stream);
     delete p;
 }
 
@@ -1973,8 +1973,8 @@ extern "C" int qsp_ba_optimize(qsp_ba_problem* p, int32_t n_iter, double delta_m
     hipEvent_t ev0 = nullptr, ev1 = nullptr, evA = nullptr, evB = nullptr;
     if (p->profiling) {
         memset(&p->prof, 0, sizeof(p->prof));
-        hipEventCreate(&ev0); hipEventCreate(&ev1); hipEventCreate(&evA); hipEventCreate(&evB);
-        hipEventRecord(ev0, s);
+        (void)hipEventCreate(&ev0); (void)hipEventCreate(&ev1); (void)hipEventCreate(&evA); (void)hipEventCreate(&evB);
+        (void)hipEventRecord(ev0, s);
     }
     const int gp = std::max(1, std::min(p->n_partial, (d.n_pt + 255) / 256));
     d.bs = d.Hs + (size_t)p->dimp * p->dimp;      // right behind the reduced matrix: one all-reduce covers both
@@ -1986,14 +1986,14 @@ extern "C" int qsp_ba_optimize(qsp_ba_problem* p, int32_t n_iter, double delta_m
         // computeActiveErrors + chi2
         launch_errors(p, par);
         // buildSystem
-        if (p->profiling) hipEventRecord(evA, s);
+        if (p->profiling) (void)hipEventRecord(evA, s);
         // (every entry of Hdiag and bp that is read is written by k_lin_poses_finish / k_lin_objects: no memsets)
         if (d.n_chunk) hipLaunchKernelGGL(k_lin_points, dim3(d.n_chunk), dim3(256), 0, s, d, par);
         if (d.n_ksplit) hipLaunchKernelGGL(k_lin_poses, dim3(d.n_ksplit), dim3(256), 0, s, d, par);
         if (d.n_oe) hipLaunchKernelGGL(k_lin_objedges, dim3((d.n_oe + 3) / 4), dim3(256), 0, s, d, par);
         hipLaunchKernelGGL(k_lin_poses_finish, dim3(d.n_kf), dim3(64), 0, s, d, par);
         if (d.n_obj) hipLaunchKernelGGL(k_lin_objects, dim3(d.n_obj), dim3(64), 0, s, d, par);
-        if (p->profiling) hipEventRecord(evB, s);
+        if (p->profiling) (void)hipEventRecord(evB, s);
         int rc = allreduce_gather(p, d.Hdiag, (size_t)36 * p->n_pose, d.bp, (size_t)p->dim, d.scal, 1);   // pose blocks, b_p, chi2
         if (rc) return rc;
         if (it == 0) {
@@ -2015,7 +2015,7 @@ extern "C" int qsp_ba_optimize(qsp_ba_problem* p, int32_t n_iter, double delta_m
         }
         if (p->profiling) {
             float ms = 0;
-            hipEventElapsedTime(&ms, evA, evB);
+            (void)hipEventElapsedTime(&ms, evA, evB);
             p->prof.ms_linearize += ms;
             p->prof.n_linearize++;
         }
@@ -2110,15 +2110,15 @@ extern "C" int qsp_ba_optimize(qsp_ba_problem* p, int32_t n_iter, double delta_m
         hipLaunchKernelGGL(k_mask_foreign_points, dim3((d.n_pt + 255) / 256), dim3(256), 0, s, d, p->rank, p->world, ids);
         int rc2 = allreduce(p, d.pt_xyz, (int64_t)3 * d.n_pt);
         QSP_HIP(hipStreamSynchronize(s));
-        hipFree(ids);
+        (void)hipFree(ids);
         if (rc2) return rc2;
     }
     QSP_HIP(hipStreamSynchronize(s));
     if (p->profiling) {
-        hipEventRecord(ev1, s);
+        (void)hipEventRecord(ev1, s);
         hipEventSynchronize(ev1);
-        hipEventElapsedTime(&p->prof.ms_total, ev0, ev1);
-        hipEventDestroy(ev0); hipEventDestroy(ev1); hipEventDestroy(evA); hipEventDestroy(evB);
+        (void)hipEventElapsedTime(&p->prof.ms_total, ev0, ev1);
+        (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1); (void)hipEventDestroy(evA); (void)hipEventDestroy(evB);
         // algorithmic bytes of one linearisation
         int64_t nm = 0, ns = 0, no = 0;
         for (int e = 0; e < d.n_edge; ++e)
@@ -2154,7 +2154,7 @@ extern "C" int qsp_ba_get_edges(qsp_ba_problem* p, double* mono_chi2, double* st
         hipLaunchKernelGGL(k_mask_foreign_chi2, dim3((std::max(d.n_edge, d.n_oe) + 255) / 256), dim3(256), 0, p->stream, d, ef, of);
         int rc = allreduce_gather(p, d.edge_chi2, (size_t)d.n_edge, d.oe_chi2, (size_t)d.n_oe, nullptr, 0);
         QSP_HIP(hipStreamSynchronize(p->stream));
-        hipFree(ef); hipFree(of);
+        (void)hipFree(ef); (void)hipFree(of);
         if (rc) return rc;
     }
     std::vector<double> c(std::max(d.n_edge, 1));
@@ -2167,7 +2167,7 @@ extern "C" int qsp_ba_get_edges(qsp_ba_problem* p, double* mono_chi2, double* st
             hipLaunchKernelGGL(k_depth_positive, dim3((d.n_edge + 255) / 256), dim3(256), 0, p->stream, d, dp);
             QSP_HIP(hipMemcpyAsync(pos.data(), dp, d.n_edge, hipMemcpyDeviceToHost, p->stream));
             QSP_HIP(hipStreamSynchronize(p->stream));
-            hipFree(dp);
+            (void)hipFree(dp);
         }
     }
     for (int e = 0; e < p->n_mono; ++e) {
@@ -2228,11 +2228,11 @@ struct qsp_pose_optimizer {
 
 extern "C" void qsp_pose_optimizer_destroy(qsp_pose_optimizer* h) {
     if (!h) return;
-    hipSetDevice(h->device);
+    (void)hipSetDevice(h->device);
     void* ptrs[] = {h->X, h->obs, h->info, h->chi2, h->stereo, h->outlier, h->level, h->out};
     for (void* p : ptrs)
-        if (p) hipFree(p);
-    if (h->stream) hipStreamDestroy(h->stream);
+        if (p) (void)hipFree(p);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
 

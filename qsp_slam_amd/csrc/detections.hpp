@@ -158,7 +158,7 @@ __global__ void __launch_bounds__(64) k_det_select(const HypState* st, const int
 struct DevPool {            // the call's temporary device arrays
     std::vector<void*> p;
     ~DevPool() {
-        for (void* q : p) hipFree(q);
+        for (void* q : p) (void)hipFree(q);
     }
     template <class T>
     int up(const T* host, size_t n, const T** out) {

@@ -214,7 +214,7 @@ extern "C" int qsp_ellipsoid_fit_planes(int device, int32_t n, const double* ell
     QSP_HIP(hipSetDevice(device));
     struct Pool {
         std::vector<void*> p;
-        ~Pool() { for (void* q : p) hipFree(q); }
+        ~Pool() { for (void* q : p) (void)hipFree(q); }
     } pool;
     auto dev = [&](size_t bytes, void** out) {
         hipError_t e = hipMalloc(out, std::max<size_t>(bytes, 8));

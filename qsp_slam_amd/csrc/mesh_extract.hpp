@@ -297,10 +297,10 @@ struct qsp_mesh_extractor {
 
 extern "C" void qsp_mesh_extractor_destroy(qsp_mesh_extractor* m) {
     if (!m) return;
-    hipSetDevice(m->device);
+    (void)hipSetDevice(m->device);
     void* ptrs[] = {m->xyz, m->sdf, m->code, m->verts, m->faces, m->flags, m->cnt, m->bsum, m->total, m->tables};
     for (void* p : ptrs)
-        if (p) hipFree(p);
+        if (p) (void)hipFree(p);
     delete m;
     (void)hipGetLastError();   // errors are ignored here; do not leave one behind for the next call's launch check
 }
@@ -363,13 +363,13 @@ static int mesh_march(qsp_mesh_extractor* m, int64_t* n_verts, int64_t* n_faces)
     m->n_verts = (int64_t)(tot & 0xffffffffull);
     m->n_faces = (int64_t)(tot >> 32);
     if (m->n_verts > m->cap_verts) {
-        if (m->verts) hipFree(m->verts);
+        if (m->verts) (void)hipFree(m->verts);
         m->verts = nullptr;
         m->cap_verts = m->n_verts + m->n_verts / 4 + 1024;
         QSP_HIP(hipMalloc((void**)&m->verts, sizeof(float) * 3 * m->cap_verts));
     }
     if (m->n_faces > m->cap_faces) {
-        if (m->faces) hipFree(m->faces);
+        if (m->faces) (void)hipFree(m->faces);
         m->faces = nullptr;
         m->cap_faces = m->n_faces + m->n_faces / 4 + 1024;
         QSP_HIP(hipMalloc((void**)&m->faces, sizeof(int32_t) * 3 * m->cap_faces));

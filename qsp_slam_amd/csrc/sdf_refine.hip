@@ -1091,9 +1091,9 @@ extern "C" int qsp_decoder_create(const qsp_decoder_desc* desc, int device, qsp_
 
 extern "C" void qsp_decoder_destroy(qsp_decoder* d) {
     if (!d) return;
-    hipSetDevice(d->device);
-    for (void* p : d->allocs) hipFree(p);
-    if (d->stream) hipStreamDestroy(d->stream);
+    (void)hipSetDevice(d->device);
+    for (void* p : d->allocs) (void)hipFree(p);
+    if (d->stream) (void)hipStreamDestroy(d->stream);
     delete d;
 }
 
@@ -1119,10 +1119,10 @@ static int decode_common(qsp_decoder* d, const float* code, const float* xyz, in
     QSP_HIP(hipMemcpyAsync(y, dy, n * sizeof(float), hipMemcpyDeviceToHost, d->stream));
     if (grad) QSP_HIP(hipMemcpyAsync(grad, dg, n * NIN * sizeof(float), hipMemcpyDeviceToHost, d->stream));
     QSP_HIP(hipStreamSynchronize(d->stream));
-    hipFree(dc);
-    hipFree(dx);
-    hipFree(dy);
-    if (dg) hipFree(dg);
+    (void)hipFree(dc);
+    (void)hipFree(dx);
+    (void)hipFree(dy);
+    if (dg) (void)hipFree(dg);
     return QSP_OK;
 }
 
@@ -1173,13 +1173,13 @@ struct qsp_refine_batch {
 
 static void batch_free(qsp_refine_batch* b) {
     if (!b) return;
-    hipSetDevice(b->device);
+    (void)hipSetDevice(b->device);
     void* ptrs[] = {b->st, b->objs, b->pts, b->rays, b->depth, b->valid_rk, b->ray_voff, b->rend_rk, b->sdf_valid,
                     b->rend_deds, b->rend_res, b->partials, b->trH, b->trb, b->trdx, b->pt_active, b->res_buf, b->rows, b->counters,
                     b->work_fwd, b->work_jtj, b->qctl, b->c0_all};
     for (void* p : ptrs)
-        if (p) hipFree(p);
-    for (hipEvent_t e : b->ev) hipEventDestroy(e);
+        if (p) (void)hipFree(p);
+    for (hipEvent_t e : b->ev) (void)hipEventDestroy(e);
     delete b;
     (void)hipGetLastError();   // errors are ignored here; do not leave one behind for the next call's launch check
 }
@@ -1323,11 +1323,11 @@ extern "C" int qsp_refine_batch_set_state(qsp_refine_batch* b, const float* t_ca
 static hipEvent_t next_event(qsp_refine_batch* b, size_t& cursor) {
     if (cursor >= b->ev.size()) {
         hipEvent_t e;
-        hipEventCreate(&e);
+        (void)hipEventCreate(&e);
         b->ev.push_back(e);
     }
     hipEvent_t e = b->ev[cursor++];
-    hipEventRecord(e, b->dec->stream);
+    (void)hipEventRecord(e, b->dec->stream);
     return e;
 }
 
@@ -1387,10 +1387,10 @@ extern "C" int qsp_refine_batch_run(qsp_refine_batch* b, int32_t n_iter) {
     if (b->prof) {
         qsp_refine_profile& p = b->profile;
         memset(&p, 0, sizeof(p));
-        hipEventElapsedTime(&p.ms_total, e_begin, e_end);
+        (void)hipEventElapsedTime(&p.ms_total, e_begin, e_end);
         for (const Span& sp : spans) {
             float ms = 0;
-            hipEventElapsedTime(&ms, sp.a, sp.b);
+            (void)hipEventElapsedTime(&ms, sp.a, sp.b);
             if (sp.kind == 0) { p.ms_mlp_jtj += ms; p.n_launch_jtj++; }
             else if (sp.kind == 1) { p.ms_mlp_fwd += ms; p.n_launch_fwd++; }
             else p.ms_other += ms;
@@ -1460,7 +1460,7 @@ extern "C" int qsp_refine_batch_rows(qsp_refine_batch* b, int enable, int32_t hy
         QSP_HIP(hipMalloc((void**)&b->rows, sizeof(float) * (size_t)b->n_hyp * b->rows_stride * NJ));
     }
     if (!enable && b->rows) {
-        hipFree(b->rows);
+        (void)hipFree(b->rows);
         b->rows = nullptr;
     }
     if (enable && (rows_sdf || rows_render)) {
@@ -1531,10 +1531,10 @@ extern "C" int qsp_estimate_pose(qsp_decoder* dec, int32_t n, const float* t_co_
 #if (QSP_EXP_VARIANT & 16)
 // timing experiment only (tools/phase_times.py): the stamps of the last launch
 extern "C" int qsp_debug_timestamps(unsigned long long* out /*96*/, int* n, unsigned long long* rt /*96*/) {
-    hipDeviceSynchronize();
-    hipMemcpyFromSymbol(out, HIP_SYMBOL(qsp::qsp_dbg_ts), sizeof(unsigned long long) * 96);
-    if (rt) hipMemcpyFromSymbol(rt, HIP_SYMBOL(qsp::qsp_dbg_rt), sizeof(unsigned long long) * 96);
-    hipMemcpyFromSymbol(n, HIP_SYMBOL(qsp::qsp_dbg_n), sizeof(int));
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(qsp::qsp_dbg_ts), sizeof(unsigned long long) * 96);
+    if (rt) (void)hipMemcpyFromSymbol(rt, HIP_SYMBOL(qsp::qsp_dbg_rt), sizeof(unsigned long long) * 96);
+    (void)hipMemcpyFromSymbol(n, HIP_SYMBOL(qsp::qsp_dbg_n), sizeof(int));
     return 0;
 }
 #endif
