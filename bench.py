@@ -5,20 +5,28 @@ A "step" is one pass of the hot path over one synthetic scene that is already re
   A. DeepSDF refinement of every object: flip_sample_num (4) yaw hypotheses x n_iter (5) Gauss-Newton iterations
      (reference: 4 serial calls of Optimizer.reconstruct_object per object, src/LocalMapping_util.cc:705-760)
   B. local joint bundle adjustment of the scene: optimize(5) + outlier pass + optimize(10)
-     (reference: Optimizer::LocalJointBundleAdjustment, src/Optimizer_util.cc:309-771)      [when built]
+     (reference: Optimizer::LocalJointBundleAdjustment, src/Optimizer_util.cc:309-771)
 
 metric  "joint-opt iters/sec (BA+SDF)": one joint-opt iteration = one Gauss-Newton iteration of one object hypothesis
         (71 unknowns, SDF + render terms) or one Levenberg-Marquardt iteration of the scene's BA; value = all such
-        iterations of all ranks / wall time of the timed steps (max over ranks).  `ms_per_object_refine` is reported beside.
-scaling weak: every rank owns its own scene of the same size (objects are independent units; no data-path collective
-        in A; B's shared camera block is reduced with one RCCL all-reduce per LM trial when ranks share a scene).
+        iterations of the job / wall time of the timed steps (max over ranks).  `ms_per_object_refine` is reported beside.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c4|c5] [--no-cpu-baseline]
-  (N > 1: launched by torch.distributed.run, one rank per GPU)
+scaling strong (default; BASELINE.json configs[3] and north_star): ONE fixed scene for every N.  Object o with its four yaw
+        hypotheses is refined on rank o % N (no collective inside the Gauss-Newton iterations, one all_gather of 82 floats
+        per object at the end of A); the scene's joint BA is ONE solve whose landmarks are sharded pt_id % N, with the shared
+        camera/object block summed by RCCL (ncclAllReduce on the library's own stream, dimp^2 + dimp doubles per LM trial).
+        weak (--scaling weak): every rank owns its own scene of the same size (independent key-frame windows; replicas).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c4|c5] [--scaling strong|weak] [--no-sublines]
+                  [--no-cpu-baseline]
+  N > 1: one rank per GPU under torch.distributed.run (the driver's launch line); `python bench.py --gpus N` without that
+  environment starts it as a child process.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,7 +36,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 WORKLOADS = {
-    # name: (n_kf, n_obj, n_pts, n_fg, n_bg, n_iter, cfg-name)
     "c2": dict(n_kf=20, n_obj=8, n_pts=2000, n_fg=256, n_bg=200, n_iter=5, n_map=2000,
                desc="C2: synthetic 20 KF / 8 objects / 2k SDF samples, 4 yaw flips x 5 GN iterations"),
     "c4": dict(n_kf=50, n_obj=64, n_pts=8000, n_fg=256, n_bg=200, n_iter=5, n_map=5000,
@@ -40,9 +47,10 @@ DM, DS, DO = float(np.float32(np.sqrt(5.991))), float(np.float32(np.sqrt(7.815))
 FLOP_FWD = 2.0 * 1835520          # per point, decoder forward            
 FLOP_FWDBWD = 2.0 * FLOP_FWD      # forward + backward-data
 PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_HBM_GBPS = 8000.0
 
 
-def joint_cfg(n_iter):
+def joint_cfg(n_iter, kitti=False):
     from qsp_slam_amd.reconstruct.utils import ForceKeyErrorDict
     # configs/config_redwood_chair_01053.json (the Redwood/RGB-D weights of the reference)
     return ForceKeyErrorDict(data_type="Redwood", optimizer=dict(
@@ -59,7 +67,26 @@ def flip_states(objs, flips):
         for k in range(flips):
             T0.append(_flip_rotation(T, k, 2.0 * np.pi / flips))     # src/LocalMapping_util.cc:722-726
             hyp.append(i)
+    if not T0:
+        return np.zeros((0, 4, 4), np.float32), hyp
     return np.stack(T0), hyp
+
+
+def select_flips(T, code, loss, good, n_obj, flips):
+    """the keep rule of src/LocalMapping_util.cc:748-752 over each object's hypotheses -> (n_obj, 82) result rows"""
+    out = np.zeros((n_obj, 82), np.float32)
+    for i in range(n_obj):
+        best = i * flips
+        for k in range(1, flips):
+            h = i * flips + k
+            if (not good[best]) or (good[h] and loss[h] < loss[best]):
+                best = h
+        if good[best]:
+            out[i, :16] = T[best].reshape(-1)
+            out[i, 16:80] = code[best][:64]
+        out[i, 80] = loss[best]
+        out[i, 81] = 1.0 if good[best] else 0.0
+    return out
 
 
 def cpu_baseline(w, objs, scene, n_hyp, budget_s=20.0):
@@ -116,68 +143,113 @@ def cpu_baseline(w, objs, scene, n_hyp, budget_s=20.0):
 def pmc_traffic(workload, kernel):
     """Memory-side bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of this same command
     (PMC counters cannot be read from inside the process); None when the workload was not profiled."""
-    try:
-        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_traffic.json")) as f:
-            return json.load(f)[workload][kernel]["bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
-        return None
+    for name in ("r02_traffic.json", "r01_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                return json.load(f)[workload][kernel]["bytes_per_launch"], name
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
-    ap.add_argument("--flips", type=int, default=4)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+class Ctx(object):
+    """process-wide state of one bench process: rank / world, device, torch.distributed group, the library's RCCL comm"""
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    import torch
-    dist = None
-    # QSP_BENCH_REHEARSAL=1: rehearse the N > 1 control flow on a one-GPU box -- all ranks share device 0 and the two
-    # scalar reductions go over gloo.  Never set by the driver; the numbers of such a run mean nothing.
-    rehearsal = os.environ.get("QSP_BENCH_REHEARSAL") == "1"
-    if world > 1:
-        import torch.distributed as dist
-        if rehearsal:
-            dist.init_process_group("gloo")
-        else:
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = local_rank if (world > 1 and not rehearsal) else 0
-    red_dev = "cpu" if rehearsal else "cuda:%d" % dev
+    def __init__(self, args):
+        self.args = args
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        import torch
+        self.torch = torch
+        self.dist = None
+        # QSP_BENCH_REHEARSAL=1: rehearse the N > 1 control flow on a one-GPU box -- all ranks share device 0, the control
+        # reductions and the BA's all-reduce hook go over gloo (RCCL refuses two ranks on one device).  Never set by the
+        # driver; the numbers of such a run mean nothing.
+        self.rehearsal = os.environ.get("QSP_BENCH_REHEARSAL") == "1"
+        if self.world > 1:
+            import torch.distributed as dist
+            self.dist = dist
+            if self.rehearsal:
+                dist.init_process_group("gloo")
+            else:
+                torch.cuda.set_device(self.local_rank)
+                dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
+        self.dev = self.local_rank if (self.world > 1 and not self.rehearsal) else 0
+        self.red_dev = "cpu" if (self.rehearsal or self.world == 1) else "cuda:%d" % self.dev
+        self.comm = None
+        self.comm_kind = "none"
+        if self.world > 1 and args.scaling == "strong":
+            from qsp_slam_amd import parallel
+            if self.rehearsal:
+                self.comm_kind = "gloo hook (rehearsal)"
+            else:
+                self.comm = parallel.RcclComm(self.rank, self.world, self.dev)     # collective over all ranks
+                self.comm_kind = "rccl on the library stream (qsp_ba_set_shard_rccl)"
 
-    from qsp_slam_amd import DeepSdfDecoder, synth
+    def sync_all(self):
+        self.torch.cuda.synchronize(self.dev)
+        if self.dist is not None:
+            self.dist.barrier()
+            self.torch.cuda.synchronize(self.dev)
+
+    def allreduce(self, x, op):
+        if self.dist is None:
+            return float(x)
+        t = self.torch.tensor([float(x)], device=self.red_dev, dtype=self.torch.float64)
+        self.dist.all_reduce(t, op=getattr(self.dist.ReduceOp, op))
+        return float(t.item())
+
+
+def run_workload(ctx, name, steps, warmup, detailed):
+    """`steps` timed passes of workload `name` (after `warmup` untimed ones); every rank returns the same dict of whole-job
+    numbers (rank 0's kernel timings)."""
+    from qsp_slam_amd import DeepSdfDecoder, parallel, synth
     from qsp_slam_amd.ba import BaProblem
     from qsp_slam_amd.reconstruct.optimizer import Optimizer, RefineBatch, _joint_cfg
-
-    w = WORKLOADS[args.workload]
+    args, rank, world, dev = ctx.args, ctx.rank, ctx.world, ctx.dev
+    strong = args.scaling == "strong"
+    w = WORKLOADS[name]
+    flips = args.flips
     dec = DeepSdfDecoder.from_npz(os.path.join(ROOT, "tests", "golden", "decoder_8x512.npz"), device=dev)
-    objs = synth.make_object_views(1000 + rank, w["n_obj"], w["n_pts"], n_fg=w["n_fg"], n_bg=w["n_bg"])
     opt = Optimizer(dec, joint_cfg(w["n_iter"]))
-    T0, hyp = flip_states(objs, args.flips)
-    batch = RefineBatch(dec, _joint_cfg(opt), [o["pts"] for o in objs], [o["rays"] for o in objs],
-                        [o["depth"] for o in objs], hyp)          # inputs resident in HBM from here on
-    batch.profile(True)
-    scene = synth.make_ba_scene(2000 + rank, w["n_kf"], w["n_map"], w["n_obj"], stereo_frac=0.2)
+    seed_off = 0 if strong else rank
+    objs_all = synth.make_object_views(1000 + seed_off, w["n_obj"], w["n_pts"], n_fg=w["n_fg"], n_bg=w["n_bg"])
+    mine = parallel.shard_objects(w["n_obj"], rank, world) if strong else list(range(w["n_obj"]))
+    objs = [objs_all[i] for i in mine]
+    T0, hyp = flip_states(objs, flips)
+    batch = None
+    if objs:
+        batch = RefineBatch(dec, _joint_cfg(opt), [o["pts"] for o in objs], [o["rays"] for o in objs],
+                            [o["depth"] for o in objs], hyp)          # inputs resident in HBM from here on
+        batch.profile(True)
+    scene = synth.make_ba_scene(2000 + seed_off, w["n_kf"], w["n_map"], w["n_obj"], stereo_frac=0.2)
     ba = BaProblem(scene, device=dev)                              # flattened graph resident in HBM
+    if strong and world > 1:
+        if ctx.comm is not None:
+            ba.set_shard_rccl(ctx.comm)
+        else:
+            ba.set_shard(rank, world, parallel.GlooAllreduce())
     ba.profile(True)
     kf0, pt0, ob0 = scene["kf_pose"], scene["pt_xyz"], scene["obj_pose"]
-    ba_stat = dict(ms=0.0, ms_lin=0.0, n_lin=0, bytes_lin=0, iters=0, trials=0)
-
-    def sync_all():
-        torch.cuda.synchronize(dev)
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize(dev)
+    ba_stat = dict(ms=0.0, ms_lin=0.0, n_lin=0, bytes_lin=0, iters=0, trials=0, ms_gather=0.0)
+    results = {}
 
     def step(record=False):
-        batch.set_state(T0, None)      # 256 x (16+64) floats H2D: part of the step, as the caller hands poses over
-        batch.run(0)
+        if batch is not None:
+            batch.set_state(T0, None)  # (16+64) floats per hypothesis H2D: part of the step, as the caller hands poses over
+            batch.run(0)
+        if strong and world > 1:       # every rank ends with the kept result of every object (82 floats each)
+            t_g = time.perf_counter()
+            if batch is not None:
+                T, code, loss, good = batch.get()
+                table = select_flips(T, code, loss, good, len(objs), flips)
+            else:
+                table = np.zeros((0, 82), np.float32)
+            results["table"] = parallel.gather_object_results(table, w["n_obj"], rank, world,
+                                                              device=None if ctx.red_dev == "cpu" else ctx.red_dev)
+            if record:
+                ba_stat["ms_gather"] += 1e3 * (time.perf_counter() - t_g)
         ba.set_state(kf0, pt0, ob0)    # the caller's current estimates (float64 poses / points)
         t_a = time.perf_counter()
         t1, t2 = ba.local_joint_ba()
@@ -190,92 +262,190 @@ def main():
             ba_stat["n_lin"] += bp.n_linearize
             ba_stat["bytes_lin"] = bp.bytes_linearize
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
-    sync_all()
+    ctx.sync_all()
     t0 = time.perf_counter()
     prof = dict(ms_total=0.0, ms_mlp_jtj=0.0, ms_mlp_fwd=0.0, ms_other=0.0, n_jtj=0, n_fwd=0, pts_jtj=0, pts_fwd=0,
                 tiles_jtj=0, tiles_fwd=0)
-    for _ in range(args.steps):
+    for _ in range(steps):
         step(record=True)
-        p = batch.profile(True)
-        prof["ms_total"] += p.ms_total
-        prof["ms_mlp_jtj"] += p.ms_mlp_jtj
-        prof["ms_mlp_fwd"] += p.ms_mlp_fwd
-        prof["ms_other"] += p.ms_other
-        prof["n_jtj"] += p.n_launch_jtj
-        prof["n_fwd"] += p.n_launch_fwd
-        prof["pts_jtj"] += p.pts_jtj
-        prof["pts_fwd"] += p.pts_fwd
-        prof["tiles_jtj"] += p.tiles_jtj
-        prof["tiles_fwd"] += p.tiles_fwd
-    sync_all()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], device=red_dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    _, _, loss, good = batch.get()
+        if batch is not None:
+            p = batch.profile(True)
+            prof["ms_total"] += p.ms_total
+            prof["ms_mlp_jtj"] += p.ms_mlp_jtj
+            prof["ms_mlp_fwd"] += p.ms_mlp_fwd
+            prof["ms_other"] += p.ms_other
+            prof["n_jtj"] += p.n_launch_jtj
+            prof["n_fwd"] += p.n_launch_fwd
+            prof["pts_jtj"] += p.pts_jtj
+            prof["pts_fwd"] += p.pts_fwd
+            prof["tiles_jtj"] += p.tiles_jtj
+            prof["tiles_fwd"] += p.tiles_fwd
+    ctx.sync_all()
+    dt = ctx.allreduce(time.perf_counter() - t0, "MAX")
+    n_good = 0
+    if batch is not None:
+        _, _, _, good = batch.get()
+        n_good = int(good.sum())
+    n_good = int(ctx.allreduce(n_good, "SUM"))
+    n_hyp_job = (w["n_obj"] * flips) if strong else int(ctx.allreduce(len(hyp), "SUM"))
+    sdf_iters = n_hyp_job * w["n_iter"] * steps
+    # strong: ONE shared BA (every rank reports the same trace); weak: one BA per rank
+    ba_iters_job = ba_stat["iters"] if strong else ctx.allreduce(ba_stat["iters"], "SUM")
+    iters_total = sdf_iters + ba_iters_job
+    flop_jtj = (FLOP_FWDBWD + 2.0 * 72 * 72) * prof["pts_jtj"]
+    avg_ms = prof["ms_mlp_jtj"] / max(prof["n_jtj"], 1)
+    achieved = flop_jtj / max(prof["n_jtj"], 1) / max(avg_ms * 1e-3, 1e-12) / 1e12
+    fwd_tf = FLOP_FWD * prof["pts_fwd"] / max(prof["ms_mlp_fwd"] * 1e-3, 1e-9) / 1e12
+    lin_us = 1e3 * ba_stat["ms_lin"] / max(ba_stat["n_lin"], 1)
+    res = dict(
+        workload=name, desc=w["desc"], value=iters_total / dt, ms_per_step=1e3 * dt / steps, steps=steps,
+        iters_per_step=iters_total / steps, n_hyp_job=n_hyp_job, hyp_this_rank=len(hyp), good_hypotheses=n_good,
+        ms_per_object_refine=1e3 * dt / steps / w["n_obj"] / (1 if strong else world),
+        ms_ba=ba_stat["ms"] / steps, ba_lm_iterations=ba_stat["iters"] / steps, ba_lm_trials=ba_stat["trials"] / steps,
+        ba_iters_per_s=ba_stat["iters"] / max(1e-3 * ba_stat["ms"], 1e-12),
+        ms_gather=ba_stat["ms_gather"] / steps,
+        ba_desc="local joint BA 5+10 LM iterations: %d KF / %d map points / %d objects, %d mono + %d stereo + %d "
+                "camera-object edges" % (w["n_kf"], w["n_map"], w["n_obj"], len(scene["mono_pt"]), len(scene["st_pt"]),
+                                         len(scene["oe_kf"])),
+        jtj=dict(achieved=achieved, avg_ms=avg_ms, launches=prof["n_jtj"],
+                 points_per_launch=prof["pts_jtj"] / max(prof["n_jtj"], 1),
+                 tile_padding_overhead=64.0 * prof["tiles_jtj"] / max(prof["pts_jtj"], 1)),
+        kernels={"k_mlp_fwd_TFLOPs": fwd_tf, "k_mlp_fwd_frac": fwd_tf / PEAK_F32_MFMA_TFLOPS,
+                 "ms_mlp_jtj": prof["ms_mlp_jtj"] / steps, "ms_mlp_fwd": prof["ms_mlp_fwd"] / steps,
+                 "ms_other": prof["ms_other"] / steps, "ms_gpu_total": prof["ms_total"] / steps,
+                 "ms_ba": ba_stat["ms"] / steps, "ba_lm_iterations": ba_stat["iters"] / steps,
+                 "ba_lm_trials": ba_stat["trials"] / steps, "ba_linearize_us": lin_us,
+                 "ba_linearize_bytes": ba_stat["bytes_lin"],
+                 "ba_linearize_GBps": ba_stat["bytes_lin"] / max(lin_us, 1e-9) / 1e3,
+                 "ba_linearize_frac_of_8TBps": ba_stat["bytes_lin"] / max(lin_us, 1e-9) / 1e3 / PEAK_HBM_GBPS})
+    if detailed:
+        res["_objs"], res["_scene"], res["_hyp"], res["_T0"] = objs, scene, hyp, T0
+        res["_dec"], res["_opt"] = dec, opt
+    if batch is not None:
+        batch.close()
+    ba.close()
+    return res
 
-    n_hyp = len(hyp)
-    iters_total = n_hyp * w["n_iter"] * args.steps + ba_stat["iters"]
-    if dist is not None:
-        t = torch.tensor([float(iters_total)], device=red_dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        iters_total_all = float(t.item())
-    else:
-        iters_total_all = float(iters_total)
-    value = iters_total_all / dt
+
+def latency_block(dec):
+    """The reference's real call pattern (BASELINE config 3 stand-in: one object per call, src/LocalMapping_util.cc:705):
+    Optimizer.reconstruct_object on 2 k surface points / 456 rays / 5 iterations, and the four yaw flips as one call."""
+    from qsp_slam_amd import synth
+    from qsp_slam_amd.reconstruct.optimizer import Optimizer
+    opt = Optimizer(dec, joint_cfg(5))
+    o = synth.make_object_views(3003, 1, 2000, n_fg=256, n_bg=200)[0]
+    obj = dict(t_cam_obj=o["t_cam_obj"], pts=o["pts"], rays=o["rays"], depth=o["depth"])
+    for _ in range(3):
+        opt.reconstruct_object(o["t_cam_obj"], o["pts"], o["rays"], o["depth"])
+    n = 20
+    t0 = time.perf_counter()
+    for _ in range(n):
+        opt.reconstruct_object(o["t_cam_obj"], o["pts"], o["rays"], o["depth"])
+    one = 1e3 * (time.perf_counter() - t0) / n
+    opt.reconstruct_objects_batched([obj], flip_sample_num=4)
+    t0 = time.perf_counter()
+    for _ in range(n):
+        opt.reconstruct_objects_batched([obj], flip_sample_num=4)
+    four = 1e3 * (time.perf_counter() - t0) / n
+    return {"workload": "C3 stand-in: one object per call, 2000 surface points, 256+200 rays, 5 GN iterations",
+            "ms_reconstruct_object": one, "ms_four_flips_one_call": four, "calls_timed": n}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"])
+    ap.add_argument("--flips", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sublines", action="store_true")
+    args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # nothing has touched the GPU yet: start the ranks as a CHILD (never exec) and hand its exit code on
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+
+    ctx = Ctx(args)
+    if ctx.world != max(args.gpus, 1) and ctx.rank == 0:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, ctx.world), file=sys.stderr)
+    world, rank = ctx.world, ctx.rank
+    main_res = run_workload(ctx, args.workload, args.steps, args.warmup, detailed=True)
+    subs = {}
+    if not args.no_sublines:
+        for name in ("c2", "c5"):
+            if name != args.workload:
+                r = run_workload(ctx, name, 2, 1, detailed=False)
+                subs[name] = {k: v for k, v in r.items() if not k.startswith("_") and k != "kernels"}
+                subs[name]["roofline_frac_k_mlp_jtj"] = r["jtj"]["achieved"] / PEAK_F32_MFMA_TFLOPS
+                subs[name]["ba_linearize_us"] = r["kernels"]["ba_linearize_us"]
+                subs[name]["ba_linearize_algorithmic_GBps"] = r["kernels"]["ba_linearize_GBps"]
+
     if rank == 0:
-        flop_jtj = FLOP_FWDBWD * prof["pts_jtj"] + 2.0 * 72 * 72 * prof["pts_jtj"]
-        avg_ms = prof["ms_mlp_jtj"] / max(prof["n_jtj"], 1)
-        achieved = flop_jtj / max(prof["n_jtj"], 1) / (avg_ms * 1e-3) / 1e12
-        fwd_tf = FLOP_FWD * prof["pts_fwd"] / max(prof["ms_mlp_fwd"] * 1e-3, 1e-9) / 1e12
+        w = WORKLOADS[args.workload]
+        m = main_res
+        traffic, traffic_src = pmc_traffic(args.workload, "k_mlp_jtj")
         out = {
-            "metric": "joint-opt iters/sec (BA+SDF)", "value": value, "unit": "iters/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "metric": "joint-opt iters/sec (BA+SDF)", "value": m["value"], "unit": "iters/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": m["ms_per_step"],
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32",
             "data": "synthetic (seeded scene, decoder fitted to an analytic shape family)",
-            "config": {"workload": w["desc"], "objects_per_gpu": w["n_obj"], "hypotheses_per_gpu": n_hyp,
+            "config": {"workload": w["desc"], "objects": w["n_obj"], "hypotheses": m["n_hyp_job"],
+                       "hypotheses_on_rank0": m["hyp_this_rank"],
                        "surface_points": w["n_pts"], "rays": w["n_fg"] + w["n_bg"], "depth_samples": 50,
-                       "gn_iterations": w["n_iter"],
-                       "ba": "local joint BA 5+10 LM iterations: %d KF / %d map points / %d objects, %d mono + %d stereo "
-                             "+ %d camera-object edges" % (w["n_kf"], w["n_map"], w["n_obj"], len(scene["mono_pt"]),
-                                                            len(scene["st_pt"]), len(scene["oe_kf"]))},
-            "ms_per_object_refine": 1e3 * dt / args.steps / w["n_obj"],
-            "good_hypotheses": int(good.sum()),
+                       "gn_iterations": w["n_iter"], "ba": m["ba_desc"],
+                       "parallelism": ("1 GPU" if world == 1 else
+                                       ("objects o %% %d; BA landmarks pt_id %% %d + all-reduce of the reduced camera/object "
+                                        "system per LM trial [%s]" % (world, world, ctx.comm_kind)) if args.scaling == "strong"
+                                       else "%d independent scenes (replicas)" % world)},
+            "ms_per_object_refine": m["ms_per_object_refine"],
+            "ms_ba": m["ms_ba"], "ba_iters_per_s": m["ba_iters_per_s"], "ms_result_gather": m["ms_gather"],
+            "good_hypotheses": m["good_hypotheses"],
             "roofline": {"bound": "mfma", "kernel": "k_mlp_jtj (decoder fwd+bwd+JtJ, f32 MFMA)",
-                         "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": pmc_traffic(args.workload, "k_mlp_jtj"),
-                         "traffic_unit": "bytes/launch, rocprofv3 PMC passes of this command (profiles/r01_traffic.json)",
-                         "avg_launch_ms": avg_ms, "launches": prof["n_jtj"],
-                         "points_per_launch": prof["pts_jtj"] / max(prof["n_jtj"], 1),
-                         "tile_padding_overhead": 64.0 * prof["tiles_jtj"] / max(prof["pts_jtj"], 1)},
-            "kernels": {"k_mlp_fwd_TFLOPs": fwd_tf, "k_mlp_fwd_frac": fwd_tf / PEAK_F32_MFMA_TFLOPS,
-                        "ms_mlp_jtj": prof["ms_mlp_jtj"] / args.steps, "ms_mlp_fwd": prof["ms_mlp_fwd"] / args.steps,
-                        "ms_other": prof["ms_other"] / args.steps, "ms_gpu_total": prof["ms_total"] / args.steps,
-                        "ms_ba": ba_stat["ms"] / args.steps, "ba_lm_iterations": ba_stat["iters"] / args.steps,
-                        "ba_lm_trials": ba_stat["trials"] / args.steps,
-                        "ba_linearize_us": 1e3 * ba_stat["ms_lin"] / max(ba_stat["n_lin"], 1),
-                        "ba_linearize_bytes": ba_stat["bytes_lin"],
-                        "ba_linearize_GBps": ba_stat["bytes_lin"] / max(1e-3 * ba_stat["ms_lin"] / max(ba_stat["n_lin"], 1), 1e-12) / 1e9,
-                        "ba_linearize_frac_of_8TBps": ba_stat["bytes_lin"] / max(1e-3 * ba_stat["ms_lin"] / max(ba_stat["n_lin"], 1), 1e-12) / 8e12},
+                         "achieved": m["jtj"]["achieved"], "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": m["jtj"]["achieved"] / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+                         "traffic_unit": "bytes/launch, rocprofv3 PMC passes of this command (profiles/%s)" % traffic_src,
+                         "avg_launch_ms": m["jtj"]["avg_ms"], "launches": m["jtj"]["launches"],
+                         "points_per_launch": m["jtj"]["points_per_launch"],
+                         "tile_padding_overhead": m["jtj"]["tile_padding_overhead"]},
+            "kernels": m["kernels"],
         }
+        if subs:
+            out["sublines"] = subs
         if world == 1:
+            from qsp_slam_amd import synth
+            from qsp_slam_amd.ba import BaProblem
+            from qsp_slam_amd.reconstruct.optimizer import RefineBatch, _joint_cfg
+            dec, opt, objs, scene, hyp, T0 = m["_dec"], m["_opt"], m["_objs"], m["_scene"], m["_hyp"], m["_T0"]
             # the BA linearisation kernels are launch-bound at the BASELINE sizes (7.5 MB per build); their bandwidth is
             # measured on a graph large enough to stream: 64 key-frames x 250 000 landmarks x 8 observations
             big = synth.make_ba_scene_large(7, 64, 250000)
-            bb = BaProblem(big, device=dev)
+            bb = BaProblem(big, device=ctx.dev)
             bb.profile(True)
             for _ in range(2):
                 bb.set_state(big["kf_pose"], big["pt_xyz"], big["obj_pose"])
                 bb.optimize(2, 0, 0, 0)
                 st = bb.profile(True)
             us = 1e3 * st.ms_linearize / max(st.n_linearize, 1)
+            n_edge = len(big["mono_pt"])
+            moved = 2 * 56 * n_edge + 24 * 250000 + (72 + 24) * 250000 + 392 * 64   # two passes over the 56 B edges + points
             out["kernels"]["ba_linearize_large"] = {
-                "graph": "64 KF / 250000 landmarks / %d mono edges" % len(big["mono_pt"]), "us": us,
-                "algorithmic_bytes": int(st.bytes_linearize), "GBps": st.bytes_linearize / us / 1e3,
-                "frac_of_8TBps": st.bytes_linearize / us / 1e3 / 8000.0}
+                "graph": "64 KF / 250000 landmarks / %d mono edges" % n_edge, "us": us,
+                "algorithmic_bytes": int(st.bytes_linearize), "algorithmic_GBps": st.bytes_linearize / us / 1e3,
+                "algorithmic_frac_of_8TBps": st.bytes_linearize / us / 1e3 / PEAK_HBM_GBPS,
+                "moved_bytes": int(moved), "moved_GBps": moved / us / 1e3,
+                "moved_frac_of_8TBps": moved / us / 1e3 / PEAK_HBM_GBPS,
+                "note": "algorithmic = SURVEY 8d's count (includes a 144 B Hpl write per edge the kernels no longer "
+                        "perform); moved = bytes the kernels actually read and write"}
             bb.close()
             # the boundary as the reference calls it: host buffers in, host results out (upload + allocation inside the
             # step); reported beside `value`, never as `value`
@@ -285,22 +455,26 @@ def main():
             b2.set_state(T0, None)
             b2.run(0)
             b2.get()
-            ba2 = BaProblem(scene, device=dev)
+            ba2 = BaProblem(scene, device=ctx.dev)
             ba2.local_joint_ba()
             ba2.state()
             th = time.perf_counter() - th
-            out["host_buffers"] = {"ms_per_step": 1e3 * th, "value": iters_total / args.steps / th, "unit": "iters/s",
+            out["host_buffers"] = {"ms_per_step": 1e3 * th, "value": m["iters_per_step"] / th, "unit": "iters/s",
                                    "note": "one step with observations, graph and results crossing PCIe and device "
                                            "buffers allocated inside the step"}
             b2.close()
             ba2.close()
-        if not args.no_cpu_baseline and world == 1:      # rank 0 at N = 1 only
-            out["cpu_baseline"] = cpu_baseline(w, objs, scene, n_hyp)
+            out["latency"] = latency_block(dec)
+            if not args.no_cpu_baseline:      # rank 0 at N = 1 only
+                out["cpu_baseline"] = cpu_baseline(w, objs, scene, len(hyp))
         print(json.dumps(out))
-    batch.close()
-    ba.close()
-    if dist is not None:
-        dist.destroy_process_group()
+        sys.stdout.flush()
+    if ctx.comm is not None:
+        ctx.torch.cuda.synchronize(ctx.dev)
+        ctx.comm.close()
+    if ctx.dist is not None:
+        ctx.dist.barrier()
+        ctx.dist.destroy_process_group()
 
 
 if __name__ == "__main__":

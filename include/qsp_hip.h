@@ -283,6 +283,38 @@ int qsp_ba_profile(qsp_ba_problem* p, int enable, qsp_ba_stats* out);
 typedef int (*qsp_allreduce_fn)(void* ctx, double* device_buf, int64_t count, void* hip_stream);
 int qsp_ba_set_shard(qsp_ba_problem* p, int32_t rank, int32_t world, qsp_allreduce_fn fn, void* ctx);
 
+/* The same sharding with the collectives issued by the library itself: ncclAllReduce(ncclDouble, ncclSum) on the
+ * problem's own HIP stream, in place on the device buffers -- no host synchronisation per collective, the stream orders
+ * each reduction between the kernels that write and read its buffer.  `nccl_comm` is an ncclComm_t of `world` ranks (one per
+ * GPU) that the caller owns: one made by qsp_comm_create below, or the embedding application's own.  Per LM iteration: one
+ * reduction of the pose blocks + b_p + chi2 (36 n_pose + dim + 1 doubles) and, in the first iteration, a 1-double MAX for
+ * lambda's initial value; per LM trial: the reduced system (dimp^2 + dimp doubles) and two scalars (chi2, rho
+ * denominator); per optimize() call: the landmarks (3 n_pt doubles).  Sums are re-associated across ranks, so a sharded
+ * solve follows the unsharded one to ~1e-9 relative, not bit for bit.  world == 1 (comm ignored) switches sharding off. */
+int qsp_ba_set_shard_rccl(qsp_ba_problem* p, int32_t rank, int32_t world, void* nccl_comm);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * RCCL communicator owned by the library (one process per GPU; xGMI inside a node).  librccl.so.1 is resolved at run time
+ * -- the copy already mapped into the process (PyTorch ships one) or the ROCm installation's -- so the library has no
+ * link-time dependency on it and single-GPU users never load it.
+ *   qsp_comm_unique_id: ncclGetUniqueId on ONE rank; the 128 bytes travel to the other ranks by any side channel
+ *                       (torch.distributed broadcast, a file, MPI).
+ *   qsp_comm_create:    ncclCommInitRank on `device`; collective over all ranks.
+ *   qsp_comm_adopt:     wrap an ncclComm_t the application already has (not destroyed by qsp_comm_destroy).
+ *   qsp_comm_allreduce_f64 / qsp_comm_allgather_f32: in-place SUM of `count` doubles / gather of `count_per_rank` floats
+ *                       per rank into recv (world x count_per_rank) on `hip_stream` (NULL: the null stream); asynchronous. */
+#define QSP_COMM_ID_BYTES 128
+typedef struct qsp_comm qsp_comm;
+int qsp_comm_unique_id(uint8_t* id_out /* [QSP_COMM_ID_BYTES] */);
+int qsp_comm_create(const uint8_t* id /* [QSP_COMM_ID_BYTES] */, int32_t rank, int32_t world, int device, qsp_comm** out);
+int qsp_comm_adopt(void* nccl_comm, int32_t rank, int32_t world, int device, qsp_comm** out);
+void qsp_comm_destroy(qsp_comm* c);
+void* qsp_comm_nccl(qsp_comm* c);     /* the ncclComm_t, for qsp_ba_set_shard_rccl */
+int32_t qsp_comm_rank(qsp_comm* c);
+int32_t qsp_comm_world(qsp_comm* c);
+int qsp_comm_allreduce_f64(qsp_comm* c, double* device_buf, int64_t count, void* hip_stream);
+int qsp_comm_allgather_f32(qsp_comm* c, const float* send, float* recv, int64_t count_per_rank, void* hip_stream);
+
 /* Reproducible mode: the Schur complement is accumulated without atomics, every sum in a fixed order (per pair of
  * key-frames over their common landmarks in landmark order, pair lists built on the host from sum_l k_l (k_l+1)/2 entries,
  * 144 B per edge of extra device storage), so repeated runs give the same bits.  It is the DEFAULT whenever the lists stay

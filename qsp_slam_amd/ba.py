@@ -81,6 +81,12 @@ class BaProblem(object):
         self._cb = _lib.ALLREDUCE_FN(_cb) if world > 1 else _lib.ALLREDUCE_FN(0)
         _lib.check(_lib.lib().qsp_ba_set_shard(self.handle, int(rank), int(world), self._cb, None))
 
+    def set_shard_rccl(self, comm):
+        """landmark sharding with the collectives issued by the library: ncclAllReduce on the problem's own stream
+        (qsp_ba_set_shard_rccl).  `comm` is a qsp_slam_amd.parallel.RcclComm (one rank per GPU)."""
+        self._comm = comm                       # keep the communicator alive as long as the problem uses it
+        _lib.check(_lib.lib().qsp_ba_set_shard_rccl(self.handle, int(comm.rank), int(comm.world), comm.nccl()))
+
     def set_deterministic(self, on=True):
         """no atomics in the Schur complement: repeated runs give the same bits (qsp_ba_set_deterministic)"""
         _lib.check(_lib.lib().qsp_ba_set_deterministic(self.handle, 1 if on else 0))

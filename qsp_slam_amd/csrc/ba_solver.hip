@@ -30,6 +30,7 @@
 
 #include "../../include/qsp_hip.h"
 #include "common.hpp"
+#include "comm_rccl.hpp"
 
 namespace qsp {
 namespace ba {
@@ -1540,6 +1541,9 @@ struct qsp_ba_problem {
     double* comm = nullptr;      // staging buffer for the small all-reduces
     size_t comm_cap = 0;
     std::vector<uint8_t> edge_foreign, oe_foreign;
+    // qsp_ba_set_shard_rccl: the collectives are ncclAllReduce calls on `stream` (no host synchronisation per collective)
+    ncclComm_t nccl = nullptr;
+    uint8_t *d_pt_foreign = nullptr, *d_edge_foreign = nullptr, *d_oe_foreign = nullptr;   // device copies of the masks
 };
 
 static int upload_levels(qsp_ba_problem* p);
@@ -1889,6 +1893,11 @@ static int upload_levels(qsp_ba_problem* p) {
 // in-place SUM over ranks of `n` doubles at `buf` (device); no-op for world == 1
 static int allreduce(qsp_ba_problem* p, double* buf, int64_t n) {
     if (p->world <= 1 || n <= 0) return QSP_OK;
+    if (p->nccl) {     // RCCL on the library's stream: ordered against the producing / consuming kernels by the stream itself
+        ncclResult_t r = rccl_api()->all_reduce(buf, buf, (size_t)n, ncclDouble, ncclSum, p->nccl, p->stream);
+        if (r != ncclSuccess) return rccl_fail(r, "ncclAllReduce");
+        return QSP_OK;
+    }
     if (p->allreduce(p->allreduce_ctx, buf, n, (void*)p->stream) != 0) return qsp_fail(QSP_ERR_DEVICE, "all-reduce callback failed");
     return QSP_OK;
 }
@@ -1910,17 +1919,17 @@ static int allreduce_gather(qsp_ba_problem* p, double* a, size_t na, double* b, 
     return QSP_OK;
 }
 
-extern "C" int qsp_ba_set_shard(qsp_ba_problem* p, int32_t rank, int32_t world, qsp_allreduce_fn fn, void* ctx) {
-    if (!p || world < 1 || rank < 0 || rank >= world || (world > 1 && !fn))
-        return qsp_fail(QSP_ERR_INVALID, "qsp_ba_set_shard: bad argument");
+static int set_shard_common(qsp_ba_problem* p, int32_t rank, int32_t world) {
     QSP_HIP(hipSetDevice(p->device));
     const Dev& d = p->d;
-    p->rank = rank; p->world = world; p->allreduce = fn; p->allreduce_ctx = ctx;
+    p->rank = rank; p->world = world;
     p->edge_foreign.assign(std::max(d.n_edge, 1), 0);
     p->oe_foreign.assign(std::max(d.n_oe, 1), 0);
     if (world > 1) {
         for (int e = 0; e < d.n_edge; ++e) p->edge_foreign[e] = (p->pt_id_h[p->edge_h[e].pt] % world) != rank;
         for (int e = 0; e < d.n_oe; ++e) p->oe_foreign[e] = (p->obj_id_h[p->oe_obj_h[e]] % world) != rank;
+        std::vector<uint8_t> ptf(std::max(d.n_pt, 1), 0);
+        for (int i = 0; i < d.n_pt; ++i) ptf[i] = (p->pt_id_h[i] % world) != rank;
         const size_t need = std::max<size_t>((size_t)36 * (d.n_kf + d.n_obj) + p->dimp_max + 64,
                                              std::max<size_t>((size_t)3 * d.n_pt + 8, (size_t)d.n_edge + d.n_oe + 8));
         if (need > p->comm_cap) {
@@ -1930,14 +1939,38 @@ extern "C" int qsp_ba_set_shard(qsp_ba_problem* p, int32_t rank, int32_t world, 
             p->comm = (double*)q;
             p->comm_cap = need;
         }
+        if (!p->d_pt_foreign) {
+            int rc = dalloc(p, &p->d_pt_foreign, (size_t)std::max(d.n_pt, 1));
+            if (!rc) rc = dalloc(p, &p->d_edge_foreign, (size_t)std::max(d.n_edge, 1));
+            if (!rc) rc = dalloc(p, &p->d_oe_foreign, (size_t)std::max(d.n_oe, 1));
+            if (rc) return rc;
+        }
+        QSP_HIP(hipMemcpy(p->d_pt_foreign, ptf.data(), ptf.size(), hipMemcpyHostToDevice));
+        QSP_HIP(hipMemcpy(p->d_edge_foreign, p->edge_foreign.data(), p->edge_foreign.size(), hipMemcpyHostToDevice));
+        QSP_HIP(hipMemcpy(p->d_oe_foreign, p->oe_foreign.data(), p->oe_foreign.size(), hipMemcpyHostToDevice));
     }
     return upload_levels(p);
 }
 
+extern "C" int qsp_ba_set_shard(qsp_ba_problem* p, int32_t rank, int32_t world, qsp_allreduce_fn fn, void* ctx) {
+    if (!p || world < 1 || rank < 0 || rank >= world || (world > 1 && !fn))
+        return qsp_fail(QSP_ERR_INVALID, "qsp_ba_set_shard: bad argument");
+    p->allreduce = fn; p->allreduce_ctx = ctx; p->nccl = nullptr;
+    return set_shard_common(p, rank, world);
+}
+
+extern "C" int qsp_ba_set_shard_rccl(qsp_ba_problem* p, int32_t rank, int32_t world, void* nccl_comm) {
+    if (!p || world < 1 || rank < 0 || rank >= world || (world > 1 && !nccl_comm))
+        return qsp_fail(QSP_ERR_INVALID, "qsp_ba_set_shard_rccl: bad argument");
+    if (world > 1 && !rccl_api()) return qsp_fail(QSP_ERR_DEVICE, "qsp_ba_set_shard_rccl: librccl.so.1 could not be resolved");
+    p->allreduce = nullptr; p->allreduce_ctx = nullptr; p->nccl = world > 1 ? (ncclComm_t)nccl_comm : nullptr;
+    return set_shard_common(p, rank, world);
+}
+
 // zero the landmark / object-edge entries this rank does not own, then SUM over ranks: every rank ends with all of them
-__global__ void k_mask_foreign_points(Dev d, int rank, int world, const int64_t* pt_id) {
+__global__ void k_mask_foreign_points(Dev d, const uint8_t* foreign) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < d.n_pt && (pt_id[i] % world) != rank) { d.pt_xyz[3 * i] = 0; d.pt_xyz[3 * i + 1] = 0; d.pt_xyz[3 * i + 2] = 0; }
+    if (i < d.n_pt && foreign[i]) { d.pt_xyz[3 * i] = 0; d.pt_xyz[3 * i + 1] = 0; d.pt_xyz[3 * i + 2] = 0; }
 }
 __global__ void k_mask_foreign_chi2(Dev d, const uint8_t* ef, const uint8_t* of) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2001,9 +2034,13 @@ extern "C" int qsp_ba_optimize(qsp_ba_problem* p, int32_t n_iter, double delta_m
             const int gm = std::max(1, std::min(256, (d.n_pt * 3 + p->n_pose * 6 + 255) / 256));
             hipLaunchKernelGGL(k_maxdiag, dim3(gm), dim3(256), 0, s, d, par);
         }
+        if (it == 0 && p->world > 1 && p->nccl) {   // max over ranks of the local maxima
+            ncclResult_t r = rccl_api()->all_reduce(d.scal + 2, d.scal + 2, 1, ncclDouble, ncclMax, p->nccl, s);
+            if (r != ncclSuccess) return rccl_fail(r, "ncclAllReduce(max)");
+        }
         rc = read_scal(p, sc);
         if (rc) return rc;
-        if (it == 0 && p->world > 1) {   // max over ranks of the local maxima, as a SUM over one-hot slots
+        if (it == 0 && p->world > 1 && !p->nccl) {   // callback hook (SUM only): max as a SUM over one-hot slots
             std::vector<double> slots(p->world, 0.0);
             slots[p->rank] = sc[2];
             QSP_HIP(hipMemcpyAsync(p->comm, slots.data(), 8 * p->world, hipMemcpyHostToDevice, s));
@@ -2104,13 +2141,8 @@ extern "C" int qsp_ba_optimize(qsp_ba_problem* p, int32_t n_iter, double delta_m
         if (nBad >= 3) { result = 1; break; }
     }
     if (p->world > 1 && d.n_pt) {   // every rank leaves with all landmarks: own values, zeros elsewhere, SUM
-        int64_t* ids = nullptr;
-        QSP_HIP(hipMalloc((void**)&ids, sizeof(int64_t) * d.n_pt));
-        QSP_HIP(hipMemcpyAsync(ids, p->pt_id_h.data(), sizeof(int64_t) * d.n_pt, hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(k_mask_foreign_points, dim3((d.n_pt + 255) / 256), dim3(256), 0, s, d, p->rank, p->world, ids);
+        hipLaunchKernelGGL(k_mask_foreign_points, dim3((d.n_pt + 255) / 256), dim3(256), 0, s, d, p->d_pt_foreign);
         int rc2 = allreduce(p, d.pt_xyz, (int64_t)3 * d.n_pt);
-        QSP_HIP(hipStreamSynchronize(s));
-        (void)hipFree(ids);
         if (rc2) return rc2;
     }
     QSP_HIP(hipStreamSynchronize(s));
@@ -2146,16 +2178,11 @@ extern "C" int qsp_ba_get_edges(qsp_ba_problem* p, double* mono_chi2, double* st
     QSP_HIP(hipSetDevice(p->device));
     const Dev& d = p->d;
     if (p->world > 1) {
-        uint8_t *ef = nullptr, *of = nullptr;
-        QSP_HIP(hipMalloc((void**)&ef, std::max(d.n_edge, 1)));
-        QSP_HIP(hipMalloc((void**)&of, std::max(d.n_oe, 1)));
-        QSP_HIP(hipMemcpyAsync(ef, p->edge_foreign.data(), std::max(d.n_edge, 1), hipMemcpyHostToDevice, p->stream));
-        QSP_HIP(hipMemcpyAsync(of, p->oe_foreign.data(), std::max(d.n_oe, 1), hipMemcpyHostToDevice, p->stream));
-        hipLaunchKernelGGL(k_mask_foreign_chi2, dim3((std::max(d.n_edge, d.n_oe) + 255) / 256), dim3(256), 0, p->stream, d, ef, of);
+        hipLaunchKernelGGL(k_mask_foreign_chi2, dim3((std::max(std::max(d.n_edge, d.n_oe), 1) + 255) / 256), dim3(256), 0, p->stream, d,
+                           p->d_edge_foreign, p->d_oe_foreign);
         int rc = allreduce_gather(p, d.edge_chi2, (size_t)d.n_edge, d.oe_chi2, (size_t)d.n_oe, nullptr, 0);
-        QSP_HIP(hipStreamSynchronize(p->stream));
-        (void)hipFree(ef); (void)hipFree(of);
         if (rc) return rc;
+        QSP_HIP(hipStreamSynchronize(p->stream));
     }
     std::vector<double> c(std::max(d.n_edge, 1));
     std::vector<uint8_t> pos(std::max(d.n_edge, 1));

@@ -4,9 +4,9 @@ set -e
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wno-unused-result -Wno-unused-value"
-SRCS="sdf_refine.hip c_abi.cpp"
+SRCS="sdf_refine.hip c_abi.cpp comm_rccl.cpp"
 [ -f ba_solver.hip ] && SRCS="$SRCS ba_solver.hip"
-$HIPCC $FLAGS -shared -o ../libqsp_hip.so $SRCS "$@"
+$HIPCC $FLAGS -shared -o ../libqsp_hip.so $SRCS -ldl "$@"
 echo "built $(cd .. && pwd)/libqsp_hip.so"
 # C++ host layer for Python embedders (pybind11 over the C-ABI; no HIP code in it)
 PYMOD=../reconstruct_hip$(python3-config --extension-suffix)

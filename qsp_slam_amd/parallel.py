@@ -95,10 +95,65 @@ class _DevArray(object):
         self.__cuda_array_interface__ = dict(shape=(n,), typestr="<f8", data=(ptr, False), version=2)
 
 
+class RcclComm(object):
+    """The library's own RCCL communicator (qsp_comm_*, include/qsp_hip.h): one rank per GPU, collectives issued on the
+    library's HIP streams.  The 128-byte unique id is made on rank 0 and handed to the other ranks by `exchange`, a
+    callable bytes -> bytes that every rank calls (default: torch.distributed.broadcast_object_list on the default group,
+    any backend).  This is the production path of BaProblem.set_shard_rccl."""
+
+    def __init__(self, rank, world, device, exchange=None):
+        import ctypes as C
+        from . import _lib
+        L = _lib.lib()
+        self.rank, self.world, self.device = int(rank), int(world), int(device)
+        ident = (C.c_uint8 * 128)()
+        if self.rank == 0:
+            _lib.check(L.qsp_comm_unique_id(ident))
+        raw = bytes(ident)
+        if self.world > 1:
+            if exchange is None:
+                import torch.distributed as dist
+                box = [raw]
+                dist.broadcast_object_list(box, src=0)
+                raw = box[0]
+            else:
+                raw = exchange(raw)
+        ident = (C.c_uint8 * 128).from_buffer_copy(raw)
+        self.handle = C.c_void_p()
+        _lib.check(L.qsp_comm_create(ident, self.rank, self.world, self.device, C.byref(self.handle)))
+
+    def nccl(self):
+        from . import _lib
+        return _lib.lib().qsp_comm_nccl(self.handle)
+
+    def allreduce_f64(self, dev_ptr, n, stream=0):
+        from . import _lib
+        _lib.check(_lib.lib().qsp_comm_allreduce_f64(self.handle, int(dev_ptr), int(n), int(stream) or None))
+
+    def allgather_f32(self, send_ptr, recv_ptr, n_per_rank, stream=0):
+        from . import _lib
+        _lib.check(_lib.lib().qsp_comm_allgather_f32(self.handle, int(send_ptr), int(recv_ptr), int(n_per_rank),
+                                                     int(stream) or None))
+
+    def close(self):
+        if getattr(self, "handle", None) is not None and self.handle.value:
+            from . import _lib
+            _lib.lib().qsp_comm_destroy(self.handle)
+            self.handle.value = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class TorchAllreduce(object):
-    """The all-reduce hook of qsp_ba_set_shard over torch.distributed: backend "nccl" is RCCL on ROCm, i.e. the sum runs
-    GPU-to-GPU over xGMI.  The library's stream and torch's stream are different streams, so both are synchronised around
-    the collective (the messages are small: one reduced camera system per LM trial)."""
+    """An all-reduce hook for qsp_ba_set_shard (the callback form: `hook(dev_ptr, count, hip_stream)`) over
+    torch.distributed: backend "nccl" is RCCL on ROCm.  The library's stream and torch's stream are different streams, so
+    the hook synchronises both around the collective -- two host synchronisations per collective.  Kept for applications
+    that must route every collective through their own process group; the production path is RcclComm +
+    BaProblem.set_shard_rccl, which has none."""
 
     def __init__(self, device, group=None):
         self.device = device
@@ -124,6 +179,26 @@ def _hip():
         import ctypes
         _HIP = ctypes.CDLL("libamdhip64.so")
     return _HIP
+
+
+class GlooAllreduce(object):
+    """Callback hook for qsp_ba_set_shard that stages through the host and sums with a CPU process group (gloo): the way
+    to run SEVERAL ranks on ONE GPU (tests, rehearsals) -- RCCL refuses two ranks on the same device."""
+
+    def __init__(self, group=None):
+        self.group = group
+
+    def __call__(self, ptr, n, stream):
+        import ctypes
+        import torch
+        import torch.distributed as dist
+        hip = _hip()
+        host = np.empty(n, np.float64)
+        hip.hipStreamSynchronize(ctypes.c_void_p(stream))
+        hip.hipMemcpy(host.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(ptr), ctypes.c_size_t(8 * n), 2)
+        t = torch.from_numpy(host)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        hip.hipMemcpy(ctypes.c_void_p(ptr), host.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(8 * n), 1)
 
 
 class ThreadAllreduce(object):

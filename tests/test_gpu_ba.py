@@ -205,6 +205,37 @@ def test_sharded_ba_with_rccl_world_of_one():
         dist.destroy_process_group()
 
 
+def test_library_rccl_communicator_world_of_one():
+    """qsp_comm_* + qsp_ba_set_shard_rccl on a 1-rank communicator: librccl resolves at run time, the collectives run on the
+    library's stream (sum over one rank = identity), world == 1 leaves the solve unsharded and bit-identical"""
+    import ctypes
+    from qsp_slam_amd import parallel
+    from qsp_slam_amd.ba import BaProblem
+    c = parallel.RcclComm(0, 1, 0)
+    assert c.nccl()
+    hip = parallel._hip()
+    buf = ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(buf), 8 * 16) == 0
+    host = np.arange(16, dtype=np.float64)
+    hip.hipMemcpy(buf, host.ctypes.data_as(ctypes.c_void_p), 128, 1)
+    c.allreduce_f64(buf.value, 16)
+    hip.hipDeviceSynchronize()
+    back = np.zeros(16)
+    hip.hipMemcpy(back.ctypes.data_as(ctypes.c_void_p), buf, 128, 2)
+    hip.hipFree(buf)
+    assert np.array_equal(back, host)
+    sc = synth.make_ba_scene(seed=62, n_kf=5, n_pt=80, n_obj=1)
+    a, b = BaProblem(sc), BaProblem(sc)
+    b.set_shard_rccl(c)
+    ta, tb = a.local_joint_ba(), b.local_joint_ba()
+    assert np.array_equal(ta[1]["chi2"], tb[1]["chi2"])
+    for x, y in zip(a.state(), b.state()):
+        assert np.array_equal(x, y)
+    a.close()
+    b.close()
+    c.close()
+
+
 def test_block_row_schur_path_on_a_large_graph():
     """>= 65536 edges switches the Schur complement to k_schur_rows (LDS row blocks per key-frame split); same bars as
     the small scenes, against the C oracle on the same graph (12 key-frames, 10 000 landmarks x 8 observations, 2 objects)."""
