@@ -184,8 +184,20 @@ class Ctx(object):
             if self.rehearsal:
                 self.comm_kind = "gloo hook (rehearsal)"
             else:
-                self.comm = parallel.RcclComm(self.rank, self.world, self.dev)     # collective over all ranks
-                self.comm_kind = "rccl on the library stream (qsp_ba_set_shard_rccl)"
+                try:
+                    self.comm = parallel.RcclComm(self.rank, self.world, self.dev)     # collective over all ranks
+                except Exception as e:                                                  # e.g. librccl not resolvable
+                    print("bench.py rank %d: library RCCL communicator failed (%r)" % (self.rank, e), file=sys.stderr)
+                    self.comm = None
+                ok = torch.tensor([1.0 if self.comm is not None else 0.0], device="cuda:%d" % self.dev)
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)                               # the same decision on every rank
+                if float(ok.item()) > 0.5:
+                    self.comm_kind = "rccl on the library stream (qsp_ba_set_shard_rccl)"
+                else:
+                    if self.comm is not None:
+                        self.comm.close()
+                    self.comm = None
+                    self.comm_kind = "torch.distributed nccl hook (fallback: qsp_ba_set_shard + TorchAllreduce)"
 
     def sync_all(self):
         self.torch.cuda.synchronize(self.dev)
@@ -228,8 +240,10 @@ def run_workload(ctx, name, steps, warmup, detailed):
     if strong and world > 1:
         if ctx.comm is not None:
             ba.set_shard_rccl(ctx.comm)
-        else:
+        elif ctx.rehearsal:
             ba.set_shard(rank, world, parallel.GlooAllreduce())
+        else:
+            ba.set_shard(rank, world, parallel.TorchAllreduce(dev))
     ba.profile(True)
     kf0, pt0, ob0 = scene["kf_pose"], scene["pt_xyz"], scene["obj_pose"]
     ba_stat = dict(ms=0.0, ms_lin=0.0, n_lin=0, bytes_lin=0, iters=0, trials=0, ms_gather=0.0)

@@ -8,14 +8,19 @@
 // back as src/Optimizer_util.cc:686-769 / :252-305 do.  tests/shim_mock/ compiles it against stand-in types and checks the
 // flattening.
 //
-// Usage in the reference tree: add this header and -lqsp_hip, then in src/LocalMapping.cc:239 / src/LoopClosing_util.cc:299
-// call ORB_SLAM2::OptimizerHip::LocalJointBundleAdjustment(...) / GlobalJointBundleAdjustemnt(...) -- or define
-// QSP_HIP_REPLACE_OPTIMIZER before including to alias the names.
+// Usage in the reference tree: NOTHING changes at the call sites.  qsp_slam_amd/orbslam/Optimizer_hip.cc (this repository)
+// takes the place of src/Optimizer.cc + src/Optimizer_util.cc in the CMake source list and defines the members of
+// `class Optimizer` exactly as include/Optimizer.h:75-107 declares them, forwarding the bundle adjustments and
+// PoseOptimization to OptimizerHip below, OptimizeSim3 / OptimizeEssentialGraph to the reference's own g2o code, and any call
+// the GPU path reports an error for to that g2o code as well.  OptimizerHip's entry points
+// return a qsp status (QSP_OK / QSP_ERR_*) instead of void so that the caller can tell; on error the map is left exactly as
+// it was found (the BA bookkeeping marks mnBALocalForKF / mnBAFixedForKF are rolled back) and qsp_last_error() is logged.
 #ifndef QSP_OPTIMIZER_SHIM_H
 #define QSP_OPTIMIZER_SHIM_H
 
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <list>
 #include <map>
 #include <mutex>
@@ -79,6 +84,22 @@ inline void pose7_to_mat(const double* p, float* T /*row-major 4x4*/) {
     }
     T[12] = T[13] = T[14] = 0.f;
     T[15] = 1.f;
+}
+
+// the reference's graph walk stamps key-frames / points / objects with the current key-frame id (src/Optimizer_util.cc:314-380);
+// when the GPU path fails those stamps are rolled back so that the g2o fallback walks the same sets
+struct Marks {
+    std::vector<std::pair<long unsigned int*, long unsigned int>> saved;
+    void set(long unsigned int& field, long unsigned int v) { saved.emplace_back(&field, field); field = v; }
+    void rollback() {
+        for (size_t i = saved.size(); i-- > 0;) *saved[i].first = saved[i].second;
+        saved.clear();
+    }
+};
+
+inline int report(const char* where, int rc) {
+    if (rc != QSP_OK) std::fprintf(stderr, "[qsp_hip] %s failed (%d): %s\n", where, rc, qsp_last_error());
+    return rc;
 }
 
 struct Flat {   // the flattened graph + back-references for the write-back
@@ -207,16 +228,17 @@ public:
     // Optimizer::LocalJointBundleAdjustment, src/Optimizer_util.cc:309-771.  with_objects = false gives
     // Optimizer::LocalBundleAdjustment (src/Optimizer.cc:458-783), whose only behavioural difference besides the missing
     // object vertices is that an abort after stage 1 still writes back (src/Optimizer.cc:667-673).
-    static void LocalJointBundleAdjustment(KeyFrame* pKF, bool* pbStopFlag, Map* pMap, bool with_objects = true) {
+    static int LocalJointBundleAdjustment(KeyFrame* pKF, bool* pbStopFlag, Map* pMap, bool with_objects = true) {
         using namespace qsp_shim;
+        Marks marks;
         // ---- local key-frames, points, objects, fixed key-frames: :311-380 ------------------------------------------
         std::list<KeyFrame*> lLocalKeyFrames;
         lLocalKeyFrames.push_back(pKF);
-        pKF->mnBALocalForKF = pKF->mnId;
+        marks.set(pKF->mnBALocalForKF, pKF->mnId);
         const std::vector<KeyFrame*> vNeighKFs = pKF->GetVectorCovisibleKeyFrames();
         for (size_t i = 0; i < vNeighKFs.size(); ++i) {
             KeyFrame* pKFi = vNeighKFs[i];
-            pKFi->mnBALocalForKF = pKF->mnId;
+            marks.set(pKFi->mnBALocalForKF, pKF->mnId);
             if (!pKFi->isBad()) lLocalKeyFrames.push_back(pKFi);
         }
         std::list<MapPoint*> lLocalMapPoints;
@@ -225,13 +247,13 @@ public:
             for (MapPoint* pMP : k->GetMapPointMatches())
                 if (pMP && !pMP->isBad() && pMP->mnBALocalForKF != pKF->mnId) {
                     lLocalMapPoints.push_back(pMP);
-                    pMP->mnBALocalForKF = pKF->mnId;
+                    marks.set(pMP->mnBALocalForKF, pKF->mnId);
                 }
             if (with_objects)
                 for (MapObject* pMO : k->GetMapObjectMatches())
                     if (pMO && pMO->mnBALocalForKF != pKF->mnId) {
                         lLocalMapObjects.push_back(pMO);
-                        pMO->mnBALocalForKF = pKF->mnId;
+                        marks.set(pMO->mnBALocalForKF, pKF->mnId);
                     }
         }
         std::list<KeyFrame*> lFixedCameras;
@@ -240,7 +262,7 @@ public:
             for (std::map<KeyFrame*, size_t>::const_iterator mit = observations.begin(); mit != observations.end(); ++mit) {
                 KeyFrame* pKFi = mit->first;
                 if (pKFi->mnBALocalForKF != pKF->mnId && pKFi->mnBAFixedForKF != pKF->mnId) {
-                    pKFi->mnBAFixedForKF = pKF->mnId;
+                    marks.set(pKFi->mnBAFixedForKF, pKF->mnId);
                     if (!pKFi->isBad()) lFixedCameras.push_back(pKFi);
                 }
             }
@@ -254,19 +276,22 @@ public:
             if (!pMO->isDynamic()) F.add_object(pMO);
         qsp_ba_scene scene;
         F.finish(&scene);
-        if (pbStopFlag && *pbStopFlag) return;                                        // :589-596
+        if (pbStopFlag && *pbStopFlag) return QSP_OK;                                 // :589-596
         qsp_ba_problem* prob = nullptr;
-        if (qsp_ba_create(&scene, device(), &prob) != QSP_OK) return;                 // failure = leave the map unchanged
+        int rc = report("qsp_ba_create", qsp_ba_create(&scene, device(), &prob));     // failure = the map is left as found
+        if (rc != QSP_OK) { marks.rollback(); return rc; }
         const volatile uint8_t* stop = reinterpret_cast<const volatile uint8_t*>(pbStopFlag);
-        if (qsp_ba_local_joint(prob, stop, nullptr, nullptr) != QSP_OK) { qsp_ba_destroy(prob); return; }
-        if (with_objects && pbStopFlag && *pbStopFlag) { qsp_ba_destroy(prob); return; }   // :603-610: no write-back
+        rc = report("qsp_ba_local_joint", qsp_ba_local_joint(prob, stop, nullptr, nullptr));
+        if (rc != QSP_OK) { qsp_ba_destroy(prob); marks.rollback(); return rc; }
+        if (with_objects && pbStopFlag && *pbStopFlag) { qsp_ba_destroy(prob); return QSP_OK; }   // :603-610: no write-back
         // ---- outlier observations (:665-711), under the map mutex (:714-736) -------------------------------------------
         std::vector<double> cm(F.mono_pt.size() + 1), cs(F.st_pt.size() + 1), co(F.oe_kf.size() + 1);
         std::vector<uint8_t> pm(F.mono_pt.size() + 1), ps(F.st_pt.size() + 1);
-        qsp_ba_get_edges(prob, cm.data(), cs.data(), co.data(), pm.data(), ps.data());
         std::vector<double> kf(F.kf_pose.size()), pt(F.pt_xyz.size() + 1), ob(F.obj_pose.size() + 1);
-        qsp_ba_get_state(prob, kf.data(), pt.data(), ob.data());
+        rc = report("qsp_ba_get_edges", qsp_ba_get_edges(prob, cm.data(), cs.data(), co.data(), pm.data(), ps.data()));
+        if (rc == QSP_OK) rc = report("qsp_ba_get_state", qsp_ba_get_state(prob, kf.data(), pt.data(), ob.data()));
         qsp_ba_destroy(prob);
+        if (rc != QSP_OK) { marks.rollback(); return rc; }
         std::unique_lock<std::mutex> lock(pMap->mMutexMapUpdate);
         for (size_t i = 0; i < F.mono_pt.size(); ++i)
             if (!F.mono_mp[i]->isBad() && (cm[i] > 5.991 || !pm[i])) {
@@ -309,20 +334,21 @@ public:
                 for (int c = 0; c < 4; ++c) Tow(r, c) = T[4 * r + c];
             pMO->SetObjectPoseSE3(Tow.inverse());            // Converter::toMatrix4f(SE3Tow).inverse(), :764-765
         }
-        nBAdone()++;
+        if (with_objects) nBAdone()++;       // Optimizer::nBAdone++ exists in the joint variant only (src/Optimizer_util.cc:769)
+        return QSP_OK;
     }
 
-    static void LocalBundleAdjustment(KeyFrame* pKF, bool* pbStopFlag, Map* pMap) {
-        LocalJointBundleAdjustment(pKF, pbStopFlag, pMap, false);
+    static int LocalBundleAdjustment(KeyFrame* pKF, bool* pbStopFlag, Map* pMap) {
+        return LocalJointBundleAdjustment(pKF, pbStopFlag, pMap, false);
     }
 
     // Optimizer::JointBundleAdjustment, src/Optimizer_util.cc:44-307 (and, with no objects, Optimizer::BundleAdjustment,
     // src/Optimizer.cc:54-242): the given key-frames (mnId 0 fixed), points and static objects; one optimize(nIterations);
     // Huber sqrt(5.99) / sqrt(7.815) / sqrt(0.1*1e3) only if bRobust; vertices left without an edge are dropped and not
     // written back; results go to the *GBA members when nLoopKF != 0.
-    static void JointBundleAdjustment(const std::vector<KeyFrame*>& vpKFs, const std::vector<MapPoint*>& vpMP,
-                                      const std::vector<MapObject*>& vpMO, int nIterations = 5, bool* pbStopFlag = nullptr,
-                                      const unsigned long nLoopKF = 0, const bool bRobust = true) {
+    static int JointBundleAdjustment(const std::vector<KeyFrame*>& vpKFs, const std::vector<MapPoint*>& vpMP,
+                                     const std::vector<MapObject*>& vpMO, int nIterations = 5, bool* pbStopFlag = nullptr,
+                                     const unsigned long nLoopKF = 0, const bool bRobust = true) {
         using namespace qsp_shim;
         Flat F;
         for (KeyFrame* k : vpKFs)
@@ -334,16 +360,18 @@ public:
         qsp_ba_scene scene;
         F.finish(&scene);
         qsp_ba_problem* prob = nullptr;
-        if (qsp_ba_create(&scene, device(), &prob) != QSP_OK) return;
+        int rc = report("qsp_ba_create", qsp_ba_create(&scene, device(), &prob));
+        if (rc != QSP_OK) return rc;                // nothing of the map has been touched yet (no *GBA member written)
         const volatile uint8_t* stop = reinterpret_cast<const volatile uint8_t*>(pbStopFlag);
         const double dm = bRobust ? (double)(float)std::sqrt(5.99) : 0.0;            // thHuber2D, :80
         const double ds = bRobust ? (double)(float)std::sqrt(7.815) : 0.0;           // thHuber3D, :81
         const double dobj = bRobust ? (double)(float)std::sqrt(0.1f * 1e3f) : 0.0;   // :82-83
-        qsp_ba_set_levels(prob, nullptr, nullptr, nullptr);
-        if (qsp_ba_optimize(prob, nIterations, dm, ds, dobj, stop, nullptr) != QSP_OK) { qsp_ba_destroy(prob); return; }
         std::vector<double> kf(F.kf_pose.size()), pt(F.pt_xyz.size() + 1), ob(F.obj_pose.size() + 1);
-        qsp_ba_get_state(prob, kf.data(), pt.data(), ob.data());
+        rc = report("qsp_ba_set_levels", qsp_ba_set_levels(prob, nullptr, nullptr, nullptr));
+        if (rc == QSP_OK) rc = report("qsp_ba_optimize", qsp_ba_optimize(prob, nIterations, dm, ds, dobj, stop, nullptr));
+        if (rc == QSP_OK) rc = report("qsp_ba_get_state", qsp_ba_get_state(prob, kf.data(), pt.data(), ob.data()));
         qsp_ba_destroy(prob);
+        if (rc != QSP_OK) return rc;
         for (size_t i = 0; i < F.kfs.size(); ++i) {                                   // :252-270
             float T[16];
             pose7_to_mat(&kf[7 * i], T);
@@ -368,13 +396,17 @@ public:
             if (nLoopKF == 0) F.objs[i]->SetObjectPoseSE3(Tow.inverse());
             else { F.objs[i]->mTwoGBA = Tow.inverse(); F.objs[i]->mnBAGlobalForKF = nLoopKF; }
         }
+        return QSP_OK;
     }
 
     // Optimizer::PoseOptimization, src/Optimizer.cc:244-456: the frame's pose against its matched map points (fixed),
     // 4 x optimize(10) with inlier / outlier re-classification; sets pFrame->mvbOutlier and the pose, returns the number
     // of inliers.  One kernel launch (qsp_pose_optimize); the optimiser object is created once per thread.
-    static int PoseOptimization(Frame* pFrame) {
+    // *status (optional) receives the qsp status; on error nothing of the frame has been changed except that the outlier
+    // flags of the matched slots were cleared, which the reference does first as well (:291).
+    static int PoseOptimization(Frame* pFrame, int* status = nullptr) {
         using namespace qsp_shim;
+        if (status) *status = QSP_OK;
         const int N = pFrame->N;
         std::vector<double> X, obs, info;
         std::vector<uint8_t> stereo;
@@ -403,7 +435,8 @@ public:
             if (ctx) qsp_pose_optimizer_destroy(ctx);
             ctx = nullptr;
             ctx_cap = n > 4096 ? 2 * n : 4096;
-            if (qsp_pose_optimizer_create(device(), ctx_cap, &ctx) != QSP_OK) { ctx = nullptr; return 0; }
+            const int rc = report("qsp_pose_optimizer_create", qsp_pose_optimizer_create(device(), ctx_cap, &ctx));
+            if (rc != QSP_OK) { ctx = nullptr; ctx_cap = 0; if (status) *status = rc; return 0; }
         }
         double pose[7], pose_out[7];
         const cv::Mat Tcw = pFrame->mTcw;
@@ -411,9 +444,9 @@ public:
         const double K[5] = {pFrame->fx, pFrame->fy, pFrame->cx, pFrame->cy, pFrame->mbf};
         std::vector<uint8_t> outlier(n, 0);
         int32_t n_inliers = 0;
-        if (qsp_pose_optimize(ctx, n, K, pose, X.data(), obs.data(), info.data(), stereo.data(), pose_out, outlier.data(),
-                              &n_inliers, nullptr) != QSP_OK)
-            return 0;
+        const int rc = report("qsp_pose_optimize", qsp_pose_optimize(ctx, n, K, pose, X.data(), obs.data(), info.data(),
+                                                                       stereo.data(), pose_out, outlier.data(), &n_inliers, nullptr));
+        if (rc != QSP_OK) { if (status) *status = rc; return 0; }
         for (int e = 0; e < n; ++e) pFrame->mvbOutlier[index[e]] = outlier[e] != 0;
         float T[16];
         pose7_to_mat(pose_out, T);
@@ -425,21 +458,21 @@ public:
     }
 
     // src/Optimizer.cc:54-242
-    static void BundleAdjustment(const std::vector<KeyFrame*>& vpKFs, const std::vector<MapPoint*>& vpMP, int nIterations = 5,
-                                 bool* pbStopFlag = nullptr, const unsigned long nLoopKF = 0, const bool bRobust = true) {
-        JointBundleAdjustment(vpKFs, vpMP, std::vector<MapObject*>(), nIterations, pbStopFlag, nLoopKF, bRobust);
+    static int BundleAdjustment(const std::vector<KeyFrame*>& vpKFs, const std::vector<MapPoint*>& vpMP, int nIterations = 5,
+                                bool* pbStopFlag = nullptr, const unsigned long nLoopKF = 0, const bool bRobust = true) {
+        return JointBundleAdjustment(vpKFs, vpMP, std::vector<MapObject*>(), nIterations, pbStopFlag, nLoopKF, bRobust);
     }
 
     // src/Optimizer.cc:46-51
-    static void GlobalBundleAdjustemnt(Map* pMap, int nIterations = 5, bool* pbStopFlag = nullptr,
-                                       const unsigned long nLoopKF = 0, const bool bRobust = true) {
-        BundleAdjustment(pMap->GetAllKeyFrames(), pMap->GetAllMapPoints(), nIterations, pbStopFlag, nLoopKF, bRobust);
+    static int GlobalBundleAdjustemnt(Map* pMap, int nIterations = 5, bool* pbStopFlag = nullptr,
+                                      const unsigned long nLoopKF = 0, const bool bRobust = true) {
+        return BundleAdjustment(pMap->GetAllKeyFrames(), pMap->GetAllMapPoints(), nIterations, pbStopFlag, nLoopKF, bRobust);
     }
 
     // src/Optimizer_util.cc:36-42
-    static void GlobalJointBundleAdjustemnt(Map* pMap, int nIterations = 5, bool* pbStopFlag = nullptr,
-                                            const unsigned long nLoopKF = 0, const bool bRobust = true) {
-        JointBundleAdjustment(pMap->GetAllKeyFrames(), pMap->GetAllMapPoints(), pMap->GetAllMapObjects(), nIterations,
+    static int GlobalJointBundleAdjustemnt(Map* pMap, int nIterations = 5, bool* pbStopFlag = nullptr,
+                                           const unsigned long nLoopKF = 0, const bool bRobust = true) {
+        return JointBundleAdjustment(pMap->GetAllKeyFrames(), pMap->GetAllMapPoints(), pMap->GetAllMapObjects(), nIterations,
                               pbStopFlag, nLoopKF, bRobust);
     }
 };

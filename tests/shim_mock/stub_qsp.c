@@ -8,10 +8,18 @@
 
 struct qsp_ba_problem { qsp_ba_scene s; double *kf, *pt, *ob; };
 
+/* failure injection: $QSP_STUB_FAIL names the entry point that reports QSP_ERR_DEVICE (create | local | optimize | pose) */
+static int fails(const char* what) {
+    const char* f = getenv("QSP_STUB_FAIL");
+    return f && strcmp(f, what) == 0;
+}
+const char* qsp_last_error(void) { return "injected by the test stub"; }
+
 static void wr(FILE* f, const void* p, size_t n) { if (n) fwrite(p, 1, n, f); }
 
 int qsp_ba_create(const qsp_ba_scene* s, int device, qsp_ba_problem** out) {
     (void)device;
+    if (fails("create")) return QSP_ERR_DEVICE;
     const char* path = getenv("QSP_STUB_DUMP");
     if (path) {
         FILE* f = fopen(path, "wb");
@@ -40,6 +48,7 @@ int qsp_ba_create(const qsp_ba_scene* s, int device, qsp_ba_problem** out) {
 void qsp_ba_destroy(qsp_ba_problem* p) { free(p->kf); free(p->pt); free(p->ob); free(p); }
 int qsp_ba_local_joint(qsp_ba_problem* p, const volatile uint8_t* stop, qsp_ba_trace* a, qsp_ba_trace* b) {
     (void)stop; (void)a; (void)b;
+    if (fails("local")) return QSP_ERR_DEVICE;
     for (int i = 0; i < p->s.n_kf; ++i) if (!p->s.kf_fixed[i]) p->kf[7 * i] += 0.5;      /* visible fake update */
     for (int i = 0; i < p->s.n_pt; ++i) p->pt[3 * i + 1] += 0.25;
     for (int i = 0; i < p->s.n_obj; ++i) p->ob[7 * i + 2] += 0.125;
@@ -47,6 +56,7 @@ int qsp_ba_local_joint(qsp_ba_problem* p, const volatile uint8_t* stop, qsp_ba_t
 }
 int qsp_ba_optimize(qsp_ba_problem* p, int32_t n, double a, double b, double c, const volatile uint8_t* s, qsp_ba_trace* t) {
     const char* path = getenv("QSP_STUB_DUMP");
+    if (fails("optimize")) return QSP_ERR_DEVICE;
     if (path) {                       /* the call's arguments beside the scene dump: <dump>.args */
         char name[4096];
         snprintf(name, sizeof(name), "%s.args", path);
@@ -84,6 +94,7 @@ int qsp_pose_optimize(qsp_pose_optimizer* h, int32_t n, const double* K, const d
                       int32_t* n_inliers, qsp_pose_trace* trace) {
     (void)trace;
     if (n > h->cap) return QSP_ERR_INVALID;
+    if (fails("pose")) return QSP_ERR_DEVICE;
     const char* path = getenv("QSP_STUB_DUMP");
     if (path) {
         char name[4096];

@@ -18,21 +18,41 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 MOCK = os.path.join(ROOT, "tests", "shim_mock")
 
 
+_BUILD_CACHE = {}
+
+
+def _cache_dir():
+    """the sanitizer builds take ~10 s each: build every binary once per test session"""
+    import atexit
+    import shutil
+    if "dir" not in _BUILD_CACHE:
+        _BUILD_CACHE["dir"] = tempfile.mkdtemp(prefix="qsp_shim_")
+        atexit.register(shutil.rmtree, _BUILD_CACHE["dir"], True)
+    return _BUILD_CACHE["dir"]
+
+
 def build_driver(tmp, real):
+    key = "real" if real else "stub"
+    if key not in _BUILD_CACHE:
+        _BUILD_CACHE[key] = _build_driver(os.path.join(_cache_dir()), real)
+    return _BUILD_CACHE[key]
+
+
+def _build_driver(tmp, real):
     out = os.path.join(tmp, "shim_driver_real" if real else "shim_driver_stub")
     inc = ["-I" + MOCK, "-I" + os.path.join(ROOT, "include")]
     # the stub build (CPU tests) runs the shim's flattening / write-back code under AddressSanitizer + UBSan: any out-of-bounds
     # index into the map vectors or the flat arrays fails the test.  (Sanitizers are for the CPU build only.)
     san = [] if real else ["-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer", "-g"]
     subprocess.check_call(["g++", "-std=c++17", "-O1"] + san + inc + ["-c", os.path.join(MOCK, "shim_driver.cpp"), "-o",
-                                                                        os.path.join(tmp, "drv.o")])
+                                                                        os.path.join(tmp, "drv_%d.o" % real)])
     if real:
         lib = os.path.join(ROOT, "qsp_slam_amd")
-        subprocess.check_call(["g++", "-o", out, os.path.join(tmp, "drv.o"), "-L" + lib, "-lqsp_hip", "-Wl,-rpath," + lib])
+        subprocess.check_call(["g++", "-o", out, os.path.join(tmp, "drv_%d.o" % real), "-L" + lib, "-lqsp_hip", "-Wl,-rpath," + lib])
     else:
         subprocess.check_call(["gcc", "-std=c11", "-O1"] + san + inc + ["-c", os.path.join(MOCK, "stub_qsp.c"), "-o",
-                                                                          os.path.join(tmp, "stub.o")])
-        subprocess.check_call(["g++"] + san + ["-o", out, os.path.join(tmp, "drv.o"), os.path.join(tmp, "stub.o")])
+                                                                          os.path.join(tmp, "stub_c.o")])
+        subprocess.check_call(["g++"] + san + ["-o", out, os.path.join(tmp, "drv_%d.o" % real), os.path.join(tmp, "stub_c.o")])
     return out
 
 
@@ -345,3 +365,88 @@ def test_pose_optimization_shim_equals_python_binding():
     assert ninl == g["n_inliers"]
     assert np.array_equal(flags[matched], g["outlier"])
     assert np.abs(T - synth.pose7_to_T(g["pose"]).astype(np.float32)).max() < 2e-6
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the drop-in `class Optimizer` (qsp_slam_amd/orbslam/Optimizer_hip.cc, boundary B2 of SURVEY.md section 8b)
+# ---------------------------------------------------------------------------------------------------------------------
+
+def build_dropin(tmp):
+    if "dropin" not in _BUILD_CACHE:
+        _BUILD_CACHE["dropin"] = _build_dropin(_cache_dir())
+    return _BUILD_CACHE["dropin"]
+
+
+def _build_dropin(tmp):
+    """A caller that only knows `Optimizer.h` (tests/shim_mock/dropin/Optimizer.h mirrors the reference's declaration) +
+    Optimizer_hip.cc + stand-ins of the reference's two g2o source files + the recording stub of the C-ABI."""
+    drop = os.path.join(MOCK, "dropin")
+    san = ["-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer", "-g"]
+    inc = ["-I" + drop, "-I" + MOCK, "-I" + os.path.join(ROOT, "include")]
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-DQSP_SHIM_MOCK_TYPES=1"] + san + inc +
+                          ["-c", os.path.join(ROOT, "qsp_slam_amd", "orbslam", "Optimizer_hip.cc"), "-o", os.path.join(tmp, "hip.o")])
+    # the caller sees the reference-shaped header only: no qsp include path, no shim macro
+    subprocess.check_call(["g++", "-std=c++17", "-O1"] + san + ["-I" + drop, "-I" + MOCK, "-c",
+                                                                 os.path.join(drop, "dropin_caller.cpp"), "-o", os.path.join(tmp, "caller.o")])
+    subprocess.check_call(["gcc", "-std=c11", "-O1"] + san + ["-I" + os.path.join(ROOT, "include"), "-c",
+                                                               os.path.join(MOCK, "stub_qsp.c"), "-o", os.path.join(tmp, "stub_c.o")])
+    out = os.path.join(tmp, "dropin_caller")
+    subprocess.check_call(["g++"] + san + ["-o", out, os.path.join(tmp, "caller.o"), os.path.join(tmp, "hip.o"), os.path.join(tmp, "stub_c.o")])
+    return out
+
+
+def _run_dropin(fail=None):
+    m = make_map(seed=21, n_kf=7, n_pt=80, n_obj=2)
+    with tempfile.TemporaryDirectory() as tmp:
+        exe = build_dropin(tmp)
+        write_scene(m, os.path.join(tmp, "scene.bin"))
+        env = dict(os.environ, QSP_G2O_LOG=os.path.join(tmp, "g2o.log"))
+        if fail:
+            env["QSP_STUB_FAIL"] = fail
+        r = subprocess.run([exe, os.path.join(tmp, "scene.bin"), os.path.join(tmp, "out.txt")], env=env, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-3000:]
+        out = dict(l.split(" ", 1) for l in open(os.path.join(tmp, "out.txt")).read().splitlines())
+        log = open(os.path.join(tmp, "g2o.log")).read().splitlines() if os.path.exists(os.path.join(tmp, "g2o.log")) else []
+    return m, out, log, r.stderr
+
+
+def test_dropin_optimizer_class_routes_hot_path_to_the_library_and_loop_closing_to_g2o():
+    """every member of include/Optimizer.h:75-107 exists with the reference's signature; the bundle adjustments and
+    PoseOptimization reach the C-ABI (the stub's visible fake updates arrive in the map), OptimizeSim3 /
+    OptimizeEssentialGraph reach the reference's g2o code (here: its logging stand-in), nBAdone is a static int that counts
+    joint local BAs only, SetGroundPlane / the constructor behave as src/Optimizer.cc:41-44, Optimizer_util.cc:773-776."""
+    m, out, log, err = _run_dropin()
+    assert out["nBAdone0"] == "0" and out["nBAdone1"] == "1" and out["nBAdone2"] == "1"
+    tx = float(m["kfT"][1][0, 3])
+    assert abs(float(out["kf1_tx"]) - (tx + 0.5)) < 1e-4            # local joint BA wrote back through SetPose
+    assert abs(float(out["kf1_tx2"]) - (tx + 1.0)) < 1e-4           # ... and so did the points-only local BA
+    assert out["gba_marks"] == "7"                                  # loop-closing mode parked the result in the *GBA members
+    n_frame = int(out["pose_inliers"].split()[2])      # (the two local BAs erased the flagged match: n_frame - 2 .. n_frame matched)
+    assert int(out["pose_inliers"].split()[0]) in [n - (n + 2) // 3 for n in range(n_frame - 2, n_frame + 1)]
+    assert out["sim3"] == "17 42.0"
+    assert out["ground0"] == "0" and out["ground1"] == "1 -1.0 1.5"
+    assert [l.split()[0] for l in log] == ["g2o:OptimizeSim3", "g2o:OptimizeEssentialGraph"]
+    assert log[0].split()[1:] == ["5", "10"] and log[1].split()[1] == "2"
+    assert "[qsp_hip]" not in err
+
+
+@pytest.mark.parametrize("fail", ["create", "local", "optimize", "pose"])
+def test_dropin_falls_back_to_g2o_when_the_gpu_path_reports_an_error(fail):
+    """a failing qsp_ba_* call must not be silent.  The error is logged, the map is left as found (the BA marks
+    are rolled back so that g2o's own walk finds the same local sets) and the call is handed to the reference's g2o code."""
+    m, out, log, err = _run_dropin(fail)
+    names = [l.split()[0] for l in log]
+    if fail in ("create", "local"):
+        assert "[qsp_hip] qsp_ba_%s" % ("create" if fail == "create" else "local_joint") in err
+        assert names[:2] == ["g2o:LocalJointBundleAdjustment", "g2o:LocalBundleAdjustment"]
+        assert log[0].split()[2] == "1" and log[1].split()[2] == "1"          # marks were clean when g2o started
+        assert out["nBAdone1"] == "1"                                        # counted by the g2o implementation
+        assert abs(float(out["kf1_tx"]) - float(m["kfT"][1][0, 3])) < 1e-6   # the GPU path wrote nothing
+    if fail in ("create", "optimize"):
+        assert "g2o:GlobalJointBundleAdjustemnt" in names and names.count("g2o:GlobalBundleAdjustemnt") == 2
+        assert out["gba_marks"] == "0"
+    if fail == "pose":
+        assert "g2o:PoseOptimization" in names and out["pose_inliers"].split()[0] == "-7"
+    else:
+        assert "g2o:PoseOptimization" not in names
+    assert "g2o:OptimizeSim3" in names
