@@ -7,6 +7,7 @@ the reference's outputs are stored.  The fixtures are data only (inputs + expect
 
     python oracle/gen_golden_sdf.py
 """
+import ast
 import os
 import sys
 
@@ -29,7 +30,7 @@ KITTI = dict(k1=1.0, k2=100.0, k3=0.25, k4=1e7, b1=0.20, b2=0.025, learning_rate
 
 def ref_decoder(dec_mod, path):
     z = np.load(path)
-    meta = eval(str(z["meta"]))
+    meta = ast.literal_eval(str(z["meta"]))
     dec = dec_mod.Decoder(meta["latent_size"], list(meta["dims"]), dropout=list(range(8)), dropout_prob=0.2,
                           norm_layers=list(meta["norm_layers"]), latent_in=list(meta["latent_in"]),
                           weight_norm=meta["weight_norm"], xyz_in_all=meta["xyz_in_all"], use_tanh=meta["use_tanh"],

@@ -10,6 +10,7 @@ those committed outputs (tests/golden/sdf_*.npz).  The reference has no tests or
 
 Every function cites the reference lines it follows (paths relative to the reference root).
 """
+import ast
 import numpy as np
 
 F32 = np.float32
@@ -58,7 +59,7 @@ def fold_state_dict(state, latent_in=(4,), code_len=64):
 
 def load_decoder_npz(path):
     z = np.load(path, allow_pickle=False)
-    meta = eval(str(z["meta"]))  # written by oracle/fit_decoder.py, a literal dict
+    meta = ast.literal_eval(str(z["meta"]))  # written by oracle/fit_decoder.py, a literal dict
     state = {k: z[k] for k in z.files if k != "meta"}
     return fold_state_dict(state, latent_in=meta["latent_in"], code_len=meta["latent_size"])
 

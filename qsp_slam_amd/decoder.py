@@ -1,6 +1,7 @@
 """DeepSDF decoder handle: weight loading (the only place PyTorch is touched, and only to read a checkpoint) and upload
 through qsp_decoder_create.  Reference: deep_sdf/workspace.py:202-224, deep_sdf/deep_sdf_decoder.py:9-72."""
 import ctypes as C
+import ast
 import json
 import os
 
@@ -71,7 +72,10 @@ class DeepSdfDecoder(object):
     @classmethod
     def from_npz(cls, path, device=0):
         z = np.load(path, allow_pickle=False)
-        meta = eval(str(z["meta"]))
+        meta = ast.literal_eval(str(z["meta"]))     # a literal dict; never evaluate file contents as code
+        if not (isinstance(meta, dict) and isinstance(meta.get("latent_size"), int)
+                and all(isinstance(i, int) for i in meta.get("latent_in", ()))):
+            raise ValueError("malformed decoder meta in %s" % path)
         return cls.from_state_dict({k: z[k] for k in z.files if k != "meta"}, latent_in=meta["latent_in"],
                                    code_len=meta["latent_size"], device=device)
 

@@ -8,6 +8,7 @@ the oracle is too slow there (numpy: ~1 hypothesis-iteration per second; C BA or
   B  g2o's index contract on 200 key-frames + 256 objects + 20 000 landmarks (bit-exact), chi2 never increases over
      accepted iterations, invariance to the ORDER in which the caller lists edges (summation order only: 1e-9),
      two-stage outlier pass removes exactly the edges above the chi2 gates it reports."""
+import ast
 import os
 
 import numpy as np
@@ -159,3 +160,57 @@ def test_more_than_1024_hypotheses_in_one_batch(gpu_decoder):
         assert bool(gs[0]) == bool(good[h])
         if good[h]:
             assert np.array_equal(Ts[0], T[h]) and np.array_equal(cs[0], code[h]) and ls[0] == loss[h]
+
+
+def kitti_cfg(n_iter=10):
+    """configs/config_kitti.json:21-41 of the reference: the weights of BASELINE config 5 (k4 = 1e7 rotation prior, 10
+    iterations); the same values the reference-generated fixture sdf_joint_kitti_m250 was produced with."""
+    from qsp_slam_amd.reconstruct.utils import ForceKeyErrorDict
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sdf_joint_kitti_m250.npz"))
+    j = ast.literal_eval(str(z["joint"]))
+    j = dict(j, num_iterations=n_iter)
+    return ForceKeyErrorDict(data_type="KITTI", optimizer=dict(code_len=64, num_depth_samples=50, cut_off_threshold=0.01,
+                                                              joint_optim=j, pose_only_optim=dict(num_iterations=5, learning_rate=1.0)))
+
+
+def test_c5_refinement_full_batch_kitti_weights(gpu_decoder):
+    """BASELINE config 5, path A at full size: 256 objects x 4 yaw flips x 10 Gauss-Newton iterations with the KITTI weights
+    (k4 = 1e7).  The per-object arithmetic is pinned by the reference-generated fixture sdf_joint_kitti_m250; here the FULL
+    batch is tied to it by batch independence (hypotheses inside the 1024-hypothesis batch == the same hypotheses alone, to
+    the bit), determinism, and the keep rule over each object's flips."""
+    from qsp_slam_amd.reconstruct.optimizer import Optimizer, RefineBatch, _joint_cfg
+    w = bench.WORKLOADS["c5"]
+    objs = synth.make_object_views(1000, w["n_obj"], w["n_pts"], n_fg=w["n_fg"], n_bg=w["n_bg"])
+    opt = Optimizer(gpu_decoder, kitti_cfg(w["n_iter"]))
+    assert opt.k4 == 1e7 and opt.num_iterations_joint_optim == 10
+    T0, hyp = bench.flip_states(objs, 4)
+    assert len(hyp) == 1024
+    batch = RefineBatch(gpu_decoder, _joint_cfg(opt), [o["pts"] for o in objs], [o["rays"] for o in objs],
+                        [o["depth"] for o in objs], hyp)
+    batch.set_state(T0, None)
+    batch.run(0)
+    T, code, loss, good = batch.get()
+    batch.set_state(T0, None)
+    batch.run(0)
+    T2, code2, loss2, good2 = batch.get()
+    batch.close()
+    assert np.array_equal(T, T2) and np.array_equal(code, code2) and np.array_equal(loss, loss2) and np.array_equal(good, good2)
+    assert good.sum() >= 0.9 * len(hyp) and np.isfinite(T[good]).all() and np.isfinite(loss[good]).all()
+    for h in (0, 3, 517, 770, 1023):
+        o = objs[hyp[h]]
+        single = RefineBatch(gpu_decoder, _joint_cfg(opt), [o["pts"]], [o["rays"]], [o["depth"]], [0])
+        single.set_state(T0[h:h + 1], None)
+        single.run(0)
+        Ts, cs, ls, gs = single.get()
+        single.close()
+        assert bool(gs[0]) == bool(good[h])
+        if good[h]:
+            assert np.array_equal(Ts[0], T[h]) and np.array_equal(cs[0], code[h]) and ls[0] == loss[h]
+    # the rotation prior keeps the object's y axis on the gravity direction: tilt of the kept hypotheses stays small
+    table = bench.select_flips(T, code, loss, good, w["n_obj"], 4)
+    kept = table[table[:, 81] > 0.5]
+    assert len(kept) >= 0.9 * w["n_obj"]
+    R = kept[:, :16].reshape(-1, 4, 4)[:, :3, :3]
+    s = np.cbrt(np.linalg.det(R.astype(np.float64)))
+    up = (R[:, :, 1] / s[:, None]) @ np.array([0.0, -1.0, 0.0])
+    assert (up > 0.999).mean() > 0.95

@@ -1,6 +1,7 @@
 """Config / decoder loading entry points with the reference's names: reconstruct/utils.py:82-95 (ForceKeyErrorDict,
 get_configs, get_decoder) and deep_sdf/workspace.py:202-224 (config_decoder: specs.json + ModelParameters/latest.pth saved
 from a DataParallel module, "module." prefixes)."""
+import ast
 import json
 import os
 
@@ -28,7 +29,7 @@ def write_experiment(dirname, golden_dir, prefix="module."):
     """an experiment directory in the reference's layout, from the committed decoder fixture"""
     import torch
     z = np.load(os.path.join(golden_dir, "decoder_8x512.npz"), allow_pickle=False)
-    meta = eval(str(z["meta"]))
+    meta = ast.literal_eval(str(z["meta"]))
     os.makedirs(os.path.join(dirname, "ModelParameters"), exist_ok=True)
     specs = {"NetworkArch": "deep_sdf_decoder", "CodeLength": int(meta["latent_size"]),
              "NetworkSpecs": {"dims": [512] * 8, "dropout": list(range(8)), "dropout_prob": 0.2, "norm_layers": list(range(8)),

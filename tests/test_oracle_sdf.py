@@ -1,6 +1,7 @@
 """CPU: the numpy restatement of hot path A (oracle/sdf_oracle.py) against vectors produced by RUNNING the reference
 (oracle/gen_golden_sdf.py, committed under tests/golden/).  Tolerances: the restatement and the reference both compute in
 float32 but sum in different orders; the north_star bar is 1e-4 relative on residuals and pose updates."""
+import ast
 import os
 
 import numpy as np
@@ -31,7 +32,7 @@ def rows_close(a, b, tol=1e-5, max_bad=0.003):
 
 
 def cfg_from(z):
-    j = eval(str(z["joint"]))
+    j = ast.literal_eval(str(z["joint"]))
     return so.JointConfig(k1=j["k1"], k2=j["k2"], k3=j["k3"], k4=j["k4"], b1=j["b1"], b2=j["b2"], lr=j["learning_rate"],
                           s_damp=j["scale_damping"], n_iter=j["num_iterations"])
 
