@@ -13,6 +13,11 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionfinish(session, exitstatus):
+    from tests import margins
+    margins.dump()
+
+
 @pytest.fixture(scope="session", autouse=True)
 def _built_in_tree():
     """The HIP library and the pybind11 module are build products (git-ignored): a clean checkout builds them once here

@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 from oracle import sdf_oracle as so
+from tests.margins import within
 from tests.test_oracle_sdf import JOINT_CASES, cfg_from, relerr, rows_close
 
 pytestmark = pytest.mark.gpu
@@ -65,6 +66,28 @@ def test_decode_empty_is_ok(gpu_decoder):
     assert gpu_decoder.decode_sdf(np.zeros(64, np.float32), np.zeros((0, 3), np.float32)).shape == (0,)
 
 
+# Tolerances = at most 4x the error measured on MI355X (profiles/r02_parity.json, profiles/r02_test_margins.json), never above
+# north_star's 1e-4 except where the table says why:
+#   dx: H and b agree to ~1e-5 (one or two ReLU knife-edge rows in a few thousand, tests/test_oracle_sdf.py:rows_close) and
+#       dx = H^-1 b amplifies that by cond(H) = 30..1e3; the reference's own float32 torch.inverse is NOT the cause (its dx is
+#       within 3e-6 of the float64 solution of its own H, b -- profiles/r02_parity.json records both).
+#   kitti (k4 = 1e7): b carries k4 * J_rot * (1 - cos tilt), a float32 cancellation whose last-bit noise (from the 4x4
+#       inverse that produces R_co: LAPACK in the reference, Gauss-Jordan here) is multiplied by 1e7.
+TEACHER_FORCED_TOL = {
+    "sdf_joint_redwood_m600": dict(H=4e-5, b=4e-5, dx=4e-4, T=2e-5, code=2.5e-5),
+    "sdf_joint_redwood_m2000": dict(H=5e-5, b=6e-5, dx=2e-3, T=4e-5, code=1e-5),
+    "sdf_joint_kitti_m250": dict(H=1e-5, b=1.5e-2, dx=6e-3, T=2.5e-4, code=1e-4),
+    "sdf_joint_code_m500": dict(H=6e-5, b=9e-5, dx=1.5e-4, T=1.5e-5, code=1.5e-5),
+}
+# the free-running 5 / 10 iterations are a chaotic map at float32: x5-8 per iteration
+FREE_RUNNING_TOL = {
+    "sdf_joint_redwood_m600": dict(T=1e-5, code=1.5e-5, loss=2e-5),
+    "sdf_joint_redwood_m2000": dict(T=7.5e-3, code=1.4e-2, loss=1.3e-3),
+    "sdf_joint_kitti_m250": dict(T=3e-4, code=1.4e-3, loss=2e-2),
+    "sdf_joint_code_m500": dict(T=1.5e-2, code=2e-2, loss=1.4e-2),
+}
+
+
 @pytest.mark.parametrize("name", JOINT_CASES)
 def test_every_iteration_teacher_forced_vs_reference(gpu_decoder, golden_dir, name):
     """Same contract as the oracle's test: restart each iteration from the reference's own state."""
@@ -73,7 +96,7 @@ def test_every_iteration_teacher_forced_vs_reference(gpu_decoder, golden_dir, na
     cfg = cfg_from(z)
     opt = Optimizer(gpu_decoder, make_cfg(z))
     batch = RefineBatch(gpu_decoder, _joint_cfg(opt), [z["pts"]], [z["rays"]], [z["depth"]], [0])
-    tol = 1e-4 if cfg.k4 == 0 else 5e-3
+    tol = TEACHER_FORCED_TOL[name]
     n_it = z["it_H"].shape[0]
     for i in range(n_it):
         T_co = np.linalg.inv(z["it_T_oc"][i].astype(np.float64)).astype(np.float32)
@@ -83,13 +106,13 @@ def test_every_iteration_teacher_forced_vs_reference(gpu_decoder, golden_dir, na
         T, code, loss, good = batch.get()
         assert good[0]
         assert int(tr["K"][0]) == int(z["it_K"][i])
-        assert relerr(tr["H"][0], z["it_H"][i]) < tol
-        assert relerr(tr["b"][0], z["it_b"][i]) < tol
-        assert relerr(tr["dx"][0], z["it_dx"][i]) < 20 * tol
+        assert within(name + "/teacher_forced/H", relerr(tr["H"][0], z["it_H"][i]), tol["H"])
+        assert within(name + "/teacher_forced/b", relerr(tr["b"][0], z["it_b"][i]), tol["b"])
+        assert within(name + "/teacher_forced/dx", relerr(tr["dx"][0], z["it_dx"][i]), tol["dx"])
         if i + 1 < n_it:
             T_oc_new = np.linalg.inv(T[0].astype(np.float64))
-            assert relerr(T_oc_new, z["it_T_oc"][i + 1]) < tol
-            assert np.abs(code[0] - z["it_code"][i + 1]).max() < tol
+            assert within(name + "/teacher_forced/T_oc_next", relerr(T_oc_new, z["it_T_oc"][i + 1]), tol["T"])
+            assert within(name + "/teacher_forced/code_next_abs", np.abs(code[0] - z["it_code"][i + 1]).max(), tol["code"])
     batch.close()
 
 
@@ -102,9 +125,10 @@ def test_reconstruct_object_free_running_vs_reference(gpu_decoder, golden_dir, n
     r = opt.reconstruct_object(z["t_cam_obj"], np.asfortranarray(z["pts"]), np.asfortranarray(z["rays"]), z["depth"])
     assert r.is_good == bool(z["is_good"])
     assert r.t_cam_obj.dtype == np.float32 and r.t_cam_obj.shape == (4, 4) and r.code.shape == (64,)
-    assert relerr(r.t_cam_obj, z["out_t_cam_obj"]) < 2e-2
-    assert np.abs(r.code - z["out_code"]).max() < 2e-2
-    assert abs(r.loss - float(z["loss"])) < 5e-2 * abs(float(z["loss"]))
+    tol = FREE_RUNNING_TOL[name]
+    assert within(name + "/free_running/t_cam_obj", relerr(r.t_cam_obj, z["out_t_cam_obj"]), tol["T"])
+    assert within(name + "/free_running/code_abs", np.abs(r.code - z["out_code"]).max(), tol["code"])
+    assert within(name + "/free_running/loss_rel", abs(r.loss - float(z["loss"])) / abs(float(z["loss"])), tol["loss"])
     with pytest.raises(KeyError):
         r["no_such_key"]
 
@@ -123,7 +147,7 @@ def test_pose_only_vs_reference(gpu_decoder, golden_dir):
     opt = Optimizer(gpu_decoder, make_cfg(so.JointConfig()))
     out = opt.estimate_pose_cam_obj(z["t_co_se3"], float(z["scale"]), z["pts"], z["code"])
     assert out.shape == (4, 4) and out.dtype == np.float32
-    assert relerr(out, z["out"]) < 1e-4
+    assert within("sdf_pose_only_m250/t_co", relerr(out, z["out"]), 1e-4)
 
 
 def test_batched_flips_match_single_calls_and_selection_rule(gpu_decoder):
@@ -170,10 +194,11 @@ def test_one_iteration_vs_oracle_other_sizes(gpu_decoder, oracle_decoder, m, n_f
     it = so.gn_iteration(oracle_decoder, cfg, T_oc, np.zeros(64, np.float32), o["pts"], o["rays"], dobs, n_fg)
     assert it["fail"] is None
     assert int(tr["n_valid"][0]) == it["n_valid"] and int(tr["K"][0]) == it["K"]
-    assert relerr(tr["H"][0], it["H"]) < 1e-4
-    assert relerr(tr["b"][0], it["b"]) < 1e-4
-    assert abs(float(tr["loss_sdf"][0]) - it["loss_sdf"]) < 1e-4 * it["loss_sdf"]
-    assert abs(float(tr["loss_render"][0]) - it["loss_render"]) < 1e-4 * it["loss_render"]
+    tag = "one_iteration_vs_oracle/m%d" % m
+    assert within(tag + "/H", relerr(tr["H"][0], it["H"]), 1e-4)
+    assert within(tag + "/b", relerr(tr["b"][0], it["b"]), 1e-4)
+    assert within(tag + "/loss_sdf_rel", abs(float(tr["loss_sdf"][0]) - it["loss_sdf"]) / it["loss_sdf"], 1e-4)
+    assert within(tag + "/loss_render_rel", abs(float(tr["loss_render"][0]) - it["loss_render"]) / it["loss_render"], 1e-4)
     batch.close()
 
 
@@ -220,7 +245,7 @@ def test_pose_only_more_iterations_exercises_the_inlier_filter(gpu_decoder, orac
     ref = so.estimate_pose_cam_obj(oracle_decoder, cfg, T_se3.astype(np.float32), float(s), pts, np.zeros(64, np.float32))
     opt = Optimizer(gpu_decoder, make_cfg(cfg))
     out = opt.estimate_pose_cam_obj(T_se3.astype(np.float32), float(s), pts, np.zeros(64, np.float32))
-    assert relerr(out, ref) < 2e-4
+    assert within("pose_only_8_iterations_vs_oracle/t_co", relerr(out, ref), 2e-4)
     ref5 = so.estimate_pose_cam_obj(oracle_decoder, so.JointConfig(n_iter_pose=5), T_se3.astype(np.float32), float(s), pts,
                                     np.zeros(64, np.float32))
     assert relerr(ref, ref5) > 1e-3                   # the filter really changed the trajectory
@@ -243,9 +268,9 @@ def test_initial_code_is_used_and_truncated_to_code_len(gpu_decoder, oracle_deco
     dobs = np.concatenate([o["depth"], np.zeros(50, np.float32)])
     it = so.gn_iteration(oracle_decoder, cfg, T_oc, code, o["pts"], o["rays"], dobs, 100)
     assert int(tr["K"][0]) == it["K"]
-    assert relerr(tr["H"][0], it["H"]) < 1e-4 and relerr(tr["b"][0], it["b"]) < 1e-4
+    assert within("initial_code/H", relerr(tr["H"][0], it["H"]), 1e-4) and within("initial_code/b", relerr(tr["b"][0], it["b"]), 1e-4)
     _, c1, _, _ = batch.get()
-    assert np.abs(c1[0] - it["code_new"]).max() < 1e-4
+    assert within("initial_code/code_next_abs", np.abs(c1[0] - it["code_new"]).max(), 1e-4)
     batch.close()
 
 
