@@ -273,10 +273,11 @@ int qsp_ba_get_index(qsp_ba_problem* p, int32_t* kf_hidx, int32_t* obj_hidx, int
 int qsp_ba_profile(qsp_ba_problem* p, int enable, qsp_ba_stats* out);
 
 /* Multi-GPU: shard ONE scene's landmarks over `world` ranks (one process per GPU, every rank created from the same scene).
- * Rank r linearises and marginalises the landmarks with pt_id % world == r and the camera-object edges of the objects with
- * obj_id % world == r; the shared camera/object block is combined with ONE sum all-reduce of the reduced system
- * (dimp^2 + dimp doubles) per Levenberg-Marquardt trial, plus three tiny ones (pose blocks after linearisation, chi2 and
- * rho scalars); every rank then solves the reduced system redundantly and updates its own landmarks.  `fn` must sum
+ * Rank r linearises and marginalises the landmarks with pt_id % world == r; the camera-object edges (a few thousand at
+ * most) are linearised by every rank and counted by rank 0; the shared camera block is combined with ONE sum all-reduce of
+ * the reduced system (dimp^2 + dimp doubles, dimp = 6 x free key-frames rounded up to 64) per Levenberg-Marquardt trial,
+ * plus three tiny ones (pose blocks after linearisation, chi2 and rho scalars); every rank then solves the reduced system
+ * redundantly and updates its own landmarks.  `fn` must sum
  * `count` doubles at `device_buf` in place over all ranks and be complete (or ordered on `hip_stream`) when it returns;
  * with torch.distributed this is all_reduce on RCCL ("nccl" backend) over xGMI -- see qsp_slam_amd/parallel.py.
  * The reference has no counterpart (single process). */
@@ -322,6 +323,14 @@ int qsp_comm_allgather_f32(qsp_comm* c, const float* send, float* recv, int64_t 
  * FP64 atomics (run-to-run spread of the final chi2 3e-15 .. 8e-9 relative).  on = 1 forces it
  * (QSP_ERR_UNSUPPORTED when the graph is too large), on = 0 selects the atomic kernels. */
 int qsp_ba_set_deterministic(qsp_ba_problem* p, int on);
+
+/* Solver options.  QSP_BA_OPT_OBJECT_ELIMINATION (default 1): the object vertices -- connected to key-frames only, so their part
+ * of the reduced system is block diagonal -- are eliminated in closed form in front of the dense factorisation, which then
+ * covers the free key-frames only (what the fill-reducing ordering of the reference's sparse LDLT achieves,
+ * Thirdparty/g2o/g2o/solvers/linear_solver_eigen.h:147-201).  0 keeps objects inside the dense system (same solution to
+ * rounding; A/B tests).  Takes effect at the next optimize() call. */
+enum { QSP_BA_OPT_OBJECT_ELIMINATION = 1 };
+int qsp_ba_set_option(qsp_ba_problem* p, int32_t option, int32_t value);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Pose-only optimisation: Optimizer::PoseOptimization(Frame*), src/Optimizer.cc:244-456 --

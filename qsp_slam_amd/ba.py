@@ -87,6 +87,10 @@ class BaProblem(object):
         self._comm = comm                       # keep the communicator alive as long as the problem uses it
         _lib.check(_lib.lib().qsp_ba_set_shard_rccl(self.handle, int(comm.rank), int(comm.world), comm.nccl()))
 
+    def set_object_elimination(self, on=True):
+        """objects eliminated in closed form in front of the dense solve (default) or kept inside it (qsp_ba_set_option)"""
+        _lib.check(_lib.lib().qsp_ba_set_option(self.handle, 1, 1 if on else 0))
+
     def set_deterministic(self, on=True):
         """no atomics in the Schur complement: repeated runs give the same bits (qsp_ba_set_deterministic)"""
         _lib.check(_lib.lib().qsp_ba_set_deterministic(self.handle, 1 if on else 0))

@@ -298,6 +298,8 @@ struct Dev {
     double *Hdiag;                  // per pose block (hessian index) 6x6
     double *Hoff;                   // per object edge 6x6 (row = key-frame, col = object)
     double *oe_rec;                 // per object edge: OE_REC doubles (see k_lin_objedges)
+    double *oe_F;                   // per object edge: F = Hoff (Hoo + lambda I)^-1 (6x6), object elimination (k_obj_prepare)
+    double *obj_G;                  // per object: (Hoo + lambda I)^-1 (36) then (Hoo + lambda I)^-1 b_o (6)
     double *bp, *bs, *xp;           // reduced rhs / solution
     double *Hs;                     // dense reduced matrix, ld = dimp
     double *Hpl;                    // deterministic mode only: materialised 6x3 blocks (k_hpl_fill)
@@ -315,6 +317,8 @@ struct Par {
     int dim, dimp, n_pose;
     int is_root;   // landmark-sharded runs: only rank 0 contributes the (already all-reduced) pose blocks and padding
     int have_hpl;  // d.Hpl holds this build's 6x3 blocks (atomic-free Schur mode)
+    int n_dense;   // pose blocks in the dense reduced system: n_pose, or the free key-frames only when the objects are
+    int elim;      // eliminated first (second Schur complement, see k_obj_prepare)
 };
 
 // block-wide sum of one double per thread (256 threads), fixed tree -> thread 0 holds the result
@@ -363,7 +367,7 @@ __global__ __launch_bounds__(256) void k_errors(Dev d, Par par) {
             c *= d.oe_info;
             d.oe_chi2[k] = c;
             huber(c, par.delta_obj, r0, r1);
-            acc += r0;
+            if (par.is_root) acc += r0;          // camera-object edges are replicated on every rank of a sharded run
         }
     }
     const double s = block_sum_256(acc, sh);
@@ -588,10 +592,11 @@ __global__ __launch_bounds__(64) void k_lin_poses_finish(Dev d, Par par) {
     }
     double a = 0;
     for (int sp = d.ksp_first[kf]; sp < d.ksp_first[kf + 1]; ++sp) a += d.kpart[27 * (size_t)sp + src];
-    for (int q = d.kfo_off[kf]; q < d.kfo_off[kf + 1]; ++q) {
-        const int k = d.kfo_edge[q];
-        if (!d.oe_level[k]) a += d.oe_rec[(size_t)OE_REC * k + roff];
-    }
+    if (par.is_root)       // (sharded runs: the camera-object edges are linearised by every rank, counted by the root)
+        for (int q = d.kfo_off[kf]; q < d.kfo_off[kf + 1]; ++q) {
+            const int k = d.kfo_edge[q];
+            if (!d.oe_level[k]) a += d.oe_rec[(size_t)OE_REC * k + roff];
+        }
     if (t < 36) d.Hdiag[36 * (size_t)h + t] = a;
     else d.bp[6 * h + (t - 36)] = a;
 }
@@ -605,10 +610,11 @@ __global__ __launch_bounds__(64) void k_lin_objects(Dev d, Par par) {
     if (t >= 42) return;
     const int roff = (t < 36) ? 36 + t : 78 + (t - 36);
     double a = 0;
-    for (int q = d.obo_off[ob]; q < d.obo_off[ob + 1]; ++q) {
-        const int k = d.obo_edge[q];
-        if (!d.oe_level[k]) a += d.oe_rec[(size_t)OE_REC * k + roff];
-    }
+    if (par.is_root)
+        for (int q = d.obo_off[ob]; q < d.obo_off[ob + 1]; ++q) {
+            const int k = d.obo_edge[q];
+            if (!d.oe_level[k]) a += d.oe_rec[(size_t)OE_REC * k + roff];
+        }
     if (t < 36) d.Hdiag[36 * (size_t)hj + t] = a;
     else d.bp[6 * hj + (t - 36)] = a;
 }
@@ -638,7 +644,7 @@ __global__ __launch_bounds__(256) void k_maxdiag(Dev d, Par par) {
 __global__ __launch_bounds__(256) void k_schur_prepare(Dev d, Par par) {
     // Hs (dimp x dimp, zeroed by a memset before) <- diagonal blocks + lambda, off-diagonal blocks; identity on the padding
     const int i = blockIdx.x * 256 + threadIdx.x;
-    const int nd = par.n_pose * 36;
+    const int nd = par.n_dense * 36;
     if (i < nd) {
         if (par.is_root) {
             const int h = i / 36, r = (i % 36) / 6, c = i % 6;
@@ -648,9 +654,15 @@ __global__ __launch_bounds__(256) void k_schur_prepare(Dev d, Par par) {
         }
     } else if (i < nd + d.n_oe * 36) {
         const int k = (i - nd) / 36, r = ((i - nd) % 36) / 6, c = (i - nd) % 6;
-        if (!d.oe_level[k]) {
+        if (!d.oe_level[k] && !par.elim && par.is_root) {
             const int hi = d.kf_h[d.oe_kf[k]], hj = d.obj_h[d.oe_obj[k]];
-            if (hi >= 0 && hj >= 0) d.Hs[(size_t)(6 * hi + r) * par.dimp + 6 * hj + c] = d.Hoff[36 * (size_t)k + 6 * r + c];
+            // only the upper block triangle of Hs is read: an object that precedes the key-frame in the hessian order
+            // (possible with a caller's own vertex ids, never with the reference's) gets the transposed block
+            if (hi >= 0 && hj >= 0) {
+                const double v = d.Hoff[36 * (size_t)k + 6 * r + c];
+                if (hi < hj) d.Hs[(size_t)(6 * hi + r) * par.dimp + 6 * hj + c] = v;
+                else d.Hs[(size_t)(6 * hj + c) * par.dimp + 6 * hi + r] = v;
+            }
         }
     } else if (i < nd + d.n_oe * 36 + (par.dimp - par.dim)) {
         const int q = par.dim + (i - nd - d.n_oe * 36);
@@ -918,6 +930,153 @@ __global__ __launch_bounds__(64) void k_schur_rhs(Dev d, Par par) {
         for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
         if (lane == r) d.bs[6 * ha + r] -= v;
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Object elimination: a second Schur complement in front of the dense solve.  In g2o's graph an object vertex is a
+// non-marginalised 6-DoF pose that is connected to key-frames only (EdgeSE3LieAlgebra, src/Optimizer_util.cc:548-584), never
+// to another object or to a landmark: the object part of the reduced system is BLOCK DIAGONAL.  Eliminating it in closed
+// form -- exactly what the fill-reducing ordering of the reference's sparse LDLT does implicitly
+// (linear_solver_eigen.h:147-201) -- leaves a dense system over the free key-frames only (C4: 704 -> 320 unknowns, C5:
+// 2752 -> 1216 after padding; the factorisation's serial pivot chain shrinks by the same factor):
+//     G_o = (H_oo + lambda I)^-1,   F_e = H_ko G_o  for every edge e = (k, o)
+//     Hs_kk' -= F_e H_k'o^T  (e = (k,o), e' = (k',o)),   bs_k -= F_e b_o,   x_o = G_o b_o - sum_e F_e^T x_k.
+// Same solution as the joint factorisation to rounding (~1e-12 relative).  Used when every free key-frame precedes every
+// object in the hessian order (always so with the reference's vertex ids); otherwise the objects stay in the dense system.
+//   k_obj_prepare  one wave per object: lane 0 inverts the damped 6x6 block (Cholesky), lanes 0..35 form F_e per edge;
+//   k_obj_rows     one wave per free key-frame: its row block of the update is accumulated in LDS in a fixed order (the
+//                  key-frame's edges in list order, per object its edges in list order) and subtracted from Hs once:
+//                  single writer per entry, no atomics, bit-reproducible;
+//   k_obj_backsub  one wave per object, after the dense solve.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ inline bool inv6_spd(const double* A, double* G) {
+    // Cholesky A = L L^T, then G = L^-T L^-1; A symmetric (only its upper triangle is read)
+    double L[36], W[36];
+    bool ok = true;
+    for (int i = 0; i < 36; ++i) { L[i] = 0; W[i] = 0; }
+    for (int j = 0; j < 6; ++j) {
+        double dd = A[6 * j + j];
+        for (int q = 0; q < j; ++q) dd -= L[6 * j + q] * L[6 * j + q];
+        if (!(dd > 0) || !isfinite(dd)) { ok = false; dd = 1.0; }
+        const double r = 1.0 / sqrt(dd);
+        L[6 * j + j] = dd * r;
+        for (int i = j + 1; i < 6; ++i) {
+            double v = A[6 * j + i];
+            for (int q = 0; q < j; ++q) v -= L[6 * i + q] * L[6 * j + q];
+            L[6 * i + j] = v * r;
+        }
+    }
+    for (int c = 0; c < 6; ++c)            // W = L^-1 (lower), column by column
+        for (int i = c; i < 6; ++i) {
+            double v = (i == c) ? 1.0 : 0.0;
+            for (int q = c; q < i; ++q) v -= L[6 * i + q] * W[6 * q + c];
+            W[6 * i + c] = v / L[6 * i + i];
+        }
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 6; ++j) {
+            double v = 0;
+            for (int q = (i > j ? i : j); q < 6; ++q) v += W[6 * q + i] * W[6 * q + j];
+            G[6 * i + j] = v;
+        }
+    return ok;
+}
+
+__global__ __launch_bounds__(64) void k_obj_prepare(Dev d, Par par) {
+    const int ob = blockIdx.x, lane = threadIdx.x;
+    const int ho = d.obj_h[ob];
+    if (ho < 0) return;
+    __shared__ double G[42];
+    double* out = d.obj_G + 42 * (size_t)ob;
+    if (lane == 0) {
+        double A[36];
+        for (int i = 0; i < 36; ++i) A[i] = d.Hdiag[36 * (size_t)ho + i];
+        for (int i = 0; i < 6; ++i) A[7 * i] += par.lambda;
+        if (!inv6_spd(A, G)) d.scal[3] = 1.0;
+        for (int i = 0; i < 6; ++i) {
+            double v = 0;
+            for (int j = 0; j < 6; ++j) v += G[6 * i + j] * d.bp[6 * ho + j];
+            G[36 + i] = v;
+        }
+    }
+    __syncthreads();
+    if (lane < 42) out[lane] = G[lane];
+    if (lane < 36) {
+        const int r = lane / 6, c = lane % 6;
+        for (int q = d.obo_off[ob]; q < d.obo_off[ob + 1]; ++q) {
+            const int k = d.obo_edge[q];
+            if (d.oe_level[k]) continue;
+            const double* E = d.Hoff + 36 * (size_t)k;          // H_ko, zero when the key-frame is fixed
+            double v = 0;
+#pragma unroll
+            for (int m = 0; m < 6; ++m) v += E[6 * r + m] * G[6 * m + c];
+            d.oe_F[36 * (size_t)k + lane] = v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void k_obj_rows(Dev d, Par par) {
+    extern __shared__ __attribute__((aligned(16))) double orow[];     // [6][dimp] row block
+    const int kf = blockIdx.x, lane = threadIdx.x;
+    const int ha = d.kf_h[kf];
+    if (ha < 0 || !par.is_root) return;
+    const int dimp = par.dimp;
+    int n_live = 0;
+    for (int q = d.kfo_off[kf]; q < d.kfo_off[kf + 1]; ++q) n_live += d.oe_level[d.kfo_edge[q]] ? 0 : 1;
+    if (n_live == 0) return;
+    for (int i = lane; i < 6 * dimp; i += 64) orow[i] = 0.0;
+    __syncthreads();
+    const int r = lane / 6, c = lane % 6;
+    double rhs = 0;
+    for (int q = d.kfo_off[kf]; q < d.kfo_off[kf + 1]; ++q) {
+        const int e = d.kfo_edge[q];
+        if (d.oe_level[e]) continue;
+        const int ob = d.oe_obj[e];
+        const int ho = d.obj_h[ob];
+        if (ho < 0) continue;
+        double Fr[6];                                             // row r of F_e
+#pragma unroll
+        for (int m = 0; m < 6; ++m) Fr[m] = (lane < 36) ? d.oe_F[36 * (size_t)e + 6 * r + m] : 0.0;
+        if (lane < 36 && c == 0) {
+#pragma unroll
+            for (int m = 0; m < 6; ++m) rhs += Fr[m] * d.bp[6 * ho + m];
+        }
+        for (int q2 = d.obo_off[ob]; q2 < d.obo_off[ob + 1]; ++q2) {
+            const int e2 = d.obo_edge[q2];
+            if (d.oe_level[e2]) continue;
+            const int hb = d.kf_h[d.oe_kf[e2]];
+            if (hb < ha) continue;                                // upper block triangle only (fixed key-frames: hb = -1)
+            if (lane < 36) {
+                const double* E2 = d.Hoff + 36 * (size_t)e2;      // H_k'o: entry (r,c) of F_e H_k'o^T = sum_m F[r][m] E2[c][m]
+                double v = 0;
+#pragma unroll
+                for (int m = 0; m < 6; ++m) v += Fr[m] * E2[6 * c + m];
+                orow[r * dimp + 6 * hb + c] += v;                 // one lane per entry, program order: reproducible
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = lane; i < 6 * dimp; i += 64) {
+        const double v = orow[i];
+        if (v != 0.0) d.Hs[(size_t)(6 * ha + i / dimp) * dimp + i % dimp] -= v;
+    }
+    if (lane < 36 && c == 0) d.bs[6 * ha + r] -= rhs;
+}
+
+__global__ __launch_bounds__(64) void k_obj_backsub(Dev d, Par par) {
+    const int ob = blockIdx.x, lane = threadIdx.x;
+    const int ho = d.obj_h[ob];
+    if (ho < 0 || lane >= 6) return;
+    double x = d.obj_G[42 * (size_t)ob + 36 + lane];
+    for (int q = d.obo_off[ob]; q < d.obo_off[ob + 1]; ++q) {
+        const int e = d.obo_edge[q];
+        if (d.oe_level[e]) continue;
+        const int hk = d.kf_h[d.oe_kf[e]];
+        if (hk < 0) continue;
+        const double* F = d.oe_F + 36 * (size_t)e;
+#pragma unroll
+        for (int m = 0; m < 6; ++m) x -= F[6 * m + lane] * d.xp[6 * hk + m];
+    }
+    d.xp[6 * ho + lane] = x;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1526,7 +1685,10 @@ struct qsp_ba_problem {
     std::vector<int64_t> kf_id_h, pt_id_h, obj_id_h;
     std::vector<int32_t> mono_pos, st_pos;   // user index -> landmark-major position
     std::vector<int32_t> kf_h, obj_h, pt_h;
-    int n_pose = 0, n_land = 0, dim = 0, dimp = 0, dimp_max = 0;
+    int n_pose = 0, n_land = 0, dim = 0, dimp = 0, dimp_max = 0;   // dim / dimp: the DENSE reduced system (padded to NB)
+    int n_dense = 0, dim_all = 0;      // pose blocks in the dense system; 6 * n_pose
+    bool elim = false;                 // objects eliminated in front of the dense solve (k_obj_*)
+    bool elim_allowed = true;          // qsp_ba_set_option(QSP_BA_OPT_OBJECT_ELIMINATION)
     int n_partial = 0;
     // LM state that persists inside one optimize call only
     qsp_ba_stats prof{};
@@ -1767,6 +1929,8 @@ extern "C" int qsp_ba_create(const qsp_ba_scene* s, int device, qsp_ba_problem**
     AL(Hdiag, 36 * (size_t)(d.n_kf + d.n_obj));
     AL(Hoff, 36 * (size_t)d.n_oe);
     AL(oe_rec, 84 * (size_t)d.n_oe);
+    AL(oe_F, 36 * (size_t)d.n_oe);
+    AL(obj_G, 42 * (size_t)d.n_obj);
     AL(bp, p->dimp_max); AL(bs, p->dimp_max); AL(xp, p->dimp_max);
     AL(Hs, (size_t)p->dimp_max * p->dimp_max + p->dimp_max);   // + room for bs right behind the matrix
     AL(Uf, (size_t)p->dimp_max * p->dimp_max); AL(Winv, (size_t)p->dimp_max * NB); AL(ych, p->dimp_max);
@@ -1785,6 +1949,7 @@ extern "C" int qsp_ba_create(const qsp_ba_scene* s, int device, qsp_ba_problem**
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_chol_first, hipFuncAttributeMaxDynamicSharedMemorySize, chol_lds);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_chol_step, hipFuncAttributeMaxDynamicSharedMemorySize, chol_lds);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_schur_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCHUR_ROW_LDS_MAX);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_obj_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCHUR_ROW_LDS_MAX);
         if (e != hipSuccess) rc = qsp_fail(QSP_ERR_DEVICE, hipGetErrorString(e));
     }
     if (rc) {
@@ -1867,7 +2032,15 @@ static void build_index(qsp_ba_problem* p) {
     std::sort(v.begin(), v.end());
     for (size_t k = 0; k < v.size(); ++k) p->pt_h[v[k].second] = (int)k;
     p->n_land = (int)v.size();
-    p->dim = 6 * p->n_pose;
+    // object elimination (k_obj_*): possible when every free key-frame precedes every object in the hessian order
+    int n_kfree = 0, max_kf_h = -1, n_obj_act = 0;
+    for (int i = 0; i < d.n_kf; ++i)
+        if (p->kf_h[i] >= 0) { ++n_kfree; max_kf_h = std::max(max_kf_h, p->kf_h[i]); }
+    for (int i = 0; i < d.n_obj; ++i) n_obj_act += p->obj_h[i] >= 0;
+    p->elim = p->elim_allowed && n_obj_act > 0 && n_kfree > 0 && max_kf_h == n_kfree - 1;
+    p->n_dense = p->elim ? n_kfree : p->n_pose;
+    p->dim_all = 6 * p->n_pose;
+    p->dim = 6 * p->n_dense;
     p->dimp = ((p->dim + NB - 1) / NB) * NB;
 }
 
@@ -1927,7 +2100,8 @@ static int set_shard_common(qsp_ba_problem* p, int32_t rank, int32_t world) {
     p->oe_foreign.assign(std::max(d.n_oe, 1), 0);
     if (world > 1) {
         for (int e = 0; e < d.n_edge; ++e) p->edge_foreign[e] = (p->pt_id_h[p->edge_h[e].pt] % world) != rank;
-        for (int e = 0; e < d.n_oe; ++e) p->oe_foreign[e] = (p->obj_id_h[p->oe_obj_h[e]] % world) != rank;
+        // the camera-object edges (n_obj x ~10, a few thousand at most) are NOT sharded: every rank linearises all of them
+        // and holds the blocks the object elimination / back-substitution needs; only rank 0 counts their sums
         std::vector<uint8_t> ptf(std::max(d.n_pt, 1), 0);
         for (int i = 0; i < d.n_pt; ++i) ptf[i] = (p->pt_id_h[i] % world) != rank;
         const size_t need = std::max<size_t>((size_t)36 * (d.n_kf + d.n_obj) + p->dimp_max + 64,
@@ -2001,7 +2175,7 @@ extern "C" int qsp_ba_optimize(qsp_ba_problem* p, int32_t n_iter, double delta_m
     if (d.n_obj) QSP_HIP(hipMemcpyAsync(d.obj_h, p->obj_h.data(), sizeof(int32_t) * d.n_obj, hipMemcpyHostToDevice, s));
     if (d.n_pt) QSP_HIP(hipMemcpyAsync(d.pt_h, p->pt_h.data(), sizeof(int32_t) * d.n_pt, hipMemcpyHostToDevice, s));
     Par par{delta_mono, delta_stereo, delta_obj, 0.0, p->dim, p->dimp, p->n_pose, p->rank == 0 ? 1 : 0,
-            (p->deterministic && p->dimp > 0) ? 1 : 0};
+            (p->deterministic && p->dimp > 0) ? 1 : 0, p->n_dense, p->elim ? 1 : 0};
     if (tr) { tr->n = 0; tr->result = 0; tr->n_pose_blocks = p->n_pose; tr->n_landmarks = p->n_land; }
     hipEvent_t ev0 = nullptr, ev1 = nullptr, evA = nullptr, evB = nullptr;
     if (p->profiling) {
@@ -2027,7 +2201,7 @@ extern "C" int qsp_ba_optimize(qsp_ba_problem* p, int32_t n_iter, double delta_m
         hipLaunchKernelGGL(k_lin_poses_finish, dim3(d.n_kf), dim3(64), 0, s, d, par);
         if (d.n_obj) hipLaunchKernelGGL(k_lin_objects, dim3(d.n_obj), dim3(64), 0, s, d, par);
         if (p->profiling) (void)hipEventRecord(evB, s);
-        int rc = allreduce_gather(p, d.Hdiag, (size_t)36 * p->n_pose, d.bp, (size_t)p->dim, d.scal, 1);   // pose blocks, b_p, chi2
+        int rc = allreduce_gather(p, d.Hdiag, (size_t)36 * p->n_pose, d.bp, (size_t)p->dim_all, d.scal, 1);   // pose blocks, b_p, chi2
         if (rc) return rc;
         if (it == 0) {
             QSP_HIP(hipMemsetAsync(d.scal + 2, 0, sizeof(double), s));
@@ -2071,7 +2245,7 @@ extern "C" int qsp_ba_optimize(qsp_ba_problem* p, int32_t n_iter, double delta_m
             QSP_HIP(hipMemsetAsync(d.scal + 3, 0, sizeof(double), s));
             if (p->dimp > 0) {
                 QSP_HIP(hipMemsetAsync(d.Hs, 0, sizeof(double) * (size_t)p->dimp * p->dimp, s));
-                const int nprep = p->n_pose * 36 + d.n_oe * 36 + (p->dimp - p->dim);
+                const int nprep = p->n_dense * 36 + d.n_oe * 36 + (p->dimp - p->dim);
                 hipLaunchKernelGGL(k_schur_prepare, dim3((std::max(nprep, p->dimp) + 255) / 256), dim3(256), 0, s, d, par);
                 const size_t row_lds = sizeof(double) * ((size_t)6 * p->dimp + 6);
                 // block rows pay off once the per-landmark kernel's global atomics collide or scatter (measured: C5 435 ->
@@ -2087,6 +2261,10 @@ extern "C" int qsp_ba_optimize(qsp_ba_problem* p, int32_t n_iter, double delta_m
                 } else if (d.n_pt) {
                     hipLaunchKernelGGL(k_schur_points, dim3((d.n_pt + 3) / 4), dim3(256), 0, s, d, par);
                 }
+                if (p->elim) {
+                    hipLaunchKernelGGL(k_obj_prepare, dim3(d.n_obj), dim3(64), 0, s, d, par);
+                    hipLaunchKernelGGL(k_obj_rows, dim3(d.n_kf), dim3(64), sizeof(double) * (size_t)6 * p->dimp, s, d, par);
+                }
                 rc = allreduce(p, d.Hs, (int64_t)p->dimp * p->dimp + p->dimp);     // reduced matrix + right-hand side
                 if (rc) return rc;
                 const int nb = p->dimp / NB;
@@ -2097,6 +2275,7 @@ extern "C" int qsp_ba_optimize(qsp_ba_problem* p, int32_t n_iter, double delta_m
                                        d.ych, p->dimp, k, d.scal);
                 for (int k = nb - 1; k >= 0; --k)
                     hipLaunchKernelGGL(k_chol_backstep, dim3(k > 0 ? k : 1), dim3(256), 0, s, d.Uf, d.Winv, d.ych, d.xp, p->dimp, k);
+                if (p->elim) hipLaunchKernelGGL(k_obj_backsub, dim3(d.n_obj), dim3(64), 0, s, d, par);
             } else if (d.n_pt) {
                 hipLaunchKernelGGL(k_schur_dinv, dim3((d.n_pt + 255) / 256), dim3(256), 0, s, d, par);   // only D^-1 is needed
             }
@@ -2180,7 +2359,7 @@ extern "C" int qsp_ba_get_edges(qsp_ba_problem* p, double* mono_chi2, double* st
     if (p->world > 1) {
         hipLaunchKernelGGL(k_mask_foreign_chi2, dim3((std::max(std::max(d.n_edge, d.n_oe), 1) + 255) / 256), dim3(256), 0, p->stream, d,
                            p->d_edge_foreign, p->d_oe_foreign);
-        int rc = allreduce_gather(p, d.edge_chi2, (size_t)d.n_edge, d.oe_chi2, (size_t)d.n_oe, nullptr, 0);
+        int rc = allreduce_gather(p, d.edge_chi2, (size_t)d.n_edge, nullptr, 0, nullptr, 0);   // (object edges: replicated)
         if (rc) return rc;
         QSP_HIP(hipStreamSynchronize(p->stream));
     }
@@ -2326,6 +2505,14 @@ extern "C" int qsp_pose_optimize(qsp_pose_optimizer* h, int32_t n, const double*
 // ---------------------------------------------------------------------------------------------------------------
 // deterministic mode
 // ---------------------------------------------------------------------------------------------------------------
+extern "C" int qsp_ba_set_option(qsp_ba_problem* p, int32_t option, int32_t value) {
+    if (!p) return qsp_fail(QSP_ERR_INVALID, "qsp_ba_set_option: null problem");
+    switch (option) {
+        case QSP_BA_OPT_OBJECT_ELIMINATION: p->elim_allowed = value != 0; return QSP_OK;
+        default: return qsp_fail(QSP_ERR_INVALID, "qsp_ba_set_option: unknown option");
+    }
+}
+
 extern "C" int qsp_ba_set_deterministic(qsp_ba_problem* p, int on) {
     if (!p) return qsp_fail(QSP_ERR_INVALID, "qsp_ba_set_deterministic: null problem");
     QSP_HIP(hipSetDevice(p->device));

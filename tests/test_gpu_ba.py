@@ -335,3 +335,50 @@ def test_atomic_schur_kernels_match_oracle(name):
     rkf, rpt, rob = ref.state()
     assert close(kf, rkf, rtol=1e-7, atol=1e-9) and close(pt, rpt, rtol=1e-7, atol=1e-9)
     gpu.close()
+
+
+@pytest.mark.parametrize("name", ["c2", "two_fixed", "tiny"])
+def test_object_elimination_equals_joint_factorisation(name):
+    """the second Schur complement over the (block-diagonal) object part == objects inside the dense system: same LM path,
+    chi2 / estimates to rounding, and bit-reproducible; both against the oracle"""
+    from qsp_slam_amd.ba import BaProblem
+    sc = synth.make_ba_scene(**SCENES[name])
+    ref = bo.BaProblem(sc)
+    r1, r2 = ref.local_joint_ba()
+    runs = []
+    for elim in (True, True, False):
+        g = BaProblem(sc)
+        g.set_object_elimination(elim)
+        t1, t2 = g.local_joint_ba()
+        runs.append((t1, t2, g.state()))
+        g.close()
+    (a1, a2, sa), (b1, b2, sb), (c1, c2, sc_) = runs
+    assert np.array_equal(a2["chi2"], b2["chi2"]) and all(np.array_equal(x, y) for x, y in zip(sa, sb))     # reproducible
+    assert a1["n_pose_blocks"] == c1["n_pose_blocks"]
+    for t, u in ((a1, c1), (a2, c2)):
+        assert list(t["trials"]) == list(u["trials"]) and list(t["accepted"]) == list(u["accepted"])
+        assert close(t["chi2"], u["chi2"], rtol=1e-8 if name != "tiny" else 1e-6)
+    tol = 1e-7 if name != "tiny" else 1e-5
+    for x, y in zip(sa, sc_):
+        assert close(x, y, rtol=tol, atol=1e-9)
+    for x, y in zip(sa, ref.state()):
+        assert close(x, y, rtol=tol, atol=1e-9)
+    assert close(a2["chi2"], r2["chi2"], rtol=1e-8 if name != "tiny" else 1e-6)
+
+
+def test_objects_with_smaller_vertex_ids_than_keyframes_stay_in_the_dense_system():
+    """the elimination needs every free key-frame in front of every object in g2o's hessian order; a caller with another id
+    scheme gets the joint factorisation and the same answer as the oracle"""
+    from qsp_slam_amd.ba import BaProblem
+    sc = dict(synth.make_ba_scene(seed=71, n_kf=6, n_pt=120, n_obj=2))
+    sc["obj_id"] = np.array([2, 4], np.int64)            # interleaved with the key-frame ids 0..5
+    sc["kf_id"] = np.array([0, 1, 3, 5, 6, 7], np.int64)
+    ref, gpu = bo.BaProblem(sc), BaProblem(sc)
+    r1, r2 = ref.local_joint_ba()
+    g1, g2 = gpu.local_joint_ba()
+    kh, oh, ph = gpu.index()
+    assert np.array_equal(kh, r2["kf_hidx"]) and np.array_equal(oh, r2["obj_hidx"]) and oh.min() < kh.max()
+    assert list(g2["trials"]) == list(r2["trials"]) and close(g2["chi2"], r2["chi2"], rtol=1e-8)
+    for x, y in zip(gpu.state(), ref.state()):
+        assert close(x, y, rtol=1e-7, atol=1e-9)
+    gpu.close()

@@ -9,6 +9,8 @@ reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 w = bench.WORKLOADS[name]
 scene = synth.make_ba_scene(2000, w["n_kf"], w["n_map"], w["n_obj"], stereo_frac=0.2)
 ba = BaProblem(scene); ba.profile(True)
+if os.environ.get("QSP_BA_ELIM") == "0":
+    ba.set_object_elimination(False)   # objects inside the dense system (round-1 behaviour)
 if os.environ.get("QSP_BA_DET") == "0":
     ba.set_deterministic(False)        # the atomic kernels
 for r in range(reps):
