@@ -306,6 +306,10 @@ struct Dev {
     int32_t *pk_ka, *pk_kb, *pk_off; // deterministic mode: key-frame pairs with common landmarks, CSR into pk_ent
     int4* pk_ent;                    //   (edge in ka, edge in kb, landmark, 0) per common landmark, in landmark order
     int32_t n_pk;
+    int32_t* pk_work;                // pair ids: the n_pk_big pairs with long lists first (a workgroup each), then the rest
+    int32_t n_pk_big;                //   (a wave each, four to a workgroup)
+    int32_t* pko_off;                // per pair: CSR into pko_ent, the common OBJECTS of the pair (object elimination)
+    int4* pko_ent;                   //   (object edge at ka, object edge at kb, object, 0), in object order
     double *Uf, *Winv, *ych;        // Cholesky: off-diagonal factor blocks, inverse diagonal factors (transposed), L^-1 b
     double *partial;                // block partials for reductions
     double *scal;                   // [0] chi2, [1] scale, [2] maxdiag, [3] chol fail flag (as double)
@@ -839,37 +843,36 @@ __global__ __launch_bounds__(256) void k_schur_rows(Dev d, Par par) {
 
 // ---------------------------------------------------------------------------------------------------------------
 // Deterministic Schur complement (qsp_ba_set_deterministic): no atomics, every sum in a fixed order.
-//   k_hpl_fill    materialises the 6x3 blocks once per build (edge-parallel);
+//   k_trial_stage1 materialises the 6x3 blocks once per trial (edge-parallel), with everything else that is independent;
 //   k_schur_pairs one wave per pair of key-frames that share landmarks (list built on the host, in landmark order):
 //                 lane (i,j) accumulates entry (i,j) of  sum_l B_a D_l^-1 B_b^T  and is the only writer of that entry;
-//   k_schur_rhs   one wave per key-frame: sum over its edges of B_a D^-1 b_l.
+//                 the diagonal pair (ka, ka) also carries the right-hand side sum over the key-frame's edges of B_a D^-1 b_l.
 // Costs one sort-free pass over sum_l k_l (k_l+1)/2 pairs on the host at creation and 144 B per edge of extra storage;
 // meant for reproducible runs and for the parity tests, not for the largest graphs.
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_hpl_fill(Dev d, Par par) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= d.n_edge) return;
-    double B[18];
-    if (d.edge_level[e]) {
-        for (int i = 0; i < 18; ++i) B[i] = 0.0;
-    } else {
-        edge_hpl(d, d.edge[e], par, B);
-    }
-    for (int i = 0; i < 18; ++i) d.Hpl[18 * (size_t)e + i] = B[i];
-}
-
-__global__ __launch_bounds__(64) void k_schur_pairs(Dev d, Par par) {
-    // lane = list entry (strided by 64): every lane accumulates the whole 6x6 of its entries, then a fixed butterfly over
-    // the lanes adds the 64 partial blocks -- the loads of 64 entries are in flight together and the order of every
-    // addition depends on list positions only
-    const int q = blockIdx.x, lane = threadIdx.x;
-    const int ha = d.kf_h[d.pk_ka[q]], hb = d.kf_h[d.pk_kb[q]];
-    if (ha < 0 || hb < 0) return;
-    double acc[36];
+__global__ __launch_bounds__(256) void k_schur_pairs(Dev d, Par par) {
+    // one workgroup per pair of key-frames (ka <= kb by scene index) that share landmarks or objects.  thread = list entry
+    // (strided by 256): every thread accumulates the whole 6x6 of its entries, then a fixed butterfly over the lanes and a
+    // fixed-order sum over the four waves -- the loads of 256 entries are in flight together and the order of every addition
+    // depends on list positions only.  The diagonal pair (ka, ka) lists every edge of the key-frame once, so it also carries
+    // the right-hand side  sum_l B_a D^-1 b_l  (and  sum_o F_e b_o  of the object elimination).
+    __shared__ double sh[4][42];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    // long lists (the diagonal pairs: every edge of a key-frame) get the whole workgroup, short ones a wave each
+    const bool big = (int)blockIdx.x < d.n_pk_big;
+    const int slot = big ? (int)blockIdx.x : d.n_pk_big + ((int)blockIdx.x - d.n_pk_big) * 4 + wave;
+    if (slot >= d.n_pk) return;                           // (only in the last block of short pairs: no barrier there)
+    const int q = d.pk_work[slot];
+    const int tid = big ? t : lane, stride = big ? 256 : 64;
+    const int ka = d.pk_ka[q], kb = d.pk_kb[q];
+    const int ha = d.kf_h[ka], hb = d.kf_h[kb];
+    if (ha < 0 || hb < 0) return;                         // (uniform per pair: a big pair leaves with all four waves)
+    const bool diag = ka == kb;
+    double acc[42];
 #pragma unroll
-    for (int i = 0; i < 36; ++i) acc[i] = 0.0;
-    for (int t = d.pk_off[q] + lane; t < d.pk_off[q + 1]; t += 64) {
-        const int4 en = d.pk_ent[t];                      // edge in ka, edge in kb, landmark
+    for (int i = 0; i < 42; ++i) acc[i] = 0.0;
+    for (int u = d.pk_off[q] + tid; u < d.pk_off[q + 1]; u += stride) {
+        const int4 en = d.pk_ent[u];                      // edge in ka, edge in kb, landmark
         if (d.edge_level[en.x] || d.edge_level[en.y] || d.pt_h[en.z] < 0) continue;
         double Ba[18], Bb[18], Di[9];
         const double* pa = d.Hpl + 18 * (size_t)en.x;
@@ -887,48 +890,72 @@ __global__ __launch_bounds__(64) void k_schur_pairs(Dev d, Par par) {
 #pragma unroll
             for (int j = 0; j < 6; ++j) acc[6 * i + j] += bd0 * Bb[3 * j] + bd1 * Bb[3 * j + 1] + bd2 * Bb[3 * j + 2];
         }
+        if (diag) {                                       // (diagonal lists hold (a, a, l) entries only)
+            const double* db = d.xl + 3 * (size_t)en.z;
+            const double d0 = db[0], d1 = db[1], d2 = db[2];
+#pragma unroll
+            for (int r = 0; r < 6; ++r) acc[36 + r] += Ba[3 * r] * d0 + Ba[3 * r + 1] * d1 + Ba[3 * r + 2] * d2;
+        }
+    }
+    if (par.elim && par.is_root) {
+        for (int u = d.pko_off[q] + tid; u < d.pko_off[q + 1]; u += stride) {
+            const int4 en = d.pko_ent[u];                 // object edge at ka, object edge at kb, object
+            if (d.oe_level[en.x] || d.oe_level[en.y]) continue;
+            const int ho = d.obj_h[en.z];
+            if (ho < 0) continue;
+            const double* F = d.oe_F + 36 * (size_t)en.x;     // F_e = H_ko (H_oo + lambda I)^-1
+            const double* E = d.Hoff + 36 * (size_t)en.y;     // H_k'o
+            double Fr[36], Er[36];
+#pragma unroll
+            for (int i = 0; i < 36; ++i) { Fr[i] = F[i]; Er[i] = E[i]; }
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    double v = 0;
+#pragma unroll
+                    for (int m = 0; m < 6; ++m) v += Fr[6 * i + m] * Er[6 * j + m];
+                    acc[6 * i + j] += v;
+                }
+            if (diag && en.x == en.y) {
+#pragma unroll
+                for (int r = 0; r < 6; ++r) {
+                    double v = 0;
+#pragma unroll
+                    for (int m = 0; m < 6; ++m) v += Fr[6 * r + m] * d.bp[6 * ho + m];
+                    acc[36 + r] += v;
+                }
+            }
+        }
     }
 #pragma unroll
-    for (int i = 0; i < 36; ++i) {
+    for (int i = 0; i < 42; ++i) {
         double v = acc[i];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
         acc[i] = v;
     }
+    if (big) {
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 42; ++i) sh[wave][i] = acc[i];
+        }
+        __syncthreads();
+        if (wave != 0) return;
+    }
     // T = sum B_a D^-1 B_b^T belongs at (ha, hb); only the upper block triangle of Hs is used: transpose if ha > hb
-    if (lane < 36) {
-        const int i = lane / 6, j = lane % 6;
+    if (lane < 42) {
         double v = 0;
 #pragma unroll
-        for (int e = 0; e < 36; ++e) v = (e == lane) ? acc[e] : v;
-        if (ha <= hb) d.Hs[(size_t)(6 * ha + i) * par.dimp + 6 * hb + j] -= v;
-        else d.Hs[(size_t)(6 * hb + j) * par.dimp + 6 * ha + i] -= v;
-    }
-}
-
-__global__ __launch_bounds__(64) void k_schur_rhs(Dev d, Par par) {
-    // lane = edge of the key-frame (strided by 64), then a fixed butterfly over the lanes, as in k_schur_pairs
-    const int kf = blockIdx.x, lane = threadIdx.x;
-    const int ha = d.kf_h[kf];
-    if (ha < 0) return;
-    double acc[6] = {0, 0, 0, 0, 0, 0};
-    for (int q = d.kf_off[kf] + lane; q < d.kf_off[kf + 1]; q += 64) {
-        const int a = d.kf_edge[q];
-        if (d.edge_level[a]) continue;
-        const int pt = d.edge[a].pt;
-        if (d.pt_h[pt] < 0) continue;
-        const double* Ba = d.Hpl + 18 * (size_t)a;
-        const double* db = d.xl + 3 * (size_t)pt;
-        const double d0 = db[0], d1 = db[1], d2 = db[2];
-#pragma unroll
-        for (int r = 0; r < 6; ++r) acc[r] += Ba[3 * r] * d0 + Ba[3 * r + 1] * d1 + Ba[3 * r + 2] * d2;
-    }
-#pragma unroll
-    for (int r = 0; r < 6; ++r) {
-        double v = acc[r];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-        if (lane == r) d.bs[6 * ha + r] -= v;
+        for (int e = 0; e < 42; ++e) v = (e == lane) ? acc[e] : v;
+        if (big) v = (sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]);
+        if (lane < 36) {
+            const int i = lane / 6, j = lane % 6;
+            if (ha <= hb) d.Hs[(size_t)(6 * ha + i) * par.dimp + 6 * hb + j] -= v;
+            else d.Hs[(size_t)(6 * hb + j) * par.dimp + 6 * ha + i] -= v;
+        } else if (diag) {
+            d.bs[6 * ha + (lane - 36)] -= v;
+        }
     }
 }
 
@@ -947,7 +974,9 @@ __global__ __launch_bounds__(64) void k_schur_rhs(Dev d, Par par) {
 //   k_obj_rows     one wave per free key-frame: its row block of the update is accumulated in LDS in a fixed order (the
 //                  key-frame's edges in list order, per object its edges in list order) and subtracted from Hs once:
 //                  single writer per entry, no atomics, bit-reproducible;
-//   k_obj_backsub  one wave per object, after the dense solve.
+//   the back-substitution of the objects is the tail of k_chol_back.
+// In the atomic-free mode k_obj_prepare is a block range of k_trial_stage1 and k_obj_rows is replaced by object entries in the
+// key-frame pair lists (k_schur_pairs).
 // ---------------------------------------------------------------------------------------------------------------
 __device__ inline bool inv6_spd(const double* A, double* G) {
     // Cholesky A = L L^T, then G = L^-T L^-1; A symmetric (only its upper triangle is read)
@@ -1062,21 +1091,111 @@ __global__ __launch_bounds__(64) void k_obj_rows(Dev d, Par par) {
     if (lane < 36 && c == 0) d.bs[6 * ha + r] -= rhs;
 }
 
-__global__ __launch_bounds__(64) void k_obj_backsub(Dev d, Par par) {
-    const int ob = blockIdx.x, lane = threadIdx.x;
-    const int ho = d.obj_h[ob];
-    if (ho < 0 || lane >= 6) return;
-    double x = d.obj_G[42 * (size_t)ob + 36 + lane];
-    for (int q = d.obo_off[ob]; q < d.obo_off[ob + 1]; ++q) {
-        const int e = d.obo_edge[q];
-        if (d.oe_level[e]) continue;
-        const int hk = d.kf_h[d.oe_kf[e]];
-        if (hk < 0) continue;
-        const double* F = d.oe_F + 36 * (size_t)e;
-#pragma unroll
-        for (int m = 0; m < 6; ++m) x -= F[6 * m + lane] * d.xp[6 * hk + m];
+// ---------------------------------------------------------------------------------------------------------------
+// Everything a Levenberg-Marquardt trial needs before the pair kernel, in ONE launch (the pieces are independent of each
+// other; at the BASELINE sizes each of them is a few microseconds of work behind a launch):
+//   blocks [0, nb_hs)            Hs <- 0, diagonal blocks + lambda, identity on the padding; bs <- b_p   (was: memset + prepare)
+//   blocks [.., + nb_pt)         D^-1 and D^-1 b_l per landmark                                          (k_schur_dinv)
+//   blocks [.., + nb_edge)       the 6x3 blocks of this linearisation                                    (k_hpl_fill)
+//   blocks [.., + nb_obj)        (H_oo + lambda I)^-1 and F_e per object                                  (k_obj_prepare)
+//   blocks [.., + nb_bk)         backup of the estimates (g2o's push(), sparse_optimizer.cpp:519-527)     (was: 3 copies)
+// ---------------------------------------------------------------------------------------------------------------
+struct Stage1 { int nb_hs, nb_pt, nb_edge, nb_obj, nb_bk; };
+
+__global__ __launch_bounds__(256) void k_trial_stage1(Dev d, Par par, Stage1 g) {
+    __shared__ double G[4][42];
+    int b = blockIdx.x;
+    const int t = threadIdx.x;
+    if (b < g.nb_hs) {
+        const size_t n = (size_t)par.dimp * par.dimp;
+        const size_t idx = (size_t)b * 256 + t;
+        if (idx < n) {
+            const int row = (int)(idx / par.dimp), col = (int)(idx % par.dimp);
+            double v = 0.0;
+            if (par.is_root) {
+                if (row < par.dim && col < par.dim) {
+                    if (row / 6 == col / 6) {
+                        v = d.Hdiag[36 * (size_t)(row / 6) + 6 * (row % 6) + col % 6];
+                        if (row == col) v += par.lambda;
+                    }
+                } else if (row == col) {
+                    v = 1.0;
+                }
+            }
+            d.Hs[idx] = v;
+        } else if (idx < n + par.dimp) {
+            const int i = (int)(idx - n);
+            d.bs[i] = (i < par.dim && par.is_root) ? d.bp[i] : 0.0;
+        }
+        return;
     }
-    d.xp[6 * ho + lane] = x;
+    b -= g.nb_hs;
+    if (b < g.nb_pt) {
+        const int pt = b * 256 + t;
+        if (pt >= d.n_pt || d.pt_h[pt] < 0) return;
+        double Dm[9], Di[9];
+        for (int i = 0; i < 9; ++i) Dm[i] = d.Hll[9 * (size_t)pt + i];
+        Dm[0] += par.lambda; Dm[4] += par.lambda; Dm[8] += par.lambda;
+        inv3(Dm, Di);
+        const double* bl = d.bl + 3 * (size_t)pt;
+        for (int i = 0; i < 9; ++i) d.Dinv[9 * (size_t)pt + i] = Di[i];
+        for (int i = 0; i < 3; ++i) d.xl[3 * (size_t)pt + i] = Di[3 * i] * bl[0] + Di[3 * i + 1] * bl[1] + Di[3 * i + 2] * bl[2];
+        return;
+    }
+    b -= g.nb_pt;
+    if (b < g.nb_edge) {
+        const int e = b * 256 + t;
+        if (e >= d.n_edge) return;
+        double B[18];
+        if (d.edge_level[e]) {
+            for (int i = 0; i < 18; ++i) B[i] = 0.0;
+        } else {
+            edge_hpl(d, d.edge[e], par, B);
+        }
+        for (int i = 0; i < 18; ++i) d.Hpl[18 * (size_t)e + i] = B[i];
+        return;
+    }
+    b -= g.nb_edge;
+    if (b < g.nb_obj) {                                   // one wave per object (block-uniform branch: barriers are safe)
+        const int wave = t >> 6, lane = t & 63;
+        const int ob = b * 4 + wave;
+        const int ho = (ob < d.n_obj) ? d.obj_h[ob] : -1;
+        if (ho >= 0 && lane == 0) {
+            double A[36];
+            for (int i = 0; i < 36; ++i) A[i] = d.Hdiag[36 * (size_t)ho + i];
+            for (int i = 0; i < 6; ++i) A[7 * i] += par.lambda;
+            if (!inv6_spd(A, G[wave])) d.scal[3] = 1.0;
+            for (int i = 0; i < 6; ++i) {
+                double v = 0;
+                for (int j = 0; j < 6; ++j) v += G[wave][6 * i + j] * d.bp[6 * ho + j];
+                G[wave][36 + i] = v;
+            }
+        }
+        __syncthreads();
+        if (ho < 0) return;
+        if (lane < 42) d.obj_G[42 * (size_t)ob + lane] = G[wave][lane];
+        if (lane < 36) {
+            const int r = lane / 6, c = lane % 6;
+            for (int q = d.obo_off[ob]; q < d.obo_off[ob + 1]; ++q) {
+                const int k = d.obo_edge[q];
+                if (d.oe_level[k]) continue;
+                const double* E = d.Hoff + 36 * (size_t)k;
+                double v = 0;
+#pragma unroll
+                for (int m = 0; m < 6; ++m) v += E[6 * r + m] * G[wave][6 * m + c];
+                d.oe_F[36 * (size_t)k + lane] = v;
+            }
+        }
+        return;
+    }
+    b -= g.nb_obj;
+    {
+        const int i = b * 256 + t;
+        const int nk = 7 * d.n_kf, no = 7 * d.n_obj, np = 3 * d.n_pt;
+        if (i < nk) d.kf_bk[i] = d.kf_pose[i];
+        else if (i < nk + no) d.obj_bk[i - nk] = d.obj_pose[i - nk];
+        else if (i < nk + no + np) d.pt_bk[i - nk - no] = d.pt_xyz[i - nk - no];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1235,6 +1354,11 @@ __global__ __launch_bounds__(256) void k_chol_step(double* A, double* Uf, double
     double* bvec = rowbuf + CHOL_ROWBUF;
     const int t = threadIdx.x, r0 = (t >> 4) * 4, c0 = (t & 15) * 4;
     const double* Wg = Winv + (size_t)k * NB * NB;
+    double S[4][4];                                       // the tile this thread updates: in flight behind the panel loads
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) S[a][q] = A[(size_t)(i * NB + r0 + a) * ld + j * NB + c0 + q];
     for (int e = t; e < NB * NB; e += 256) {
         X[e] = Wg[e];
         Yi[e] = A[(size_t)(k * NB + e / NB) * ld + i * NB + e % NB];
@@ -1255,14 +1379,19 @@ __global__ __launch_bounds__(256) void k_chol_step(double* A, double* Uf, double
     __syncthreads();
     double acc[4][4] = {};
     gemm_tn64(Yi, Yj, r0, c0, acc);
-    double S[4][4];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) S[a][q] = A[(size_t)(i * NB + r0 + a) * ld + j * NB + c0 + q] - acc[a][q];
+        for (int q = 0; q < 4; ++q) S[a][q] -= acc[a][q];
     const bool first_row = (i == k + 1);
     if (first_row) {
-        for (int e = t; e < NB * NB; e += 256) Uf[(size_t)(k * NB + e / NB) * ld + j * NB + e % NB] = Yj[e];
+        // factor block U_kj = P_j (64 x 64) is stored TRANSPOSED, element (m, c) at Uf[(j NB + c) ld + k NB + m]: the backward
+        // substitution walks it by rows m with a lane per row.  Straight from the registers (4 consecutive m per store group).
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+                Uf[(size_t)(j * NB + c0 + q) * ld + k * NB + r0 + a] = (i == j) ? pi[a][q] : pj[a][q];
         if (t < NB) {
             double v = b[j * NB + t];
             for (int q = 0; q < NB; ++q) v -= Yj[q * NB + t] * y[k * NB + q];
@@ -1281,45 +1410,68 @@ __global__ __launch_bounds__(256) void k_chol_step(double* A, double* Uf, double
     }
 }
 
-// backward substitution, one launch per block step k = nb-1 .. 0 with k workgroups (1 for k = 0): every workgroup forms
-// x_k = W_k^T y_k itself (64x64 matrix-vector product), workgroup m < k then takes U_mk x_k off y_m.
-__global__ __launch_bounds__(256) void k_chol_backstep(const double* __restrict__ Uf, const double* __restrict__ Winv,
-                                                       double* y, double* x, int n, int k) {
-    __shared__ double yk[NB], xk[NB];
-    const int t = threadIdx.x, wave = t >> 6, lane = t & 63, m = blockIdx.x;
-    if (t < NB) yk[t] = y[k * NB + t];
+// backward substitution x_k = W_k^T (y_k - sum_{j>k} U_kj x_j), k = nb-1 .. 0, in ONE launch of ONE workgroup of 512
+// threads (8 waves): y lives in LDS; at step j the waves form x_j = W_j^T y_j (8 rows each), then wave w takes the blocks
+// k = w, w+8, ... < j and subtracts U_kj x_j from y_k with a lane per row (the factor is stored transposed, so a wave-load
+// is 64 consecutive doubles; all 64 loads of a block are in flight at once -- the blocks come from other XCDs' kernels, i.e.
+// from the Infinity Cache at ~2 us a round trip).  Afterwards the same workgroup back-substitutes the eliminated objects (k_obj_backsub).
+// The 2 nb workgroup barriers replace nb launches of ~10 us each.
+__global__ __launch_bounds__(512) void k_chol_back(Dev d, Par par, const double* __restrict__ Uf, const double* __restrict__ Winv,
+                                                   const double* __restrict__ y, double* x, int n) {
+    extern __shared__ __attribute__((aligned(16))) double ysh[];       // [n] y, then [NB] x_j
+    double* xj = ysh + n;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int nb = n / NB;
+    for (int i = t; i < n; i += 512) ysh[i] = y[i];
     __syncthreads();
-    const double* WT = Winv + (size_t)k * NB * NB;     // WT[r][q] = W[q][r];  x[r] = sum_q W[q][r] y[q]
-    double v[NB / 4];
+    for (int j = nb - 1; j >= 0; --j) {
+        {                                                 // x_j[r] = sum_q W_j[q][r] y_j[q];  Winv holds WT[r][q] = W[q][r]
+            const double* WT = Winv + (size_t)j * NB * NB;
+            const double yq = ysh[j * NB + lane];
 #pragma unroll
-    for (int q = 0; q < NB / 4; ++q) v[q] = WT[(wave + 4 * q) * NB + lane];          // all 16 loads in flight together
-    if (m < k) {
-        double u[NB / 4];
+            for (int i = 0; i < NB / 8; ++i) {
+                const int r = wave + 8 * i;
+                double v = WT[r * NB + lane] * yq;
 #pragma unroll
-        for (int q = 0; q < NB / 4; ++q) u[q] = Uf[(size_t)(m * NB + wave + 4 * q) * n + k * NB + lane];
-#pragma unroll
-        for (int q = 0; q < NB / 4; ++q) {
-            double w = v[q] * yk[lane];
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) w += __shfl_xor(w, o, 64);
-            if (lane == 0) xk[wave + 4 * q] = w;
+                for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+                if (lane == 0) { xj[r] = v; x[j * NB + r] = v; }
+            }
         }
         __syncthreads();
-        if (m == 0 && t < NB) x[k * NB + t] = xk[t];
+        for (int k = wave; k < j; k += 8) {
+            const double* U = Uf + (size_t)(j * NB) * n + k * NB;      // element (m, c) at U[c * n + m]
+            double u[NB];
 #pragma unroll
-        for (int q = 0; q < NB / 4; ++q) {
-            double w = u[q] * xk[lane];
+            for (int c = 0; c < NB; ++c) u[c] = U[(size_t)c * n + lane];
+            double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) w += __shfl_xor(w, o, 64);
-            if (lane == 0) y[m * NB + wave + 4 * q] -= w;
+            for (int c = 0; c < NB; c += 4) {
+                a0 += u[c + 0] * xj[c + 0];
+                a1 += u[c + 1] * xj[c + 1];
+                a2 += u[c + 2] * xj[c + 2];
+                a3 += u[c + 3] * xj[c + 3];
+            }
+            ysh[k * NB + lane] -= (a0 + a1) + (a2 + a3);
         }
-    } else {   // k == 0: only x_0 is left
+        __syncthreads();
+    }
+    if (par.elim) {                                       // x_o = G_o b_o - sum_e F_e^T x_k  (the dense x is complete in global memory)
+        __threadfence_block();
+        for (int i = t; i < 6 * d.n_obj; i += 512) {
+            const int ob = i / 6, c = i % 6;
+            const int ho = d.obj_h[ob];
+            if (ho < 0) continue;
+            double v = d.obj_G[42 * (size_t)ob + 36 + c];
+            for (int q = d.obo_off[ob]; q < d.obo_off[ob + 1]; ++q) {
+                const int e = d.obo_edge[q];
+                if (d.oe_level[e]) continue;
+                const int hk = d.kf_h[d.oe_kf[e]];
+                if (hk < 0) continue;
+                const double* F = d.oe_F + 36 * (size_t)e;
 #pragma unroll
-        for (int q = 0; q < NB / 4; ++q) {
-            double w = v[q] * yk[lane];
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) w += __shfl_xor(w, o, 64);
-            if (lane == 0) x[k * NB + wave + 4 * q] = w;
+                for (int m = 0; m < 6; ++m) v -= F[6 * m + c] * x[6 * hk + m];
+            }
+            x[6 * ho + c] = v;
         }
     }
 }
@@ -1339,7 +1491,7 @@ __global__ __launch_bounds__(256) void k_update_points(Dev d, Par par) {
             const int ha = d.kf_h[d.edge[a].kf];
             if (ha < 0) continue;
             double B[18];
-            if (par.have_hpl) {                      // atomic-free mode keeps the blocks of this build (k_hpl_fill)
+            if (par.have_hpl) {                      // atomic-free mode keeps the blocks of this build (k_trial_stage1)
                 const double* Bg = d.Hpl + 18 * (size_t)a;
                 for (int i = 0; i < 18; ++i) B[i] = Bg[i];
             } else {
@@ -1770,7 +1922,7 @@ static int build_pair_lists(qsp_ba_problem* p) {
         const int nk = d.n_kf;
         const std::vector<Edge>& E = p->edge_h;
         const std::vector<int32_t>& off = p->pt_off_h;
-        std::vector<int64_t> cnt((size_t)nk * nk + 1, 0);
+        std::vector<int64_t> cnt((size_t)nk * nk, 0), cnto((size_t)nk * nk, 0);
         auto for_pairs = [&](auto&& fn) {
             for (int l = 0; l < d.n_pt; ++l)
                 for (int a = off[l]; a < off[l + 1]; ++a)
@@ -1781,25 +1933,53 @@ static int build_pair_lists(qsp_ba_problem* p) {
                         else fn(kb, ka, b, a);
                     }
         };
-        for_pairs([&](int ka, int kb, int, int) { cnt[(size_t)ka * nk + kb + 1]++; });
-        std::vector<int32_t> pk_ka, pk_kb, pk_off(1, 0);
-        std::vector<int64_t> start((size_t)nk * nk, -1);
-        int64_t tot = 0;
+        // pairs of key-frames that observe a common OBJECT (object elimination): per object every ordered choice of two of
+        // its edges whose key-frames satisfy ka <= kb, the edge with itself included
+        std::vector<std::vector<int32_t>> obj_edges(d.n_obj);
+        for (int e = 0; e < d.n_oe; ++e) obj_edges[p->oe_obj_h[e]].push_back(e);
+        auto for_obj_pairs = [&](auto&& fn) {
+            for (int o = 0; o < d.n_obj; ++o)
+                for (int32_t e : obj_edges[o])
+                    for (int32_t e2 : obj_edges[o]) {
+                        const int ka = p->oe_kf_h[e], kb = p->oe_kf_h[e2];
+                        if (ka < kb || (ka == kb && e <= e2)) fn(ka, kb, e, e2, o);
+                        if (ka == kb && e < e2) fn(ka, kb, e2, e, o);     // both orders land in the same diagonal block
+                    }
+        };
+        for_pairs([&](int ka, int kb, int, int) { cnt[(size_t)ka * nk + kb]++; });
+        for_obj_pairs([&](int ka, int kb, int, int, int) { cnto[(size_t)ka * nk + kb]++; });
+        std::vector<int32_t> pk_ka, pk_kb, pk_off(1, 0), pko_off(1, 0);
+        std::vector<int64_t> start((size_t)nk * nk, -1), starto((size_t)nk * nk, -1);
+        int64_t tot = 0, toto = 0;
         for (int ka = 0; ka < nk; ++ka)
             for (int kb = ka; kb < nk; ++kb) {
-                const int64_t c = cnt[(size_t)ka * nk + kb + 1];
-                if (!c) continue;
+                const int64_t c = cnt[(size_t)ka * nk + kb], co = cnto[(size_t)ka * nk + kb];
+                if (!c && !co) continue;
                 start[(size_t)ka * nk + kb] = tot;
+                starto[(size_t)ka * nk + kb] = toto;
                 tot += c;
-                pk_ka.push_back(ka); pk_kb.push_back(kb); pk_off.push_back((int32_t)tot);
+                toto += co;
+                pk_ka.push_back(ka); pk_kb.push_back(kb);
+                pk_off.push_back((int32_t)tot); pko_off.push_back((int32_t)toto);
             }
-        std::vector<int4> ent((size_t)std::max<int64_t>(tot, 1));
+        std::vector<int4> ent((size_t)std::max<int64_t>(tot, 1)), ento((size_t)std::max<int64_t>(toto, 1));
         for_pairs([&](int ka, int kb, int a, int b) { ent[(size_t)start[(size_t)ka * nk + kb]++] = make_int4(a, b, E[a].pt, 0); });
+        for_obj_pairs([&](int ka, int kb, int e, int e2, int o) { ento[(size_t)starto[(size_t)ka * nk + kb]++] = make_int4(e, e2, o, 0); });
         d.n_pk = (int32_t)pk_ka.size();
+        std::vector<int32_t> work, small;
+        for (int q = 0; q < d.n_pk; ++q) {
+            const int len = (pk_off[q + 1] - pk_off[q]) + (pko_off[q + 1] - pko_off[q]);
+            (len > 192 ? work : small).push_back(q);
+        }
+        d.n_pk_big = (int32_t)work.size();
+        work.insert(work.end(), small.begin(), small.end());
         int rc = dupload(p, &d.pk_ka, pk_ka.data(), pk_ka.size());
+        if (!rc) rc = dupload(p, &d.pk_work, work.data(), work.size());
         if (!rc) rc = dupload(p, &d.pk_kb, pk_kb.data(), pk_kb.size());
         if (!rc) rc = dupload(p, &d.pk_off, pk_off.data(), pk_off.size());
         if (!rc) rc = dupload(p, &d.pk_ent, ent.data(), ent.size());
+        if (!rc) rc = dupload(p, &d.pko_off, pko_off.data(), pko_off.size());
+        if (!rc) rc = dupload(p, &d.pko_ent, ento.data(), ento.size());
         if (!rc) rc = dalloc(p, &d.Hpl, 18 * (size_t)std::max(d.n_edge, 1));
         if (rc) return rc;
     }
@@ -2185,13 +2365,15 @@ extern "C" int qsp_ba_optimize(qsp_ba_problem* p, int32_t n_iter, double delta_m
     }
     const int gp = std::max(1, std::min(p->n_partial, (d.n_pt + 255) / 256));
     d.bs = d.Hs + (size_t)p->dimp * p->dimp;      // right behind the reduced matrix: one all-reduce covers both
-    double lambda = 0, ni = 2;
+    double lambda = 0, ni = 2, currentChi = 0;
     int nBad = 0, done = 0, result = 0;
     double sc[4];
     for (int it = 0; it < n_iter; ++it) {
         if (stop_flag && *stop_flag) { result = 2; break; }
-        // computeActiveErrors + chi2
-        launch_errors(p, par);
+        // computeActiveErrors + chi2 (sparse_optimizer.cpp:61-114).  After the first iteration the state is the one the last
+        // accepted trial was evaluated on -- the same kernel on the same numbers -- so its chi2 is carried over instead of
+        // being recomputed and read back (an iteration never starts after a rejected trial: that ends the call).
+        if (it == 0) launch_errors(p, par);
         // buildSystem
         if (p->profiling) (void)hipEventRecord(evA, s);
         // (every entry of Hdiag and bp that is read is written by k_lin_poses_finish / k_lin_objects: no memsets)
@@ -2201,69 +2383,81 @@ extern "C" int qsp_ba_optimize(qsp_ba_problem* p, int32_t n_iter, double delta_m
         hipLaunchKernelGGL(k_lin_poses_finish, dim3(d.n_kf), dim3(64), 0, s, d, par);
         if (d.n_obj) hipLaunchKernelGGL(k_lin_objects, dim3(d.n_obj), dim3(64), 0, s, d, par);
         if (p->profiling) (void)hipEventRecord(evB, s);
-        int rc = allreduce_gather(p, d.Hdiag, (size_t)36 * p->n_pose, d.bp, (size_t)p->dim_all, d.scal, 1);   // pose blocks, b_p, chi2
+        int rc = allreduce_gather(p, d.Hdiag, (size_t)36 * p->n_pose, d.bp, (size_t)p->dim_all, d.scal, it == 0 ? 1 : 0);   // pose blocks, b_p, chi2
         if (rc) return rc;
         if (it == 0) {
             QSP_HIP(hipMemsetAsync(d.scal + 2, 0, sizeof(double), s));
             const int gm = std::max(1, std::min(256, (d.n_pt * 3 + p->n_pose * 6 + 255) / 256));
             hipLaunchKernelGGL(k_maxdiag, dim3(gm), dim3(256), 0, s, d, par);
-        }
-        if (it == 0 && p->world > 1 && p->nccl) {   // max over ranks of the local maxima
-            ncclResult_t r = rccl_api()->all_reduce(d.scal + 2, d.scal + 2, 1, ncclDouble, ncclMax, p->nccl, s);
-            if (r != ncclSuccess) return rccl_fail(r, "ncclAllReduce(max)");
-        }
-        rc = read_scal(p, sc);
-        if (rc) return rc;
-        if (it == 0 && p->world > 1 && !p->nccl) {   // callback hook (SUM only): max as a SUM over one-hot slots
-            std::vector<double> slots(p->world, 0.0);
-            slots[p->rank] = sc[2];
-            QSP_HIP(hipMemcpyAsync(p->comm, slots.data(), 8 * p->world, hipMemcpyHostToDevice, s));
-            rc = allreduce(p, p->comm, p->world);
+            if (p->world > 1 && p->nccl) {   // max over ranks of the local maxima
+                ncclResult_t r = rccl_api()->all_reduce(d.scal + 2, d.scal + 2, 1, ncclDouble, ncclMax, p->nccl, s);
+                if (r != ncclSuccess) return rccl_fail(r, "ncclAllReduce(max)");
+            }
+            rc = read_scal(p, sc);
             if (rc) return rc;
-            QSP_HIP(hipMemcpyAsync(slots.data(), p->comm, 8 * p->world, hipMemcpyDeviceToHost, s));
-            QSP_HIP(hipStreamSynchronize(s));
-            for (double v : slots) sc[2] = std::max(sc[2], v);
+            if (p->world > 1 && !p->nccl) {   // callback hook (SUM only): max as a SUM over one-hot slots
+                std::vector<double> slots(p->world, 0.0);
+                slots[p->rank] = sc[2];
+                QSP_HIP(hipMemcpyAsync(p->comm, slots.data(), 8 * p->world, hipMemcpyHostToDevice, s));
+                rc = allreduce(p, p->comm, p->world);
+                if (rc) return rc;
+                QSP_HIP(hipMemcpyAsync(slots.data(), p->comm, 8 * p->world, hipMemcpyDeviceToHost, s));
+                QSP_HIP(hipStreamSynchronize(s));
+                for (double v : slots) sc[2] = std::max(sc[2], v);
+            }
+            currentChi = sc[0];
         }
         if (p->profiling) {
             float ms = 0;
+            (void)hipEventSynchronize(evB);      // (profiling only: iterations after the first have no read-back to wait on)
             (void)hipEventElapsedTime(&ms, evA, evB);
             p->prof.ms_linearize += ms;
             p->prof.n_linearize++;
         }
-        double currentChi = sc[0];
         const double iniChi = currentChi;
         if (it == 0) { lambda = 1e-5 * sc[2]; ni = 2; nBad = 0; }
         double rho = 0;
         int qmax = 0, accepted = 0;
         do {
             par.lambda = lambda;
-            // push
-            QSP_HIP(hipMemcpyAsync(d.kf_bk, d.kf_pose, sizeof(double) * 7 * d.n_kf, hipMemcpyDeviceToDevice, s));
-            if (d.n_obj) QSP_HIP(hipMemcpyAsync(d.obj_bk, d.obj_pose, sizeof(double) * 7 * d.n_obj, hipMemcpyDeviceToDevice, s));
-            if (d.n_pt) QSP_HIP(hipMemcpyAsync(d.pt_bk, d.pt_xyz, sizeof(double) * 3 * d.n_pt, hipMemcpyDeviceToDevice, s));
-            // solve
             QSP_HIP(hipMemsetAsync(d.scal + 3, 0, sizeof(double), s));
+            const bool fused = p->deterministic && p->dimp > 0 && d.n_pk > 0;
+            if (!fused) {   // push (g2o: sparse_optimizer.cpp:519-527); the fused path backs up inside k_trial_stage1
+                QSP_HIP(hipMemcpyAsync(d.kf_bk, d.kf_pose, sizeof(double) * 7 * d.n_kf, hipMemcpyDeviceToDevice, s));
+                if (d.n_obj) QSP_HIP(hipMemcpyAsync(d.obj_bk, d.obj_pose, sizeof(double) * 7 * d.n_obj, hipMemcpyDeviceToDevice, s));
+                if (d.n_pt) QSP_HIP(hipMemcpyAsync(d.pt_bk, d.pt_xyz, sizeof(double) * 3 * d.n_pt, hipMemcpyDeviceToDevice, s));
+            }
+            // solve
             if (p->dimp > 0) {
-                QSP_HIP(hipMemsetAsync(d.Hs, 0, sizeof(double) * (size_t)p->dimp * p->dimp, s));
                 const int nprep = p->n_dense * 36 + d.n_oe * 36 + (p->dimp - p->dim);
-                hipLaunchKernelGGL(k_schur_prepare, dim3((std::max(nprep, p->dimp) + 255) / 256), dim3(256), 0, s, d, par);
                 const size_t row_lds = sizeof(double) * ((size_t)6 * p->dimp + 6);
-                // block rows pay off once the per-landmark kernel's global atomics collide or scatter (measured: C5 435 ->
-                // 157 us, 2 M edges 5.4 -> 0.8 ms); below ~64 k edges both are latency-bound and the single launch wins
-                if (d.n_pt && p->deterministic) {
-                    hipLaunchKernelGGL(k_schur_dinv, dim3((d.n_pt + 255) / 256), dim3(256), 0, s, d, par);
-                    hipLaunchKernelGGL(k_hpl_fill, dim3((d.n_edge + 255) / 256), dim3(256), 0, s, d, par);
-                    if (d.n_pk) hipLaunchKernelGGL(k_schur_pairs, dim3(d.n_pk), dim3(64), 0, s, d, par);
-                    hipLaunchKernelGGL(k_schur_rhs, dim3(d.n_kf), dim3(64), 0, s, d, par);
-                } else if (d.n_pt && row_lds <= SCHUR_ROW_LDS_MAX && d.n_ksplit && d.n_edge >= SCHUR_ROWS_MIN_EDGES) {
-                    hipLaunchKernelGGL(k_schur_dinv, dim3((d.n_pt + 255) / 256), dim3(256), 0, s, d, par);
-                    hipLaunchKernelGGL(k_schur_rows, dim3(d.n_ksplit), dim3(256), row_lds, s, d, par);
-                } else if (d.n_pt) {
-                    hipLaunchKernelGGL(k_schur_points, dim3((d.n_pt + 3) / 4), dim3(256), 0, s, d, par);
-                }
-                if (p->elim) {
-                    hipLaunchKernelGGL(k_obj_prepare, dim3(d.n_obj), dim3(64), 0, s, d, par);
-                    hipLaunchKernelGGL(k_obj_rows, dim3(d.n_kf), dim3(64), sizeof(double) * (size_t)6 * p->dimp, s, d, par);
+                if (fused) {
+                    // atomic-free path, two launches: everything that is independent, then one workgroup per key-frame pair
+                    Stage1 g;
+                    g.nb_hs = (int)(((size_t)p->dimp * p->dimp + p->dimp + 255) / 256);
+                    g.nb_pt = (d.n_pt + 255) / 256;
+                    g.nb_edge = (d.n_edge + 255) / 256;
+                    g.nb_obj = p->elim ? (d.n_obj + 3) / 4 : 0;
+                    g.nb_bk = (7 * d.n_kf + 7 * d.n_obj + 3 * d.n_pt + 255) / 256;
+                    hipLaunchKernelGGL(k_trial_stage1, dim3(g.nb_hs + g.nb_pt + g.nb_edge + g.nb_obj + g.nb_bk), dim3(256), 0, s, d, par, g);
+                    if (!p->elim && d.n_oe)     // objects inside the dense system: their off-diagonal blocks
+                        hipLaunchKernelGGL(k_schur_prepare, dim3((std::max(nprep, p->dimp) + 255) / 256), dim3(256), 0, s, d, par);
+                    hipLaunchKernelGGL(k_schur_pairs, dim3(d.n_pk_big + (d.n_pk - d.n_pk_big + 3) / 4), dim3(256), 0, s, d, par);
+                } else {
+                    QSP_HIP(hipMemsetAsync(d.Hs, 0, sizeof(double) * (size_t)p->dimp * p->dimp, s));
+                    hipLaunchKernelGGL(k_schur_prepare, dim3((std::max(nprep, p->dimp) + 255) / 256), dim3(256), 0, s, d, par);
+                    // block rows pay off once the per-landmark kernel's global atomics collide or scatter (measured: C5 435 ->
+                    // 157 us, 2 M edges 5.4 -> 0.8 ms); below ~64 k edges both are latency-bound and the single launch wins
+                    if (d.n_pt && row_lds <= SCHUR_ROW_LDS_MAX && d.n_ksplit && d.n_edge >= SCHUR_ROWS_MIN_EDGES) {
+                        hipLaunchKernelGGL(k_schur_dinv, dim3((d.n_pt + 255) / 256), dim3(256), 0, s, d, par);
+                        hipLaunchKernelGGL(k_schur_rows, dim3(d.n_ksplit), dim3(256), row_lds, s, d, par);
+                    } else if (d.n_pt) {
+                        hipLaunchKernelGGL(k_schur_points, dim3((d.n_pt + 3) / 4), dim3(256), 0, s, d, par);
+                    }
+                    if (p->elim) {
+                        hipLaunchKernelGGL(k_obj_prepare, dim3(d.n_obj), dim3(64), 0, s, d, par);
+                        hipLaunchKernelGGL(k_obj_rows, dim3(d.n_kf), dim3(64), sizeof(double) * (size_t)6 * p->dimp, s, d, par);
+                    }
                 }
                 rc = allreduce(p, d.Hs, (int64_t)p->dimp * p->dimp + p->dimp);     // reduced matrix + right-hand side
                 if (rc) return rc;
@@ -2273,10 +2467,10 @@ extern "C" int qsp_ba_optimize(qsp_ba_problem* p, int32_t n_iter, double delta_m
                 for (int k = 0; k + 1 < nb; ++k)
                     hipLaunchKernelGGL(k_chol_step, dim3(nb - k - 1, nb - k - 1), dim3(256), lds, s, d.Hs, d.Uf, d.Winv, d.bs,
                                        d.ych, p->dimp, k, d.scal);
-                for (int k = nb - 1; k >= 0; --k)
-                    hipLaunchKernelGGL(k_chol_backstep, dim3(k > 0 ? k : 1), dim3(256), 0, s, d.Uf, d.Winv, d.ych, d.xp, p->dimp, k);
-                if (p->elim) hipLaunchKernelGGL(k_obj_backsub, dim3(d.n_obj), dim3(64), 0, s, d, par);
+                hipLaunchKernelGGL(k_chol_back, dim3(1), dim3(512), sizeof(double) * (size_t)(p->dimp + NB), s, d, par, d.Uf, d.Winv,
+                                   d.ych, d.xp, p->dimp);
             } else if (d.n_pt) {
+                if (fused) { /* unreachable: fused needs dimp > 0 */ }
                 hipLaunchKernelGGL(k_schur_dinv, dim3((d.n_pt + 255) / 256), dim3(256), 0, s, d, par);   // only D^-1 is needed
             }
             // update (oplus) + rho denominator
