@@ -1410,27 +1410,29 @@ __global__ __launch_bounds__(256) void k_chol_step(double* A, double* Uf, double
     }
 }
 
-// backward substitution x_k = W_k^T (y_k - sum_{j>k} U_kj x_j), k = nb-1 .. 0, in ONE launch of ONE workgroup of 512
-// threads (8 waves): y lives in LDS; at step j the waves form x_j = W_j^T y_j (8 rows each), then wave w takes the blocks
-// k = w, w+8, ... < j and subtracts U_kj x_j from y_k with a lane per row (the factor is stored transposed, so a wave-load
-// is 64 consecutive doubles; all 64 loads of a block are in flight at once -- the blocks come from other XCDs' kernels, i.e.
-// from the Infinity Cache at ~2 us a round trip).  Afterwards the same workgroup back-substitutes the eliminated objects (k_obj_backsub).
-// The 2 nb workgroup barriers replace nb launches of ~10 us each.
-__global__ __launch_bounds__(512) void k_chol_back(Dev d, Par par, const double* __restrict__ Uf, const double* __restrict__ Winv,
+// backward substitution x_k = W_k^T (y_k - sum_{j>k} U_kj x_j), k = nb-1 .. 0, in ONE launch of ONE workgroup of 1024
+// threads (16 waves): y lives in LDS; at step j the waves form x_j = W_j^T y_j (4 rows each), then wave w takes the blocks
+// k = w, w+16, ... < j and subtracts U_kj x_j from y_k with a lane per row (the factor is stored transposed, so a wave-load
+// is 64 consecutive doubles).  Afterwards the same workgroup back-substitutes the eliminated objects.  2 nb workgroup
+// barriers replace nb launches.  Measured alternatives at C5 (19 block rows), same box: this kernel 174 us; 512 threads with
+// all 64 loads of a block in flight 201 us; one workgroup per block row chained by device-scope flags (all partial sums
+// but the last off the critical path) 176-195 us -- a dependent round trip to another XCD's data costs ~3 us whichever way
+// it is made, and every row needs three of them.  The simplest form was kept.
+__global__ __launch_bounds__(1024) void k_chol_back(Dev d, Par par, const double* __restrict__ Uf, const double* __restrict__ Winv,
                                                    const double* __restrict__ y, double* x, int n) {
     extern __shared__ __attribute__((aligned(16))) double ysh[];       // [n] y, then [NB] x_j
     double* xj = ysh + n;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int nb = n / NB;
-    for (int i = t; i < n; i += 512) ysh[i] = y[i];
+    for (int i = t; i < n; i += 1024) ysh[i] = y[i];
     __syncthreads();
     for (int j = nb - 1; j >= 0; --j) {
         {                                                 // x_j[r] = sum_q W_j[q][r] y_j[q];  Winv holds WT[r][q] = W[q][r]
             const double* WT = Winv + (size_t)j * NB * NB;
             const double yq = ysh[j * NB + lane];
 #pragma unroll
-            for (int i = 0; i < NB / 8; ++i) {
-                const int r = wave + 8 * i;
+            for (int i = 0; i < NB / 16; ++i) {
+                const int r = wave + 16 * i;
                 double v = WT[r * NB + lane] * yq;
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -1438,18 +1440,21 @@ __global__ __launch_bounds__(512) void k_chol_back(Dev d, Par par, const double*
             }
         }
         __syncthreads();
-        for (int k = wave; k < j; k += 8) {
+        for (int k = wave; k < j; k += 16) {
             const double* U = Uf + (size_t)(j * NB) * n + k * NB;      // element (m, c) at U[c * n + m]
-            double u[NB];
-#pragma unroll
-            for (int c = 0; c < NB; ++c) u[c] = U[(size_t)c * n + lane];
             double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+#pragma unroll 1
+            for (int c0 = 0; c0 < NB; c0 += 16) {         // 16 independent wave-loads in flight, four accumulator chains
+                double u[16];
 #pragma unroll
-            for (int c = 0; c < NB; c += 4) {
-                a0 += u[c + 0] * xj[c + 0];
-                a1 += u[c + 1] * xj[c + 1];
-                a2 += u[c + 2] * xj[c + 2];
-                a3 += u[c + 3] * xj[c + 3];
+                for (int c = 0; c < 16; ++c) u[c] = U[(size_t)(c0 + c) * n + lane];
+#pragma unroll
+                for (int c = 0; c < 16; c += 4) {
+                    a0 += u[c + 0] * xj[c0 + c + 0];
+                    a1 += u[c + 1] * xj[c0 + c + 1];
+                    a2 += u[c + 2] * xj[c0 + c + 2];
+                    a3 += u[c + 3] * xj[c0 + c + 3];
+                }
             }
             ysh[k * NB + lane] -= (a0 + a1) + (a2 + a3);
         }
@@ -1457,7 +1462,7 @@ __global__ __launch_bounds__(512) void k_chol_back(Dev d, Par par, const double*
     }
     if (par.elim) {                                       // x_o = G_o b_o - sum_e F_e^T x_k  (the dense x is complete in global memory)
         __threadfence_block();
-        for (int i = t; i < 6 * d.n_obj; i += 512) {
+        for (int i = t; i < 6 * d.n_obj; i += 1024) {
             const int ob = i / 6, c = i % 6;
             const int ho = d.obj_h[ob];
             if (ho < 0) continue;
@@ -2467,7 +2472,7 @@ extern "C" int qsp_ba_optimize(qsp_ba_problem* p, int32_t n_iter, double delta_m
                 for (int k = 0; k + 1 < nb; ++k)
                     hipLaunchKernelGGL(k_chol_step, dim3(nb - k - 1, nb - k - 1), dim3(256), lds, s, d.Hs, d.Uf, d.Winv, d.bs,
                                        d.ych, p->dimp, k, d.scal);
-                hipLaunchKernelGGL(k_chol_back, dim3(1), dim3(512), sizeof(double) * (size_t)(p->dimp + NB), s, d, par, d.Uf, d.Winv,
+                hipLaunchKernelGGL(k_chol_back, dim3(1), dim3(1024), sizeof(double) * (size_t)(p->dimp + NB), s, d, par, d.Uf, d.Winv,
                                    d.ych, d.xp, p->dimp);
             } else if (d.n_pt) {
                 if (fused) { /* unreachable: fused needs dimp > 0 */ }
