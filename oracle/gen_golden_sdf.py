@@ -40,23 +40,23 @@ def ref_decoder(dec_mod, path):
     return dec
 
 
-def ref_configs(utils_mod, joint, data_type):
+def ref_configs(utils_mod, joint, data_type, code_len=64):
     return utils_mod.ForceKeyErrorDict(**dict(
         data_type=data_type,
-        optimizer=dict(code_len=64, num_depth_samples=50, cut_off_threshold=0.01, joint_optim=dict(joint),
+        optimizer=dict(code_len=code_len, num_depth_samples=50, cut_off_threshold=0.01, joint_optim=dict(joint),
                        pose_only_optim=dict(num_iterations=5, learning_rate=1.0))))
 
 
-def run_joint_case(mods, dec, name, joint, data_type, seed, n_pts, n_fg, n_bg, code_scale=0.0, mutate=None):
+def run_joint_case(mods, dec, name, joint, data_type, seed, n_pts, n_fg, n_bg, code_scale=0.0, mutate=None, code_len=64):
     opt_mod, loss_mod, lu, _, utils_mod = mods
-    cfg = ref_configs(utils_mod, joint, data_type)
+    cfg = ref_configs(utils_mod, joint, data_type, code_len)
     obj = synth.make_object_views(seed, 1, n_pts, n_fg=n_fg, n_bg=n_bg, code_scale=code_scale)[0]
     if mutate:
         mutate(obj)
     opt = opt_mod.Optimizer(dec, cfg)
     # --- per-iteration trace of the first iteration's terms, straight from the reference's loss functions -----
     t_obj_cam = torch.inverse(torch.from_numpy(obj["t_cam_obj"].copy()))
-    z0 = torch.zeros(64)
+    z0 = torch.zeros(code_len)
     out = dict(t_cam_obj=obj["t_cam_obj"], pts=obj["pts"], rays=obj["rays"], depth=obj["depth"],
                joint=np.array(repr(dict(joint, data_type=data_type))))
     jp, jc, res = loss_mod.compute_sdf_loss(dec, torch.from_numpy(obj["pts"]), t_obj_cam, z0)
@@ -83,12 +83,12 @@ def run_joint_case(mods, dec, name, joint, data_type, seed, n_pts, n_fg, n_bg, c
         return r_
 
     def tap_inv(x):
-        if x.shape[0] == 71:
+        if x.shape[0] == 7 + code_len:
             Hs.append(x.numpy().copy())
         return orig_inv(x)
 
     def tap_mv(a, v):
-        if a.shape[0] == 71:
+        if a.shape[0] == 7 + code_len:
             bs.append(v.numpy().copy())
         return orig_mv(a, v)
 
@@ -115,6 +115,25 @@ def run_joint_case(mods, dec, name, joint, data_type, seed, n_pts, n_fg, n_bg, c
     print(name, "is_good", bool(r.is_good), "loss", float(r.loss),
           "K0", None if rr is None else rr[2].shape[0])
     return obj, r
+
+
+def main_small():
+    """a second member of the decoder family (4 hidden layers x 256, code 32, latent_in [2]; oracle/fit_decoder.py --arch
+    4x256_c32): decoder-level vectors and one joint refinement run by the reference with code_len = 32 (39 unknowns)"""
+    mods = import_reference()
+    opt_mod, loss_mod, lu, dec_mod, utils_mod = mods
+    torch.set_num_threads(8)
+    dec = ref_decoder(dec_mod, os.path.join(GOLD, "decoder_4x256_c32.npz"))
+    rng = np.random.default_rng(17)
+    x = rng.uniform(-0.9, 0.9, size=(300, 3)).astype(np.float32)
+    code = np.zeros(32, np.float32)
+    code[:3] = [0.2, -0.1, 0.3]
+    code[3:] = rng.normal(scale=0.05, size=29).astype(np.float32)
+    sdf = lu.decode_sdf(dec, torch.from_numpy(code), torch.from_numpy(x)).numpy()
+    y, g = lu.get_batch_sdf_jacobian(dec, torch.from_numpy(code), torch.from_numpy(x), 1)
+    np.savez_compressed(os.path.join(GOLD, "sdf_small_decoder_vectors.npz"), x=x, code=code, sdf=sdf,
+                        y=y.reshape(-1).numpy(), grad=g.squeeze(1).numpy())
+    run_joint_case(mods, dec, "sdf_small_joint_m400", REDWOOD, "Redwood", seed=31, n_pts=400, n_fg=128, n_bg=64, code_len=32)
 
 
 def main():
@@ -178,5 +197,7 @@ def main():
     print("pose-only done")
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "small":
+    main_small()
+elif __name__ == "__main__":
     main()

@@ -26,6 +26,7 @@ struct Inputs {             // device pointers
     const int32_t *pts_off, *fg_off, *bg_off;
     const float *pts_world, *fg_px, *fg_world, *bg_rays;
     const float* Ry;        // (max_flip, 9) rotation about e_y by k * flip_angle, built on the host (libm cosf / sinf)
+    int code_len;           // of the decoder (<= 64): row stride of `code`
 };
 
 // one row of cv::Mat (3x3 f32) * (3x1 f32) + (3x1 f32)
@@ -125,7 +126,7 @@ __global__ void __launch_bounds__(64) k_det_init(Inputs in, HypState* st, float*
         for (int i = 0; i < 16; ++i) t_init_tap[16 * h + i] = T0[i];
     HypState& S = st[h];
     inv4_gj(T0, S.T_oc);   // optimizer.py:123
-    for (int i = 0; i < CODE_LEN; ++i) S.code[i] = in.code ? in.code[(int64_t)CODE_LEN * d + i] : 0.f;
+    for (int i = 0; i < CODE_LEN; ++i) S.code[i] = (in.code && i < in.code_len) ? in.code[(int64_t)in.code_len * d + i] : 0.f;
     for (int i = 0; i < 16; ++i) S.T_co[i] = 0.f;
     S.scale = S.d_min = S.d_max = S.loss = S.loss_sdf = S.loss_render = 0.f;
     S.alive = 1;
@@ -136,7 +137,8 @@ __global__ void __launch_bounds__(64) k_det_init(Inputs in, HypState* st, float*
 
 // one thread per detection: the keep rule of :738-752 over its hypotheses, in order
 __global__ void __launch_bounds__(64) k_det_select(const HypState* st, const int32_t* hyp_off, int n_det, float* t_cam_obj,
-                                                   float* code, float* loss, uint8_t* good, int32_t* kept, float* losses) {
+                                                   float* code, float* loss, uint8_t* good, int32_t* kept, float* losses,
+                                                   int code_len) {
     const int d = blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= n_det) return;
     const int h0 = hyp_off[d], h1 = hyp_off[d + 1];
@@ -149,7 +151,7 @@ __global__ void __launch_bounds__(64) k_det_select(const HypState* st, const int
         if (!state || (l > lf && state_f)) best = h;
     }
     inv4_gj(st[best].T_oc, t_cam_obj + 16 * d);   // optimizer.py:273
-    for (int i = 0; i < CODE_LEN; ++i) code[(int64_t)CODE_LEN * d + i] = st[best].code[i];
+    for (int i = 0; i < code_len; ++i) code[(int64_t)code_len * d + i] = st[best].code[i];
     loss[d] = st[best].loss;
     good[d] = st[best].alive ? 1 : 0;
     kept[d] = best - h0;
@@ -189,7 +191,7 @@ extern "C" int qsp_refine_detections(qsp_decoder* dec, const qsp_joint_cfg* cfg,
     const int n = in->n_det;
     if (n <= 0 || !in->T_cw || !in->K || !in->T_wo || !in->pts_off || !in->fg_off || !in->bg_off)
         return qsp_fail(QSP_ERR_INVALID, "qsp_refine_detections: bad argument");
-    if (cfg->code_len != CODE_LEN) return qsp_fail(QSP_ERR_UNSUPPORTED, "code_len must be 64");
+    if (cfg->code_len != dec->code_len) return qsp_fail(QSP_ERR_INVALID, "code_len of the optimizer config differs from the decoder's");
     std::vector<int32_t> n_pts(n), n_rays(n), n_fg(n), hyp_off(n + 1, 0), hyp_obj;
     int max_flip = 1, max_items = 1;
     for (int d = 0; d < n; ++d) {
@@ -227,7 +229,8 @@ extern "C" int qsp_refine_detections(qsp_decoder* dec, const qsp_joint_cfg* cfg,
     }
 
     qsp_refine_batch* b = nullptr;
-    RefineCfg c{cfg->k1, cfg->k2, cfg->k3, cfg->k4, cfg->b1, cfg->b2, cfg->lr, cfg->s_damp, cfg->cut_off, cfg->n_depth, 0, 0};
+    RefineCfg c{cfg->k1, cfg->k2, cfg->k3, cfg->k4, cfg->b1, cfg->b2, cfg->lr, cfg->s_damp, cfg->cut_off, cfg->n_depth, 0, 0,
+                dec->code_len};
     int rc = batch_create(dec, c, cfg->n_iter, n, nullptr, n_pts.data(), nullptr, n_rays.data(), nullptr, n_fg.data(), n_hyp,
                           hyp_obj.data(), &b, true);
     if (rc) return rc;
@@ -245,7 +248,8 @@ extern "C" int qsp_refine_detections(qsp_decoder* dec, const qsp_joint_cfg* cfg,
         (rc = pool.up(in->fg_px, tot_fg * 2, &I.fg_px)) || (rc = pool.up(in->fg_world, tot_fg * 3, &I.fg_world)) ||
         (rc = pool.up(in->bg_rays, tot_bg * 3, &I.bg_rays)) || (rc = pool.up(Ry.data(), Ry.size(), &I.Ry)))
         return rc;
-    if (in->code && (rc = pool.up(in->code, (size_t)n * CODE_LEN, &I.code))) return rc;
+    if (in->code && (rc = pool.up(in->code, (size_t)n * dec->code_len, &I.code))) return rc;
+    I.code_len = dec->code_len;
     if (in->n_flip && (rc = pool.up(in->n_flip, (size_t)n, &I.n_flip))) return rc;
     float *d_T = nullptr, *d_code = nullptr, *d_loss = nullptr, *d_losses = nullptr, *d_tinit = nullptr;
     uint8_t* d_good = nullptr;
@@ -263,13 +267,13 @@ extern "C" int qsp_refine_detections(qsp_decoder* dec, const qsp_joint_cfg* cfg,
     QSP_HIP(hipGetLastError());
     if ((rc = qsp_refine_batch_run(b, 0))) return rc;
     hipLaunchKernelGGL(k_det_select, dim3((n + 63) / 64), dim3(64), 0, s, b->st, I.hyp_off, n, d_T, d_code, d_loss, d_good, d_kept,
-                       d_losses);
+                       d_losses, dec->code_len);
     QSP_HIP(hipGetLastError());
     QSP_HIP(hipStreamSynchronize(s));
 #define QSP_DOWN(dst, src, count)                                                                               \
     if ((dst) && (count)) QSP_HIP(hipMemcpy((dst), (src), sizeof(*(dst)) * (size_t)(count), hipMemcpyDeviceToHost));
     QSP_DOWN(out->t_cam_obj, d_T, (size_t)n * 16)
-    QSP_DOWN(out->code, d_code, (size_t)n * CODE_LEN)
+    QSP_DOWN(out->code, d_code, (size_t)n * dec->code_len)
     QSP_DOWN(out->loss, d_loss, n)
     QSP_DOWN(out->is_good, d_good, n)
     QSP_DOWN(out->kept_flip, d_kept, n)

@@ -390,7 +390,10 @@ extern "C" int qsp_mesh_extract(qsp_mesh_extractor* m, const float* code, int64_
     if (!m || !code) return qsp_fail(QSP_ERR_INVALID, "qsp_mesh_extract: null argument");
     QSP_HIP(hipSetDevice(m->dec->device));
     hipStream_t s = m->dec->stream;
-    QSP_HIP(hipMemcpyAsync(m->code, code, CODE_LEN * sizeof(float), hipMemcpyHostToDevice, s));
+    float code64[CODE_LEN] = {};                       // `code` holds the decoder's code_len entries
+    memcpy(code64, code, sizeof(float) * m->dec->code_len);
+    QSP_HIP(hipMemcpyAsync(m->code, code64, CODE_LEN * sizeof(float), hipMemcpyHostToDevice, s));
+    QSP_HIP(hipStreamSynchronize(s));                  // (code64 lives on this stack frame)
     const int64_t tiles = (m->n + TILE_P - 1) / TILE_P;
     const int grid = (int)std::min<int64_t>(tiles, 4096);
     hipLaunchKernelGGL(k_decode<false>, dim3(grid), dim3(MLP_THREADS), sizeof(MlpSmem), s, m->code, m->xyz, m->n, m->dec->Pd,

@@ -67,6 +67,7 @@ struct RefineCfg {
     int32_t n_depth;
     int32_t pose_only;      // estimate_pose_cam_obj mode
     int32_t iter;           // current iteration index (pose-only inlier filter)
+    int32_t code_len;       // the decoder's code length L <= 64: code unknowns L..63 are padding (decoupled in k_solve)
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -729,6 +730,9 @@ __global__ __launch_bounds__(256) void k_solve(HypState* __restrict__ st, const 
             } else {
                 v = (cfg.k1 * sr) / Kf + (cfg.k2 * ss) / M;
                 if (a == b && a >= 7) v += cfg.k3;
+                // code unknowns beyond the decoder's code length have zero Jacobian columns: unit diagonal, zero right-hand
+                // side -> they stay 0 whatever k3 is and never mix into the other 7 + L unknowns
+                if (a >= 7 + cfg.code_len || b >= 7 + cfg.code_len) v = (a == b) ? 1.f : 0.f;
             }
             Hd[a * (N + 1) + b] = (double)v;
             Hd[b * (N + 1) + a] = (double)v;
@@ -739,6 +743,7 @@ __global__ __launch_bounds__(256) void k_solve(HypState* __restrict__ st, const 
             else {
                 v = -(cfg.k1 * sr) / Kf + (-(cfg.k2 * ss) / M);
                 if (a >= 7) v -= cfg.k3 * S.code[a - 7];
+                if (a >= 7 + cfg.code_len) v = 0.f;
             }
             Hd[a * (N + 1) + N] = (double)v;
         } else {                           // (71,71): sum of squared robust residuals
@@ -943,23 +948,86 @@ struct qsp_decoder {
     MlpParams* Pd = nullptr;   // device copy, read by the kernels
     std::vector<void*> allocs;
     double mac_per_point = 0;
+    int code_len = CODE_LEN;   // the caller's code length L <= 64; the tile always works on 64 (columns L..63 are zero)
 };
 
-static int pack_weights(qsp_decoder* d, const qsp_decoder_desc* desc) {
-    // validate the supported family (see header)
-    if (desc->n_layers != 9 || desc->code_len != CODE_LEN || desc->latent_in_layer != 4)
-        return qsp_fail(QSP_ERR_UNSUPPORTED, "decoder family: need 9 layers, code_len 64, latent_in [4]");
-    for (int l = 0; l < 9; ++l) {
-        const int in_expect = (l == 0) ? NIN : HID;
-        const int out_expect = (l == 8) ? 1 : (l == 3 ? SKIP_COL : HID);
-        if (desc->in_dim[l] != in_expect || desc->out_dim[l] != out_expect)
-            return qsp_fail(QSP_ERR_UNSUPPORTED, "decoder family: layer dims must be 67-512-512-512-445|512-...-1");
+// The family deep_sdf/deep_sdf_decoder.py:29-63 builds -- `dims` hidden layers of any width, one (or no) latent_in layer, any
+// code length -- mapped EXACTLY onto the one network shape the tile kernels run (8 hidden layers x 512, code 64, skip into layer
+// 4), so that specs.json decides the architecture, not the library:
+//   * narrower layers: zero rows / columns (a unit with zero weights and zero bias outputs relu(0) = 0 and feeds nothing);
+//   * fewer layers: identity layers.  Every hidden activation is a ReLU output, i.e. >= 0, and relu(1 * h + 0) == h bit for
+//     bit (the other products of the row are exact zeros); in the backward pass the identity's ReLU mask (h > 0) only removes
+//     gradient that the producing layer's own mask (pre-activation > 0, the same condition) removes anyway;
+//   * shorter codes: zero code columns; the normal equations keep 64 code unknowns whose extra rows are decoupled (k_solve);
+//   * the latent_in layer goes to slot 4, the layers before it to slots 0.., identity layers fill up to slot 3; the
+//     layers after it to slots 5.., identity layers fill up to slot 7; the output layer is slot 8.
+// Needs: at most 4 hidden layers before and at most 4 from the latent_in layer on, widths <= 512 (<= 445 in front of the skip).
+// Cost: the arithmetic of the full 8 x 512 tile whatever the network's own size.
+static int embed_family(const qsp_decoder_desc* desc, const std::vector<std::vector<float>>& W,
+                        std::vector<std::vector<float>>& Wc, std::vector<std::vector<float>>& Bc) {
+    const int nl = desc->n_layers, m = nl - 1, L = desc->code_len;
+    if (nl < 3 || nl > 9 || L < 1 || L > CODE_LEN)
+        return qsp_fail(QSP_ERR_UNSUPPORTED, "decoder family: 2..8 hidden layers and a code of 1..64 are supported");
+    int s = desc->latent_in_layer;
+    const bool has_skip = s >= 0;
+    if (!has_skip) s = std::max(1, m - 4);                 // no latent_in: any split with <= 4 layers on either side
+    if (s < 1 || s > 4 || s > m - 1 || m - s > 4)
+        return qsp_fail(QSP_ERR_UNSUPPORTED, "decoder family: the latent_in layer needs 1..4 hidden layers in front of it and "
+                                              "at most 4 from it on");
+    if (desc->in_dim[0] != L + 3 || desc->out_dim[m] != 1)
+        return qsp_fail(QSP_ERR_UNSUPPORTED, "decoder family: first layer takes [code | xyz], last layer has one output");
+    for (int l = 0; l < m; ++l) {
+        const int lim = (l == s - 1 && has_skip) ? SKIP_COL : HID;
+        if (desc->out_dim[l] < 1 || desc->out_dim[l] > lim)
+            return qsp_fail(QSP_ERR_UNSUPPORTED, "decoder family: hidden width above 512 (445 in front of the latent_in layer)");
     }
-    // fold weight norm:  W = g * v / ||v||_row   (torch.nn.utils.weight_norm, dim=0)
-    std::vector<std::vector<float>> W(9);
-    for (int l = 0; l < 9; ++l) {
+    for (int l = 1; l <= m; ++l) {
+        const int expect = desc->out_dim[l - 1] + ((l == s && has_skip) ? L + 3 : 0);
+        if (desc->in_dim[l] != expect) return qsp_fail(QSP_ERR_UNSUPPORTED, "decoder family: layer input widths do not chain");
+    }
+    auto in_c = [](int c) { return c == 0 ? NIN : HID; };
+    auto out_c = [](int c) { return c == 8 ? 1 : (c == 3 ? SKIP_COL : HID); };
+    Wc.assign(9, std::vector<float>());
+    Bc.assign(9, std::vector<float>());
+    std::vector<int> src(9, -1);                            // canonical slot -> source layer (-1: identity)
+    for (int l = 0; l < s; ++l) src[l] = l;
+    for (int l = s; l < m; ++l) src[4 + (l - s)] = l;
+    src[8] = m;
+    for (int c = 0; c < 9; ++c) {
+        const int ic = in_c(c), oc = out_c(c);
+        Wc[c].assign((size_t)oc * ic, 0.f);
+        Bc[c].assign((size_t)oc, 0.f);
+        const int l = src[c];
+        if (l < 0) {                                        // identity on the (<= 445 / 512 wide) activation
+            for (int r = 0; r < oc; ++r) Wc[c][(size_t)r * ic + r] = 1.f;
+            continue;
+        }
         const int in = desc->in_dim[l], out = desc->out_dim[l];
-        W[l].assign((size_t)out * in, 0.f);
+        for (int o = 0; o < out; ++o) {
+            Bc[c][o] = desc->bias[l][o];
+            for (int k = 0; k < in; ++k) {
+                int kc = k;
+                if (c == 0) kc = (k < L) ? k : CODE_LEN + (k - L);                       // [code L | xyz] -> [code 64 | xyz]
+                if (c == 4 && has_skip) {
+                    const int w = desc->out_dim[l - 1];                                  // [prev w | code L | xyz]
+                    kc = (k < w) ? k : (k < w + L ? SKIP_COL + (k - w) : SKIP_COL + CODE_LEN + (k - w - L));
+                }
+                Wc[c][(size_t)o * ic + kc] = W[l][(size_t)o * in + k];
+            }
+        }
+    }
+    return QSP_OK;
+}
+
+static int pack_weights(qsp_decoder* d, const qsp_decoder_desc* desc) {
+    if (desc->n_layers < 1 || desc->n_layers > 64) return qsp_fail(QSP_ERR_UNSUPPORTED, "decoder family: layer count");
+    // fold weight norm:  W = g * v / ||v||_row   (torch.nn.utils.weight_norm, dim=0)
+    std::vector<std::vector<float>> Wsrc(desc->n_layers);
+    for (int l = 0; l < desc->n_layers; ++l) {
+        const int in = desc->in_dim[l], out = desc->out_dim[l];
+        if (in < 1 || out < 1 || in > 4096 || out > 4096 || !desc->weight[l] || !desc->bias[l])
+            return qsp_fail(QSP_ERR_UNSUPPORTED, "decoder family: layer dims");
+        Wsrc[l].assign((size_t)out * in, 0.f);
         const float* v = desc->weight[l];
         const float* g = (desc->weight_g && desc->weight_g[l]) ? desc->weight_g[l] : nullptr;
         for (int o = 0; o < out; ++o) {
@@ -969,10 +1037,19 @@ static int pack_weights(qsp_decoder* d, const qsp_decoder_desc* desc) {
                 for (int k = 0; k < in; ++k) ss += v[(size_t)o * in + k] * v[(size_t)o * in + k];
                 sc = g[o] / sqrtf(ss);
             }
-            for (int k = 0; k < in; ++k) W[l][(size_t)o * in + k] = v[(size_t)o * in + k] * sc;
+            for (int k = 0; k < in; ++k) Wsrc[l][(size_t)o * in + k] = v[(size_t)o * in + k] * sc;
         }
         d->mac_per_point += (double)in * out;
     }
+    std::vector<std::vector<float>> W, Bias;
+    {
+        const int rc = embed_family(desc, Wsrc, W, Bias);
+        if (rc) return rc;
+    }
+    d->code_len = desc->code_len;
+    // from here on: the canonical 9-layer shape
+    const int in_dim[9] = {NIN, HID, HID, HID, HID, HID, HID, HID, HID};
+    const int out_dim[9] = {HID, HID, HID, SKIP_COL, HID, HID, HID, HID, 1};
     auto upload = [&](const std::vector<float>& h, const void** dst) -> int {
         void* p = nullptr;
         QSP_HIP(hipMalloc(&p, h.size() * sizeof(float) + 16384));   // + prefetch over-read slack (gemm_2x2)
@@ -982,7 +1059,7 @@ static int pack_weights(qsp_decoder* d, const qsp_decoder_desc* desc) {
         return QSP_OK;
     };
     for (int l = 0; l < 8; ++l) {
-        const int in = desc->in_dim[l], out = desc->out_dim[l];
+        const int in = in_dim[l], out = out_dim[l];
         int rc = QSP_OK;
         if (l == 0) {
             // layer 0 is evaluated directly (mlp_prepare + mlp_tile): code columns row-major, xyz columns per unit quad
@@ -1038,14 +1115,14 @@ static int pack_weights(qsp_decoder* d, const qsp_decoder_desc* desc) {
         rc = upload(pb, (const void**)&d->P.wb[l]);
         if (rc) return rc;
         std::vector<float> bias(HID, 0.f);
-        for (int o = 0; o < out; ++o) bias[o] = desc->bias[l][o];
+        for (int o = 0; o < out; ++o) bias[o] = Bias[l][o];
         rc = upload(bias, (const void**)&d->P.bias[l]);
         if (rc) return rc;
     }
     std::vector<float> w8(W[8].begin(), W[8].end());
     int rc = upload(w8, (const void**)&d->P.w8);
     if (rc) return rc;
-    d->P.b8 = desc->bias[8][0];
+    d->P.b8 = Bias[8][0];
     void* pd = nullptr;
     QSP_HIP(hipMalloc(&pd, sizeof(MlpParams)));
     d->allocs.push_back(pd);
@@ -1106,7 +1183,9 @@ static int decode_common(qsp_decoder* d, const float* code, const float* xyz, in
     QSP_HIP(hipMalloc((void**)&dx, n * 3 * sizeof(float)));
     QSP_HIP(hipMalloc((void**)&dy, n * sizeof(float)));
     if (grad) QSP_HIP(hipMalloc((void**)&dg, n * NIN * sizeof(float)));
-    QSP_HIP(hipMemcpyAsync(dc, code, CODE_LEN * sizeof(float), hipMemcpyHostToDevice, d->stream));
+    float code64[CODE_LEN] = {};                       // the caller's code has d->code_len entries
+    memcpy(code64, code, sizeof(float) * d->code_len);
+    QSP_HIP(hipMemcpyAsync(dc, code64, CODE_LEN * sizeof(float), hipMemcpyHostToDevice, d->stream));
     QSP_HIP(hipMemcpyAsync(dx, xyz, n * 3 * sizeof(float), hipMemcpyHostToDevice, d->stream));
     const int64_t tiles = (n + TILE_P - 1) / TILE_P;
     const int grid = (int)std::min<int64_t>(tiles, 4096);
@@ -1117,8 +1196,23 @@ static int decode_common(qsp_decoder* d, const float* code, const float* xyz, in
                            (float*)nullptr);
     QSP_HIP(hipGetLastError());
     QSP_HIP(hipMemcpyAsync(y, dy, n * sizeof(float), hipMemcpyDeviceToHost, d->stream));
-    if (grad) QSP_HIP(hipMemcpyAsync(grad, dg, n * NIN * sizeof(float), hipMemcpyDeviceToHost, d->stream));
+    std::vector<float> g67;
+    if (grad) {
+        if (d->code_len == CODE_LEN) {
+            QSP_HIP(hipMemcpyAsync(grad, dg, n * NIN * sizeof(float), hipMemcpyDeviceToHost, d->stream));
+        } else {
+            g67.resize((size_t)n * NIN);
+            QSP_HIP(hipMemcpyAsync(g67.data(), dg, n * NIN * sizeof(float), hipMemcpyDeviceToHost, d->stream));
+        }
+    }
     QSP_HIP(hipStreamSynchronize(d->stream));
+    if (grad && d->code_len != CODE_LEN) {               // [code 64 | xyz] -> [code L | xyz]
+        const int L = d->code_len;
+        for (int64_t i = 0; i < n; ++i) {
+            memcpy(grad + i * (L + 3), g67.data() + i * NIN, sizeof(float) * L);
+            memcpy(grad + i * (L + 3) + L, g67.data() + i * NIN + CODE_LEN, sizeof(float) * 3);
+        }
+    }
     (void)hipFree(dc);
     (void)hipFree(dx);
     (void)hipFree(dy);
@@ -1142,6 +1236,7 @@ struct qsp_refine_batch {
     qsp_decoder* dec = nullptr;
     int device = 0;                 // of the decoder, cached: destroy must not touch a decoder that may already be gone
     RefineCfg cfg{};
+    int code_len = CODE_LEN;        // dec->code_len, cached like `device`
     int n_iter_cfg = 5;
     int n_obj = 0, n_hyp = 0;
     int max_pts = 0, max_rays = 0;
@@ -1198,7 +1293,9 @@ static int batch_create(qsp_decoder* dec, const RefineCfg& cfg, int n_iter, int3
     qsp_refine_batch* b = new qsp_refine_batch();
     b->dec = dec;
     b->device = dec->device;
+    b->code_len = dec->code_len;
     b->cfg = cfg;
+    b->cfg.code_len = dec->code_len;
     b->n_iter_cfg = n_iter;
     b->n_obj = n_obj;
     b->n_hyp = n_hyp;
@@ -1296,8 +1393,9 @@ extern "C" int qsp_refine_batch_create(qsp_decoder* dec, const qsp_joint_cfg* cf
                                        const float* const* depth, const int32_t* n_fg, int32_t n_hyp,
                                        const int32_t* hyp_obj, qsp_refine_batch** out) {
     if (!cfg) return qsp_fail(QSP_ERR_INVALID, "cfg is null");
-    if (cfg->code_len != CODE_LEN) return qsp_fail(QSP_ERR_UNSUPPORTED, "code_len must be 64");
-    RefineCfg c{cfg->k1, cfg->k2, cfg->k3, cfg->k4, cfg->b1, cfg->b2, cfg->lr, cfg->s_damp, cfg->cut_off, cfg->n_depth, 0, 0};
+    if (cfg->code_len != dec->code_len) return qsp_fail(QSP_ERR_INVALID, "code_len of the optimizer config differs from the decoder's");
+    RefineCfg c{cfg->k1, cfg->k2, cfg->k3, cfg->k4, cfg->b1, cfg->b2, cfg->lr, cfg->s_damp, cfg->cut_off, cfg->n_depth, 0, 0,
+                dec->code_len};
     return batch_create(dec, c, cfg->n_iter, n_obj, pts, n_pts, rays, n_rays, depth, n_fg, n_hyp, hyp_obj, out);
 }
 
@@ -1311,7 +1409,7 @@ extern "C" int qsp_refine_batch_set_state(qsp_refine_batch* b, const float* t_ca
         HypState& S = hs[h];
         memset(&S, 0, sizeof(S));
         inv4_gj(t_cam_obj + 16 * h, S.T_oc);   // t_obj_cam = inverse(t_cam_obj)  (optimizer.py:123)
-        if (code) memcpy(S.code, code + (size_t)h * CODE_LEN, sizeof(float) * CODE_LEN);
+        if (code) memcpy(S.code, code + (size_t)h * b->code_len, sizeof(float) * b->code_len);   // rest stays 0
         S.alive = 1;
         S.obj = b->hyp_obj[h];
     }
@@ -1423,7 +1521,7 @@ extern "C" int qsp_refine_batch_get(qsp_refine_batch* b, float* t_cam_obj_out, f
         if (t_cam_obj_out) {
             inv4_gj(S.T_oc, t_cam_obj_out + 16 * h);   // t_cam_obj = inverse(t_obj_cam)  (optimizer.py:273)
         }
-        if (code_out) memcpy(code_out + (size_t)h * CODE_LEN, S.code, sizeof(float) * CODE_LEN);
+        if (code_out) memcpy(code_out + (size_t)h * b->code_len, S.code, sizeof(float) * b->code_len);
         if (loss_out) loss_out[h] = S.loss;
         if (is_good_out) is_good_out[h] = S.alive ? 1 : 0;
     }

@@ -15,8 +15,9 @@ class DeepSdfDecoder(object):
 
     def __init__(self, layers, latent_in=(4,), code_len=64, device=0):
         L = _lib.lib()
-        if len(latent_in) != 1:
-            raise _lib.QspError(_lib.QSP_ERR_UNSUPPORTED, "exactly one latent_in layer is supported")
+        latent_in = tuple(latent_in or ())
+        if len(latent_in) > 1:
+            raise _lib.QspError(_lib.QSP_ERR_UNSUPPORTED, "at most one latent_in layer is supported")
         n = len(layers)
         self._keep = []
         in_dim = np.array([l[0].shape[1] for l in layers], np.int32)
@@ -29,7 +30,7 @@ class DeepSdfDecoder(object):
         gp = fpp(*[(_lib.fptr(a) if a is not None else _lib.c_float_p()) for a in g])
         bp = fpp(*[_lib.fptr(a) for a in b])
         self._keep = [w, g, b, in_dim, out_dim]
-        desc = _lib.DecoderDesc(n, int(code_len), int(latent_in[0]), _lib.i32ptr(in_dim), _lib.i32ptr(out_dim),
+        desc = _lib.DecoderDesc(n, int(code_len), int(latent_in[0]) if latent_in else -1, _lib.i32ptr(in_dim), _lib.i32ptr(out_dim),
                                 C.cast(wp, C.POINTER(_lib.c_float_p)), C.cast(gp, C.POINTER(_lib.c_float_p)),
                                 C.cast(bp, C.POINTER(_lib.c_float_p)))
         h = C.c_void_p()

@@ -10,7 +10,7 @@ import pytest
 
 from oracle import mc_oracle as mo
 from oracle import sdf_oracle as so
-from tests.test_oracle_mesh import noise_volume, sphere_volume
+from tests.test_oracle_mesh import canonical_mesh, noise_volume, sphere_volume
 
 pytestmark = pytest.mark.gpu
 
@@ -111,3 +111,15 @@ def test_full_size_properties_128(gpu_decoder):
         assert missing == 0                              # closed when the shape does not touch the grid border
     assert out.faces.min() >= 0 and out.faces.max() < len(out.vertices)
     assert dt < 5.0
+
+
+@pytest.mark.parametrize("dim,kind", [(24, "sphere"), (17, "noise")])
+def test_mesh_equals_oracle_after_canonical_sorting(gpu_decoder, dim, kind):
+    """the order-independent comparison (vertex set + oriented triangles), which is the one that stays meaningful against
+    another marching-cubes implementation's output order"""
+    vol = sphere_volume(dim) if kind == "sphere" else noise_volume(dim, dim)
+    v, f = extractor(gpu_decoder, dim).mesh_from_volume(vol)
+    ov, of = mo.marching_cubes(vol)
+    cv, cf = canonical_mesh(v, f)
+    cov, cof = canonical_mesh(ov, of)
+    assert np.array_equal(cv.view(np.uint32), cov.view(np.uint32)) and np.array_equal(cf, cof)

@@ -23,11 +23,11 @@ def gpu_decoder(golden_dir):
     d.close()
 
 
-def make_cfg(z_or_cfg):
+def make_cfg(z_or_cfg, code_len=64):
     from qsp_slam_amd.reconstruct.utils import ForceKeyErrorDict
     c = cfg_from(z_or_cfg) if not isinstance(z_or_cfg, so.JointConfig) else z_or_cfg
     return ForceKeyErrorDict(data_type="KITTI", optimizer=dict(
-        code_len=64, num_depth_samples=c.n_depth, cut_off_threshold=c.cut_off,
+        code_len=code_len, num_depth_samples=c.n_depth, cut_off_threshold=c.cut_off,
         joint_optim=dict(k1=c.k1, k2=c.k2, k3=c.k3, k4=c.k4, b1=c.b1, b2=c.b2, learning_rate=c.lr,
                          scale_damping=c.s_damp, num_iterations=c.n_iter),
         pose_only_optim=dict(num_iterations=c.n_iter_pose, learning_rate=1.0)))
@@ -310,3 +310,56 @@ def test_zero_surface_points_is_a_failure_not_a_crash(gpu_decoder):
     r = Optimizer(gpu_decoder, make_cfg(so.JointConfig())).reconstruct_object(o["t_cam_obj"], np.zeros((0, 3), np.float32),
                                                                               o["rays"], o["depth"])
     assert r.is_good is False and r.loss == 0.0
+
+
+# ---- decoder family (deep_sdf/deep_sdf_decoder.py:29-63): 4 hidden layers x 256, code 32, latent_in [2], mapped exactly onto the
+# ---- 8 x 512 tile (csrc/sdf_refine.hip:embed_family); fixtures produced by running the reference with that decoder
+@pytest.fixture(scope="module")
+def small_gpu_decoder(golden_dir):
+    from qsp_slam_amd import DeepSdfDecoder
+    d = DeepSdfDecoder.from_npz(os.path.join(golden_dir, "decoder_4x256_c32.npz"))
+    yield d
+    d.close()
+
+
+def test_small_decoder_decode_and_grad_vs_reference_vectors(small_gpu_decoder, golden_dir):
+    z = np.load(os.path.join(golden_dir, "sdf_small_decoder_vectors.npz"))
+    assert small_gpu_decoder.code_len == 32
+    sdf = small_gpu_decoder.decode_sdf(z["code"], z["x"])
+    assert within("small_decoder/sdf_abs", np.abs(sdf - z["sdf"]).max(), 2e-6)
+    y, g = small_gpu_decoder.sdf_value_grad(z["code"], z["x"])
+    assert g.shape == (300, 35)
+    assert within("small_decoder/y_abs", np.abs(y - z["y"]).max(), 2e-6)
+    assert rows_close(g, z["grad"], tol=1e-5, max_bad=0.01)
+
+
+def test_small_decoder_teacher_forced_and_free_running_vs_reference(small_gpu_decoder, golden_dir):
+    """code_len = 32: 39 unknowns in the reference; the library keeps 71 with the 32 padding unknowns decoupled -- the leading
+    39 x 39 block, right-hand side, update and next state must be the reference's"""
+    from qsp_slam_amd.reconstruct.optimizer import Optimizer, RefineBatch, _joint_cfg
+    z = np.load(os.path.join(golden_dir, "sdf_small_joint_m400.npz"))
+    opt = Optimizer(small_gpu_decoder, make_cfg(z, code_len=32))
+    assert opt.code_len == 32
+    batch = RefineBatch(small_gpu_decoder, _joint_cfg(opt), [z["pts"]], [z["rays"]], [z["depth"]], [0])
+    n_it = z["it_H"].shape[0]
+    for i in range(n_it):
+        T_co = np.linalg.inv(z["it_T_oc"][i].astype(np.float64)).astype(np.float32)
+        batch.set_state(T_co[None], z["it_code"][i][None])
+        batch.run(1)
+        tr = batch.trace()
+        T, code, loss, good = batch.get()
+        assert good[0] and code.shape == (1, 32)
+        assert int(tr["K"][0]) == int(z["it_K"][i])
+        H, b, dx = tr["H"][0], tr["b"][0], tr["dx"][0]
+        assert np.array_equal(H[39:, 39:], np.eye(32, dtype=np.float32)) and not H[:39, 39:].any() and not dx[39:].any()
+        assert within("small_joint/teacher_forced/H", relerr(H[:39, :39], z["it_H"][i]), 1e-4)
+        assert within("small_joint/teacher_forced/b", relerr(b[:39], z["it_b"][i]), 1e-4)
+        assert within("small_joint/teacher_forced/dx", relerr(dx[:39], z["it_dx"][i]), 2e-3)
+        if i + 1 < n_it:
+            assert within("small_joint/teacher_forced/T_oc_next", relerr(np.linalg.inv(T[0].astype(np.float64)), z["it_T_oc"][i + 1]), 1e-4)
+            assert within("small_joint/teacher_forced/code_next_abs", np.abs(code[0] - z["it_code"][i + 1]).max(), 1e-4)
+    batch.close()
+    r = opt.reconstruct_object(z["t_cam_obj"], z["pts"], z["rays"], z["depth"])
+    assert r.is_good == bool(z["is_good"]) and r.code.shape == (32,)
+    assert within("small_joint/free_running/t_cam_obj", relerr(r.t_cam_obj, z["out_t_cam_obj"]), 2e-2)
+    assert within("small_joint/free_running/code_abs", np.abs(r.code - z["out_code"]).max(), 2e-2)

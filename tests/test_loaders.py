@@ -70,12 +70,57 @@ def test_get_decoder_from_experiment_directory(tmp_path, golden_dir):
 
 @pytest.mark.gpu
 def test_unsupported_decoder_family_is_refused(golden_dir):
-    """anything but 9 layers / code 64 / latent_in [4] / 8x512 is QSP_ERR_UNSUPPORTED, not a silent fallback"""
+    """what cannot be mapped exactly onto the 8 x 512 tile (csrc/sdf_refine.hip:embed_family) is QSP_ERR_UNSUPPORTED, not a
+    silent fallback: a latent_in layer with more than 4 hidden layers in front of or from it on, hidden widths above 512,
+    two latent_in layers, input widths that do not chain"""
     from qsp_slam_amd import DeepSdfDecoder, _lib
     z = np.load(os.path.join(golden_dir, "decoder_8x512.npz"), allow_pickle=False)
     state = {k: z[k] for k in z.files if k != "meta"}
-    with pytest.raises(_lib.QspError):
-        DeepSdfDecoder.from_state_dict(state, latent_in=(3,), code_len=64)
-    small = {k: v for k, v in state.items() if not k.startswith("lin8")}
-    with pytest.raises(_lib.QspError):
-        DeepSdfDecoder.from_state_dict(small, latent_in=(4,), code_len=64)
+    for latent_in in ((3,), (5,), (4, 6)):            # dims no longer chain / two skips
+        with pytest.raises(_lib.QspError) as e:
+            DeepSdfDecoder.from_state_dict(state, latent_in=latent_in, code_len=64)
+        assert e.value.code == _lib.QSP_ERR_UNSUPPORTED
+    rng = np.random.default_rng(0)
+
+    def mlp(dims_in_out):
+        return [(rng.normal(size=(o, i)).astype(np.float32) * 0.05, None, np.zeros(o, np.float32)) for i, o in dims_in_out]
+    wide = mlp([(67, 640), (640, 640 - 67), (640, 640), (640, 1)])           # width 640 > 512
+    deep = mlp([(67, 64)] + [(64, 64)] * 9 + [(64, 1)])                       # 10 hidden layers
+    for layers, lin in ((wide, (2,)), (deep, ())):
+        with pytest.raises(_lib.QspError) as e:
+            DeepSdfDecoder(layers, latent_in=lin, code_len=64)
+        assert e.value.code == _lib.QSP_ERR_UNSUPPORTED
+
+
+@pytest.mark.gpu
+def test_decoder_family_members_match_the_oracle():
+    """shapes specs.json may ask for (deep_sdf/deep_sdf_decoder.py:29-63), random weights, against the numpy decoder: no
+    latent_in at all, latent_in at the first possible layer, 8 hidden layers of unequal widths, code lengths 8 / 32 / 64"""
+    from oracle import sdf_oracle as so
+    from qsp_slam_amd import DeepSdfDecoder
+    rng = np.random.default_rng(5)
+
+    def family(L, dims, latent_in):
+        full = [L + 3] + list(dims) + [1]
+        layers = []
+        for l in range(len(full) - 1):
+            out = full[l + 1] - (full[0] if (l + 1) in latent_in else 0)
+            w = (rng.normal(size=(out, full[l])) / np.sqrt(full[l])).astype(np.float32)
+            layers.append((w, None, (0.1 * rng.normal(size=out)).astype(np.float32)))
+        return layers
+    cases = [(32, [256] * 4, (2,)), (64, [128, 192, 96], ()), (8, [64, 64], (1,)),
+             (64, [512, 300, 400, 512, 256, 512, 100, 512], (4,)), (16, [200] * 7, (3,)), (64, [512] * 5, (1,))]
+    for L, dims, lin in cases:
+        layers = family(L, dims, lin)
+        dec = DeepSdfDecoder(layers, latent_in=lin, code_len=L)
+        ref = so.DecoderWeights([(w, b) for w, _, b in layers], lin, L)
+        x = rng.uniform(-1, 1, size=(200, 3)).astype(np.float32)
+        code = (0.3 * rng.normal(size=L)).astype(np.float32)
+        assert np.abs(dec.decode_sdf(code, x) - so.decode_sdf(ref, code, x)).max() < 5e-6, (L, dims, lin)
+        inp = np.concatenate([np.broadcast_to(code, (200, L)), x], -1)
+        yr, gr = so.decoder_value_and_input_grad(ref, inp)
+        y, g = dec.sdf_value_grad(code, x)
+        assert g.shape == (200, L + 3) and np.abs(y - yr).max() < 5e-6
+        d = np.abs(g - gr).max(1) / np.abs(gr).max()
+        assert (d > 1e-5).mean() <= 0.02, (L, dims, lin, float(d.max()))
+        dec.close()

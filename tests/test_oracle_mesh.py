@@ -116,3 +116,40 @@ def test_zero_is_outside():
     d = 4
     hit = np.isclose(v, np.array([2, 1, 1], np.float32) * np.float32(2.0 / (d - 1)) - 1).all(1)
     assert hit.sum() == 1
+
+
+def canonical_mesh(verts, faces):
+    """order-independent form of a triangle mesh: vertices sorted lexicographically (bit patterns), faces re-indexed, each
+    face rotated so that its smallest index comes first (orientation kept), faces sorted.  Two meshes with the same vertex
+    set and the same oriented triangles are equal in this form whatever order a marching-cubes implementation emits them
+    in -- the comparison a maintainer would run against skimage's Lewiner output (reconstruct/utils.py:131), whose ORDER
+    differs from this library's by construction (known deviations)."""
+    verts = np.asarray(verts, np.float32)
+    faces = np.asarray(faces, np.int64)
+    order = np.lexsort((verts[:, 2], verts[:, 1], verts[:, 0]))
+    rank = np.empty(len(verts), np.int64)
+    rank[order] = np.arange(len(verts))
+    f = rank[faces] if len(faces) else faces.reshape(0, 3)
+    k = np.argmin(f, axis=1) if len(f) else np.zeros(0, np.int64)
+    f = np.stack([np.take_along_axis(f, ((k + i) % 3)[:, None], 1)[:, 0] for i in range(3)], axis=1) if len(f) else f
+    f = f[np.lexsort((f[:, 2], f[:, 1], f[:, 0]))] if len(f) else f
+    return verts[order], f
+
+
+def test_canonical_form_is_order_independent():
+    vol = sphere_volume(14)
+    v, f = mo.marching_cubes(vol)
+    rng = np.random.default_rng(3)
+    pv = rng.permutation(len(v))                       # shuffle vertices, faces and the starting corner of every face
+    inv = np.empty(len(v), np.int64)
+    inv[pv] = np.arange(len(v))
+    f2 = inv[f][rng.permutation(len(f))]
+    rot = rng.integers(0, 3, len(f2))
+    f2 = np.stack([np.take_along_axis(f2, ((rot + i) % 3)[:, None], 1)[:, 0] for i in range(3)], axis=1)
+    cv, cf = canonical_mesh(v, f)
+    cv2, cf2 = canonical_mesh(v[pv], f2)
+    assert np.array_equal(cv.view(np.uint32), cv2.view(np.uint32)) and np.array_equal(cf, cf2)
+    # a flipped triangle is a different mesh
+    f3 = f.copy()
+    f3[0] = f3[0][::-1]
+    assert not np.array_equal(canonical_mesh(v, f3)[1], cf)

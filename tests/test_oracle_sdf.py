@@ -138,3 +138,32 @@ def test_pose_only(oracle_decoder, golden_dir):
     z = np.load(os.path.join(golden_dir, "sdf_pose_only_m250.npz"))
     out = so.estimate_pose_cam_obj(oracle_decoder, so.JointConfig(), z["t_co_se3"], float(z["scale"]), z["pts"], z["code"])
     assert relerr(out, z["out"]) < 1e-4
+
+
+# ---- a second member of the decoder family: 4 hidden layers x 256, code 32, latent_in [2] (the `code_len == 32` branch of
+# ---- src/LocalMapping_util.cc:789-800); fixtures produced by running the reference (oracle/gen_golden_sdf.py small)
+@pytest.fixture(scope="module")
+def small_decoder(golden_dir):
+    return so.load_decoder_npz(os.path.join(golden_dir, "decoder_4x256_c32.npz"))
+
+
+def test_small_decoder_value_and_grad(small_decoder, golden_dir):
+    z = np.load(os.path.join(golden_dir, "sdf_small_decoder_vectors.npz"))
+    assert small_decoder.code_len == 32 and len(small_decoder.layers) == 5 and tuple(small_decoder.latent_in) == (2,)
+    assert np.abs(so.decode_sdf(small_decoder, z["code"], z["x"]) - z["sdf"]).max() < 2e-6
+    inp = np.concatenate([np.broadcast_to(z["code"], (z["x"].shape[0], 32)), z["x"]], -1)
+    y, g = so.decoder_value_and_input_grad(small_decoder, inp)
+    assert g.shape == (300, 35) and np.abs(y - z["y"]).max() < 2e-6
+    assert rows_close(g, z["grad"], tol=1e-5, max_bad=0.01)
+
+
+def test_small_decoder_teacher_forced_iterations(small_decoder, golden_dir):
+    z = np.load(os.path.join(golden_dir, "sdf_small_joint_m400.npz"))
+    c = cfg_from(z)
+    cfg = so.JointConfig(k1=c.k1, k2=c.k2, k3=c.k3, k4=c.k4, b1=c.b1, b2=c.b2, lr=c.lr, s_damp=c.s_damp, n_iter=c.n_iter, code_len=32)
+    dobs = np.concatenate([z["depth"], np.zeros(z["rays"].shape[0] - z["depth"].shape[0], np.float32)])
+    assert z["it_H"].shape[1:] == (39, 39)
+    for i in range(z["it_H"].shape[0]):
+        it = so.gn_iteration(small_decoder, cfg, z["it_T_oc"][i], z["it_code"][i], z["pts"], z["rays"], dobs, z["depth"].shape[0])
+        assert it["fail"] is None and it["K"] == int(z["it_K"][i])
+        assert relerr(it["H"], z["it_H"][i]) < 1e-4 and relerr(it["b"], z["it_b"][i]) < 1e-4
