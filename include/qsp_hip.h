@@ -64,6 +64,17 @@ int qsp_decoder_create(const qsp_decoder_desc* desc, int device, qsp_decoder** o
  * them after its decoder only frees its own memory and is harmless; any other call on it is undefined.) */
 void qsp_decoder_destroy(qsp_decoder* dec);
 
+/* Decoder options.  QSP_DEC_OPT_FORWARD_PRECISION selects the arithmetic of the FORWARD-ONLY decoder passes (qsp_decode_sdf,
+ * the voxel-grid decode of qsp_mesh_extract, the ray-sample forward pass of the refinement, reconstruct/loss.py:78):
+ *   0 (default)  exact float32 multiply-adds on the f32 matrix pipe (v_mfma_f32_32x32x2_f32);
+ *   1            every f32 weight and activation as the exact sum of three bf16 values, six bf16 products per multiply-add on
+ *                the bf16 matrix pipe with f32 accumulation (v_mfma_f32_32x32x16_bf16): float32-equivalent accuracy (2.2e-7
+ *                relative on the SDF value against float64; plain f32: 1.8e-7) at up to 2.67 x the f32 pipe's rate.  Results
+ *                differ from mode 0 in the last bits, as two float32 implementations with different summation orders do.
+ * The forward+backward pass that builds the Jacobians and normal equations always runs in float32. */
+enum { QSP_DEC_OPT_FORWARD_PRECISION = 1 };
+int qsp_decoder_set_option(qsp_decoder* dec, int32_t option, int32_t value);
+
 /* decode_sdf, reconstruct/loss_utils.py:51-79.  Host pointers: code (code_len), xyz (n,3) row-major, sdf_out (n). */
 int qsp_decode_sdf(qsp_decoder* dec, const float* code, const float* xyz, int64_t n, float* sdf_out);
 

@@ -91,7 +91,7 @@ class DetectionResults(C.Structure):
 
 SYMBOLS = [
     "qsp_last_error", "qsp_version", "qsp_device_count",
-    "qsp_decoder_create", "qsp_decoder_destroy", "qsp_decode_sdf", "qsp_sdf_value_grad",
+    "qsp_decoder_create", "qsp_decoder_destroy", "qsp_decoder_set_option", "qsp_decode_sdf", "qsp_sdf_value_grad",
     "qsp_refine_batch_create", "qsp_refine_batch_destroy", "qsp_refine_batch_set_state", "qsp_refine_batch_run",
     "qsp_refine_batch_get", "qsp_refine_batch_trace", "qsp_refine_batch_profile", "qsp_refine_batch_rows",
     "qsp_reconstruct_objects", "qsp_estimate_pose", "qsp_refine_detections",
@@ -120,6 +120,7 @@ def lib():
     vp = C.c_void_p
     L.qsp_decoder_create.argtypes = [C.POINTER(DecoderDesc), C.c_int, C.POINTER(vp)]
     L.qsp_decoder_destroy.argtypes = [vp]
+    L.qsp_decoder_set_option.argtypes = [vp, C.c_int32, C.c_int32]
     L.qsp_decoder_destroy.restype = None
     L.qsp_decode_sdf.argtypes = [vp, c_float_p, c_float_p, C.c_int64, c_float_p]
     L.qsp_sdf_value_grad.argtypes = [vp, c_float_p, c_float_p, C.c_int64, c_float_p, c_float_p]

@@ -396,8 +396,12 @@ extern "C" int qsp_mesh_extract(qsp_mesh_extractor* m, const float* code, int64_
     QSP_HIP(hipStreamSynchronize(s));                  // (code64 lives on this stack frame)
     const int64_t tiles = (m->n + TILE_P - 1) / TILE_P;
     const int grid = (int)std::min<int64_t>(tiles, 4096);
-    hipLaunchKernelGGL(k_decode<false>, dim3(grid), dim3(MLP_THREADS), sizeof(MlpSmem), s, m->code, m->xyz, m->n, m->dec->Pd,
-                       m->sdf, (float*)nullptr);
+    if (m->dec->fwd_bf3)
+        hipLaunchKernelGGL((k_decode<false, true>), dim3(grid), dim3(MLP_THREADS), sizeof(MlpSmem), s, m->code, m->xyz, m->n,
+                           m->dec->Pd, m->sdf, (float*)nullptr);
+    else
+        hipLaunchKernelGGL(k_decode<false>, dim3(grid), dim3(MLP_THREADS), sizeof(MlpSmem), s, m->code, m->xyz, m->n, m->dec->Pd,
+                           m->sdf, (float*)nullptr);
     QSP_HIP(hipGetLastError());
     return mesh_march(m, n_verts, n_faces);
 }

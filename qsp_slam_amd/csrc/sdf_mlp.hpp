@@ -80,6 +80,7 @@ struct MlpParams {
     const float* w0c;       // [512][64] layer-0 weights of the latent code (row-major)
     const float* w4c;       // [512][64] layer-4 weights of the latent code (input columns 445..508)
     const float4* w0x;      // [128 unit quads][3] layer-0 weights of x, y, z for four consecutive units
+    const float4* wf3[8];   // split-bf16 forward weights of layers 1..7: [col block 16][slab K/16][plane hi|mid|lo][lane 64][8 bf16]
 };
 
 // LDS carve (bytes): act 132096 | stash 17408 | inp 64*4*4 | code 256 | y 256 | red 2048 | row scale/res 512
@@ -687,6 +688,267 @@ __device__ __forceinline__ void mlp_tile(MlpSmem& s, const MlpParams* __restrict
     QSP_TS()
     __syncthreads();
     QSP_TS()
+}
+
+// ===================================================================================================================
+// Split-bf16 forward tile (qsp_decoder_set_option(QSP_DEC_OPT_FORWARD_PRECISION, 1)).
+//
+// The f32 MFMA runs at 1/16 of the bf16 rate.  An f32 value is the EXACT sum of three bf16 values' worth of mantissa
+// (8 + 8 + 8 bits): x = x_hi + x_mid + x_lo with x_hi = bf16(x), x_mid = bf16(x - x_hi), x_lo = bf16(x - x_hi - x_mid).
+// A product of two such numbers needs six of the nine cross terms to keep every contribution above 2^-24 of it:
+//     w x  ~=  w_hi x_hi + (w_hi x_mid + w_mid x_hi) + (w_hi x_lo + w_mid x_mid + w_lo x_hi)
+// all accumulated in f32 by v_mfma_f32_32x32x16_bf16: 6 MFMAs of 32 cycles do the work of 8 f32 MFMAs of 64 cycles, 2.67 x
+// the f32 pipe.  Measured against float64 on the fitted decoder (tools/studies/bf16_split_accuracy.py): 2.2e-7 relative on the
+// SDF value, f32 itself 1.8e-7.
+//   * weights: split once on the host, streamed as three 1 KiB fragments per (column block, slab of 16 k) -- 1.5 x the bytes
+//     per multiply-add of the f32 path at 2.67 x its rate;
+//   * activations stay f32 in LDS (6 bytes per value would not fit a 64-point tile) and are split by the consuming wave
+//     after the LDS read: ~5.5 VALU operations per value, which ride in the issue slots the MFMAs leave free (an MFMA holds
+//     the SIMD's vector issue for 8 of its 32 cycles);
+//   * same wave -> (64 units x 64 points) map, same C/D layout as the f32 MFMA, so the write-out code is shared.
+// Forward only: the discrete decisions of the render term (|sdf| < cut-off) see values that differ from the f32 tile's in
+// the last bits, like any two float32 implementations do; the fwd+bwd tile that feeds the normal equations stays on the f32 pipe.
+// ===================================================================================================================
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+struct Bf3 {
+    bf16x8 hi, mid, lo;
+};
+
+// 8 consecutive f32 activations -> their three bf16 planes (the lane's B-operand fragments of one 32x32x16 MFMA)
+__device__ __forceinline__ Bf3 split3(f32x4 a, f32x4 b) {
+    Bf3 o;
+    float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const __bf16 h = (__bf16)v[j];
+        const float r = v[j] - (float)h;
+        const __bf16 m = (__bf16)r;
+        const float r2 = r - (float)m;
+        o.hi[j] = h;
+        o.mid[j] = m;
+        o.lo[j] = (__bf16)r2;
+    }
+    return o;
+}
+
+__device__ __forceinline__ bf16x8 as_bf16x8(f32x4 q) {
+    union { f32x4 f; bf16x8 b; } u;
+    u.f = q;
+    return u.b;
+}
+
+template <int PF>
+struct WRing3 {
+    f32x4 q[PF][2][3];      // [slab in flight][column block][plane]: 16-byte fragments (8 bf16 each)
+};
+
+template <int PF>
+__device__ __forceinline__ void ring3_prime(WRing3<PF>& R, const float4* __restrict__ w0_, const float4* __restrict__ w1_, int lane) {
+    gptr4 w0 = (gptr4)w0_;
+    gptr4 w1 = (gptr4)w1_;
+#pragma unroll
+    for (int d = 0; d < PF; ++d)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            R.q[d][0][p] = w0[(d * 3 + p) * 64 + lane];
+            R.q[d][1][p] = w1[(d * 3 + p) * 64 + lane];
+        }
+}
+
+#define QSP_MFMA_BF(acc_, a_, b_) acc_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, b_, acc_, 0, 0, 0)
+
+// acc[r][c] += act[32r.., 0..16*KS) * W for this wave's two column blocks, six bf16 products per term.
+// Ring protocol as gemm_2x2: on entry the ring holds slabs 0..PF-1 of this GEMM, on exit slabs 0..PF-1 of the next one.
+template <int KS, int PF>
+__device__ __forceinline__ void gemm_2x2_bf3(const float* __restrict__ act, const float4* __restrict__ w0_,
+                                             const float4* __restrict__ w1_, const float4* __restrict__ n0_,
+                                             const float4* __restrict__ n1_, WRing3<PF>& R, f32x16 (&acc)[2][2], int lane) {
+    static_assert(KS % PF == 0 && KS >= 2 * PF, "slab count must be a multiple of the prefetch depth, at least twice it");
+    gptr4 w0 = (gptr4)w0_;
+    gptr4 w1 = (gptr4)w1_;
+    gptr4 n0 = (gptr4)n0_;
+    gptr4 n1 = (gptr4)n1_;
+    // lane (r = lane & 31, h = lane >> 5) supplies act[point r][k = 16 s + 8 h + j], j = 0..7
+    const float* a_row0 = act + (lane & 31) * LDA + 8 * (lane >> 5);
+    const float* a_row1 = a_row0 + 32 * LDA;
+#ifndef QSP_BF3_PIPE
+#define QSP_BF3_PIPE 1
+#endif
+#if QSP_BF3_PIPE
+    // software pipeline: the bf16 planes of slab s+1 are produced (VALU) while the 24 MFMAs of slab s run; the raw f32 of
+    // slab s+2 is in flight from LDS meanwhile
+    Bf3 b0 = split3(lds4(a_row0), lds4(a_row0 + 4)), b1 = split3(lds4(a_row1), lds4(a_row1 + 4));
+    f32x4 x00 = lds4(a_row0 + 16), x01 = lds4(a_row0 + 20), x10 = lds4(a_row1 + 16), x11 = lds4(a_row1 + 20);
+#else
+    f32x4 x00 = lds4(a_row0), x01 = lds4(a_row0 + 4), x10 = lds4(a_row1), x11 = lds4(a_row1 + 4);
+#endif
+#pragma nounroll
+    for (int ks = 0; ks < KS; ks += PF) {
+#pragma unroll
+        for (int d = 0; d < PF; ++d) {
+            bf16x8 wa[2][3];
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) wa[c][p] = as_bf16x8(R.q[d][c][p]);
+            // refill this ring slot: slab ks + d + PF of this GEMM, or slab d of the next one
+            if (ks + PF < KS) {
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    R.q[d][0][p] = w0[((ks + d + PF) * 3 + p) * 64 + lane];
+                    R.q[d][1][p] = w1[((ks + d + PF) * 3 + p) * 64 + lane];
+                }
+            } else {
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    R.q[d][0][p] = n0[(d * 3 + p) * 64 + lane];
+                    R.q[d][1][p] = n1[(d * 3 + p) * 64 + lane];
+                }
+            }
+#if !QSP_BF3_PIPE
+            const Bf3 b0 = split3(x00, x01), b1 = split3(x10, x11);
+            // next slab's activations (one slab past the end stays inside MlpSmem)
+            x00 = lds4(a_row0 + 16 * (ks + d + 1));
+            x01 = lds4(a_row0 + 16 * (ks + d + 1) + 4);
+            x10 = lds4(a_row1 + 16 * (ks + d + 1));
+            x11 = lds4(a_row1 + 16 * (ks + d + 1) + 4);
+#endif
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                // small terms first
+                QSP_MFMA_BF(acc[0][c], wa[c][2], b0.hi);
+                QSP_MFMA_BF(acc[1][c], wa[c][2], b1.hi);
+                QSP_MFMA_BF(acc[0][c], wa[c][0], b0.lo);
+                QSP_MFMA_BF(acc[1][c], wa[c][0], b1.lo);
+                QSP_MFMA_BF(acc[0][c], wa[c][1], b0.mid);
+                QSP_MFMA_BF(acc[1][c], wa[c][1], b1.mid);
+                QSP_MFMA_BF(acc[0][c], wa[c][1], b0.hi);
+                QSP_MFMA_BF(acc[1][c], wa[c][1], b1.hi);
+                QSP_MFMA_BF(acc[0][c], wa[c][0], b0.mid);
+                QSP_MFMA_BF(acc[1][c], wa[c][0], b1.mid);
+                QSP_MFMA_BF(acc[0][c], wa[c][0], b0.hi);
+                QSP_MFMA_BF(acc[1][c], wa[c][0], b1.hi);
+            }
+#if QSP_BF3_PIPE
+            {   // (the slabs past the end of this GEMM stay inside MlpSmem; their fragments are never used)
+                const Bf3 n0b = split3(x00, x01), n1b = split3(x10, x11);
+                x00 = lds4(a_row0 + 16 * (ks + d + 2));
+                x01 = lds4(a_row0 + 16 * (ks + d + 2) + 4);
+                x10 = lds4(a_row1 + 16 * (ks + d + 2));
+                x11 = lds4(a_row1 + 16 * (ks + d + 2) + 4);
+                b0 = n0b;
+                b1 = n1b;
+            }
+#endif
+        }
+    }
+}
+
+// Forward network on the split-bf16 pipe for the tile staged in s.code / s.xin / s.c0 / s.c4; on return s.y[row] = sdf value.
+// The biases of layers 1..7 are staged in s.stash (unused by forward-only kernels) so that no vector-memory wait has to drain
+// the weight ring between layers.
+#ifndef QSP_BF3_PF
+#define QSP_BF3_PF 2
+#endif
+template <int PF>
+__device__ __forceinline__ void mlp_tile_bf3(MlpSmem& s, const MlpParams* __restrict__ Pm) {
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    int oz;
+    asm volatile("s_mov_b32 %0, 0" : "=s"(oz));
+    const MlpParams& P = Pm[oz];
+    f32x16 acc[2][2];
+    uint32_t mlo, mhi;
+    s.w8[tid] = P.w8[tid];
+    float* bias_sh = s.stash;                              // [7][512] biases of layers 1..7 (17408 B >= 14336 B)
+#pragma unroll
+    for (int l = 1; l < 8; ++l) bias_sh[(l - 1) * HID + tid] = P.bias[l][tid];
+    const int cb0 = 2 * wave;
+    constexpr int KSH = HID / 16, KS4 = K4 / 16;
+#define QSP_W3(L, KS_) (P.wf3[L] + (size_t)(cb0 * (KS_) * 3) * 64)
+#define QSP_W31(L, KS_) (P.wf3[L] + (size_t)((cb0 + 1) * (KS_) * 3) * 64)
+    WRing3<PF> ring;
+    ring3_prime(ring, QSP_W3(1, KSH), QSP_W31(1, KSH), lane);
+    BiasQuads bq;
+    // ---- layer 0 (exact f32, as in mlp_tile) ---------------------------------------------------------------------
+    {
+        const int h = lane >> 5;
+        const f32x4 x0 = lds4(s.xin + 4 * (lane & 31)), x1 = lds4(s.xin + 4 * (32 + (lane & 31)));
+        typedef const __attribute__((address_space(1))) f32x4* gq;
+        gq wx = (gq)P.w0x;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int u0 = 64 * wave + 32 * c + 8 * g + 4 * h;
+                const f32x4 cq = lds4(s.c0 + u0);
+                const f32x4 w0 = wx[3 * (u0 >> 2)], w1 = wx[3 * (u0 >> 2) + 1], w2 = wx[3 * (u0 >> 2) + 2];
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const f32x4 xp = r == 0 ? x0 : x1;
+                    const int p = 32 * r + (lane & 31);
+                    f32x4 v;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float x = cq[q] + w0[q] * xp.x + w1[q] * xp.y + w2[q] * xp.z;
+                        v[q] = x > 0.f ? x : 0.f;
+                    }
+                    *reinterpret_cast<f32x4*>(s.act + p * LDA + u0) = v;
+                }
+            }
+    }
+    __syncthreads();
+#define QSP_BIAS_FROM(ptr)                                                                          \
+    _Pragma("unroll") for (int c = 0; c < 2; ++c) _Pragma("unroll") for (int g = 0; g < 4; ++g)     \
+        bq.v[c][g] = lds4((ptr) + 64 * wave + 32 * c + 8 * g + 4 * (lane >> 5));
+#define QSP_FWD3(L, KS_, NL, NKS, BIASPTR)                                                                             \
+    zero_acc(acc);                                                                                                     \
+    gemm_2x2_bf3<KS_, PF>(s.act, QSP_W3(L, KS_), QSP_W31(L, KS_), QSP_W3(NL, NKS), QSP_W31(NL, NKS), ring, acc, lane); \
+    QSP_BIAS_FROM(BIASPTR)                                                                                             \
+    __syncthreads();                                                                                                   \
+    fwd_writeout<L>(s, bq, acc, wave, lane, mlo, mhi);                                                                 \
+    __syncthreads();
+    QSP_FWD3(1, KSH, 2, KSH, bias_sh + 0 * HID)
+    QSP_FWD3(2, KSH, 3, KSH, bias_sh + 1 * HID)
+    QSP_FWD3(3, KSH, 4, KS4, bias_sh + 2 * HID)
+    pass_through(s);
+    __syncthreads();
+    QSP_FWD3(4, KS4, 5, KSH, s.c4)
+    QSP_FWD3(5, KSH, 6, KSH, bias_sh + 4 * HID)
+    QSP_FWD3(6, KSH, 7, KSH, bias_sh + 5 * HID)
+    QSP_FWD3(7, KSH, 1, KSH, bias_sh + 6 * HID)
+#undef QSP_FWD3
+#undef QSP_BIAS_FROM
+#undef QSP_W3
+#undef QSP_W31
+    (void)mlo; (void)mhi;
+    // ---- layer 8: 512 -> 1, tanh (f32) ---------------------------------------------------------------------------
+    {
+        const float* a = s.act + lane * LDA + 64 * wave;
+        const float* w = s.w8 + 64 * wave;
+        float part = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const float4 av = *reinterpret_cast<const float4*>(a + 4 * q);
+            const float4 wv = *reinterpret_cast<const float4*>(w + 4 * q);
+            part += av.x * wv.x;
+            part += av.y * wv.y;
+            part += av.z * wv.z;
+            part += av.w * wv.w;
+        }
+        s.red[wave * TILE_P + lane] = part;
+    }
+    __syncthreads();
+    if (tid < TILE_P) {
+        float t = P.b8;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t += s.red[q * TILE_P + tid];
+        s.y[tid] = tanhf(t);
+    }
+    __syncthreads();
 }
 
 }  // namespace qsp

@@ -295,6 +295,7 @@ __global__ __launch_bounds__(1024) void k_plan(int mode, const HypState* __restr
 // ---------------------------------------------------------------------------------------------------------------
 // k_mlp_fwd: decoder forward on the valid ray samples (loss.py:78)
 // ---------------------------------------------------------------------------------------------------------------
+template <bool BF3>
 __global__ __launch_bounds__(MLP_THREADS, 2) void k_mlp_fwd(const HypState* __restrict__ st,
                                                             const ObjView* __restrict__ objs,
                                                             const float* __restrict__ rays, RefineCfg cfg, const MlpParams* __restrict__ P,
@@ -342,7 +343,8 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void k_mlp_fwd(const HypState* __re
             s.xin[4 * threadIdx.x + 3] = 0.f;
         }
         __syncthreads();
-        mlp_tile<false, 4>(s, P);
+        if (BF3) mlp_tile_bf3<QSP_BF3_PF>(s, P);
+        else mlp_tile<false, 4>(s, P);
         if (threadIdx.x < TILE_P) {
             const int v = t * TILE_P + threadIdx.x;
             if (v < n) out[v] = s.y[threadIdx.x];
@@ -866,7 +868,7 @@ __global__ void k_inlier_filter(const HypState* __restrict__ st, const ObjView* 
 // ---------------------------------------------------------------------------------------------------------------
 // generic decode kernels for the API-level entry points (loss_utils.py:51-103): points already in the object frame
 // ---------------------------------------------------------------------------------------------------------------
-template <bool GRAD>
+template <bool GRAD, bool BF3 = false>
 __global__ __launch_bounds__(MLP_THREADS, 2) void k_decode(const float* __restrict__ code, const float* __restrict__ xyz,
                                                            int64_t n, const MlpParams* __restrict__ P, float* __restrict__ y_out,
                                                            float* __restrict__ grad_out) {
@@ -886,7 +888,8 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void k_decode(const float* __restri
             s.xin[4 * threadIdx.x + 3] = 0.f;
         }
         __syncthreads();
-        mlp_tile<GRAD, 4>(s, P);
+        if (BF3 && !GRAD) mlp_tile_bf3<QSP_BF3_PF>(s, P);
+        else mlp_tile<GRAD, 4>(s, P);
         if (threadIdx.x < TILE_P) {
             const int64_t v = t * TILE_P + threadIdx.x;
             if (v < n) y_out[v] = s.y[threadIdx.x];
@@ -949,6 +952,7 @@ struct qsp_decoder {
     std::vector<void*> allocs;
     double mac_per_point = 0;
     int code_len = CODE_LEN;   // the caller's code length L <= 64; the tile always works on 64 (columns L..63 are zero)
+    int fwd_bf3 = 0;           // QSP_DEC_OPT_FORWARD_PRECISION: forward-only passes on the split-bf16 pipe (mlp_tile_bf3)
 };
 
 // The family deep_sdf/deep_sdf_decoder.py:29-63 builds -- `dims` hidden layers of any width, one (or no) latent_in layer, any
@@ -1072,6 +1076,7 @@ static int pack_weights(qsp_decoder* d, const qsp_decoder_desc* desc) {
             rc = upload(wc, (const void**)&d->P.w0c);
             if (!rc) rc = upload(wx, (const void**)&d->P.w0x);
             d->P.wf[0] = nullptr;
+            d->P.wf3[0] = nullptr;
         } else {
             // forward: B[k][o]; column blocks over o (16 blocks of 32), k-groups of 8 over K = 512.
             // Layer 4 (latent_in): K = 448 = [h3 (445) | xyz (3)]; its 64 code columns go to w4c (folded into a bias per
@@ -1090,6 +1095,48 @@ static int pack_weights(qsp_decoder* d, const qsp_decoder_desc* desc) {
                             pf[(((size_t)cb * KG + kg) * 64 + lane) * 4 + e] = v;
                         }
             rc = upload(pf, (const void**)&d->P.wf[l]);
+            if (!rc) {
+                // split-bf16 planes for mlp_tile_bf3: [col block][slab of 16 k][plane][lane][8 bf16]; lane (r, h) holds
+                // W[unit 32 cb + r][k = 16 s + 8 h + j] (the A-operand map of v_mfma_f32_32x32x16_bf16)
+                const int KS = KG / 2;
+                std::vector<uint16_t> p3((size_t)16 * KS * 3 * 64 * 8, 0);
+                auto bf16_rne = [](float x) -> uint16_t {
+                    uint32_t u;
+                    memcpy(&u, &x, 4);
+                    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);       // NaN stays NaN
+                    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+                };
+                auto bf16_f32 = [](uint16_t b) -> float {
+                    const uint32_t u = (uint32_t)b << 16;
+                    float x;
+                    memcpy(&x, &u, 4);
+                    return x;
+                };
+                for (int cb = 0; cb < 16; ++cb)
+                    for (int ks = 0; ks < KS; ++ks)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int j = 0; j < 8; ++j) {
+                                const int o = 32 * cb + (lane & 31);
+                                int k = 16 * ks + 8 * (lane >> 5) + j;
+                                if (l == 4 && k >= SKIP_COL) k += CODE_LEN;
+                                float v = 0.f;
+                                if (o < out && k < in) v = W[l][(size_t)o * in + k];
+                                const uint16_t hi = bf16_rne(v);
+                                const float r1 = v - bf16_f32(hi);
+                                const uint16_t mid = bf16_rne(r1);
+                                const float r2 = r1 - bf16_f32(mid);
+                                const uint16_t lo = bf16_rne(r2);
+                                const size_t base = (((size_t)cb * KS + ks) * 3) * 64 * 8 + (size_t)lane * 8 + j;
+                                p3[base] = hi;
+                                p3[base + 64 * 8] = mid;
+                                p3[base + 2 * 64 * 8] = lo;
+                            }
+                void* p3d = nullptr;
+                QSP_HIP(hipMalloc(&p3d, p3.size() * sizeof(uint16_t) + 16384));
+                d->allocs.push_back(p3d);
+                QSP_HIP(hipMemcpy(p3d, p3.data(), p3.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+                d->P.wf3[l] = (const float4*)p3d;
+            }
             if (!rc && l == 4) {
                 std::vector<float> wc((size_t)HID * CODE_LEN);
                 for (int o = 0; o < HID; ++o)
@@ -1135,7 +1182,9 @@ static int mlp_attr_once() {
     static bool done = false;
     if (done) return QSP_OK;
     const int bytes = (int)sizeof(MlpSmem);
-    QSP_HIP(hipFuncSetAttribute((const void*)k_mlp_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    QSP_HIP(hipFuncSetAttribute((const void*)k_mlp_fwd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    QSP_HIP(hipFuncSetAttribute((const void*)k_mlp_fwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    QSP_HIP(hipFuncSetAttribute((const void*)k_decode<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     QSP_HIP(hipFuncSetAttribute((const void*)k_mlp_jtj, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     QSP_HIP(hipFuncSetAttribute((const void*)k_decode<false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     QSP_HIP(hipFuncSetAttribute((const void*)k_decode<true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
@@ -1166,6 +1215,17 @@ extern "C" int qsp_decoder_create(const qsp_decoder_desc* desc, int device, qsp_
     return QSP_OK;
 }
 
+extern "C" int qsp_decoder_set_option(qsp_decoder* d, int32_t option, int32_t value) {
+    if (!d) return qsp_fail(QSP_ERR_INVALID, "qsp_decoder_set_option: null decoder");
+    switch (option) {
+        case QSP_DEC_OPT_FORWARD_PRECISION:
+            if (value != 0 && value != 1) return qsp_fail(QSP_ERR_INVALID, "forward precision: 0 (f32 MFMA) or 1 (split bf16)");
+            d->fwd_bf3 = value;
+            return QSP_OK;
+        default: return qsp_fail(QSP_ERR_INVALID, "qsp_decoder_set_option: unknown option");
+    }
+}
+
 extern "C" void qsp_decoder_destroy(qsp_decoder* d) {
     if (!d) return;
     (void)hipSetDevice(d->device);
@@ -1191,6 +1251,9 @@ static int decode_common(qsp_decoder* d, const float* code, const float* xyz, in
     const int grid = (int)std::min<int64_t>(tiles, 4096);
     if (grad)
         hipLaunchKernelGGL(k_decode<true>, dim3(grid), dim3(MLP_THREADS), sizeof(MlpSmem), d->stream, dc, dx, n, d->Pd, dy, dg);
+    else if (d->fwd_bf3)
+        hipLaunchKernelGGL((k_decode<false, true>), dim3(grid), dim3(MLP_THREADS), sizeof(MlpSmem), d->stream, dc, dx, n, d->Pd, dy,
+                           (float*)nullptr);
     else
         hipLaunchKernelGGL(k_decode<false>, dim3(grid), dim3(MLP_THREADS), sizeof(MlpSmem), d->stream, dc, dx, n, d->Pd, dy,
                            (float*)nullptr);
@@ -1455,8 +1518,12 @@ extern "C" int qsp_refine_batch_run(qsp_refine_batch* b, int32_t n_iter) {
             if (b->prof) a = next_event(b, cur);
             hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, s, 0, b->st, b->objs, nH, b->nw_sdf, nw_total - b->nw_sdf,
                                b->work_fwd, b->qctl);
-            hipLaunchKernelGGL(k_mlp_fwd, dim3(b->n_cu), dim3(MLP_THREADS), sizeof(MlpSmem), s, b->st, b->objs, b->rays,
-                               cfg, b->dec->Pd, b->valid_rk, b->rk_stride, b->sdf_valid, b->work_fwd, b->qctl, b->c0_all);
+            if (b->dec->fwd_bf3)
+                hipLaunchKernelGGL(k_mlp_fwd<true>, dim3(b->n_cu), dim3(MLP_THREADS), sizeof(MlpSmem), s, b->st, b->objs, b->rays,
+                                   cfg, b->dec->Pd, b->valid_rk, b->rk_stride, b->sdf_valid, b->work_fwd, b->qctl, b->c0_all);
+            else
+                hipLaunchKernelGGL(k_mlp_fwd<false>, dim3(b->n_cu), dim3(MLP_THREADS), sizeof(MlpSmem), s, b->st, b->objs, b->rays,
+                                   cfg, b->dec->Pd, b->valid_rk, b->rk_stride, b->sdf_valid, b->work_fwd, b->qctl, b->c0_all);
             if (b->prof) spans.push_back({a, next_event(b, cur), 1});
             if (b->prof) a = next_event(b, cur);
             hipLaunchKernelGGL(k_scan, dim3(nH), dim3(512), 0, s, b->st, b->objs, b->depth, cfg, b->valid_rk, b->rk_stride,

@@ -40,6 +40,11 @@ class DeepSdfDecoder(object):
         self.device = int(device)
         self.mac_per_point = int(sum(int(i) * int(o) for i, o in zip(in_dim, out_dim)))
 
+    def set_forward_precision(self, split_bf16):
+        """forward-only passes (decode_sdf, mesh grid, ray samples) on the exact-f32 matrix pipe (False, default) or as three
+        bf16 terms per operand / six products on the bf16 pipe (True); see QSP_DEC_OPT_FORWARD_PRECISION in qsp_hip.h"""
+        _lib.check(_lib.lib().qsp_decoder_set_option(self.handle, 1, 1 if split_bf16 else 0))
+
     def close(self):
         if getattr(self, "handle", None):
             _lib.lib().qsp_decoder_destroy(self.handle)
