@@ -71,8 +71,10 @@ void qsp_decoder_destroy(qsp_decoder* dec);
  *                the bf16 matrix pipe with f32 accumulation (v_mfma_f32_32x32x16_bf16): float32-equivalent accuracy (2.2e-7
  *                relative on the SDF value against float64; plain f32: 1.8e-7) at up to 2.67 x the f32 pipe's rate.  Results
  *                differ from mode 0 in the last bits, as two float32 implementations with different summation orders do.
- * The forward+backward pass that builds the Jacobians and normal equations always runs in float32. */
-enum { QSP_DEC_OPT_FORWARD_PRECISION = 1 };
+ * QSP_DEC_OPT_JACOBIAN_PRECISION selects the same for the forward+backward pass that builds the Jacobian rows and the normal
+ * equations (qsp_sdf_value_grad and the fused kernel of the refinement, reconstruct/loss_utils.py:82-103): that pass has no
+ * discrete decision besides the ReLU masks, so mode 1 moves H, b by float32 rounding noise only. */
+enum { QSP_DEC_OPT_FORWARD_PRECISION = 1, QSP_DEC_OPT_JACOBIAN_PRECISION = 2 };
 int qsp_decoder_set_option(qsp_decoder* dec, int32_t option, int32_t value);
 
 /* decode_sdf, reconstruct/loss_utils.py:51-79.  Host pointers: code (code_len), xyz (n,3) row-major, sdf_out (n). */

@@ -81,6 +81,7 @@ struct MlpParams {
     const float* w4c;       // [512][64] layer-4 weights of the latent code (input columns 445..508)
     const float4* w0x;      // [128 unit quads][3] layer-0 weights of x, y, z for four consecutive units
     const float4* wf3[8];   // split-bf16 forward weights of layers 1..7: [col block 16][slab K/16][plane hi|mid|lo][lane 64][8 bf16]
+    const float4* wb3[8];   // split-bf16 backward weights of layers 0..7 (column blocks over the layer's inputs, slabs over outputs)
 };
 
 // LDS carve (bytes): act 132096 | stash 17408 | inp 64*4*4 | code 256 | y 256 | red 2048 | row scale/res 512
@@ -409,13 +410,201 @@ __device__ __forceinline__ void mlp_prepare(MlpSmem& s, const MlpParams* __restr
     s.c4[u] = a4;
 }
 
+// ---- split-bf16 GEMM primitives (see the note in front of mlp_tile_bf3) ---------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+struct Bf3 {
+    bf16x8 hi, mid, lo;
+};
+
+// 8 consecutive f32 activations -> their three bf16 planes (the lane's B-operand fragments of one 32x32x16 MFMA)
+__device__ __forceinline__ Bf3 split3(f32x4 a, f32x4 b) {
+    Bf3 o;
+    float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const __bf16 h = (__bf16)v[j];
+        const float r = v[j] - (float)h;
+        const __bf16 m = (__bf16)r;
+        const float r2 = r - (float)m;
+        o.hi[j] = h;
+        o.mid[j] = m;
+        o.lo[j] = (__bf16)r2;
+    }
+    return o;
+}
+
+__device__ __forceinline__ bf16x8 as_bf16x8(f32x4 q) {
+    union { f32x4 f; bf16x8 b; } u;
+    u.f = q;
+    return u.b;
+}
+
+template <int PF>
+struct WRing3 {
+    f32x4 q[PF][2][3];      // [slab in flight][column block][plane]: 16-byte fragments (8 bf16 each)
+};
+
+template <int PF>
+__device__ __forceinline__ void ring3_prime(WRing3<PF>& R, const float4* __restrict__ w0_, const float4* __restrict__ w1_, int lane) {
+    gptr4 w0 = (gptr4)w0_;
+    gptr4 w1 = (gptr4)w1_;
+#pragma unroll
+    for (int d = 0; d < PF; ++d)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            R.q[d][0][p] = w0[(d * 3 + p) * 64 + lane];
+            R.q[d][1][p] = w1[(d * 3 + p) * 64 + lane];
+        }
+}
+
+// v_mfma_f32_32x32x16_bf16 with the accumulator tile in AccVGPRs (AG; see mfma32t) or left to the compiler
+template <bool AG>
+__device__ __forceinline__ f32x16 mfma_bf(bf16x8 a, bf16x8 b, f32x16 c) {
+    if (AG) {
+        union { bf16x8 h; f32x4 f; } ua, ub;
+        ua.h = a;
+        ub.h = b;
+        asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(ua.f), "v"(ub.f));
+        return c;
+    }
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+#define QSP_MFMA_BF(acc_, a_, b_) acc_ = mfma_bf<AG>(a_, b_, acc_)
+
+// acc[r][c] += act[32r.., 0..16*KS) * W for this wave's two column blocks, six bf16 products per term.
+// Ring protocol as gemm_2x2: on entry the ring holds slabs 0..PF-1 of this GEMM, on exit slabs 0..PF-1 of the next one.
+template <int KS, int PF, bool AG = false, bool PIPE = false>
+__device__ __forceinline__ void gemm_2x2_bf3(const float* __restrict__ act, const float4* __restrict__ w0_,
+                                             const float4* __restrict__ w1_, const float4* __restrict__ n0_,
+                                             const float4* __restrict__ n1_, WRing3<PF>& R, f32x16 (&acc)[2][2], int lane) {
+    static_assert(KS % PF == 0 && KS >= 2 * PF, "slab count must be a multiple of the prefetch depth, at least twice it");
+    gptr4 w0 = (gptr4)w0_;
+    gptr4 w1 = (gptr4)w1_;
+    gptr4 n0 = (gptr4)n0_;
+    gptr4 n1 = (gptr4)n1_;
+    // lane (r = lane & 31, h = lane >> 5) supplies act[point r][k = 16 s + 8 h + j], j = 0..7
+    const float* a_row0 = act + (lane & 31) * LDA + 8 * (lane >> 5);
+    const float* a_row1 = a_row0 + 32 * LDA;
+    // PIPE: software pipeline -- the bf16 planes of slab s+1 are produced (VALU) while the 24 MFMAs of slab s run, the raw
+    // f32 of slab s+2 is in flight from LDS meanwhile (24 more registers: the forward-only tile affords them, 298 instead of
+    // 306 ms for C4's k_mlp_fwd; the forward+backward tile does not)
+    Bf3 b0, b1;
+    f32x4 x00, x01, x10, x11;
+    if (PIPE) {
+        b0 = split3(lds4(a_row0), lds4(a_row0 + 4));
+        b1 = split3(lds4(a_row1), lds4(a_row1 + 4));
+        x00 = lds4(a_row0 + 16); x01 = lds4(a_row0 + 20); x10 = lds4(a_row1 + 16); x11 = lds4(a_row1 + 20);
+    } else {
+        x00 = lds4(a_row0); x01 = lds4(a_row0 + 4); x10 = lds4(a_row1); x11 = lds4(a_row1 + 4);
+    }
+#pragma nounroll
+    for (int ks = 0; ks < KS; ks += PF) {
+#pragma unroll
+        for (int d = 0; d < PF; ++d) {
+            bf16x8 wa[2][3];
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) wa[c][p] = as_bf16x8(R.q[d][c][p]);
+            // refill this ring slot: slab ks + d + PF of this GEMM, or slab d of the next one
+            if (ks + PF < KS) {
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    R.q[d][0][p] = w0[((ks + d + PF) * 3 + p) * 64 + lane];
+                    R.q[d][1][p] = w1[((ks + d + PF) * 3 + p) * 64 + lane];
+                }
+            } else {
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    R.q[d][0][p] = n0[(d * 3 + p) * 64 + lane];
+                    R.q[d][1][p] = n1[(d * 3 + p) * 64 + lane];
+                }
+            }
+            if (!PIPE) {
+                b0 = split3(x00, x01);
+                b1 = split3(x10, x11);
+                // next slab's activations (one slab past the end stays inside MlpSmem)
+                x00 = lds4(a_row0 + 16 * (ks + d + 1));
+                x01 = lds4(a_row0 + 16 * (ks + d + 1) + 4);
+                x10 = lds4(a_row1 + 16 * (ks + d + 1));
+                x11 = lds4(a_row1 + 16 * (ks + d + 1) + 4);
+            }
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                // small terms first
+                QSP_MFMA_BF(acc[0][c], wa[c][2], b0.hi);
+                QSP_MFMA_BF(acc[1][c], wa[c][2], b1.hi);
+                QSP_MFMA_BF(acc[0][c], wa[c][0], b0.lo);
+                QSP_MFMA_BF(acc[1][c], wa[c][0], b1.lo);
+                QSP_MFMA_BF(acc[0][c], wa[c][1], b0.mid);
+                QSP_MFMA_BF(acc[1][c], wa[c][1], b1.mid);
+                QSP_MFMA_BF(acc[0][c], wa[c][1], b0.hi);
+                QSP_MFMA_BF(acc[1][c], wa[c][1], b1.hi);
+                QSP_MFMA_BF(acc[0][c], wa[c][0], b0.mid);
+                QSP_MFMA_BF(acc[1][c], wa[c][0], b1.mid);
+                QSP_MFMA_BF(acc[0][c], wa[c][0], b0.hi);
+                QSP_MFMA_BF(acc[1][c], wa[c][0], b1.hi);
+            }
+            if (PIPE) {   // (the slabs past the end of this GEMM stay inside MlpSmem; their fragments are never used)
+                const Bf3 n0b = split3(x00, x01), n1b = split3(x10, x11);
+                x00 = lds4(a_row0 + 16 * (ks + d + 2));
+                x01 = lds4(a_row0 + 16 * (ks + d + 2) + 4);
+                x10 = lds4(a_row1 + 16 * (ks + d + 2));
+                x11 = lds4(a_row1 + 16 * (ks + d + 2) + 4);
+                b0 = n0b;
+                b1 = n1b;
+            }
+        }
+    }
+    mfma_acc_settle<AG>(acc[0][0], acc[0][1], acc[1][0], acc[1][1]);
+}
+
+// one 32x32 tile over 16*KS contraction columns (the 67-column backward of layer 0), no ring: PF slabs in flight
+template <int KS, int PF, bool AG>
+__device__ __forceinline__ void gemm_1x1_bf3(const float* __restrict__ act_rows, const float4* __restrict__ w0_, f32x16& acc, int lane) {
+    gptr4 w0 = (gptr4)w0_;
+    const float* a_row0 = act_rows + (lane & 31) * LDA + 8 * (lane >> 5);
+    f32x4 q[PF][3];
+#pragma unroll
+    for (int d = 0; d < PF; ++d)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) q[d][p] = w0[(d * 3 + p) * 64 + lane];
+    f32x4 x0 = lds4(a_row0), x1 = lds4(a_row0 + 4);
+#pragma nounroll
+    for (int ks = 0; ks < KS; ks += PF) {
+#pragma unroll
+        for (int d = 0; d < PF; ++d) {
+            const bf16x8 whi = as_bf16x8(q[d][0]), wmid = as_bf16x8(q[d][1]), wlo = as_bf16x8(q[d][2]);
+            if (ks + PF < KS) {
+#pragma unroll
+                for (int p = 0; p < 3; ++p) q[d][p] = w0[((ks + d + PF) * 3 + p) * 64 + lane];
+            }
+            const Bf3 b = split3(x0, x1);
+            x0 = lds4(a_row0 + 16 * (ks + d + 1));
+            x1 = lds4(a_row0 + 16 * (ks + d + 1) + 4);
+            QSP_MFMA_BF(acc, wlo, b.hi);
+            QSP_MFMA_BF(acc, whi, b.lo);
+            QSP_MFMA_BF(acc, wmid, b.mid);
+            QSP_MFMA_BF(acc, wmid, b.hi);
+            QSP_MFMA_BF(acc, whi, b.mid);
+            QSP_MFMA_BF(acc, whi, b.hi);
+        }
+    }
+    mfma_acc_settle<AG>(acc);
+}
+
 // Whole network for the tile whose inputs are staged in s.code / s.xin.
 // On return (all threads, after a barrier):
 //   s.y[row]                         = sdf value
 //   BWD: s.act viewed as G[row*LDST_G + c], c < 67 = d sdf / d [code | xyz] (skip gradient already added)
 constexpr int LDG = 72;
-template <bool BWD, int PF, bool AGT = false>
+template <bool BWD, int PF, bool AGT = false, bool B3 = false>
 __device__ __forceinline__ void mlp_tile(MlpSmem& s, const MlpParams* __restrict__ Pm) {
+    // B3: every GEMM of the tile on the split-bf16 pipe (gemm_2x2_bf3 / gemm_1x1_bf3: three bf16 terms per operand, six
+    // products, f32 accumulation) instead of the f32 MFMA; everything else -- layer 0, write-outs, masks, layer 8, the seed --
+    // is the same code.
     // AGT: AccVGPR accumulators (see mfma32t).  Only `k_mlp_jtj` asks for them.  Measured on one box, C4: forward-only tile with
     // them 0.908-0.910 of peak against 0.918 with the builtin; with the bias quads parked in AccVGPRs as well 0.910 and
     // `k_mlp_jtj` 0.895 instead of 0.900; accumulators pinned by an empty asm around the builtin MFMA 0.897 / 0.909; the
@@ -439,26 +628,43 @@ __device__ __forceinline__ void mlp_tile(MlpSmem& s, const MlpParams* __restrict
 
     const int cb0 = 2 * wave;   // this wave's first column block
     constexpr int KGH = HID / 8;
+    constexpr int KSH = HID / 16, KS4 = K4 / 16, PF3 = 2;     // split-bf16: slabs of 16 k, two slabs in flight (one: k_mlp_jtj 386 instead of 357 ms at C4)
     // column-block bases of this wave in every packed matrix
-#define QSP_WF(L) (P.wf[L] + (cb0 * KGH) * 64)
-#define QSP_WF1(L) (P.wf[L] + ((cb0 + 1) * KGH) * 64)
-#define QSP_WF4 (P.wf[4] + (cb0 * KG4) * 64)
-#define QSP_WF41 (P.wf[4] + ((cb0 + 1) * KG4) * 64)
-#define QSP_WB(L) (P.wb[L] + (cb0 * KGH) * 64)
-#define QSP_WB1(L) (P.wb[L] + ((cb0 + 1) * KGH) * 64)
+#define QSP_WF(L) (B3 ? P.wf3[L] + (size_t)(cb0 * KSH * 3) * 64 : P.wf[L] + (cb0 * KGH) * 64)
+#define QSP_WF1(L) (B3 ? P.wf3[L] + (size_t)((cb0 + 1) * KSH * 3) * 64 : P.wf[L] + ((cb0 + 1) * KGH) * 64)
+#define QSP_WF4 (B3 ? P.wf3[4] + (size_t)(cb0 * KS4 * 3) * 64 : P.wf[4] + (cb0 * KG4) * 64)
+#define QSP_WF41 (B3 ? P.wf3[4] + (size_t)((cb0 + 1) * KS4 * 3) * 64 : P.wf[4] + ((cb0 + 1) * KG4) * 64)
+#define QSP_WB(L) (B3 ? P.wb3[L] + (size_t)(cb0 * KSH * 3) * 64 : P.wb[L] + (cb0 * KGH) * 64)
+#define QSP_WB1(L) (B3 ? P.wb3[L] + (size_t)((cb0 + 1) * KSH * 3) * 64 : P.wb[L] + ((cb0 + 1) * KGH) * 64)
+    // one GEMM of the tile on whichever pipe: KG k-groups of 8 (f32) = KG / 2 slabs of 16 (split bf16)
+#define QSP_GEMM(KG, BIAS, W0, W1, N0, N1, BIASPTR)                                                              \
+    if constexpr (B3) {                                                                                          \
+        gemm_2x2_bf3<(KG) / 2, PF3, AGT>(s.act, W0, W1, N0, N1, ring3, acc, lane);                               \
+        if (BIAS) {                                                                                              \
+            typedef const __attribute__((address_space(1))) f32x4* gq_;                                          \
+            gq_ bp_ = (gq_)((BIASPTR) + 4 * (lane >> 5));                                                        \
+            _Pragma("unroll") for (int c_ = 0; c_ < 2; ++c_) _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_)   \
+                bq.v[c_][g_] = bp_[(32 * c_ + 8 * g_) / 4];                                                      \
+        }                                                                                                        \
+    } else {                                                                                                     \
+        gemm_2x2<KG, PF, BIAS, AGT>(s.act, W0, W1, N0, N1, ring, acc, lane, BIASPTR, bq);                        \
+    }
     // layer-0 backward: six 32x32 output tiles (2 point blocks x 3 column blocks of the 96 padded inputs) on four SIMDs:
     // waves 0..3 (one per SIMD) take tiles 0..3 over the whole K; tiles 4 and 5 are split in K between the two waves of
     // SIMDs 0/2 (waves 4, 6) and 1/3 (waves 5, 7) -- 1.5 tiles of MFMA work on every SIMD instead of 2/2/1/1
     const int l0_tile = wave < 4 ? wave : 4 + (wave & 1);
     const int l0_half = wave < 4 ? 0 : (wave >> 1) - 2;          // 0 = first (or whole) K range, 1 = second half
     const int r0 = l0_tile / 3, c0 = l0_tile % 3;
-    const float4* wb0 = P.wb[0] + (c0 * KGH + l0_half * (KGH / 2)) * 64;
+    const float4* wb0 = B3 ? P.wb3[0] + (size_t)((c0 * KSH + l0_half * (KSH / 2)) * 3) * 64
+                           : P.wb[0] + (c0 * KGH + l0_half * (KGH / 2)) * 64;
 
     // ---- layer 0: a0 = relu(c0 + W0[:, 64:67] xyz), written in the MFMA write-out's lane/register pattern ------------
     // The 64 code columns of layer 0 are the same for every point of the workgroup: folded into c0 by mlp_prepare().
     static_assert(PF == 4, "ring depth");
     WRing<PF> ring;
-    ring_prime(ring, QSP_WF(1), QSP_WF1(1), lane);
+    WRing3<PF3> ring3;
+    if constexpr (B3) ring3_prime(ring3, QSP_WF(1), QSP_WF1(1), lane);
+    else ring_prime(ring, QSP_WF(1), QSP_WF1(1), lane);
     BiasQuads bq;
     {
         const int h = lane >> 5;
@@ -502,8 +708,7 @@ __device__ __forceinline__ void mlp_tile(MlpSmem& s, const MlpParams* __restrict
     // ---- layers 1..7 (K = 512) ---------------------------------------------------------------------------------
 #define QSP_FWD_LAYER(L)                                                                                      \
     zero_acc(acc);                                                                                            \
-    gemm_2x2<KGH, PF, true, AGT>(s.act, QSP_WF(L), QSP_WF1(L), QSP_WF((L) + 1), QSP_WF1((L) + 1), ring, acc, lane,  \
-                            P.bias[L] + 64 * wave, bq);                                                       \
+    QSP_GEMM(KGH, true, QSP_WF(L), QSP_WF1(L), QSP_WF((L) + 1), QSP_WF1((L) + 1), P.bias[L] + 64 * wave)      \
     QSP_TS()                                                                                                  \
     __syncthreads();                                                                                          \
     QSP_TS()                                                                                                  \
@@ -514,7 +719,7 @@ __device__ __forceinline__ void mlp_tile(MlpSmem& s, const MlpParams* __restrict
     QSP_FWD_LAYER(1)
     QSP_FWD_LAYER(2)
     zero_acc(acc);
-    gemm_2x2<KGH, PF, true, AGT>(s.act, QSP_WF(3), QSP_WF1(3), QSP_WF4, QSP_WF41, ring, acc, lane, P.bias[3] + 64 * wave, bq);
+    QSP_GEMM(KGH, true, QSP_WF(3), QSP_WF1(3), QSP_WF4, QSP_WF41, P.bias[3] + 64 * wave)
     QSP_TS()
     __syncthreads();
     QSP_TS()
@@ -528,7 +733,7 @@ __device__ __forceinline__ void mlp_tile(MlpSmem& s, const MlpParams* __restrict
     QSP_TS()
     // layer 4: K = 448, bias = c4 of this hypothesis (LDS)
     zero_acc(acc);
-    gemm_2x2<KG4, PF, false, AGT>(s.act, QSP_WF4, QSP_WF41, QSP_WF(5), QSP_WF1(5), ring, acc, lane, nullptr, bq);
+    QSP_GEMM(KG4, false, QSP_WF4, QSP_WF41, QSP_WF(5), QSP_WF1(5), (const float*)nullptr)
 #pragma unroll
     for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -543,8 +748,8 @@ __device__ __forceinline__ void mlp_tile(MlpSmem& s, const MlpParams* __restrict
     QSP_FWD_LAYER(5)
     QSP_FWD_LAYER(6)
     zero_acc(acc);
-    if (BWD) gemm_2x2<KGH, PF, true, AGT>(s.act, QSP_WF(7), QSP_WF1(7), QSP_WB(7), QSP_WB1(7), ring, acc, lane, P.bias[7] + 64 * wave, bq);
-    else gemm_2x2<KGH, PF, true, AGT>(s.act, QSP_WF(7), QSP_WF1(7), QSP_WF(1), QSP_WF1(1), ring, acc, lane, P.bias[7] + 64 * wave, bq);
+    if (BWD) { QSP_GEMM(KGH, true, QSP_WF(7), QSP_WF1(7), QSP_WB(7), QSP_WB1(7), P.bias[7] + 64 * wave) }
+    else { QSP_GEMM(KGH, true, QSP_WF(7), QSP_WF1(7), QSP_WF(1), QSP_WF1(1), P.bias[7] + 64 * wave) }
     QSP_TS()
     __syncthreads();
     QSP_TS()
@@ -613,8 +818,8 @@ __device__ __forceinline__ void mlp_tile(MlpSmem& s, const MlpParams* __restrict
     // ---- backward through layers 7..1: g_in = g_a . W_L, masked by layer L-1 ------------------------------------
 #define QSP_BWD_LAYER(L)                                                                                      \
     zero_acc(acc);                                                                                            \
-    gemm_2x2<KGH, PF, false, AGT>(s.act, QSP_WB(L), QSP_WB1(L), (L) > 1 ? QSP_WB((L) - 1) : wb0,                   \
-                             (L) > 1 ? QSP_WB1((L) - 1) : wb0, ring, acc, lane, nullptr, bq);                 \
+    QSP_GEMM(KGH, false, QSP_WB(L), QSP_WB1(L), (L) > 1 ? QSP_WB((L) - 1) : wb0, (L) > 1 ? QSP_WB1((L) - 1) : wb0, \
+             (const float*)nullptr)                                                                           \
     QSP_TS()                                                                                                  \
     __syncthreads();                                                                                          \
     QSP_TS()                                                                                                  \
@@ -633,7 +838,7 @@ __device__ __forceinline__ void mlp_tile(MlpSmem& s, const MlpParams* __restrict
     // layer 3 has 445 outputs: its backward contraction runs over K4 = 448 gradient columns (445..447 were zeroed by
     // stash_extract, the packed rows 445..511 are zero)
     zero_acc(acc);
-    gemm_2x2<KG4, PF, false, AGT>(s.act, QSP_WB(3), QSP_WB1(3), QSP_WB(2), QSP_WB1(2), ring, acc, lane, nullptr, bq);
+    QSP_GEMM(KG4, false, QSP_WB(3), QSP_WB1(3), QSP_WB(2), QSP_WB1(2), (const float*)nullptr)
     QSP_TS()
     __syncthreads();
     QSP_TS()
@@ -649,14 +854,20 @@ __device__ __forceinline__ void mlp_tile(MlpSmem& s, const MlpParams* __restrict
     f32x16 g0;
 #pragma unroll
     for (int i = 0; i < 16; ++i) g0[i] = 0.f;
-    if (wave < 4) gemm_1x1<KGH, PF, AGT>(s.act + 32 * r0 * LDA, wb0, ring, g0, lane);
-    else gemm_1x1<KGH / 2, PF, AGT>(s.act + 32 * r0 * LDA + l0_half * (HID / 2), wb0, ring, g0, lane);
+    if constexpr (B3) {     // (the ring's prefetch of wb0 by the last GEMM is not used on this pipe: gemm_1x1_bf3 loads its own)
+        if (wave < 4) gemm_1x1_bf3<KSH, PF3, AGT>(s.act + 32 * r0 * LDA, wb0, g0, lane);
+        else gemm_1x1_bf3<KSH / 2, PF3, AGT>(s.act + 32 * r0 * LDA + l0_half * (HID / 2), wb0, g0, lane);
+    } else {
+        if (wave < 4) gemm_1x1<KGH, PF, AGT>(s.act + 32 * r0 * LDA, wb0, ring, g0, lane);
+        else gemm_1x1<KGH / 2, PF, AGT>(s.act + 32 * r0 * LDA + l0_half * (HID / 2), wb0, ring, g0, lane);
+    }
 #undef QSP_WF
 #undef QSP_WF1
 #undef QSP_WF4
 #undef QSP_WF41
 #undef QSP_WB
 #undef QSP_WB1
+#undef QSP_GEMM
     QSP_TS()
     __syncthreads();
     QSP_TS()
@@ -709,143 +920,6 @@ __device__ __forceinline__ void mlp_tile(MlpSmem& s, const MlpParams* __restrict
 // Forward only: the discrete decisions of the render term (|sdf| < cut-off) see values that differ from the f32 tile's in
 // the last bits, like any two float32 implementations do; the fwd+bwd tile that feeds the normal equations stays on the f32 pipe.
 // ===================================================================================================================
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef short s16x8 __attribute__((ext_vector_type(8)));
-
-struct Bf3 {
-    bf16x8 hi, mid, lo;
-};
-
-// 8 consecutive f32 activations -> their three bf16 planes (the lane's B-operand fragments of one 32x32x16 MFMA)
-__device__ __forceinline__ Bf3 split3(f32x4 a, f32x4 b) {
-    Bf3 o;
-    float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const __bf16 h = (__bf16)v[j];
-        const float r = v[j] - (float)h;
-        const __bf16 m = (__bf16)r;
-        const float r2 = r - (float)m;
-        o.hi[j] = h;
-        o.mid[j] = m;
-        o.lo[j] = (__bf16)r2;
-    }
-    return o;
-}
-
-__device__ __forceinline__ bf16x8 as_bf16x8(f32x4 q) {
-    union { f32x4 f; bf16x8 b; } u;
-    u.f = q;
-    return u.b;
-}
-
-template <int PF>
-struct WRing3 {
-    f32x4 q[PF][2][3];      // [slab in flight][column block][plane]: 16-byte fragments (8 bf16 each)
-};
-
-template <int PF>
-__device__ __forceinline__ void ring3_prime(WRing3<PF>& R, const float4* __restrict__ w0_, const float4* __restrict__ w1_, int lane) {
-    gptr4 w0 = (gptr4)w0_;
-    gptr4 w1 = (gptr4)w1_;
-#pragma unroll
-    for (int d = 0; d < PF; ++d)
-#pragma unroll
-        for (int p = 0; p < 3; ++p) {
-            R.q[d][0][p] = w0[(d * 3 + p) * 64 + lane];
-            R.q[d][1][p] = w1[(d * 3 + p) * 64 + lane];
-        }
-}
-
-#define QSP_MFMA_BF(acc_, a_, b_) acc_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, b_, acc_, 0, 0, 0)
-
-// acc[r][c] += act[32r.., 0..16*KS) * W for this wave's two column blocks, six bf16 products per term.
-// Ring protocol as gemm_2x2: on entry the ring holds slabs 0..PF-1 of this GEMM, on exit slabs 0..PF-1 of the next one.
-template <int KS, int PF>
-__device__ __forceinline__ void gemm_2x2_bf3(const float* __restrict__ act, const float4* __restrict__ w0_,
-                                             const float4* __restrict__ w1_, const float4* __restrict__ n0_,
-                                             const float4* __restrict__ n1_, WRing3<PF>& R, f32x16 (&acc)[2][2], int lane) {
-    static_assert(KS % PF == 0 && KS >= 2 * PF, "slab count must be a multiple of the prefetch depth, at least twice it");
-    gptr4 w0 = (gptr4)w0_;
-    gptr4 w1 = (gptr4)w1_;
-    gptr4 n0 = (gptr4)n0_;
-    gptr4 n1 = (gptr4)n1_;
-    // lane (r = lane & 31, h = lane >> 5) supplies act[point r][k = 16 s + 8 h + j], j = 0..7
-    const float* a_row0 = act + (lane & 31) * LDA + 8 * (lane >> 5);
-    const float* a_row1 = a_row0 + 32 * LDA;
-#ifndef QSP_BF3_PIPE
-#define QSP_BF3_PIPE 1
-#endif
-#if QSP_BF3_PIPE
-    // software pipeline: the bf16 planes of slab s+1 are produced (VALU) while the 24 MFMAs of slab s run; the raw f32 of
-    // slab s+2 is in flight from LDS meanwhile
-    Bf3 b0 = split3(lds4(a_row0), lds4(a_row0 + 4)), b1 = split3(lds4(a_row1), lds4(a_row1 + 4));
-    f32x4 x00 = lds4(a_row0 + 16), x01 = lds4(a_row0 + 20), x10 = lds4(a_row1 + 16), x11 = lds4(a_row1 + 20);
-#else
-    f32x4 x00 = lds4(a_row0), x01 = lds4(a_row0 + 4), x10 = lds4(a_row1), x11 = lds4(a_row1 + 4);
-#endif
-#pragma nounroll
-    for (int ks = 0; ks < KS; ks += PF) {
-#pragma unroll
-        for (int d = 0; d < PF; ++d) {
-            bf16x8 wa[2][3];
-#pragma unroll
-            for (int c = 0; c < 2; ++c)
-#pragma unroll
-                for (int p = 0; p < 3; ++p) wa[c][p] = as_bf16x8(R.q[d][c][p]);
-            // refill this ring slot: slab ks + d + PF of this GEMM, or slab d of the next one
-            if (ks + PF < KS) {
-#pragma unroll
-                for (int p = 0; p < 3; ++p) {
-                    R.q[d][0][p] = w0[((ks + d + PF) * 3 + p) * 64 + lane];
-                    R.q[d][1][p] = w1[((ks + d + PF) * 3 + p) * 64 + lane];
-                }
-            } else {
-#pragma unroll
-                for (int p = 0; p < 3; ++p) {
-                    R.q[d][0][p] = n0[(d * 3 + p) * 64 + lane];
-                    R.q[d][1][p] = n1[(d * 3 + p) * 64 + lane];
-                }
-            }
-#if !QSP_BF3_PIPE
-            const Bf3 b0 = split3(x00, x01), b1 = split3(x10, x11);
-            // next slab's activations (one slab past the end stays inside MlpSmem)
-            x00 = lds4(a_row0 + 16 * (ks + d + 1));
-            x01 = lds4(a_row0 + 16 * (ks + d + 1) + 4);
-            x10 = lds4(a_row1 + 16 * (ks + d + 1));
-            x11 = lds4(a_row1 + 16 * (ks + d + 1) + 4);
-#endif
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                // small terms first
-                QSP_MFMA_BF(acc[0][c], wa[c][2], b0.hi);
-                QSP_MFMA_BF(acc[1][c], wa[c][2], b1.hi);
-                QSP_MFMA_BF(acc[0][c], wa[c][0], b0.lo);
-                QSP_MFMA_BF(acc[1][c], wa[c][0], b1.lo);
-                QSP_MFMA_BF(acc[0][c], wa[c][1], b0.mid);
-                QSP_MFMA_BF(acc[1][c], wa[c][1], b1.mid);
-                QSP_MFMA_BF(acc[0][c], wa[c][1], b0.hi);
-                QSP_MFMA_BF(acc[1][c], wa[c][1], b1.hi);
-                QSP_MFMA_BF(acc[0][c], wa[c][0], b0.mid);
-                QSP_MFMA_BF(acc[1][c], wa[c][0], b1.mid);
-                QSP_MFMA_BF(acc[0][c], wa[c][0], b0.hi);
-                QSP_MFMA_BF(acc[1][c], wa[c][0], b1.hi);
-            }
-#if QSP_BF3_PIPE
-            {   // (the slabs past the end of this GEMM stay inside MlpSmem; their fragments are never used)
-                const Bf3 n0b = split3(x00, x01), n1b = split3(x10, x11);
-                x00 = lds4(a_row0 + 16 * (ks + d + 2));
-                x01 = lds4(a_row0 + 16 * (ks + d + 2) + 4);
-                x10 = lds4(a_row1 + 16 * (ks + d + 2));
-                x11 = lds4(a_row1 + 16 * (ks + d + 2) + 4);
-                b0 = n0b;
-                b1 = n1b;
-            }
-#endif
-        }
-    }
-}
-
 // Forward network on the split-bf16 pipe for the tile staged in s.code / s.xin / s.c0 / s.c4; on return s.y[row] = sdf value.
 // The biases of layers 1..7 are staged in s.stash (unused by forward-only kernels) so that no vector-memory wait has to drain
 // the weight ring between layers.
@@ -906,7 +980,7 @@ __device__ __forceinline__ void mlp_tile_bf3(MlpSmem& s, const MlpParams* __rest
         bq.v[c][g] = lds4((ptr) + 64 * wave + 32 * c + 8 * g + 4 * (lane >> 5));
 #define QSP_FWD3(L, KS_, NL, NKS, BIASPTR)                                                                             \
     zero_acc(acc);                                                                                                     \
-    gemm_2x2_bf3<KS_, PF>(s.act, QSP_W3(L, KS_), QSP_W31(L, KS_), QSP_W3(NL, NKS), QSP_W31(NL, NKS), ring, acc, lane); \
+    gemm_2x2_bf3<KS_, PF, false, true>(s.act, QSP_W3(L, KS_), QSP_W31(L, KS_), QSP_W3(NL, NKS), QSP_W31(NL, NKS), ring, acc, lane); \
     QSP_BIAS_FROM(BIASPTR)                                                                                             \
     __syncthreads();                                                                                                   \
     fwd_writeout<L>(s, bq, acc, wave, lane, mlo, mhi);                                                                 \

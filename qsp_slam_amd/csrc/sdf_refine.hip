@@ -455,6 +455,7 @@ __global__ __launch_bounds__(512) void k_scan(HypState* __restrict__ st, const O
 // ---------------------------------------------------------------------------------------------------------------
 // k_mlp_jtj: surface points + kept render rows -> Jacobian rows -> J~^T J~ tile partials
 // ---------------------------------------------------------------------------------------------------------------
+template <bool B3>
 __global__ __launch_bounds__(MLP_THREADS, 2) void k_mlp_jtj(const HypState* __restrict__ st,
                                                             const ObjView* __restrict__ objs,
                                                             const float* __restrict__ pts,
@@ -536,7 +537,7 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void k_mlp_jtj(const HypState* __re
         }
         __syncthreads();
         QSP_TSK(2)
-        mlp_tile<true, 4, true>(s, P);
+        mlp_tile<true, 4, !B3, B3>(s, P);      // (AccVGPR accumulators leave the split-bf16 tile too few ArchVGPRs)
         QSP_TSK(3)
         // ---- Jacobian rows: J~[p] = [ s*(g_x . [I | -x^ | x]) (7) | s*g_z (64) | r~ ] -------------------------------
         // G (gradient w.r.t. [code | xyz]) sits in s.act with row stride LDG; J~ goes behind it.
@@ -586,8 +587,8 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void k_mlp_jtj(const HypState* __re
             const float* A = Jt + (lane >> 5) * LDJ + 32 * ta + (lane & 31);
             const float* B = Jt + (lane >> 5) * LDJ + 32 * tb + (lane & 31);
 #pragma unroll 8
-            for (int ks = 0; ks < TILE_P / 2; ++ks) hacc = mfma32t<true>(A[2 * ks * LDJ], B[2 * ks * LDJ], hacc);
-            mfma_acc_settle<true>(hacc);
+            for (int ks = 0; ks < TILE_P / 2; ++ks) hacc = mfma32t<!B3>(A[2 * ks * LDJ], B[2 * ks * LDJ], hacc);
+            mfma_acc_settle<!B3>(hacc);
         }
         QSP_TSK(4)
     }
@@ -889,7 +890,7 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void k_decode(const float* __restri
         }
         __syncthreads();
         if (BF3 && !GRAD) mlp_tile_bf3<QSP_BF3_PF>(s, P);
-        else mlp_tile<GRAD, 4>(s, P);
+        else mlp_tile<GRAD, 4, false, BF3>(s, P);
         if (threadIdx.x < TILE_P) {
             const int64_t v = t * TILE_P + threadIdx.x;
             if (v < n) y_out[v] = s.y[threadIdx.x];
@@ -953,6 +954,7 @@ struct qsp_decoder {
     double mac_per_point = 0;
     int code_len = CODE_LEN;   // the caller's code length L <= 64; the tile always works on 64 (columns L..63 are zero)
     int fwd_bf3 = 0;           // QSP_DEC_OPT_FORWARD_PRECISION: forward-only passes on the split-bf16 pipe (mlp_tile_bf3)
+    int jac_bf3 = 0;           // QSP_DEC_OPT_JACOBIAN_PRECISION: the forward+backward pass (mlp_tile<true, .., B3>)
 };
 
 // The family deep_sdf/deep_sdf_decoder.py:29-63 builds -- `dims` hidden layers of any width, one (or no) latent_in layer, any
@@ -1021,6 +1023,27 @@ static int embed_family(const qsp_decoder_desc* desc, const std::vector<std::vec
         }
     }
     return QSP_OK;
+}
+
+static inline uint16_t bf16_rne(float x) {
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);       // NaN stays NaN
+    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+static inline float bf16_f32(uint16_t b) {
+    const uint32_t u = (uint32_t)b << 16;
+    float x;
+    memcpy(&x, &u, 4);
+    return x;
+}
+// x = hi + mid + lo, each a bf16: 8 + 8 + 8 mantissa bits
+static inline void bf16_split3(float v, uint16_t& hi, uint16_t& mid, uint16_t& lo) {
+    hi = bf16_rne(v);
+    const float r1 = v - bf16_f32(hi);
+    mid = bf16_rne(r1);
+    const float r2 = r1 - bf16_f32(mid);
+    lo = bf16_rne(r2);
 }
 
 static int pack_weights(qsp_decoder* d, const qsp_decoder_desc* desc) {
@@ -1100,18 +1123,6 @@ static int pack_weights(qsp_decoder* d, const qsp_decoder_desc* desc) {
                 // W[unit 32 cb + r][k = 16 s + 8 h + j] (the A-operand map of v_mfma_f32_32x32x16_bf16)
                 const int KS = KG / 2;
                 std::vector<uint16_t> p3((size_t)16 * KS * 3 * 64 * 8, 0);
-                auto bf16_rne = [](float x) -> uint16_t {
-                    uint32_t u;
-                    memcpy(&u, &x, 4);
-                    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);       // NaN stays NaN
-                    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
-                };
-                auto bf16_f32 = [](uint16_t b) -> float {
-                    const uint32_t u = (uint32_t)b << 16;
-                    float x;
-                    memcpy(&x, &u, 4);
-                    return x;
-                };
                 for (int cb = 0; cb < 16; ++cb)
                     for (int ks = 0; ks < KS; ++ks)
                         for (int lane = 0; lane < 64; ++lane)
@@ -1121,11 +1132,8 @@ static int pack_weights(qsp_decoder* d, const qsp_decoder_desc* desc) {
                                 if (l == 4 && k >= SKIP_COL) k += CODE_LEN;
                                 float v = 0.f;
                                 if (o < out && k < in) v = W[l][(size_t)o * in + k];
-                                const uint16_t hi = bf16_rne(v);
-                                const float r1 = v - bf16_f32(hi);
-                                const uint16_t mid = bf16_rne(r1);
-                                const float r2 = r1 - bf16_f32(mid);
-                                const uint16_t lo = bf16_rne(r2);
+                                uint16_t hi, mid, lo;
+                                bf16_split3(v, hi, mid, lo);
                                 const size_t base = (((size_t)cb * KS + ks) * 3) * 64 * 8 + (size_t)lane * 8 + j;
                                 p3[base] = hi;
                                 p3[base + 64 * 8] = mid;
@@ -1161,6 +1169,30 @@ static int pack_weights(qsp_decoder* d, const qsp_decoder_desc* desc) {
                     }
         rc = upload(pb, (const void**)&d->P.wb[l]);
         if (rc) return rc;
+        {   // split-bf16 planes of the same matrix: [col block over inputs k][slab of 16 outputs o][plane][lane][8 bf16]
+            const int KS = HID / 16;
+            std::vector<uint16_t> p3((size_t)NCB * KS * 3 * 64 * 8, 0);
+            for (int cb = 0; cb < NCB; ++cb)
+                for (int ks = 0; ks < KS; ++ks)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 8; ++j) {
+                            const int k = 32 * cb + (lane & 31);
+                            const int o = 16 * ks + 8 * (lane >> 5) + j;
+                            float v = 0.f;
+                            if (o < out && k < in) v = W[l][(size_t)o * in + k];
+                            uint16_t hi, mid, lo;
+                            bf16_split3(v, hi, mid, lo);
+                            const size_t base = (((size_t)cb * KS + ks) * 3) * 64 * 8 + (size_t)lane * 8 + j;
+                            p3[base] = hi;
+                            p3[base + 64 * 8] = mid;
+                            p3[base + 2 * 64 * 8] = lo;
+                        }
+            void* p3d = nullptr;
+            QSP_HIP(hipMalloc(&p3d, p3.size() * sizeof(uint16_t) + 16384));
+            d->allocs.push_back(p3d);
+            QSP_HIP(hipMemcpy(p3d, p3.data(), p3.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+            d->P.wb3[l] = (const float4*)p3d;
+        }
         std::vector<float> bias(HID, 0.f);
         for (int o = 0; o < out; ++o) bias[o] = Bias[l][o];
         rc = upload(bias, (const void**)&d->P.bias[l]);
@@ -1185,7 +1217,9 @@ static int mlp_attr_once() {
     QSP_HIP(hipFuncSetAttribute((const void*)k_mlp_fwd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     QSP_HIP(hipFuncSetAttribute((const void*)k_mlp_fwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     QSP_HIP(hipFuncSetAttribute((const void*)k_decode<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    QSP_HIP(hipFuncSetAttribute((const void*)k_mlp_jtj, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    QSP_HIP(hipFuncSetAttribute((const void*)k_mlp_jtj<false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    QSP_HIP(hipFuncSetAttribute((const void*)k_mlp_jtj<true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    QSP_HIP(hipFuncSetAttribute((const void*)k_decode<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     QSP_HIP(hipFuncSetAttribute((const void*)k_decode<false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     QSP_HIP(hipFuncSetAttribute((const void*)k_decode<true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     done = true;
@@ -1222,6 +1256,10 @@ extern "C" int qsp_decoder_set_option(qsp_decoder* d, int32_t option, int32_t va
             if (value != 0 && value != 1) return qsp_fail(QSP_ERR_INVALID, "forward precision: 0 (f32 MFMA) or 1 (split bf16)");
             d->fwd_bf3 = value;
             return QSP_OK;
+        case QSP_DEC_OPT_JACOBIAN_PRECISION:
+            if (value != 0 && value != 1) return qsp_fail(QSP_ERR_INVALID, "jacobian precision: 0 (f32 MFMA) or 1 (split bf16)");
+            d->jac_bf3 = value;
+            return QSP_OK;
         default: return qsp_fail(QSP_ERR_INVALID, "qsp_decoder_set_option: unknown option");
     }
 }
@@ -1249,7 +1287,9 @@ static int decode_common(qsp_decoder* d, const float* code, const float* xyz, in
     QSP_HIP(hipMemcpyAsync(dx, xyz, n * 3 * sizeof(float), hipMemcpyHostToDevice, d->stream));
     const int64_t tiles = (n + TILE_P - 1) / TILE_P;
     const int grid = (int)std::min<int64_t>(tiles, 4096);
-    if (grad)
+    if (grad && d->jac_bf3)
+        hipLaunchKernelGGL((k_decode<true, true>), dim3(grid), dim3(MLP_THREADS), sizeof(MlpSmem), d->stream, dc, dx, n, d->Pd, dy, dg);
+    else if (grad)
         hipLaunchKernelGGL(k_decode<true>, dim3(grid), dim3(MLP_THREADS), sizeof(MlpSmem), d->stream, dc, dx, n, d->Pd, dy, dg);
     else if (d->fwd_bf3)
         hipLaunchKernelGGL((k_decode<false, true>), dim3(grid), dim3(MLP_THREADS), sizeof(MlpSmem), d->stream, dc, dx, n, d->Pd, dy,
@@ -1533,10 +1573,16 @@ extern "C" int qsp_refine_batch_run(qsp_refine_batch* b, int32_t n_iter) {
         if (b->prof) a = next_event(b, cur);
         hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, s, 1, b->st, b->objs, nH, b->nw_sdf, nw_total - b->nw_sdf,
                            b->work_jtj, b->qctl);
-        hipLaunchKernelGGL(k_mlp_jtj, dim3(b->n_cu), dim3(MLP_THREADS), sizeof(MlpSmem), s, b->st, b->objs, b->pts,
-                           b->rays, cfg, b->dec->Pd, b->nw_sdf, b->rend_rk, b->rend_deds, b->rend_res, b->rk_stride,
-                           b->pt_active, b->act_stride, b->res_buf, b->rows, b->rows_stride, b->partials, nw_total,
-                           b->work_jtj, b->qctl, b->c0_all);
+        if (b->dec->jac_bf3)
+            hipLaunchKernelGGL(k_mlp_jtj<true>, dim3(b->n_cu), dim3(MLP_THREADS), sizeof(MlpSmem), s, b->st, b->objs, b->pts,
+                               b->rays, cfg, b->dec->Pd, b->nw_sdf, b->rend_rk, b->rend_deds, b->rend_res, b->rk_stride,
+                               b->pt_active, b->act_stride, b->res_buf, b->rows, b->rows_stride, b->partials, nw_total,
+                               b->work_jtj, b->qctl, b->c0_all);
+        else
+            hipLaunchKernelGGL(k_mlp_jtj<false>, dim3(b->n_cu), dim3(MLP_THREADS), sizeof(MlpSmem), s, b->st, b->objs, b->pts,
+                               b->rays, cfg, b->dec->Pd, b->nw_sdf, b->rend_rk, b->rend_deds, b->rend_res, b->rk_stride,
+                               b->pt_active, b->act_stride, b->res_buf, b->rows, b->rows_stride, b->partials, nw_total,
+                               b->work_jtj, b->qctl, b->c0_all);
         if (b->prof) spans.push_back({a, next_event(b, cur), 0});
         if (b->prof) a = next_event(b, cur);
         hipLaunchKernelGGL(k_solve, dim3(nH), dim3(256), 0, s, b->st, b->objs, cfg, b->partials, b->nw_sdf, nw_total,

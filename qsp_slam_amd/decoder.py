@@ -45,6 +45,11 @@ class DeepSdfDecoder(object):
         bf16 terms per operand / six products on the bf16 pipe (True); see QSP_DEC_OPT_FORWARD_PRECISION in qsp_hip.h"""
         _lib.check(_lib.lib().qsp_decoder_set_option(self.handle, 1, 1 if split_bf16 else 0))
 
+    def set_jacobian_precision(self, split_bf16):
+        """the forward+backward pass (sdf_value_grad, the fused Jacobian / normal-equation kernel) likewise
+        (QSP_DEC_OPT_JACOBIAN_PRECISION)"""
+        _lib.check(_lib.lib().qsp_decoder_set_option(self.handle, 2, 1 if split_bf16 else 0))
+
     def close(self):
         if getattr(self, "handle", None):
             _lib.lib().qsp_decoder_destroy(self.handle)
