@@ -17,8 +17,14 @@ scaling strong (default; BASELINE.json configs[3] and north_star): ONE fixed sce
         camera/object block summed by RCCL (ncclAllReduce on the library's own stream, dimp^2 + dimp doubles per LM trial).
         weak (--scaling weak): every rank owns its own scene of the same size (independent key-frame windows; replicas).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c4|c5] [--scaling strong|weak] [--no-sublines]
-                  [--no-cpu-baseline]
+precision bf16x3 (default): the decoder's multiply-adds with every f32 operand as the exact sum of three bf16 terms, six bf16
+        products per multiply-add on the bf16 matrix pipe, f32 accumulation -- float32-equivalent (2.5e-7 against float64; the
+        f32 pipe: 2.0e-7), parity-gated like the f32 tile (tests/test_gpu_bf16x3.py: K / n_valid exact on every fixture,
+        teacher-forced H, b, dx, next state inside the same bars).  --precision f32 runs the exact-f32 matrix pipe; its step time
+        is reported beside `value` in every default run (`f32_mfma`).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c4|c5] [--scaling strong|weak] [--precision bf16x3|f32]
+                  [--no-sublines] [--no-cpu-baseline]
   N > 1: one rank per GPU under torch.distributed.run (the driver's launch line); `python bench.py --gpus N` without that
   environment starts it as a child process.
 """
@@ -47,6 +53,8 @@ DM, DS, DO = float(np.float32(np.sqrt(5.991))), float(np.float32(np.sqrt(7.815))
 FLOP_FWD = 2.0 * 1835520          # per point, decoder forward            
 FLOP_FWDBWD = 2.0 * FLOP_FWD      # forward + backward-data
 PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # same table, "Peak BF16/FP16 MFMA", dense
+BF3_PRODUCTS = 6                  # bf16 products per f32-equivalent multiply-add on the split-bf16 pipe (csrc/sdf_mlp.hpp)
 PEAK_HBM_GBPS = 8000.0
 
 
@@ -213,7 +221,7 @@ class Ctx(object):
         return float(t.item())
 
 
-def run_workload(ctx, name, steps, warmup, detailed):
+def run_workload(ctx, name, steps, warmup, detailed, precision=None):
     """`steps` timed passes of workload `name` (after `warmup` untimed ones); every rank returns the same dict of whole-job
     numbers (rank 0's kernel timings)."""
     from qsp_slam_amd import DeepSdfDecoder, parallel, synth
@@ -224,6 +232,7 @@ def run_workload(ctx, name, steps, warmup, detailed):
     w = WORKLOADS[name]
     flips = args.flips
     dec = DeepSdfDecoder.from_npz(os.path.join(ROOT, "tests", "golden", "decoder_8x512.npz"), device=dev)
+    dec.set_precision(precision or args.precision)
     opt = Optimizer(dec, joint_cfg(w["n_iter"]))
     seed_off = 0 if strong else rank
     objs_all = synth.make_object_views(1000 + seed_off, w["n_obj"], w["n_pts"], n_fg=w["n_fg"], n_bg=w["n_bg"])
@@ -326,7 +335,7 @@ def run_workload(ctx, name, steps, warmup, detailed):
         jtj=dict(achieved=achieved, avg_ms=avg_ms, launches=prof["n_jtj"],
                  points_per_launch=prof["pts_jtj"] / max(prof["n_jtj"], 1),
                  tile_padding_overhead=64.0 * prof["tiles_jtj"] / max(prof["pts_jtj"], 1)),
-        kernels={"k_mlp_fwd_TFLOPs": fwd_tf, "k_mlp_fwd_frac": fwd_tf / PEAK_F32_MFMA_TFLOPS,
+        kernels={"k_mlp_fwd_TFLOPs": fwd_tf, "k_mlp_fwd_frac_of_f32_mfma_peak": fwd_tf / PEAK_F32_MFMA_TFLOPS,
                  "ms_mlp_jtj": prof["ms_mlp_jtj"] / steps, "ms_mlp_fwd": prof["ms_mlp_fwd"] / steps,
                  "ms_other": prof["ms_other"] / steps, "ms_gpu_total": prof["ms_total"] / steps,
                  "ms_ba": ba_stat["ms"] / steps, "ba_lm_iterations": ba_stat["iters"] / steps,
@@ -374,6 +383,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"])
+    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "f32"])
     ap.add_argument("--flips", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sublines", action="store_true")
@@ -394,24 +404,35 @@ def main():
         print("bench.py: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, ctx.world), file=sys.stderr)
     world, rank = ctx.world, ctx.rank
     main_res = run_workload(ctx, args.workload, args.steps, args.warmup, detailed=True)
+    other = None
+    if args.precision == "bf16x3" and not args.no_sublines:      # the exact-f32 matrix pipe on the same workload, beside `value`
+        other = run_workload(ctx, args.workload, 1, 1, detailed=False, precision="f32")
     subs = {}
     if not args.no_sublines:
         for name in ("c2", "c5"):
             if name != args.workload:
                 r = run_workload(ctx, name, 2, 1, detailed=False)
                 subs[name] = {k: v for k, v in r.items() if not k.startswith("_") and k != "kernels"}
-                subs[name]["roofline_frac_k_mlp_jtj"] = r["jtj"]["achieved"] / PEAK_F32_MFMA_TFLOPS
+                subs[name]["roofline_frac_k_mlp_jtj"] = r["jtj"]["achieved"] / (
+                    PEAK_BF16_MFMA_TFLOPS / BF3_PRODUCTS if args.precision == "bf16x3" else PEAK_F32_MFMA_TFLOPS)
                 subs[name]["ba_linearize_us"] = r["kernels"]["ba_linearize_us"]
                 subs[name]["ba_linearize_algorithmic_GBps"] = r["kernels"]["ba_linearize_GBps"]
 
     if rank == 0:
         w = WORKLOADS[args.workload]
         m = main_res
-        traffic, traffic_src = pmc_traffic(args.workload, "k_mlp_jtj")
+        traffic, traffic_src = pmc_traffic(args.workload, "k_mlp_jtj" if args.precision == "f32" else "k_mlp_jtj_bf16x3")
+        bf3 = args.precision == "bf16x3"
+        # roofline of the dominant kernel.  f32 pipe: algorithmic FLOP / time against the f32 MFMA peak.  Split-bf16 pipe: every
+        # algorithmic multiply-add is six bf16 multiply-adds on the matrix pipe, so the peak for ALGORITHMIC flops is the dense
+        # bf16 peak / 6; the pipe's own rate (6 x achieved) against the 2.5 PF peak is the same fraction.
+        peak = PEAK_BF16_MFMA_TFLOPS / BF3_PRODUCTS if bf3 else PEAK_F32_MFMA_TFLOPS
         out = {
             "metric": "joint-opt iters/sec (BA+SDF)", "value": m["value"], "unit": "iters/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": m["ms_per_step"],
-            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+            "dtype": ("f32 as 3 x bf16 per operand, 6 bf16 products per multiply-add, f32 accumulate (decoder); f64 (bundle "
+                      "adjustment)") if bf3 else "f32 (decoder, exact f32 matrix pipe); f64 (bundle adjustment)",
             "data": "synthetic (seeded scene, decoder fitted to an analytic shape family)",
             "config": {"workload": w["desc"], "objects": w["n_obj"], "hypotheses": m["n_hyp_job"],
                        "hypotheses_on_rank0": m["hyp_this_rank"],
@@ -424,15 +445,28 @@ def main():
             "ms_per_object_refine": m["ms_per_object_refine"],
             "ms_ba": m["ms_ba"], "ba_iters_per_s": m["ba_iters_per_s"], "ms_result_gather": m["ms_gather"],
             "good_hypotheses": m["good_hypotheses"],
-            "roofline": {"bound": "mfma", "kernel": "k_mlp_jtj (decoder fwd+bwd+JtJ, f32 MFMA)",
-                         "achieved": m["jtj"]["achieved"], "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": m["jtj"]["achieved"] / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+            "roofline": {"bound": "mfma",
+                         "kernel": "k_mlp_jtj (decoder fwd+bwd+JtJ; %s)" % ("v_mfma_f32_32x32x16_bf16, 6 products per f32 "
+                                                                            "multiply-add" if bf3 else "v_mfma_f32_32x32x2_f32"),
+                         "achieved": m["jtj"]["achieved"], "peak": peak, "unit": "TFLOP/s",
+                         "frac": m["jtj"]["achieved"] / peak,
+                         "peak_note": ("dense bf16 MFMA peak 2500 TFLOP/s / 6 bf16 products per algorithmic multiply-add"
+                                       if bf3 else "f32 MFMA peak"),
+                         "bf16_pipe_TFLOPs": BF3_PRODUCTS * m["jtj"]["achieved"] if bf3 else None,
+                         "effective_vs_f32_mfma_peak": m["jtj"]["achieved"] / PEAK_F32_MFMA_TFLOPS,
+                         "traffic": traffic,
                          "traffic_unit": "bytes/launch, rocprofv3 PMC passes of this command (profiles/%s)" % traffic_src,
                          "avg_launch_ms": m["jtj"]["avg_ms"], "launches": m["jtj"]["launches"],
                          "points_per_launch": m["jtj"]["points_per_launch"],
                          "tile_padding_overhead": m["jtj"]["tile_padding_overhead"]},
             "kernels": m["kernels"],
         }
+        if other is not None:
+            out["f32_mfma"] = {"note": "the same workload with --precision f32 (exact f32 matrix pipe), 1 step",
+                               "value": other["value"], "ms_per_step": other["ms_per_step"],
+                               "k_mlp_jtj_TFLOPs": other["jtj"]["achieved"],
+                               "k_mlp_jtj_frac_of_f32_peak": other["jtj"]["achieved"] / PEAK_F32_MFMA_TFLOPS,
+                               "k_mlp_fwd_TFLOPs": other["kernels"]["k_mlp_fwd_TFLOPs"]}
         if subs:
             out["sublines"] = subs
         if world == 1:

@@ -38,7 +38,20 @@ class DeepSdfDecoder(object):
         self.handle = h
         self.code_len = int(code_len)
         self.device = int(device)
+        self.precision = "f32"
+        if os.environ.get("QSP_PRECISION"):        # e.g. to run a whole test session on the split-bf16 pipe
+            self.set_precision(os.environ["QSP_PRECISION"])
         self.mac_per_point = int(sum(int(i) * int(o) for i, o in zip(in_dim, out_dim)))
+
+    def set_precision(self, name):
+        """"f32": every multiply-add of the decoder on the exact-f32 matrix pipe (default).  "bf16x3": operands as three bf16
+        terms, six products per multiply-add on the bf16 matrix pipe, f32 accumulation -- float32-equivalent accuracy
+        (include/qsp_hip.h, QSP_DEC_OPT_*), ~1.5 x faster refinement."""
+        if name not in ("f32", "bf16x3"):
+            raise ValueError("precision must be 'f32' or 'bf16x3'")
+        self.set_forward_precision(name == "bf16x3")
+        self.set_jacobian_precision(name == "bf16x3")
+        self.precision = name
 
     def set_forward_precision(self, split_bf16):
         """forward-only passes (decode_sdf, mesh grid, ray samples) on the exact-f32 matrix pipe (False, default) or as three
