@@ -417,10 +417,22 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 struct Bf3 {
     bf16x8 hi, mid, lo;
 };
+__device__ __forceinline__ bf16x8 as_bf16x8_raw(f32x4 q) {
+    union { f32x4 f; bf16x8 b; } u;
+    u.f = q;
+    return u.b;
+}
 
 // 8 consecutive f32 activations -> their three bf16 planes (the lane's B-operand fragments of one 32x32x16 MFMA)
+#ifndef QSP_BF3_EXP
+#define QSP_BF3_EXP 0     // timing experiments only: bit 0 = no operand split (garbage planes), bit 1 = no weight loads in the loop
+#endif
 __device__ __forceinline__ Bf3 split3(f32x4 a, f32x4 b) {
     Bf3 o;
+#if (QSP_BF3_EXP & 1)
+    o.hi = as_bf16x8_raw(a); o.mid = as_bf16x8_raw(b); o.lo = as_bf16x8_raw(a);
+    return o;
+#endif
     float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -509,7 +521,11 @@ __device__ __forceinline__ void gemm_2x2_bf3(const float* __restrict__ act, cons
 #pragma unroll
                 for (int p = 0; p < 3; ++p) wa[c][p] = as_bf16x8(R.q[d][c][p]);
             // refill this ring slot: slab ks + d + PF of this GEMM, or slab d of the next one
+#if (QSP_BF3_EXP & 2)
+            if (false) {
+#else
             if (ks + PF < KS) {
+#endif
 #pragma unroll
                 for (int p = 0; p < 3; ++p) {
                     R.q[d][0][p] = w0[((ks + d + PF) * 3 + p) * 64 + lane];
