@@ -387,6 +387,8 @@ def main():
     ap.add_argument("--flips", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sublines", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the large-graph linearisation, host-buffer and latency measurements (for profiler runs)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -469,7 +471,7 @@ def main():
                                "k_mlp_fwd_TFLOPs": other["kernels"]["k_mlp_fwd_TFLOPs"]}
         if subs:
             out["sublines"] = subs
-        if world == 1:
+        if world == 1 and not args.no_extras:
             from qsp_slam_amd import synth
             from qsp_slam_amd.ba import BaProblem
             from qsp_slam_amd.reconstruct.optimizer import RefineBatch, _joint_cfg
@@ -513,8 +515,8 @@ def main():
             b2.close()
             ba2.close()
             out["latency"] = latency_block(dec)
-            if not args.no_cpu_baseline:      # rank 0 at N = 1 only
-                out["cpu_baseline"] = cpu_baseline(w, objs, scene, len(hyp))
+        if world == 1 and not args.no_cpu_baseline:      # rank 0 at N = 1 only
+            out["cpu_baseline"] = cpu_baseline(w, m["_objs"], m["_scene"], len(m["_hyp"]))
         print(json.dumps(out))
         sys.stdout.flush()
     if ctx.comm is not None:

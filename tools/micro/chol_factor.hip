@@ -1,0 +1,207 @@
+// Micro-benchmark of the 64x64 diagonal-block factorisation of the BA's blocked Cholesky (csrc/ba_solver.hip:factor_tile64): the
+// serial chain of every block step.  One workgroup of 256 threads factorises a 64x64 SPD matrix held as 4x4 register tiles and
+// produces W = L^-1; wave 3's last thread stamps the shader clock at the phase boundaries of every 4-row round.
+//   hipcc --offload-arch=gfx950 -O3 -o chol_factor tools/micro/chol_factor.hip && ./chol_factor [variant]
+//   variant 0: as shipped in round 2 (W carried through the rounds, 16 workgroup barriers)
+//   variant 1: U only in the rounds (no W), to see what the chain costs without the inverse
+//   variant 2: wave-local sub-rounds: a wave's four rounds need no workgroup barrier (4 barriers, rank-16 catch-up for the rest)
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+constexpr int NB = 64;
+
+__device__ inline double rsqrt_nr(double d) {
+    double r = __builtin_amdgcn_rsq(d);
+    r = r * (1.5 - 0.5 * d * r * r);
+    r = r * (1.5 - 0.5 * d * r * r);
+    return r;
+}
+
+__device__ unsigned long long g_ts[16][4];
+
+template <bool WITH_W>
+__device__ inline void pivot_rows(double (&S)[4][4], double (&W)[4][4], double* rb, int jb, int lane, int c0) {
+    const int src = (lane & 48) | jb;
+    double D[4][4], rs[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = a; b < 4; ++b) D[a][b] = __shfl(S[a][b], src, 64);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        double dd = D[q][q];
+        rs[q] = rsqrt_nr(dd);
+#pragma unroll
+        for (int b = q + 1; b < 4; ++b) D[q][b] *= rs[q];
+#pragma unroll
+        for (int a = q + 1; a < 4; ++a)
+#pragma unroll
+            for (int b = a; b < 4; ++b) D[a][b] -= D[q][a] * D[q][b];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            double sv = S[q][b], wv = W[q][b];
+#pragma unroll
+            for (int pp = 0; pp < q; ++pp) {
+                sv -= D[pp][q] * S[pp][b];
+                if (WITH_W) wv -= D[pp][q] * W[pp][b];
+            }
+            S[q][b] = sv * rs[q];
+            rb[q * NB + c0 + b] = S[q][b];
+            if (WITH_W) {
+                W[q][b] = wv * rs[q];
+                rb[(4 + q) * NB + c0 + b] = W[q][b];
+            }
+        }
+}
+
+template <bool WITH_W>
+__device__ inline void rank4(double (&S)[4][4], double (&W)[4][4], const double* rb, int r0, int c0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        double ur[4], uc[4], wc[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            ur[a] = rb[q * NB + r0 + a];
+            uc[a] = rb[q * NB + c0 + a];
+            if (WITH_W) wc[a] = rb[(4 + q) * NB + c0 + a];
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                S[a][b] -= ur[a] * uc[b];
+                if (WITH_W) W[a][b] -= ur[a] * wc[b];
+            }
+    }
+}
+
+template <int VAR>
+__global__ __launch_bounds__(256) void k_factor(const double* A, double* Wout, double* Uout) {
+    __shared__ double rowbuf[16 * 8 * NB];      // one 8 x 64 buffer per round (64 KiB)
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r0 = (t >> 4) * 4, c0 = (t & 15) * 4;
+    double S[4][4], W[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            S[a][b] = A[(r0 + a) * NB + c0 + b];
+            W[a][b] = (r0 + a == c0 + b) ? 1.0 : 0.0;
+        }
+    __syncthreads();
+    constexpr bool WW = VAR != 1;
+    if (VAR == 0 || VAR == 1) {
+#pragma nounroll
+        for (int jb = 0; jb < 16; ++jb) {
+            double* rb = rowbuf + jb * 8 * NB;
+            if (t == 255) g_ts[jb][0] = __builtin_readcyclecounter();
+            if ((t >> 4) == jb) pivot_rows<WW>(S, W, rb, jb, lane, c0);
+            if (t == 255) g_ts[jb][1] = __builtin_readcyclecounter();
+            __syncthreads();
+            if (t == 255) g_ts[jb][2] = __builtin_readcyclecounter();
+            if (r0 > 4 * jb) rank4<WW>(S, W, rb, r0, c0);
+            if (t == 255) g_ts[jb][3] = __builtin_readcyclecounter();
+        }
+    } else {
+#pragma nounroll
+        for (int w = 0; w < 4; ++w) {
+            if (t == 255) g_ts[4 * w][0] = __builtin_readcyclecounter();
+            if (wave == w) {
+#pragma nounroll
+                for (int u = 0; u < 4; ++u) {
+                    const int jb = 4 * w + u;
+                    double* rb = rowbuf + jb * 8 * NB;
+                    if ((lane >> 4) == u) pivot_rows<true>(S, W, rb, jb, lane, c0);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // this wave's LDS stores have landed ...
+                    __builtin_amdgcn_wave_barrier();                            // ... before its other lanes read them
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    if ((lane >> 4) > u) rank4<true>(S, W, rb, r0, c0);
+                }
+            }
+            if (t == 255) g_ts[4 * w][1] = __builtin_readcyclecounter();
+            __syncthreads();
+            if (t == 255) g_ts[4 * w][2] = __builtin_readcyclecounter();
+            if (wave > w) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) rank4<true>(S, W, rowbuf + (4 * w + u) * 8 * NB, r0, c0);
+            }
+            if (t == 255) g_ts[4 * w][3] = __builtin_readcyclecounter();
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            Wout[(r0 + a) * NB + c0 + b] = W[a][b];
+            Uout[(r0 + a) * NB + c0 + b] = S[a][b];
+        }
+}
+
+int main(int argc, char** argv) {
+    const int var = argc > 1 ? atoi(argv[1]) : 0;
+    std::vector<double> A(NB * NB), M(NB * NB);
+    srand(1);
+    for (auto& v : M) v = rand() / (double)RAND_MAX - 0.5;
+    for (int i = 0; i < NB; ++i)
+        for (int j = 0; j < NB; ++j) {
+            double s = (i == j) ? 4.0 : 0.0;
+            for (int k = 0; k < NB; ++k) s += M[i * NB + k] * M[j * NB + k];
+            A[i * NB + j] = s;
+        }
+    double *dA, *dW, *dU;
+    hipMalloc(&dA, sizeof(double) * NB * NB);
+    hipMalloc(&dW, sizeof(double) * NB * NB);
+    hipMalloc(&dU, sizeof(double) * NB * NB);
+    hipMemcpy(dA, A.data(), sizeof(double) * NB * NB, hipMemcpyHostToDevice);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    float ms = 0;
+    for (int rep = 0; rep < 5; ++rep) {
+        hipEventRecord(e0);
+        for (int i = 0; i < 100; ++i) {
+            if (var == 0) hipLaunchKernelGGL(k_factor<0>, dim3(1), dim3(256), 0, 0, dA, dW, dU);
+            else if (var == 1) hipLaunchKernelGGL(k_factor<1>, dim3(1), dim3(256), 0, 0, dA, dW, dU);
+            else hipLaunchKernelGGL(k_factor<2>, dim3(1), dim3(256), 0, 0, dA, dW, dU);
+        }
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        hipEventElapsedTime(&ms, e0, e1);
+    }
+    std::vector<double> Wh(NB * NB), Uh(NB * NB);
+    hipMemcpy(Wh.data(), dW, sizeof(double) * NB * NB, hipMemcpyDeviceToHost);
+    hipMemcpy(Uh.data(), dU, sizeof(double) * NB * NB, hipMemcpyDeviceToHost);
+    // checks: U^T U = A (upper part of U), W U^T = I
+    double eU = 0, eW = 0;
+    for (int i = 0; i < NB; ++i)
+        for (int j = i; j < NB; ++j) {
+            double s = 0;
+            for (int k = 0; k <= i; ++k) s += Uh[k * NB + i] * Uh[k * NB + j];
+            eU = fmax(eU, fabs(s - A[i * NB + j]));
+        }
+    if (var != 1)
+        for (int i = 0; i < NB; ++i)
+            for (int j = 0; j < NB; ++j) {
+                double s = 0;                                   // (W L)[i][j], L = U^T: L[k][j] = U[j][k], k >= j
+                for (int k = j; k < NB; ++k) s += Wh[i * NB + k] * Uh[j * NB + k];
+                eW = fmax(eW, fabs(s - (i == j)));
+            }
+    unsigned long long ts[16][4];
+    hipMemcpyFromSymbol(ts, HIP_SYMBOL(g_ts), sizeof(ts));
+    printf("variant %d: %.2f us per launch (100 back-to-back); |U^T U - A| %.1e, |W L - I| %.1e\n", var, 10.0 * ms, eU, eW);
+    const int step = var == 2 ? 4 : 1;
+    unsigned long long tot_p = 0, tot_b = 0, tot_u = 0;
+    for (int jb = 0; jb < 16; jb += step) {
+        tot_p += ts[jb][1] - ts[jb][0];
+        tot_b += ts[jb][2] - ts[jb][1];
+        tot_u += ts[jb][3] - ts[jb][2];
+    }
+    printf("  thread 255, cycles summed over rounds: own pivot section %llu, waiting at the barrier %llu, update %llu; whole loop %llu\n",
+           tot_p, tot_b, tot_u, ts[16 - step][3] - ts[0][0]);
+    return 0;
+}

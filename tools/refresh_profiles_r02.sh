@@ -8,7 +8,7 @@ O=gpurun_out/refresh2
 mkdir -p $O
 timeout -k 10 600 python3 bench.py > $O/r02_bench_c4.json 2> $O/bench.err
 echo "bench done"
-timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o c4 -- python3 bench.py --workload c4 --steps 2 --warmup 1 --no-cpu-baseline --no-sublines > $O/trace.log 2>&1
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o c4 -- python3 bench.py --workload c4 --steps 2 --warmup 1 --no-cpu-baseline --no-sublines --no-extras > $O/trace.log 2>&1
 python3 tools/kstats.py $O/trace > $O/r02_c4_kernel_stats.txt
 cp "$(find $O/trace -name '*kernel_stats.csv' | head -1)" $O/r02_c4_kernel_stats.csv
 rm -rf $O/trace
