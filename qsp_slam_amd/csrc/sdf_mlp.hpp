@@ -453,6 +453,14 @@ __device__ __forceinline__ bf16x8 as_bf16x8(f32x4 q) {
     return u.b;
 }
 
+#ifndef QSP_BF3_NT
+#define QSP_BF3_NT 0      // experiment: non-temporal weight loads (the weights of a slab are used once per wave)
+#endif
+#if QSP_BF3_NT
+#define QSP_WLD(p_) __builtin_nontemporal_load(&(p_))
+#else
+#define QSP_WLD(p_) (p_)
+#endif
 template <int PF>
 struct WRing3 {
     f32x4 q[PF][2][3];      // [slab in flight][column block][plane]: 16-byte fragments (8 bf16 each)
@@ -528,14 +536,14 @@ __device__ __forceinline__ void gemm_2x2_bf3(const float* __restrict__ act, cons
 #endif
 #pragma unroll
                 for (int p = 0; p < 3; ++p) {
-                    R.q[d][0][p] = w0[((ks + d + PF) * 3 + p) * 64 + lane];
-                    R.q[d][1][p] = w1[((ks + d + PF) * 3 + p) * 64 + lane];
+                    R.q[d][0][p] = QSP_WLD(w0[((ks + d + PF) * 3 + p) * 64 + lane]);
+                    R.q[d][1][p] = QSP_WLD(w1[((ks + d + PF) * 3 + p) * 64 + lane]);
                 }
             } else {
 #pragma unroll
                 for (int p = 0; p < 3; ++p) {
-                    R.q[d][0][p] = n0[(d * 3 + p) * 64 + lane];
-                    R.q[d][1][p] = n1[(d * 3 + p) * 64 + lane];
+                    R.q[d][0][p] = QSP_WLD(n0[(d * 3 + p) * 64 + lane]);
+                    R.q[d][1][p] = QSP_WLD(n1[(d * 3 + p) * 64 + lane]);
                 }
             }
             if (!PIPE) {

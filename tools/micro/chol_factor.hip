@@ -5,6 +5,9 @@
 //   variant 0: as shipped in round 2 (W carried through the rounds, 16 workgroup barriers)
 //   variant 1: U only in the rounds (no W), to see what the chain costs without the inverse
 //   variant 2: wave-local sub-rounds: a wave's four rounds need no workgroup barrier (4 barriers, rank-16 catch-up for the rest)
+//   variant 3: one tile per thread and round: U is upper and W = L^-1 lower triangular, so a thread right of / on the diagonal
+//              only ever needs its S tile and a thread left of it only its W tile (the diagonal W tiles stay the identity until
+//              their own pivot round and are final after it)
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>
@@ -81,6 +84,109 @@ __device__ inline void rank4(double (&S)[4][4], double (&W)[4][4], const double*
     }
 }
 
+// variant 3 helpers: X is the thread's one live tile (S if c0 >= r0, else W)
+__device__ inline void pivot_rows_sel(double (&S)[4][4], double (&W)[4][4], double* rb, int jb, int lane, int r0, int c0) {
+    const int src = (lane & 48) | jb;
+    double D[4][4], rs[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = a; b < 4; ++b) D[a][b] = __shfl(S[a][b], src, 64);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        double dd = D[q][q];
+        rs[q] = rsqrt_nr(dd);
+#pragma unroll
+        for (int b = q + 1; b < 4; ++b) D[q][b] *= rs[q];
+#pragma unroll
+        for (int a = q + 1; a < 4; ++a)
+#pragma unroll
+            for (int b = a; b < 4; ++b) D[a][b] -= D[q][a] * D[q][b];
+    }
+    // (r0 == 4 jb here)  columns right of the diagonal: rows of U;  left of it: rows of W;  the diagonal tile: both
+    const bool isU = c0 >= r0, isW = c0 <= r0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            double sv = S[q][b], wv = W[q][b];
+#pragma unroll
+            for (int pp = 0; pp < q; ++pp) {
+                sv -= D[pp][q] * S[pp][b];
+                wv -= D[pp][q] * W[pp][b];
+            }
+            S[q][b] = sv * rs[q];
+            W[q][b] = wv * rs[q];
+            if (isU) rb[q * NB + c0 + b] = S[q][b];
+            if (isW) rb[(4 + q) * NB + c0 + b] = W[q][b];
+        }
+}
+
+__device__ inline void rank4_sel(double (&X)[4][4], const double* rb, int r0, int c0, bool upper) {
+    const double* colbase = rb + (upper ? 0 : 4 * NB) + c0;      // U rows for the S tiles, W rows for the W tiles
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        double ur[4], xc[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            ur[a] = rb[q * NB + r0 + a];
+            xc[a] = colbase[q * NB + a];
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) X[a][b] -= ur[a] * xc[b];
+    }
+}
+
+// variant 4: ONE live register tile X per thread (S on / right of the diagonal, W left of it) and one instruction stream; the
+// diagonal threads get their W tile (Wd) in their own pivot round
+__device__ inline void pivot_rows_one(double (&X)[4][4], double (&Wd)[4][4], double* rb, int jb, int lane, int r0, int c0) {
+    const int src = (lane & 48) | jb;
+    double D[4][4], rs[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = a; b < 4; ++b) D[a][b] = __shfl(X[a][b], src, 64);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        double dd = D[q][q];
+        rs[q] = rsqrt_nr(dd);
+#pragma unroll
+        for (int b = q + 1; b < 4; ++b) D[q][b] *= rs[q];
+#pragma unroll
+        for (int a = q + 1; a < 4; ++a)
+#pragma unroll
+            for (int b = a; b < 4; ++b) D[a][b] -= D[q][a] * D[q][b];
+    }
+    const bool lower = c0 < r0, diag = c0 == r0;
+    double* out = rb + (lower ? 4 * NB : 0) + c0;               // W rows go to the second half of the buffer
+    double* other = rb + (lower ? 0 : 4 * NB) + c0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            double xv = X[q][b];
+#pragma unroll
+            for (int pp = 0; pp < q; ++pp) xv -= D[pp][q] * X[pp][b];
+            X[q][b] = xv * rs[q];
+            out[q * NB + b] = X[q][b];
+            if (!diag) other[q * NB + b] = 0.0;                   // U left of the diagonal / W right of it: zero
+        }
+    if (diag) {                                                    // W of the diagonal tile: the same row operations on the identity
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                double wv = (q == b) ? 1.0 : 0.0;
+#pragma unroll
+                for (int pp = 0; pp < q; ++pp) wv -= D[pp][q] * Wd[pp][b];
+                Wd[q][b] = wv * rs[q];
+                rb[(4 + q) * NB + c0 + b] = Wd[q][b];
+            }
+    }
+}
+
 template <int VAR>
 __global__ __launch_bounds__(256) void k_factor(const double* A, double* Wout, double* Uout) {
     __shared__ double rowbuf[16 * 8 * NB];      // one 8 x 64 buffer per round (64 KiB)
@@ -95,7 +201,48 @@ __global__ __launch_bounds__(256) void k_factor(const double* A, double* Wout, d
         }
     __syncthreads();
     constexpr bool WW = VAR != 1;
-    if (VAR == 0 || VAR == 1) {
+    if (VAR == 4) {
+        const bool upper = c0 >= r0;
+        double X[4][4], Wd[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) { X[a][b] = upper ? S[a][b] : 0.0; Wd[a][b] = 0.0; }
+#pragma nounroll
+        for (int jb = 0; jb < 16; ++jb) {
+            double* rb = rowbuf + jb * 8 * NB;
+            if (t == 255) g_ts[jb][0] = __builtin_readcyclecounter();
+            if ((t >> 4) == jb) pivot_rows_one(X, Wd, rb, jb, lane, r0, c0);
+            if (t == 255) g_ts[jb][1] = __builtin_readcyclecounter();
+            __syncthreads();
+            if (t == 255) g_ts[jb][2] = __builtin_readcyclecounter();
+            if (r0 > 4 * jb) rank4_sel(X, rb, r0, c0, upper);
+            if (t == 255) g_ts[jb][3] = __builtin_readcyclecounter();
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                S[a][b] = upper ? X[a][b] : 0.0;
+                W[a][b] = (c0 < r0) ? X[a][b] : (c0 == r0 ? Wd[a][b] : 0.0);
+            }
+    } else if (VAR == 3) {
+        const bool upper = c0 >= r0;
+#pragma nounroll
+        for (int jb = 0; jb < 16; ++jb) {
+            double* rb = rowbuf + jb * 8 * NB;
+            if (t == 255) g_ts[jb][0] = __builtin_readcyclecounter();
+            if ((t >> 4) == jb) pivot_rows_sel(S, W, rb, jb, lane, r0, c0);
+            if (t == 255) g_ts[jb][1] = __builtin_readcyclecounter();
+            __syncthreads();
+            if (t == 255) g_ts[jb][2] = __builtin_readcyclecounter();
+            if (r0 > 4 * jb) {
+                if (upper) rank4_sel(S, rb, r0, c0, true);
+                else rank4_sel(W, rb, r0, c0, false);
+            }
+            if (t == 255) g_ts[jb][3] = __builtin_readcyclecounter();
+        }
+    } else if (VAR == 0 || VAR == 1) {
 #pragma nounroll
         for (int jb = 0; jb < 16; ++jb) {
             double* rb = rowbuf + jb * 8 * NB;
@@ -167,7 +314,9 @@ int main(int argc, char** argv) {
         for (int i = 0; i < 100; ++i) {
             if (var == 0) hipLaunchKernelGGL(k_factor<0>, dim3(1), dim3(256), 0, 0, dA, dW, dU);
             else if (var == 1) hipLaunchKernelGGL(k_factor<1>, dim3(1), dim3(256), 0, 0, dA, dW, dU);
-            else hipLaunchKernelGGL(k_factor<2>, dim3(1), dim3(256), 0, 0, dA, dW, dU);
+            else if (var == 2) hipLaunchKernelGGL(k_factor<2>, dim3(1), dim3(256), 0, 0, dA, dW, dU);
+            else if (var == 3) hipLaunchKernelGGL(k_factor<3>, dim3(1), dim3(256), 0, 0, dA, dW, dU);
+            else hipLaunchKernelGGL(k_factor<4>, dim3(1), dim3(256), 0, 0, dA, dW, dU);
         }
         hipEventRecord(e1);
         hipEventSynchronize(e1);
