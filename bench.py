@@ -322,6 +322,11 @@ def run_workload(ctx, name, steps, warmup, detailed, precision=None):
     achieved = flop_jtj / max(prof["n_jtj"], 1) / max(avg_ms * 1e-3, 1e-12) / 1e12
     fwd_tf = FLOP_FWD * prof["pts_fwd"] / max(prof["ms_mlp_fwd"] * 1e-3, 1e-9) / 1e12
     lin_us = 1e3 * ba_stat["ms_lin"] / max(ba_stat["n_lin"], 1)
+    # bytes one linearisation actually moves (upper bound with every edge active): the 56-byte edges are read by the landmark
+    # pass and by the key-frame pass, points 24 B in x 2 + Hll / bl 96 B out, pose blocks 56 B + K 40 B in x 2 and 336 B out,
+    # camera-object edges 56 B in, 84 + 36 doubles out
+    n_e = len(scene["mono_pt"]) + len(scene["st_pt"])
+    moved_lin = (2 * 56 * n_e + (2 * 24 + 96) * w["n_map"] + (2 * 96 + 336) * (w["n_kf"] + w["n_obj"]) + (56 + 960) * len(scene["oe_kf"]))
     res = dict(
         workload=name, desc=w["desc"], value=iters_total / dt, ms_per_step=1e3 * dt / steps, steps=steps,
         iters_per_step=iters_total / steps, n_hyp_job=n_hyp_job, hyp_this_rank=len(hyp), good_hypotheses=n_good,
@@ -342,7 +347,10 @@ def run_workload(ctx, name, steps, warmup, detailed, precision=None):
                  "ba_lm_trials": ba_stat["trials"] / steps, "ba_linearize_us": lin_us,
                  "ba_linearize_bytes": ba_stat["bytes_lin"],
                  "ba_linearize_GBps": ba_stat["bytes_lin"] / max(lin_us, 1e-9) / 1e3,
-                 "ba_linearize_frac_of_8TBps": ba_stat["bytes_lin"] / max(lin_us, 1e-9) / 1e3 / PEAK_HBM_GBPS})
+                 "ba_linearize_frac_of_8TBps": ba_stat["bytes_lin"] / max(lin_us, 1e-9) / 1e3 / PEAK_HBM_GBPS,
+                 "ba_linearize_moved_bytes": moved_lin, "ba_linearize_moved_GBps": moved_lin / max(lin_us, 1e-9) / 1e3,
+                 "ba_linearize_note": "launch-bound at the BASELINE sizes: 5 launches for a few MB; `ba_linearize_large` "
+                                      "(N = 1 only) is the same code on a graph large enough to stream"})
     if detailed:
         res["_objs"], res["_scene"], res["_hyp"], res["_T0"] = objs, scene, hyp, T0
         res["_dec"], res["_opt"] = dec, opt
@@ -419,6 +427,7 @@ def main():
                     PEAK_BF16_MFMA_TFLOPS / BF3_PRODUCTS if args.precision == "bf16x3" else PEAK_F32_MFMA_TFLOPS)
                 subs[name]["ba_linearize_us"] = r["kernels"]["ba_linearize_us"]
                 subs[name]["ba_linearize_algorithmic_GBps"] = r["kernels"]["ba_linearize_GBps"]
+                subs[name]["ba_linearize_moved_GBps"] = r["kernels"]["ba_linearize_moved_GBps"]
 
     if rank == 0:
         w = WORKLOADS[args.workload]
