@@ -89,3 +89,30 @@ def test_partition_is_a_partition():
             assert flat == list(range(n))
             assert all(parallel.owner_of(i, world) == r for r, s in enumerate(shards) for i in s)
             assert max(len(s) for s in shards) - min(len(s) for s in shards) <= 1
+
+
+def test_bench_keep_rule_equals_the_reference_loop():
+    """bench.select_flips (used by the strong-scaling step before the all_gather) == the serial keep rule of
+    src/LocalMapping_util.cc:748-752: keep the first result, replace it if it is not good, or if the new one is good with a
+    smaller loss"""
+    import bench
+    rng = np.random.default_rng(4)
+    n_obj, flips = 40, 4
+    T = rng.normal(size=(n_obj * flips, 4, 4)).astype(np.float32)
+    code = rng.normal(size=(n_obj * flips, 64)).astype(np.float32)
+    loss = rng.uniform(0.1, 2.0, size=n_obj * flips).astype(np.float32)
+    good = rng.random(n_obj * flips) > 0.35
+    good[:flips] = False                                   # an object without any good hypothesis
+    loss[2 * flips + 1] = loss[2 * flips]                  # a tie keeps the earlier one
+    table = bench.select_flips(T, code, loss, good, n_obj, flips)
+    for i in range(n_obj):
+        kept, kept_good, kept_loss = None, False, None
+        for k in range(flips):
+            h = i * flips + k
+            if k == 0 or (not kept_good) or (good[h] and loss[h] < kept_loss):
+                kept, kept_good, kept_loss = h, bool(good[h]), loss[h]
+        assert table[i, 81] == (1.0 if kept_good else 0.0) and table[i, 80] == kept_loss
+        if kept_good:
+            assert np.array_equal(table[i, :16], T[kept].reshape(-1)) and np.array_equal(table[i, 16:80], code[kept])
+        else:
+            assert not table[i, :80].any()
