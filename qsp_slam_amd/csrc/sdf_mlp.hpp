@@ -649,6 +649,10 @@ __device__ __forceinline__ void mlp_tile(MlpSmem& s, const MlpParams* __restrict
 
     // the last layer's row is read from LDS later so that no vector-memory wait has to drain the weight ring
     s.w8[tid] = P.w8[tid];
+    if constexpr (B3) {      // and so are the biases of layers 1..7 on the split-bf16 pipe (s.stash is free until the backward
+#pragma unroll           //  pass reaches layer 4; the f32 pipe fetches them ahead of its ring's cross-layer prefetch instead)
+        for (int l = 1; l < 8; ++l) s.stash[(l - 1) * HID + tid] = P.bias[l][tid];
+    }
 
     const int cb0 = 2 * wave;   // this wave's first column block
     constexpr int KGH = HID / 8;
@@ -661,14 +665,13 @@ __device__ __forceinline__ void mlp_tile(MlpSmem& s, const MlpParams* __restrict
 #define QSP_WB(L) (B3 ? P.wb3[L] + (size_t)(cb0 * KSH * 3) * 64 : P.wb[L] + (cb0 * KGH) * 64)
 #define QSP_WB1(L) (B3 ? P.wb3[L] + (size_t)((cb0 + 1) * KSH * 3) * 64 : P.wb[L] + ((cb0 + 1) * KGH) * 64)
     // one GEMM of the tile on whichever pipe: KG k-groups of 8 (f32) = KG / 2 slabs of 16 (split bf16)
-#define QSP_GEMM(KG, BIAS, W0, W1, N0, N1, BIASPTR)                                                              \
+#define QSP_GEMM(KG, BIAS, W0, W1, N0, N1, BIASPTR, LIDX)                                                        \
     if constexpr (B3) {                                                                                          \
         gemm_2x2_bf3<(KG) / 2, PF3, AGT>(s.act, W0, W1, N0, N1, ring3, acc, lane);                               \
-        if (BIAS) {                                                                                              \
-            typedef const __attribute__((address_space(1))) f32x4* gq_;                                          \
-            gq_ bp_ = (gq_)((BIASPTR) + 4 * (lane >> 5));                                                        \
+        if (BIAS) {   /* biases staged in LDS (s.stash, free until the backward pass reaches layer 4): no vector-memory wait */ \
+            const float* bp_ = s.stash + ((LIDX) - 1) * HID + 64 * wave + 4 * (lane >> 5);                       \
             _Pragma("unroll") for (int c_ = 0; c_ < 2; ++c_) _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_)   \
-                bq.v[c_][g_] = bp_[(32 * c_ + 8 * g_) / 4];                                                      \
+                bq.v[c_][g_] = lds4(bp_ + 32 * c_ + 8 * g_);                                                     \
         }                                                                                                        \
     } else {                                                                                                     \
         gemm_2x2<KG, PF, BIAS, AGT>(s.act, W0, W1, N0, N1, ring, acc, lane, BIASPTR, bq);                        \
@@ -732,7 +735,7 @@ __device__ __forceinline__ void mlp_tile(MlpSmem& s, const MlpParams* __restrict
     // ---- layers 1..7 (K = 512) ---------------------------------------------------------------------------------
 #define QSP_FWD_LAYER(L)                                                                                      \
     zero_acc(acc);                                                                                            \
-    QSP_GEMM(KGH, true, QSP_WF(L), QSP_WF1(L), QSP_WF((L) + 1), QSP_WF1((L) + 1), P.bias[L] + 64 * wave)      \
+    QSP_GEMM(KGH, true, QSP_WF(L), QSP_WF1(L), QSP_WF((L) + 1), QSP_WF1((L) + 1), P.bias[L] + 64 * wave, L)   \
     QSP_TS()                                                                                                  \
     __syncthreads();                                                                                          \
     QSP_TS()                                                                                                  \
@@ -743,7 +746,7 @@ __device__ __forceinline__ void mlp_tile(MlpSmem& s, const MlpParams* __restrict
     QSP_FWD_LAYER(1)
     QSP_FWD_LAYER(2)
     zero_acc(acc);
-    QSP_GEMM(KGH, true, QSP_WF(3), QSP_WF1(3), QSP_WF4, QSP_WF41, P.bias[3] + 64 * wave)
+    QSP_GEMM(KGH, true, QSP_WF(3), QSP_WF1(3), QSP_WF4, QSP_WF41, P.bias[3] + 64 * wave, 3)
     QSP_TS()
     __syncthreads();
     QSP_TS()
@@ -757,7 +760,7 @@ __device__ __forceinline__ void mlp_tile(MlpSmem& s, const MlpParams* __restrict
     QSP_TS()
     // layer 4: K = 448, bias = c4 of this hypothesis (LDS)
     zero_acc(acc);
-    QSP_GEMM(KG4, false, QSP_WF4, QSP_WF41, QSP_WF(5), QSP_WF1(5), (const float*)nullptr)
+    QSP_GEMM(KG4, false, QSP_WF4, QSP_WF41, QSP_WF(5), QSP_WF1(5), (const float*)nullptr, 4)
 #pragma unroll
     for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -772,8 +775,8 @@ __device__ __forceinline__ void mlp_tile(MlpSmem& s, const MlpParams* __restrict
     QSP_FWD_LAYER(5)
     QSP_FWD_LAYER(6)
     zero_acc(acc);
-    if (BWD) { QSP_GEMM(KGH, true, QSP_WF(7), QSP_WF1(7), QSP_WB(7), QSP_WB1(7), P.bias[7] + 64 * wave) }
-    else { QSP_GEMM(KGH, true, QSP_WF(7), QSP_WF1(7), QSP_WF(1), QSP_WF1(1), P.bias[7] + 64 * wave) }
+    if (BWD) { QSP_GEMM(KGH, true, QSP_WF(7), QSP_WF1(7), QSP_WB(7), QSP_WB1(7), P.bias[7] + 64 * wave, 7) }
+    else { QSP_GEMM(KGH, true, QSP_WF(7), QSP_WF1(7), QSP_WF(1), QSP_WF1(1), P.bias[7] + 64 * wave, 7) }
     QSP_TS()
     __syncthreads();
     QSP_TS()
@@ -843,7 +846,7 @@ __device__ __forceinline__ void mlp_tile(MlpSmem& s, const MlpParams* __restrict
 #define QSP_BWD_LAYER(L)                                                                                      \
     zero_acc(acc);                                                                                            \
     QSP_GEMM(KGH, false, QSP_WB(L), QSP_WB1(L), (L) > 1 ? QSP_WB((L) - 1) : wb0, (L) > 1 ? QSP_WB1((L) - 1) : wb0, \
-             (const float*)nullptr)                                                                           \
+             (const float*)nullptr, L)                                                                        \
     QSP_TS()                                                                                                  \
     __syncthreads();                                                                                          \
     QSP_TS()                                                                                                  \
@@ -862,7 +865,7 @@ __device__ __forceinline__ void mlp_tile(MlpSmem& s, const MlpParams* __restrict
     // layer 3 has 445 outputs: its backward contraction runs over K4 = 448 gradient columns (445..447 were zeroed by
     // stash_extract, the packed rows 445..511 are zero)
     zero_acc(acc);
-    QSP_GEMM(KG4, false, QSP_WB(3), QSP_WB1(3), QSP_WB(2), QSP_WB1(2), (const float*)nullptr)
+    QSP_GEMM(KG4, false, QSP_WB(3), QSP_WB1(3), QSP_WB(2), QSP_WB1(2), (const float*)nullptr, 3)
     QSP_TS()
     __syncthreads();
     QSP_TS()
