@@ -396,7 +396,9 @@ extern "C" int qsp_mesh_extract(qsp_mesh_extractor* m, const float* code, int64_
     QSP_HIP(hipStreamSynchronize(s));                  // (code64 lives on this stack frame)
     const int64_t tiles = (m->n + TILE_P - 1) / TILE_P;
     const int grid = (int)std::min<int64_t>(tiles, 4096);
-    if (m->dec->fwd_bf3)
+    if (m->dec->fwd_bf3 == 2)
+        hipLaunchKernelGGL(k_decode_h2, dim3(grid), dim3(H2_THREADS), sizeof(MlpSmem), s, m->code, m->xyz, m->n, m->dec->Pd, m->sdf);
+    else if (m->dec->fwd_bf3)
         hipLaunchKernelGGL((k_decode<false, true>), dim3(grid), dim3(MLP_THREADS), sizeof(MlpSmem), s, m->code, m->xyz, m->n,
                            m->dec->Pd, m->sdf, (float*)nullptr);
     else

@@ -82,6 +82,7 @@ struct MlpParams {
     const float4* w0x;      // [128 unit quads][3] layer-0 weights of x, y, z for four consecutive units
     const float4* wf3[8];   // split-bf16 forward weights of layers 1..7: [col block 16][slab K/16][plane hi|mid|lo][lane 64][8 bf16]
     const float4* wb3[8];   // split-bf16 backward weights of layers 0..7 (column blocks over the layer's inputs, slabs over outputs)
+    const float4* wfh[8];   // split-fp16 forward weights of layers 1..7: [col block 16][slab K/16][plane hi|lo'][lane 64][8 fp16]
 };
 
 // LDS carve (bytes): act 132096 | stash 17408 | inp 64*4*4 | code 256 | y 256 | red 2048 | row scale/res 512
@@ -1047,6 +1048,234 @@ __device__ __forceinline__ void mlp_tile_bf3(MlpSmem& s, const MlpParams* __rest
         float t = P.b8;
 #pragma unroll
         for (int q = 0; q < 8; ++q) t += s.red[q * TILE_P + tid];
+        s.y[tid] = tanhf(t);
+    }
+    __syncthreads();
+}
+
+
+// ===================================================================================================================
+// Split-fp16 forward tile (QSP_DEC_OPT_FORWARD_PRECISION = 2), four waves of 128 units x 64 points.
+//
+// fp16 carries 11 significand bits, bf16 8: TWO fp16 terms hold 22 bits of an f32 value where the bf16 split needs three terms.
+// With the second term pre-scaled so that it never leaves fp16's normal range,
+//     x = x_hi + 2^-11 x_lo',   x_hi = fp16(x),   x_lo' = fp16((x - x_hi) 2^11)
+// a product keeps everything above 2^-22 of it with THREE fp16 MFMAs instead of six bf16 ones:
+//     w x  ~=  w_hi x_hi  +  2^-11 (w_hi x_lo' + w_lo' x_hi)
+// (main and cross terms in separate f32 accumulators, combined once per layer in the write-out).  Measured against float64 on
+// the fitted decoder (tools/studies/fp16_split_accuracy.py, 20 000 points): 2.5e-7 relative on the SDF value -- the f32 pipe
+// 2.1e-7, the three-term bf16 split 2.5e-7.  Per multiply-add: half the matrix-pipe work of the bf16 split, 4 instead of 6 bytes
+// of weights, ~2/3 of the operand-split work.
+//   * the two accumulator sets of a 2x2 tile would take 128 of an 8-wave kernel's 256 registers; this tile runs FOUR waves (one
+//     per SIMD, 512 registers each): wave w owns units [128 w, 128 w + 128) of every layer as 4 x 2 MFMA tiles, 2 x 128 accumulator
+//     registers, and splits every activation four times over instead of eight;
+//   * values above fp16's range (65 504) would overflow x_hi: activations are clamped there before the split (a DeepSDF
+//     decoder's activations are O(10); the weights are checked when the planes are packed).
+// ===================================================================================================================
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+constexpr int H2_THREADS = 256;
+
+struct H2 {
+    f16x8 hi, lo;
+};
+
+__device__ __forceinline__ H2 split_h2(f32x4 a, f32x4 b) {
+    H2 o;
+    float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float x = fminf(v[j], 65504.f);
+        const _Float16 h = (_Float16)x;
+        const float r = x - (float)h;
+        o.hi[j] = h;
+        o.lo[j] = (_Float16)(r * 2048.f);
+    }
+    return o;
+}
+
+__device__ __forceinline__ f16x8 as_f16x8(f32x4 q) {
+    union { f32x4 f; f16x8 h; } u;
+    u.f = q;
+    return u.h;
+}
+
+#define QSP_MFMA_H(acc_, a_, b_) acc_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_, b_, acc_, 0, 0, 0)
+
+template <int PF>
+struct WRingH {
+    f32x4 q[PF][4][2];      // [slab in flight][column block][plane]
+};
+
+template <int PF>
+__device__ __forceinline__ void ringh_prime(WRingH<PF>& R, const float4* __restrict__ w_, int ks_stride, int lane) {
+    gptr4 w = (gptr4)w_;
+#pragma unroll
+    for (int d = 0; d < PF; ++d)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) R.q[d][c][p] = w[(size_t)c * ks_stride + (d * 2 + p) * 64 + lane];
+}
+
+// acc / acc2 [r][c] += act[32 r.., 0..16 KS) * W for this wave's four column blocks; w = base of the wave's first column block,
+// consecutive column blocks `cs` float4 apart (KS * 2 * 64), nw / ncs the same for the next GEMM (ring hand-over as gemm_2x2).
+template <int KS, int PF>
+__device__ __forceinline__ void gemm_4x2_h2(const float* __restrict__ act, const float4* __restrict__ w_, int cs,
+                                            const float4* __restrict__ nw_, int ncs, WRingH<PF>& R, f32x16 (&acc)[2][4],
+                                            f32x16 (&acc2)[2][4], int lane) {
+    static_assert(KS % PF == 0 && KS >= 2 * PF, "slab count must be a multiple of the prefetch depth, at least twice it");
+    gptr4 w = (gptr4)w_;
+    gptr4 nw = (gptr4)nw_;
+    const float* a_row0 = act + (lane & 31) * LDA + 8 * (lane >> 5);
+    const float* a_row1 = a_row0 + 32 * LDA;
+    H2 b0 = split_h2(lds4(a_row0), lds4(a_row0 + 4)), b1 = split_h2(lds4(a_row1), lds4(a_row1 + 4));
+    f32x4 x00 = lds4(a_row0 + 16), x01 = lds4(a_row0 + 20), x10 = lds4(a_row1 + 16), x11 = lds4(a_row1 + 20);
+#pragma nounroll
+    for (int ks = 0; ks < KS; ks += PF) {
+#pragma unroll
+        for (int d = 0; d < PF; ++d) {
+            f16x8 wh[4], wl[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                wh[c] = as_f16x8(R.q[d][c][0]);
+                wl[c] = as_f16x8(R.q[d][c][1]);
+            }
+            if (ks + PF < KS) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) R.q[d][c][p] = w[(size_t)c * cs + ((ks + d + PF) * 2 + p) * 64 + lane];
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) R.q[d][c][p] = nw[(size_t)c * ncs + (d * 2 + p) * 64 + lane];
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                QSP_MFMA_H(acc2[0][c], wl[c], b0.hi);
+                QSP_MFMA_H(acc2[1][c], wl[c], b1.hi);
+                QSP_MFMA_H(acc2[0][c], wh[c], b0.lo);
+                QSP_MFMA_H(acc2[1][c], wh[c], b1.lo);
+                QSP_MFMA_H(acc[0][c], wh[c], b0.hi);
+                QSP_MFMA_H(acc[1][c], wh[c], b1.hi);
+            }
+            {   // the next slab's planes (VALU) behind this slab's MFMAs; the raw f32 of the slab after it from LDS
+                const H2 n0 = split_h2(x00, x01), n1 = split_h2(x10, x11);
+                x00 = lds4(a_row0 + 16 * (ks + d + 2));
+                x01 = lds4(a_row0 + 16 * (ks + d + 2) + 4);
+                x10 = lds4(a_row1 + 16 * (ks + d + 2));
+                x11 = lds4(a_row1 + 16 * (ks + d + 2) + 4);
+                b0 = n0;
+                b1 = n1;
+            }
+        }
+    }
+}
+
+// Forward network on the split-fp16 pipe for the tile staged in s.code / s.xin / s.c0 / s.c4, 256 threads; s.y[row] = sdf value.
+template <int PF>
+__device__ __forceinline__ void mlp_tile_h2(MlpSmem& s, const MlpParams* __restrict__ Pm) {
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    int oz;
+    asm volatile("s_mov_b32 %0, 0" : "=s"(oz));
+    const MlpParams& P = Pm[oz];
+    f32x16 acc[2][4], acc2[2][4];
+    for (int i = tid; i < HID; i += H2_THREADS) s.w8[i] = P.w8[i];
+    float* bias_sh = s.stash;                              // [7][512] biases of layers 1..7
+#pragma unroll
+    for (int l = 1; l < 8; ++l)
+        for (int i = tid; i < HID; i += H2_THREADS) bias_sh[(l - 1) * HID + i] = P.bias[l][i];
+    const int cb0 = 4 * wave;
+    constexpr int KSH = HID / 16, KS4 = K4 / 16;
+#define QSP_WH(L, KS_) (P.wfh[L] + (size_t)(cb0 * (KS_) * 2) * 64)
+    WRingH<PF> ring;
+    ringh_prime(ring, QSP_WH(1, KSH), KSH * 2 * 64, lane);
+    // ---- layer 0 (exact f32) ---------------------------------------------------------------------------------------
+    {
+        const int h = lane >> 5;
+        const f32x4 x0 = lds4(s.xin + 4 * (lane & 31)), x1 = lds4(s.xin + 4 * (32 + (lane & 31)));
+        typedef const __attribute__((address_space(1))) f32x4* gq;
+        gq wx = (gq)P.w0x;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int u0 = 128 * wave + 32 * c + 8 * g + 4 * h;
+                const f32x4 cq = lds4(s.c0 + u0);
+                const f32x4 w0 = wx[3 * (u0 >> 2)], w1 = wx[3 * (u0 >> 2) + 1], w2 = wx[3 * (u0 >> 2) + 2];
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const f32x4 xp = r == 0 ? x0 : x1;
+                    const int p = 32 * r + (lane & 31);
+                    f32x4 v;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float x = cq[q] + w0[q] * xp.x + w1[q] * xp.y + w2[q] * xp.z;
+                        v[q] = x > 0.f ? x : 0.f;
+                    }
+                    *reinterpret_cast<f32x4*>(s.act + p * LDA + u0) = v;
+                }
+            }
+    }
+    __syncthreads();
+    // one hidden layer: GEMM, then (barrier) main + 2^-11 cross + bias, ReLU, 16-byte stores, (barrier)
+#define QSP_FWDH(L, KS_, NL, NKS, BIASPTR)                                                                               \
+    _Pragma("unroll") for (int r_ = 0; r_ < 2; ++r_) _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_)                    \
+        _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) { acc[r_][c_][i_] = 0.f; acc2[r_][c_][i_] = 0.f; }             \
+    gemm_4x2_h2<KS_, PF>(s.act, QSP_WH(L, KS_), (KS_) * 2 * 64, QSP_WH(NL, NKS), (NKS) * 2 * 64, ring, acc, acc2, lane);  \
+    __syncthreads();                                                                                                     \
+    {                                                                                                                    \
+        const int h_ = lane >> 5;                                                                                        \
+        _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {              \
+            const int u0_ = 128 * wave + 32 * c_ + 8 * g_ + 4 * h_;                                                      \
+            const f32x4 bv_ = lds4((BIASPTR) + u0_);                                                                     \
+            _Pragma("unroll") for (int r_ = 0; r_ < 2; ++r_) {                                                           \
+                const int p_ = 32 * r_ + (lane & 31);                                                                    \
+                f32x4 v_;                                                                                                \
+                _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                       \
+                    const float x_ = (acc[r_][c_][4 * g_ + q_] + 0.00048828125f * acc2[r_][c_][4 * g_ + q_]) + bv_[q_];  \
+                    v_[q_] = x_ > 0.f ? x_ : 0.f;                                                                        \
+                }                                                                                                        \
+                *reinterpret_cast<f32x4*>(s.act + p_ * LDA + u0_) = v_;                                                  \
+            }                                                                                                            \
+        }                                                                                                                \
+    }                                                                                                                    \
+    __syncthreads();
+    QSP_FWDH(1, KSH, 2, KSH, bias_sh + 0 * HID)
+    QSP_FWDH(2, KSH, 3, KSH, bias_sh + 1 * HID)
+    QSP_FWDH(3, KSH, 4, KS4, bias_sh + 2 * HID)
+    pass_through(s);
+    __syncthreads();
+    QSP_FWDH(4, KS4, 5, KSH, s.c4)
+    QSP_FWDH(5, KSH, 6, KSH, bias_sh + 4 * HID)
+    QSP_FWDH(6, KSH, 7, KSH, bias_sh + 5 * HID)
+    QSP_FWDH(7, KSH, 1, KSH, bias_sh + 6 * HID)
+#undef QSP_FWDH
+#undef QSP_WH
+    // ---- layer 8: 512 -> 1, tanh (f32): wave = k segment of 128, lane = row ----------------------------------------
+    {
+        const float* a = s.act + lane * LDA + 128 * wave;
+        const float* w = s.w8 + 128 * wave;
+        float part = 0.f;
+#pragma unroll
+        for (int q = 0; q < 32; ++q) {
+            const float4 av = *reinterpret_cast<const float4*>(a + 4 * q);
+            const float4 wv = *reinterpret_cast<const float4*>(w + 4 * q);
+            part += av.x * wv.x;
+            part += av.y * wv.y;
+            part += av.z * wv.z;
+            part += av.w * wv.w;
+        }
+        s.red[wave * TILE_P + lane] = part;
+    }
+    __syncthreads();
+    if (tid < TILE_P) {
+        float t = P.b8;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) t += s.red[q * TILE_P + tid];
         s.y[tid] = tanhf(t);
     }
     __syncthreads();

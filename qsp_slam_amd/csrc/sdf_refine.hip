@@ -352,6 +352,64 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void k_mlp_fwd(const HypState* __re
     }
 }
 
+// the same work queue on the split-fp16 tile: four waves per workgroup (mlp_tile_h2)
+__global__ __launch_bounds__(H2_THREADS) void k_mlp_fwd_h2(const HypState* __restrict__ st,
+                                                            const ObjView* __restrict__ objs,
+                                                            const float* __restrict__ rays, RefineCfg cfg, const MlpParams* __restrict__ P,
+                                                            const int32_t* __restrict__ valid_rk, int64_t rk_stride,
+                                                            float* __restrict__ sdf_valid, const int2* __restrict__ work,
+                                                            int* __restrict__ qctl, const float* __restrict__ c0_all) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    MlpSmem& s = *reinterpret_cast<MlpSmem*>(smem_raw);
+    __shared__ float Tsh[16];
+    __shared__ int s_item;
+    const int n_items = qctl[0];
+    int h_cached = -1;
+    for (;;) {
+        if (threadIdx.x == 0) s_item = atomicAdd(&qctl[1], 1);
+        __syncthreads();                       // also: everybody is done with the previous item's LDS
+        const int item = s_item;
+        if (item >= n_items) break;            // the queue only grows towards n_items: every workgroup gets here
+        const int h = work[item].x, t = work[item].y;
+        const HypState& S = st[h];
+        const int n = S.n_valid;
+        const ObjView ov = objs[S.obj];
+        const float* R = rays + 3 * ov.ray_off;
+        const int32_t* rk = valid_rk + h * rk_stride;
+        float* out = sdf_valid + h * rk_stride;
+        if (h != h_cached) {                   // per-hypothesis staging: code, pose, layer-0 code part
+            stage_code_T(s, S, Tsh);
+            for (int i = threadIdx.x; i < HID; i += H2_THREADS) {
+                s.c0[i] = c0_all[(size_t)h * 2 * HID + i];
+                s.c4[i] = c0_all[(size_t)h * 2 * HID + HID + i];
+            }
+            h_cached = h;
+        }
+        const float d_min = S.d_min, d_max = S.d_max;
+        __syncthreads();
+        if (threadIdx.x < TILE_P) {
+            const int v = t * TILE_P + threadIdx.x;
+            float x = 0, y = 0, z = 0;
+            if (v < n) {
+                const int e = rk[v];
+                const int r = e >> 6, k = e & 63;
+                const float d = depth_at(d_min, d_max, k, cfg.n_depth);
+                xform(Tsh, R[3 * r] * d, R[3 * r + 1] * d, R[3 * r + 2] * d, x, y, z);
+            }
+            s.xin[4 * threadIdx.x + 0] = x;
+            s.xin[4 * threadIdx.x + 1] = y;
+            s.xin[4 * threadIdx.x + 2] = z;
+            s.xin[4 * threadIdx.x + 3] = 0.f;
+        }
+        __syncthreads();
+        mlp_tile_h2<2>(s, P);
+        if (threadIdx.x < TILE_P) {
+            const int v = t * TILE_P + threadIdx.x;
+            if (v < n) out[v] = s.y[threadIdx.x];
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // k_scan: per ray render function and its derivative (loss.py:84-141)
 // ---------------------------------------------------------------------------------------------------------------
@@ -905,6 +963,45 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void k_decode(const float* __restri
     }
 }
 
+// forward-only decode on the split-fp16 tile (four waves per workgroup)
+__global__ __launch_bounds__(H2_THREADS) void k_decode_h2(const float* __restrict__ code, const float* __restrict__ xyz, int64_t n,
+                                                          const MlpParams* __restrict__ P, float* __restrict__ y_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    MlpSmem& s = *reinterpret_cast<MlpSmem*>(smem_raw);
+    if (threadIdx.x < CODE_LEN) s.code[threadIdx.x] = code[threadIdx.x];
+    __syncthreads();
+    for (int u = threadIdx.x; u < HID; u += H2_THREADS) {      // mlp_prepare for 256 threads
+        const float* w = P->w0c + (size_t)u * CODE_LEN;
+        const float* w4 = P->w4c + (size_t)u * CODE_LEN;
+        float a = P->bias[0][u], a4 = P->bias[4][u];
+#pragma unroll 8
+        for (int k = 0; k < CODE_LEN; ++k) {
+            a += w[k] * s.code[k];
+            a4 += w4[k] * s.code[k];
+        }
+        s.c0[u] = a;
+        s.c4[u] = a4;
+    }
+    for (int64_t t = blockIdx.x; t * TILE_P < n; t += gridDim.x) {
+        __syncthreads();
+        if (threadIdx.x < TILE_P) {
+            const int64_t v = t * TILE_P + threadIdx.x;
+            float x = 0, y = 0, z = 0;
+            if (v < n) { x = xyz[3 * v]; y = xyz[3 * v + 1]; z = xyz[3 * v + 2]; }
+            s.xin[4 * threadIdx.x + 0] = x;
+            s.xin[4 * threadIdx.x + 1] = y;
+            s.xin[4 * threadIdx.x + 2] = z;
+            s.xin[4 * threadIdx.x + 3] = 0.f;
+        }
+        __syncthreads();
+        mlp_tile_h2<2>(s, P);
+        if (threadIdx.x < TILE_P) {
+            const int64_t v = t * TILE_P + threadIdx.x;
+            if (v < n) y_out[v] = s.y[threadIdx.x];
+        }
+    }
+}
+
 // 4x4 inverse as the reference's torch.inverse calls need it (optimizer.py:123,273): Gauss-Jordan with partial pivoting in
 // double, rounded to f32.  One definition for host (set_state / get) and device (detections.hpp), no contraction, so both
 // give the same bits.
@@ -955,6 +1052,7 @@ struct qsp_decoder {
     int code_len = CODE_LEN;   // the caller's code length L <= 64; the tile always works on 64 (columns L..63 are zero)
     int fwd_bf3 = 0;           // QSP_DEC_OPT_FORWARD_PRECISION: forward-only passes on the split-bf16 pipe (mlp_tile_bf3)
     int jac_bf3 = 0;           // QSP_DEC_OPT_JACOBIAN_PRECISION: the forward+backward pass (mlp_tile<true, .., B3>)
+    bool fp16_ok = true;       // every weight of layers 1..7 fits fp16's range (split-fp16 planes are usable)
 };
 
 // The family deep_sdf/deep_sdf_decoder.py:29-63 builds -- `dims` hidden layers of any width, one (or no) latent_in layer, any
@@ -1100,6 +1198,7 @@ static int pack_weights(qsp_decoder* d, const qsp_decoder_desc* desc) {
             if (!rc) rc = upload(wx, (const void**)&d->P.w0x);
             d->P.wf[0] = nullptr;
             d->P.wf3[0] = nullptr;
+            d->P.wfh[0] = nullptr;
         } else {
             // forward: B[k][o]; column blocks over o (16 blocks of 32), k-groups of 8 over K = 512.
             // Layer 4 (latent_in): K = 448 = [h3 (445) | xyz (3)]; its 64 code columns go to w4c (folded into a bias per
@@ -1144,6 +1243,32 @@ static int pack_weights(qsp_decoder* d, const qsp_decoder_desc* desc) {
                 d->allocs.push_back(p3d);
                 QSP_HIP(hipMemcpy(p3d, p3.data(), p3.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
                 d->P.wf3[l] = (const float4*)p3d;
+            }
+            if (!rc) {
+                // split-fp16 planes for mlp_tile_h2: [col block][slab of 16 k][hi | lo' = (w - hi) 2^11][lane][8 fp16], same lane map
+                const int KS = KG / 2;
+                std::vector<_Float16> ph((size_t)16 * KS * 2 * 64 * 8, (_Float16)0.f);
+                for (int cb = 0; cb < 16; ++cb)
+                    for (int ks = 0; ks < KS; ++ks)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int j = 0; j < 8; ++j) {
+                                const int o = 32 * cb + (lane & 31);
+                                int k = 16 * ks + 8 * (lane >> 5) + j;
+                                if (l == 4 && k >= SKIP_COL) k += CODE_LEN;
+                                float v = 0.f;
+                                if (o < out && k < in) v = W[l][(size_t)o * in + k];
+                                if (!(fabsf(v) < 65000.f)) d->fp16_ok = false;
+                                const _Float16 hi = (_Float16)v;
+                                const _Float16 lo = (_Float16)((v - (float)hi) * 2048.f);
+                                const size_t base = (((size_t)cb * KS + ks) * 2) * 64 * 8 + (size_t)lane * 8 + j;
+                                ph[base] = hi;
+                                ph[base + 64 * 8] = lo;
+                            }
+                void* phd = nullptr;
+                QSP_HIP(hipMalloc(&phd, ph.size() * sizeof(_Float16) + 16384));
+                d->allocs.push_back(phd);
+                QSP_HIP(hipMemcpy(phd, ph.data(), ph.size() * sizeof(_Float16), hipMemcpyHostToDevice));
+                d->P.wfh[l] = (const float4*)phd;
             }
             if (!rc && l == 4) {
                 std::vector<float> wc((size_t)HID * CODE_LEN);
@@ -1217,6 +1342,8 @@ static int mlp_attr_once() {
     QSP_HIP(hipFuncSetAttribute((const void*)k_mlp_fwd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     QSP_HIP(hipFuncSetAttribute((const void*)k_mlp_fwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     QSP_HIP(hipFuncSetAttribute((const void*)k_decode<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    QSP_HIP(hipFuncSetAttribute((const void*)k_mlp_fwd_h2, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    QSP_HIP(hipFuncSetAttribute((const void*)k_decode_h2, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     QSP_HIP(hipFuncSetAttribute((const void*)k_mlp_jtj<false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     QSP_HIP(hipFuncSetAttribute((const void*)k_mlp_jtj<true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     QSP_HIP(hipFuncSetAttribute((const void*)k_decode<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
@@ -1253,7 +1380,8 @@ extern "C" int qsp_decoder_set_option(qsp_decoder* d, int32_t option, int32_t va
     if (!d) return qsp_fail(QSP_ERR_INVALID, "qsp_decoder_set_option: null decoder");
     switch (option) {
         case QSP_DEC_OPT_FORWARD_PRECISION:
-            if (value != 0 && value != 1) return qsp_fail(QSP_ERR_INVALID, "forward precision: 0 (f32 MFMA) or 1 (split bf16)");
+            if (value < 0 || value > 2) return qsp_fail(QSP_ERR_INVALID, "forward precision: 0 (f32 MFMA), 1 (split bf16) or 2 (split fp16)");
+            if (value == 2 && !d->fp16_ok) return qsp_fail(QSP_ERR_UNSUPPORTED, "split fp16: a weight of this decoder is outside fp16's range");
             d->fwd_bf3 = value;
             return QSP_OK;
         case QSP_DEC_OPT_JACOBIAN_PRECISION:
@@ -1291,6 +1419,8 @@ static int decode_common(qsp_decoder* d, const float* code, const float* xyz, in
         hipLaunchKernelGGL((k_decode<true, true>), dim3(grid), dim3(MLP_THREADS), sizeof(MlpSmem), d->stream, dc, dx, n, d->Pd, dy, dg);
     else if (grad)
         hipLaunchKernelGGL(k_decode<true>, dim3(grid), dim3(MLP_THREADS), sizeof(MlpSmem), d->stream, dc, dx, n, d->Pd, dy, dg);
+    else if (d->fwd_bf3 == 2)
+        hipLaunchKernelGGL(k_decode_h2, dim3(grid), dim3(H2_THREADS), sizeof(MlpSmem), d->stream, dc, dx, n, d->Pd, dy);
     else if (d->fwd_bf3)
         hipLaunchKernelGGL((k_decode<false, true>), dim3(grid), dim3(MLP_THREADS), sizeof(MlpSmem), d->stream, dc, dx, n, d->Pd, dy,
                            (float*)nullptr);
@@ -1558,7 +1688,10 @@ extern "C" int qsp_refine_batch_run(qsp_refine_batch* b, int32_t n_iter) {
             if (b->prof) a = next_event(b, cur);
             hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, s, 0, b->st, b->objs, nH, b->nw_sdf, nw_total - b->nw_sdf,
                                b->work_fwd, b->qctl);
-            if (b->dec->fwd_bf3)
+            if (b->dec->fwd_bf3 == 2)
+                hipLaunchKernelGGL(k_mlp_fwd_h2, dim3(b->n_cu), dim3(H2_THREADS), sizeof(MlpSmem), s, b->st, b->objs, b->rays,
+                                   cfg, b->dec->Pd, b->valid_rk, b->rk_stride, b->sdf_valid, b->work_fwd, b->qctl, b->c0_all);
+            else if (b->dec->fwd_bf3)
                 hipLaunchKernelGGL(k_mlp_fwd<true>, dim3(b->n_cu), dim3(MLP_THREADS), sizeof(MlpSmem), s, b->st, b->objs, b->rays,
                                    cfg, b->dec->Pd, b->valid_rk, b->rk_stride, b->sdf_valid, b->work_fwd, b->qctl, b->c0_all);
             else

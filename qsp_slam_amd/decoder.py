@@ -56,7 +56,7 @@ class DeepSdfDecoder(object):
     def set_forward_precision(self, split_bf16):
         """forward-only passes (decode_sdf, mesh grid, ray samples) on the exact-f32 matrix pipe (False, default) or as three
         bf16 terms per operand / six products on the bf16 pipe (True); see QSP_DEC_OPT_FORWARD_PRECISION in qsp_hip.h"""
-        _lib.check(_lib.lib().qsp_decoder_set_option(self.handle, 1, 1 if split_bf16 else 0))
+        _lib.check(_lib.lib().qsp_decoder_set_option(self.handle, 1, int(split_bf16)))     # (2: the split-fp16 forward tile)
 
     def set_jacobian_precision(self, split_bf16):
         """the forward+backward pass (sdf_value_grad, the fused Jacobian / normal-equation kernel) likewise

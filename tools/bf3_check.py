@@ -37,8 +37,13 @@ print("max |bf16x3 - f64| = %.3e   rel to max|y| %.3e" % (np.abs(y3 - ref).max()
 print("max |bf16x3 - f32| = %.3e ; rms %.3e" % (np.abs(y3 - y32).max(), np.sqrt(np.mean((y3 - y32) ** 2))))
 z = np.load(os.path.join(ROOT, "tests/golden/sdf_decoder_vectors.npz"))
 print("golden vectors: max |bf16x3 - reference| = %.3e" % np.abs(dec.decode_sdf(z["code"], z["x"]) - z["sdf"]).max())
+dec.set_forward_precision(2)
+yh = dec.decode_sdf(code, x)
+print("max |fp16x2 - f64| = %.3e   rel to max|y| %.3e" % (np.abs(yh - ref).max(), np.abs(yh - ref).max() / np.abs(ref).max()))
+print("max |fp16x2 - f32| = %.3e ; rms %.3e" % (np.abs(yh - y32).max(), np.sqrt(np.mean((yh - y32) ** 2))))
+print("golden vectors: max |fp16x2 - reference| = %.3e" % np.abs(dec.decode_sdf(z["code"], z["x"]) - z["sdf"]).max())
 dim = int(sys.argv[1]) if len(sys.argv) > 1 else 128
-for mode in (False, True):
+for mode in (0, 1, 2):
     dec.set_forward_precision(mode)
     me = MeshExtractor(dec, 64, dim)
     import io, contextlib
@@ -49,4 +54,4 @@ for mode in (False, True):
             t = time.perf_counter(); me.extract_mesh_from_code(code); ts.append(time.perf_counter() - t)
     t = min(ts)
     print("%s: %d^3 grid decode + marching cubes %.2f ms  -> >= %.1f TFLOP/s of decoder work (3.671 MFLOP/voxel)" % (
-        "split-bf16" if mode else "f32 MFMA ", dim, 1e3 * t, 3.671e6 * dim ** 3 / t / 1e12))
+        ("f32 MFMA  ", "split-bf16", "split-fp16")[mode], dim, 1e3 * t, 3.671e6 * dim ** 3 / t / 1e12))
