@@ -379,6 +379,10 @@ static int mesh_march(qsp_mesh_extractor* m, int64_t* n_verts, int64_t* n_faces)
                            m->flags, m->cnt, m->bsum, m->verts, m->faces);
     QSP_HIP(hipGetLastError());
     QSP_HIP(hipStreamSynchronize(s));
+    {
+        const int rc = check_range(m->dec);
+        if (rc) return rc;
+    }
     m->have_volume = true;
     if (n_verts) *n_verts = m->n_verts;
     if (n_faces) *n_faces = m->n_faces;
@@ -397,7 +401,8 @@ extern "C" int qsp_mesh_extract(qsp_mesh_extractor* m, const float* code, int64_
     const int64_t tiles = (m->n + TILE_P - 1) / TILE_P;
     const int grid = (int)std::min<int64_t>(tiles, 4096);
     if (m->dec->fwd_bf3 == 2)
-        hipLaunchKernelGGL(k_decode_h2, dim3(grid), dim3(H2_THREADS), sizeof(MlpSmem), s, m->code, m->xyz, m->n, m->dec->Pd, m->sdf);
+        hipLaunchKernelGGL(k_decode_h2<false>, dim3(grid), dim3(H2_THREADS), sizeof(MlpSmem), s, m->code, m->xyz, m->n, m->dec->Pd, m->sdf,
+                           (float*)nullptr);
     else if (m->dec->fwd_bf3)
         hipLaunchKernelGGL((k_decode<false, true>), dim3(grid), dim3(MLP_THREADS), sizeof(MlpSmem), s, m->code, m->xyz, m->n,
                            m->dec->Pd, m->sdf, (float*)nullptr);

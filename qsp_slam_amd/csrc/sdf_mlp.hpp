@@ -83,6 +83,9 @@ struct MlpParams {
     const float4* wf3[8];   // split-bf16 forward weights of layers 1..7: [col block 16][slab K/16][plane hi|mid|lo][lane 64][8 bf16]
     const float4* wb3[8];   // split-bf16 backward weights of layers 0..7 (column blocks over the layer's inputs, slabs over outputs)
     const float4* wfh[8];   // split-fp16 forward weights of layers 1..7: [col block 16][slab K/16][plane hi|lo'][lane 64][8 fp16]
+    const float4* wbh[8];   // split-fp16 backward weights of layers 0..7 (column blocks over the layer's inputs, slabs over outputs)
+    const float4* wbh4s;    // split-fp16 backward weights of layer 4's skip columns (inputs 445..511 = [code | xyz]), packed like wbh[0]
+    int* range_flag;        // set by the split-fp16 kernels when a value they had to split was outside fp16's range
 };
 
 // LDS carve (bytes): act 132096 | stash 17408 | inp 64*4*4 | code 256 | y 256 | red 2048 | row scale/res 512
@@ -1055,7 +1058,7 @@ __device__ __forceinline__ void mlp_tile_bf3(MlpSmem& s, const MlpParams* __rest
 
 
 // ===================================================================================================================
-// Split-fp16 forward tile (QSP_DEC_OPT_FORWARD_PRECISION = 2), four waves of 128 units x 64 points.
+// Split-fp16 tile (QSP_DEC_OPT_*_PRECISION = 2), four waves of 128 units x 64 points, forward and forward+backward.
 //
 // fp16 carries 11 significand bits, bf16 8: TWO fp16 terms hold 22 bits of an f32 value where the bf16 split needs three terms.
 // With the second term pre-scaled so that it never leaves fp16's normal range,
@@ -1064,34 +1067,62 @@ __device__ __forceinline__ void mlp_tile_bf3(MlpSmem& s, const MlpParams* __rest
 //     w x  ~=  w_hi x_hi  +  2^-11 (w_hi x_lo' + w_lo' x_hi)
 // (main and cross terms in separate f32 accumulators, combined once per layer in the write-out).  Measured against float64 on
 // the fitted decoder (tools/studies/fp16_split_accuracy.py, 20 000 points): 2.5e-7 relative on the SDF value -- the f32 pipe
-// 2.1e-7, the three-term bf16 split 2.5e-7.  Per multiply-add: half the matrix-pipe work of the bf16 split, 4 instead of 6 bytes
-// of weights, ~2/3 of the operand-split work.
+// 2.1e-7, the three-term bf16 split 2.5e-7.  Per multiply-add: half the matrix-pipe work of the bf16 split and 4 instead of 6
+// bytes of weights.
+//   * two fp16 planes are 4 bytes per value -- what the f32 activation image takes.  So the image in LDS IS the pair of planes:
+//     the write-out of a layer splits every value once ([row][k-group of 8][hi x 8 | lo' x 8], the f32 image's row stride) and
+//     the GEMM loop reads its B operands with two ds_read_b128 and no arithmetic at all.  (The bf16 split needs 6 bytes per
+//     value and re-splits every activation in every consuming wave.)
 //   * the two accumulator sets of a 2x2 tile would take 128 of an 8-wave kernel's 256 registers; this tile runs FOUR waves (one
-//     per SIMD, 512 registers each): wave w owns units [128 w, 128 w + 128) of every layer as 4 x 2 MFMA tiles, 2 x 128 accumulator
-//     registers, and splits every activation four times over instead of eight;
-//   * values above fp16's range (65 504) would overflow x_hi: activations are clamped there before the split (a DeepSDF
-//     decoder's activations are O(10); the weights are checked when the planes are packed).
+//     per SIMD, 512 registers each): wave w owns units [128 w, 128 w + 128) of every layer as 4 x 2 MFMA tiles, 2 x 128
+//     accumulator registers = the whole AccVGPR file;
+//   * the bias is the accumulators' initial value; the skip connection's gradient goes from layer 4's backward write-out
+//     straight to the stash in f32;
+//   * |value| above fp16's range (65 504) cannot be split: the write-outs track the largest magnitude they split, the kernels
+//     raise the decoder's range flag and the host fails the call (a DeepSDF decoder's activations are O(10); the weights are
+//     checked when the planes are packed).
 // ===================================================================================================================
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+#ifndef QSP_H2_EXP
+#define QSP_H2_EXP 0      // timing experiments only (tools/micro/h2_tile.hip): bit 0 = no pinned issue order in the GEMM loop,
+#endif                    // bit 1 = write-outs store without splitting, bit 2 = no weight loads in the loop, bit 3 = no MFMAs
+#ifdef QSP_H2_STAMPS   // tools/micro/h2_tile.hip: shader-clock stamps of wave 0 at the phase boundaries of one tile
+__device__ unsigned long long qsp_h2_ts[64];
+__device__ int qsp_h2_nts;
+#define QSP_HTS() { if (threadIdx.x == 0 && blockIdx.x == 0 && hts_n < 64) qsp_h2_ts[hts_n++] = __builtin_readcyclecounter(); }
+#else
+#define QSP_HTS()
+#endif
 constexpr int H2_THREADS = 256;
+constexpr int LDH = 2 * LDA;            // row stride of the split image in halfs (= the f32 image's 2064 bytes)
+constexpr float H2_MAX = 65504.f;
 
-struct H2 {
-    f16x8 hi, lo;
-};
+// position of (row, unit u) in the split image, in halfs; its lo' term is 8 halfs further
+__device__ __forceinline__ int h2_at(int row, int u) { return row * LDH + (u >> 3) * 16 + (u & 7); }
 
-__device__ __forceinline__ H2 split_h2(f32x4 a, f32x4 b) {
-    H2 o;
-    float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+// four consecutive units (u0 % 4 == 0) of one row: split and store (two 8-byte stores)
+__device__ __forceinline__ void h2_store4(_Float16* img, int row, int u0, f32x4 v, float& amax) {
+    amax = fmaxf(fmaxf(amax, fabsf(v[0])), fmaxf(fabsf(v[1]), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+    asm volatile("" : "+v"(amax));      // (otherwise the maximum is deferred and every split value stays live until then)
+    f16x4 hi, lo;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const float x = fminf(v[j], 65504.f);
-        const _Float16 h = (_Float16)x;
-        const float r = x - (float)h;
-        o.hi[j] = h;
-        o.lo[j] = (_Float16)(r * 2048.f);
+    for (int q = 0; q < 4; ++q) {
+        const _Float16 h = (_Float16)v[q];
+        hi[q] = h;
+        lo[q] = (QSP_H2_EXP & 2) ? h : (_Float16)((v[q] - (float)h) * 2048.f);
     }
-    return o;
+    _Float16* d = img + h2_at(row, u0);
+    *reinterpret_cast<f16x4*>(d) = hi;
+    *reinterpret_cast<f16x4*>(d + 8) = lo;
 }
+
+#define QSP_MFMA_H(acc_, a_, b_) acc_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_, b_, acc_, 0, 0, 0)
+
+template <int PF, int NCB>
+struct WRingH {
+    f32x4 q[PF][NCB][2];      // [slab in flight][column block][plane]
+};
 
 __device__ __forceinline__ f16x8 as_f16x8(f32x4 q) {
     union { f32x4 f; f16x8 h; } u;
@@ -1099,106 +1130,201 @@ __device__ __forceinline__ f16x8 as_f16x8(f32x4 q) {
     return u.h;
 }
 
-#define QSP_MFMA_H(acc_, a_, b_) acc_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_, b_, acc_, 0, 0, 0)
+// Packed planes are addressed as (uniform base in SGPRs) + (this lane's 32-bit byte offset): one VGPR of address for the whole
+// ring instead of a 64-bit pointer per fragment in flight.
+typedef const __attribute__((address_space(1))) char* gbytes;
+__device__ __forceinline__ f32x4 ldw(gbytes base, uint32_t voff) { return *reinterpret_cast<gptr4>(base + voff); }
 
-template <int PF>
-struct WRingH {
-    f32x4 q[PF][4][2];      // [slab in flight][column block][plane]
-};
-
-template <int PF>
-__device__ __forceinline__ void ringh_prime(WRingH<PF>& R, const float4* __restrict__ w_, int ks_stride, int lane) {
-    gptr4 w = (gptr4)w_;
+template <int PF, int NCB>
+__device__ __forceinline__ void ringh_prime(WRingH<PF, NCB>& R, const float4* __restrict__ w_, int cs, int lane) {
+    gbytes w = (gbytes)w_;
+    const uint32_t voff = 16u * lane;
 #pragma unroll
     for (int d = 0; d < PF; ++d)
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
+        for (int c = 0; c < NCB; ++c)
 #pragma unroll
-            for (int p = 0; p < 2; ++p) R.q[d][c][p] = w[(size_t)c * ks_stride + (d * 2 + p) * 64 + lane];
+            for (int p = 0; p < 2; ++p) R.q[d][c][p] = ldw(w + ((size_t)c * cs + (d * 2 + p) * 64) * 16, voff);
 }
 
-// acc / acc2 [r][c] += act[32 r.., 0..16 KS) * W for this wave's four column blocks; w = base of the wave's first column block,
-// consecutive column blocks `cs` float4 apart (KS * 2 * 64), nw / ncs the same for the next GEMM (ring hand-over as gemm_2x2).
-template <int KS, int PF>
-__device__ __forceinline__ void gemm_4x2_h2(const float* __restrict__ act, const float4* __restrict__ w_, int cs,
-                                            const float4* __restrict__ nw_, int ncs, WRingH<PF>& R, f32x16 (&acc)[2][4],
-                                            f32x16 (&acc2)[2][4], int lane) {
+// acc / acc2 [r][c] += image rows [32 r, 32 r + 32) x slabs [0, KS) * W for NCB column blocks; w = base of the first column
+// block, consecutive column blocks `cs` float4 apart, nw / ncs the same for the next GEMM (its first PF slabs are fetched by
+// this one's last iterations).  img = the first row of row block 0.
+template <int KS, int PF, int NCB, int NR, bool HAND = true>
+__device__ __forceinline__ void gemm_h2(const _Float16* __restrict__ img, const float4* __restrict__ w_, int cs,
+                                        const float4* __restrict__ nw_, int ncs, WRingH<PF, NCB>& R, f32x16 (&acc)[NR][NCB],
+                                        f32x16 (&acc2)[NR][NCB], int lane) {
     static_assert(KS % PF == 0 && KS >= 2 * PF, "slab count must be a multiple of the prefetch depth, at least twice it");
-    gptr4 w = (gptr4)w_;
-    gptr4 nw = (gptr4)nw_;
-    const float* a_row0 = act + (lane & 31) * LDA + 8 * (lane >> 5);
-    const float* a_row1 = a_row0 + 32 * LDA;
-    H2 b0 = split_h2(lds4(a_row0), lds4(a_row0 + 4)), b1 = split_h2(lds4(a_row1), lds4(a_row1 + 4));
-    f32x4 x00 = lds4(a_row0 + 16), x01 = lds4(a_row0 + 20), x10 = lds4(a_row1 + 16), x11 = lds4(a_row1 + 20);
+    static_assert(PF % 2 == 0, "the operand sets alternate between consecutive slabs");
+    // HAND: this GEMM's first PF slabs were fetched by the previous one and it fetches the next one's (the ring lives across the
+    // write-out in between).  Without: fetch them here, none for the next (one exposed fetch per GEMM, 64 registers less held
+    // across the write-outs).
+    if (!HAND) ringh_prime(R, w_, cs, lane);
+    gbytes w = (gbytes)w_;
+    gbytes nw = HAND ? (gbytes)nw_ : w;         // (without: the last round's fetches land in registers nobody reads)
+    if (!HAND) ncs = cs;
+    uint32_t voff = 16u * lane;
+    int b_idx = (lane & 31) * LDH + (lane >> 5) * 16;
+    // Every vector-memory operation issued so far retires here -- the ring's first fragments (needed in a moment anyway) and,
+    // above all, any register the allocator spilled around the write-out and reloads for the loop: a reload still pending at
+    // the loop header makes the wait-count pass guard that register with vmcnt(0) in EVERY iteration, which serialises the
+    // whole prefetch (measured: 38 instead of 29 kcycles per GEMM).  The empty asm pins the loop-carried address registers'
+    // reloads in front of the wait.
+    asm volatile("" : "+v"(voff), "+v"(b_idx));
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    const _Float16* b_row = img + b_idx;
+    // B operands of two consecutive slabs: set d & 1 is consumed by slab d of a round while the other is being read
+    f16x8 bh[2][NR], bl[2][NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        bh[0][r] = *reinterpret_cast<const f16x8*>(b_row + r * 32 * LDH);
+        bl[0][r] = *reinterpret_cast<const f16x8*>(b_row + r * 32 * LDH + 8);
+    }
+    // The order below is the issue order (pinned with scheduling barriers: one wave per SIMD, nobody else fills the gaps):
+    // a fragment register is refilled right after the last MFMA that reads it -- no second register set, no copies -- and the
+    // refills and the LDS reads of the next slab sit between MFMAs, which keep the matrix pipe busy for 8 passes each.
+#if QSP_H2_EXP & 1
+#define QSP_PIN
+#else
+#define QSP_PIN __builtin_amdgcn_sched_barrier(0);
+#endif
+#if QSP_H2_EXP & 4
+#define QSP_LDW(dst_, ...)
+#else
+#define QSP_LDW(dst_, ...) dst_ = ldw(__VA_ARGS__)
+#endif
+#if QSP_H2_EXP & 8
+#undef QSP_MFMA_H
+#define QSP_MFMA_H(acc_, a_, b_) asm volatile("" : "+a"(acc_) : "v"(a_), "v"(b_))
+#endif
 #pragma nounroll
     for (int ks = 0; ks < KS; ks += PF) {
+        // fragments to fetch during this round: slabs ks + PF.. of this matrix, or the first PF slabs of the next one
+        const bool more = ks + PF < KS;
+        gbytes fb = more ? w + (size_t)(ks + PF) * 2 * 64 * 16 : nw;
+        const size_t fcs = (size_t)(more ? cs : ncs) * 16;
 #pragma unroll
         for (int d = 0; d < PF; ++d) {
-            f16x8 wh[4], wl[4];
+            const _Float16* nb = b_row + 32 * (ks + d + 1);   // (the last slab reads one slab past the row: image or tail padding)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                wh[c] = as_f16x8(R.q[d][c][0]);
-                wl[c] = as_f16x8(R.q[d][c][1]);
+            for (int c = 0; c < NCB; ++c) {
+                const f16x8 wh = as_f16x8(R.q[d][c][0]), wl = as_f16x8(R.q[d][c][1]);
+#pragma unroll
+                for (int r = 0; r < NR; ++r) QSP_MFMA_H(acc2[r][c], wl, bh[d & 1][r]);
+                QSP_PIN
+                if (c == 0) {
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) bh[(d & 1) ^ 1][r] = *reinterpret_cast<const f16x8*>(nb + r * 32 * LDH);
+                } else {
+                    QSP_LDW(R.q[d][c - 1][0], fb + (c - 1) * fcs + (d * 2 + 0) * 64 * 16, voff);
+                }
+                QSP_PIN
+#pragma unroll
+                for (int r = 0; r < NR; ++r) QSP_MFMA_H(acc2[r][c], wh, bl[d & 1][r]);
+                QSP_PIN
+                if (c == 0) {
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) bl[(d & 1) ^ 1][r] = *reinterpret_cast<const f16x8*>(nb + r * 32 * LDH + 8);
+                } else {
+                    QSP_LDW(R.q[d][c - 1][1], fb + (c - 1) * fcs + (d * 2 + 1) * 64 * 16, voff);
+                }
+                QSP_PIN
+#pragma unroll
+                for (int r = 0; r < NR; ++r) QSP_MFMA_H(acc[r][c], wh, bh[d & 1][r]);
+                QSP_PIN
             }
-            if (ks + PF < KS) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-#pragma unroll
-                    for (int p = 0; p < 2; ++p) R.q[d][c][p] = w[(size_t)c * cs + ((ks + d + PF) * 2 + p) * 64 + lane];
-            } else {
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-#pragma unroll
-                    for (int p = 0; p < 2; ++p) R.q[d][c][p] = nw[(size_t)c * ncs + (d * 2 + p) * 64 + lane];
-            }
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                QSP_MFMA_H(acc2[0][c], wl[c], b0.hi);
-                QSP_MFMA_H(acc2[1][c], wl[c], b1.hi);
-                QSP_MFMA_H(acc2[0][c], wh[c], b0.lo);
-                QSP_MFMA_H(acc2[1][c], wh[c], b1.lo);
-                QSP_MFMA_H(acc[0][c], wh[c], b0.hi);
-                QSP_MFMA_H(acc[1][c], wh[c], b1.hi);
-            }
-            {   // the next slab's planes (VALU) behind this slab's MFMAs; the raw f32 of the slab after it from LDS
-                const H2 n0 = split_h2(x00, x01), n1 = split_h2(x10, x11);
-                x00 = lds4(a_row0 + 16 * (ks + d + 2));
-                x01 = lds4(a_row0 + 16 * (ks + d + 2) + 4);
-                x10 = lds4(a_row1 + 16 * (ks + d + 2));
-                x11 = lds4(a_row1 + 16 * (ks + d + 2) + 4);
-                b0 = n0;
-                b1 = n1;
-            }
+            QSP_LDW(R.q[d][NCB - 1][0], fb + (NCB - 1) * fcs + (d * 2 + 0) * 64 * 16, voff);
+            QSP_LDW(R.q[d][NCB - 1][1], fb + (NCB - 1) * fcs + (d * 2 + 1) * 64 * 16, voff);
+            QSP_PIN
         }
     }
+#undef QSP_PIN
+#undef QSP_LDW
 }
 
-// Forward network on the split-fp16 pipe for the tile staged in s.code / s.xin / s.c0 / s.c4, 256 threads; s.y[row] = sdf value.
+// ReLU masks of the split-fp16 tile: one 32-bit word per (row block, column-block pair), filled by 32 pushes in the write-out's
+// (column block, register) order -- compare into VCC, then word = 2 word + carry: two instructions per value and no shift-count
+// constants (the compiler's form keeps 32 of them in registers across the whole tile).  The k-th push ends up at bit 31 - k.
+__device__ __forceinline__ void h2_mask_push(uint32_t& m, float x) {
+    asm volatile("v_cmp_lt_f32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(x) : "vcc");
+}
+__device__ __forceinline__ float h2_mask_sel(float v, uint32_t m, int k) {      // v if push k was positive, else +0
+    return __int_as_float(__float_as_int(v) & __builtin_amdgcn_sbfe((int)m, 31 - k, 1));
+}
+
+// image (64 points x 512) x a matrix packed in three column blocks (96 padded columns), as six 32x32 tiles: waves 0, 1 take
+// column blocks 0, 1 for both point blocks, waves 2, 3 column block 2 for one point block each.  out[r][g] = the lane's register
+// quad g of point block r (wave 2, 3: r = 0 only, its point block is wave - 2): columns 32 c0 + 8 g + 4 (lane >> 5) .. + 3.
 template <int PF>
-__device__ __forceinline__ void mlp_tile_h2(MlpSmem& s, const MlpParams* __restrict__ Pm) {
-    const int tid = threadIdx.x;
+__device__ __forceinline__ void gemm_side_h2(const _Float16* __restrict__ img, const float4* __restrict__ wb, int wave, int lane,
+                                             f32x4 (&out)[2][4]) {
+    constexpr int KSH = HID / 16, CS = KSH * 2 * 64;
+    const int c0 = wave < 2 ? wave : 2;
+    const int r0 = wave < 2 ? 0 : wave - 2;
+    const float4* w0 = wb + (size_t)(c0 * KSH * 2) * 64;
+    WRingH<PF, 1> ring0;
+    f32x16 g0[2][1], g2[2][1];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { g0[r][0][i] = 0.f; g2[r][0][i] = 0.f; }
+    if (wave < 2) {
+        gemm_h2<KSH, PF, 1, 2, false>(img, w0, CS, w0, CS, ring0, g0, g2, lane);
+    } else {
+        f32x16 g01[1][1], g21[1][1];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { g01[0][0][i] = 0.f; g21[0][0][i] = 0.f; }
+        gemm_h2<KSH, PF, 1, 1, false>(img + r0 * 32 * LDH, w0, CS, w0, CS, ring0, g01, g21, lane);
+        g0[0][0] = g01[0][0];
+        g2[0][0] = g21[0][0];
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) out[r][g][q] = fmaf(g2[r][0][4 * g + q], 0.00048828125f, g0[r][0][4 * g + q]);
+}
+
+// Network on the split-fp16 pipe for the tile staged in s.code / s.xin / s.c0 / s.c4, 256 threads.  On return s.y[row] = sdf
+// value and, with BWD, rows of d sdf / d [code | xyz] in s.act (row stride LDG) like mlp_tile<true>.  amax: running maximum of
+// the magnitudes this thread has split (the caller compares it with H2_MAX once per kernel).
+template <bool BWD, int PF, bool HAND = !BWD>
+__device__ __forceinline__ void mlp_tile_h2(MlpSmem& s, const MlpParams* __restrict__ Pm, float& amax) {
+    int hts_n = 0;
+    (void)hts_n;
+    QSP_HTS()
+    int tid = threadIdx.x;
+    // opaque per tile: otherwise every LDS address below that depends on the lane is computed once per kernel, ahead of the
+    // caller's tile loop, and held (spilled) across it
+    asm volatile("" : "+v"(tid));
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
+    const int h = lane >> 5;
     int oz;
     asm volatile("s_mov_b32 %0, 0" : "=s"(oz));
     const MlpParams& P = Pm[oz];
     f32x16 acc[2][4], acc2[2][4];
+    uint32_t mk[8][2][2];                                  // ReLU masks [layer][row block][column-block pair]
+    _Float16* img = reinterpret_cast<_Float16*>(s.act);
     for (int i = tid; i < HID; i += H2_THREADS) s.w8[i] = P.w8[i];
-    float* bias_sh = s.stash;                              // [7][512] biases of layers 1..7
+    float* bias_sh = s.stash;                              // [7][512] biases of layers 1..7 (the stash is free until layer 4's backward)
 #pragma unroll
     for (int l = 1; l < 8; ++l)
         for (int i = tid; i < HID; i += H2_THREADS) bias_sh[(l - 1) * HID + i] = P.bias[l][i];
     const int cb0 = 4 * wave;
-    constexpr int KSH = HID / 16, KS4 = K4 / 16;
+    constexpr int KSH = HID / 16, KS4 = K4 / 16, CS = KSH * 2 * 64, CS4 = KS4 * 2 * 64;
 #define QSP_WH(L, KS_) (P.wfh[L] + (size_t)(cb0 * (KS_) * 2) * 64)
-    WRingH<PF> ring;
-    ringh_prime(ring, QSP_WH(1, KSH), KSH * 2 * 64, lane);
+#define QSP_WBH(L) (P.wbh[L] + (size_t)(cb0 * KSH * 2) * 64)
+    WRingH<PF, 4> ring;
+    if (HAND) ringh_prime(ring, QSP_WH(1, KSH), CS, lane);
+    QSP_HTS()
     // ---- layer 0 (exact f32) ---------------------------------------------------------------------------------------
     {
-        const int h = lane >> 5;
         const f32x4 x0 = lds4(s.xin + 4 * (lane & 31)), x1 = lds4(s.xin + 4 * (32 + (lane & 31)));
         typedef const __attribute__((address_space(1))) f32x4* gq;
         gq wx = (gq)P.w0x;
+        uint32_t m[2][2] = {{0, 0}, {0, 0}};
 #pragma unroll
         for (int c = 0; c < 4; ++c)
 #pragma unroll
@@ -1209,65 +1335,97 @@ __device__ __forceinline__ void mlp_tile_h2(MlpSmem& s, const MlpParams* __restr
 #pragma unroll
                 for (int r = 0; r < 2; ++r) {
                     const f32x4 xp = r == 0 ? x0 : x1;
-                    const int p = 32 * r + (lane & 31);
                     f32x4 v;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const float x = cq[q] + w0[q] * xp.x + w1[q] * xp.y + w2[q] * xp.z;
+                        if (BWD) h2_mask_push(m[r][c >> 1], x);
                         v[q] = x > 0.f ? x : 0.f;
                     }
-                    *reinterpret_cast<f32x4*>(s.act + p * LDA + u0) = v;
+                    h2_store4(img, 32 * r + (lane & 31), u0, v, amax);
                 }
             }
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int cp = 0; cp < 2; ++cp) {
+                asm volatile("" : "+v"(m[r][cp]));
+                mk[0][r][cp] = m[r][cp];
+            }
     }
+    QSP_HTS()
     __syncthreads();
-    // one hidden layer: GEMM, then (barrier) main + 2^-11 cross + bias, ReLU, 16-byte stores, (barrier)
+    QSP_HTS()
+    // one hidden layer: accumulators start from the bias, GEMM, then (barrier) main + 2^-11 cross, ReLU, split, (barrier)
 #define QSP_FWDH(L, KS_, NL, NKS, BIASPTR)                                                                               \
-    _Pragma("unroll") for (int r_ = 0; r_ < 2; ++r_) _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_)                    \
-        _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) { acc[r_][c_][i_] = 0.f; acc2[r_][c_][i_] = 0.f; }             \
-    gemm_4x2_h2<KS_, PF>(s.act, QSP_WH(L, KS_), (KS_) * 2 * 64, QSP_WH(NL, NKS), (NKS) * 2 * 64, ring, acc, acc2, lane);  \
+    _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {                  \
+        const f32x4 bv_ = lds4((BIASPTR) + 128 * wave + 32 * c_ + 8 * g_ + 4 * h);                                       \
+        _Pragma("unroll") for (int r_ = 0; r_ < 2; ++r_) _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {              \
+            acc[r_][c_][4 * g_ + q_] = bv_[q_];                                                                          \
+            acc2[r_][c_][4 * g_ + q_] = 0.f;                                                                             \
+        }                                                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                               \
+    }                                                                                                                    \
+    QSP_HTS()                                                                                                            \
+    gemm_h2<KS_, PF, 4, 2, HAND>(img, QSP_WH(L, KS_), (KS_) * 2 * 64, (NL) > 0 ? QSP_WH((NL) > 0 ? (NL) : 1, NKS) : QSP_WBH(7), \
+                           (NKS) * 2 * 64, ring, acc, acc2, lane);                                                       \
+    QSP_HTS()                                                                                                            \
     __syncthreads();                                                                                                     \
+    QSP_HTS()                                                                                                            \
     {                                                                                                                    \
-        const int h_ = lane >> 5;                                                                                        \
+        uint32_t m_[2][2] = {{0, 0}, {0, 0}};                                                                            \
         _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {              \
-            const int u0_ = 128 * wave + 32 * c_ + 8 * g_ + 4 * h_;                                                      \
-            const f32x4 bv_ = lds4((BIASPTR) + u0_);                                                                     \
+            const int u0_ = 128 * wave + 32 * c_ + 8 * g_ + 4 * h;                                                       \
             _Pragma("unroll") for (int r_ = 0; r_ < 2; ++r_) {                                                           \
-                const int p_ = 32 * r_ + (lane & 31);                                                                    \
                 f32x4 v_;                                                                                                \
                 _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                       \
-                    const float x_ = (acc[r_][c_][4 * g_ + q_] + 0.00048828125f * acc2[r_][c_][4 * g_ + q_]) + bv_[q_];  \
+                    const float x_ = fmaf(acc2[r_][c_][4 * g_ + q_], 0.00048828125f, acc[r_][c_][4 * g_ + q_]);         \
+                    if (BWD) h2_mask_push(m_[r_][c_ >> 1], x_);                                                          \
                     v_[q_] = x_ > 0.f ? x_ : 0.f;                                                                        \
                 }                                                                                                        \
-                *reinterpret_cast<f32x4*>(s.act + p_ * LDA + u0_) = v_;                                                  \
+                h2_store4(img, 32 * r_ + (lane & 31), u0_, v_, amax);                                                    \
             }                                                                                                            \
+            __builtin_amdgcn_sched_barrier(0);     /* one register quad pair at a time: bounded temporaries */            \
+        }                                                                                                                \
+        _Pragma("unroll") for (int r_ = 0; r_ < 2; ++r_) _Pragma("unroll") for (int cp_ = 0; cp_ < 2; ++cp_) {           \
+            asm volatile("" : "+v"(m_[r_][cp_]));                                                                        \
+            mk[L][r_][cp_] = m_[r_][cp_];                                                                                \
         }                                                                                                                \
     }                                                                                                                    \
-    __syncthreads();
+    QSP_HTS()                                                                                                            \
+    __syncthreads();                                                                                                     \
+    QSP_HTS()
     QSP_FWDH(1, KSH, 2, KSH, bias_sh + 0 * HID)
     QSP_FWDH(2, KSH, 3, KSH, bias_sh + 1 * HID)
     QSP_FWDH(3, KSH, 4, KS4, bias_sh + 2 * HID)
-    pass_through(s);
+    if (tid < TILE_P * 3) {        // the skip connection's xyz into columns 445..447 (zeros from layer 3's write-out until now)
+        const int row = tid / 3, ci = tid - row * 3;
+        const float x = s.xin[row * 4 + ci];
+        const _Float16 xh = (_Float16)x;
+        _Float16* d = img + h2_at(row, SKIP_COL + ci);
+        d[0] = xh;
+        d[8] = (_Float16)((x - (float)xh) * 2048.f);
+        amax = fmaxf(amax, fabsf(x));
+    }
     __syncthreads();
     QSP_FWDH(4, KS4, 5, KSH, s.c4)
     QSP_FWDH(5, KSH, 6, KSH, bias_sh + 4 * HID)
     QSP_FWDH(6, KSH, 7, KSH, bias_sh + 5 * HID)
-    QSP_FWDH(7, KSH, 1, KSH, bias_sh + 6 * HID)
+    QSP_FWDH(7, KSH, (BWD ? 0 : 1), KSH, bias_sh + 6 * HID)
 #undef QSP_FWDH
-#undef QSP_WH
-    // ---- layer 8: 512 -> 1, tanh (f32): wave = k segment of 128, lane = row ----------------------------------------
+    // ---- layer 8: 512 -> 1, tanh (f32): wave = k segment of 128, lane = row; a7 = hi + 2^-11 lo' from the two planes
+    // (every layer's write-out is the same code: a special case for layer 7 costs the register allocator its footing) ---------
     {
-        const float* a = s.act + lane * LDA + 128 * wave;
+        const _Float16* a = img + lane * LDH + 16 * (16 * wave);
         const float* w = s.w8 + 128 * wave;
         float part = 0.f;
 #pragma unroll
-        for (int q = 0; q < 32; ++q) {
-            const float4 av = *reinterpret_cast<const float4*>(a + 4 * q);
-            const float4 wv = *reinterpret_cast<const float4*>(w + 4 * q);
-            part += av.x * wv.x;
-            part += av.y * wv.y;
-            part += av.z * wv.z;
-            part += av.w * wv.w;
+        for (int g = 0; g < 16; ++g) {
+            const f16x8 hi = *reinterpret_cast<const f16x8*>(a + 16 * g), lo = *reinterpret_cast<const f16x8*>(a + 16 * g + 8);
+            const f32x4 w0 = lds4(w + 8 * g), w1 = lds4(w + 8 * g + 4);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                part = fmaf(fmaf((float)lo[j], 0.00048828125f, (float)hi[j]), j < 4 ? w0[j] : w1[j - 4], part);
         }
         s.red[wave * TILE_P + lane] = part;
     }
@@ -1279,6 +1437,107 @@ __device__ __forceinline__ void mlp_tile_h2(MlpSmem& s, const MlpParams* __restr
         s.y[tid] = tanhf(t);
     }
     __syncthreads();
+    QSP_HTS()
+#ifdef QSP_H2_STAMPS
+    if (threadIdx.x == 0 && blockIdx.x == 0) qsp_h2_nts = hts_n;
+#endif
+    if constexpr (BWD) {
+        // ---- backward seed: d y / d a7 = (1 - y^2) * w8[unit] * [a7 > 0] ---------------------------------------------
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int p = 32 * r + (lane & 31);
+            const float yy = s.y[p];
+            const float dy = 1.f - yy * yy;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int u0 = 128 * wave + 32 * c + 8 * g + 4 * h;
+                    const f32x4 wv = lds4(s.w8 + u0);
+                    f32x4 v;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        v[q] = h2_mask_sel(dy * wv[q], mk[7][r][c >> 1], (c & 1) * 16 + 4 * g + q);
+                    }
+                    h2_store4(img, p, u0, v, amax);
+                }
+        }
+        __syncthreads();
+        // ---- backward through layers 7..1: g_in = g_a . W_L, masked by layer L-1; the skip gradient of layer 4 to the stash ----
+#define QSP_BWDH(L, KS_, NWB)                                                                                            \
+    _Pragma("unroll") for (int r_ = 0; r_ < 2; ++r_) _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_)                    \
+        _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) { acc[r_][c_][i_] = 0.f; acc2[r_][c_][i_] = 0.f; }             \
+    gemm_h2<KS_, PF, 4, 2, HAND>(img, QSP_WBH(L), CS, NWB, CS, ring, acc, acc2, lane);                                         \
+    __syncthreads();                                                                                                     \
+    _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {                  \
+        const int u0_ = 128 * wave + 32 * c_ + 8 * g_ + 4 * h;                                                           \
+        _Pragma("unroll") for (int r_ = 0; r_ < 2; ++r_) {                                                               \
+            const int p_ = 32 * r_ + (lane & 31);                                                                        \
+            f32x4 v_;                                                                                                    \
+            _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                           \
+                const float x_ = fmaf(acc2[r_][c_][4 * g_ + q_], 0.00048828125f, acc[r_][c_][4 * g_ + q_]);             \
+                const float m_ = h2_mask_sel(x_, mk[(L) - 1][r_][c_ >> 1], (c_ & 1) * 16 + 4 * g_ + q_);                       \
+                v_[q_] = m_;                                                                                             \
+            }                                                                                                            \
+            h2_store4(img, p_, u0_, v_, amax);                                                                           \
+        }                                                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                               \
+    }                                                                                                                    \
+    __syncthreads();
+        QSP_BWDH(7, KSH, QSP_WBH(6))
+        QSP_BWDH(6, KSH, QSP_WBH(5))
+        QSP_BWDH(5, KSH, QSP_WBH(4))
+        {   // the skip connection's gradient d y / d [code | xyz] = g_a4 . W4[:, 445:512]: its own 64 x 96 product, to the stash
+            // in f32 (layer 4's write-out below masks those columns to zero like any dead unit: mk[3] has no bit set there)
+            f32x4 sk[2][4];
+            gemm_side_h2<PF>(img, P.wbh4s, wave, lane, sk);
+            const int c0 = wave < 2 ? wave : 2;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                if (r == 1 && wave >= 2) break;
+                const int p = 32 * (wave < 2 ? r : wave - 2) + (lane & 31);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int k0 = 32 * c0 + 8 * g + 4 * h;
+                    if (k0 < NIN) *reinterpret_cast<f32x4*>(s.stash + p * LDST + k0) = sk[r][g];
+                }
+            }
+        }
+        QSP_BWDH(4, KSH, QSP_WBH(3))
+        // layer 3 has 445 outputs: its backward contraction runs over K4 = 448 gradient columns (445..447 are zeros)
+        QSP_BWDH(3, KS4, QSP_WBH(2))
+        QSP_BWDH(2, KSH, QSP_WBH(1))
+        QSP_BWDH(1, KSH, QSP_WBH(1))       // (hand-over fetch unused: layer 0's GEMM has its own shape and primes its own ring)
+#undef QSP_BWDH
+        // ---- backward through layer 0: 67 (padded 96) input columns = 2 x 3 output tiles: waves 0, 1 take column blocks 0, 1
+        // for both point blocks, waves 2, 3 column block 2 (inputs 64..66) for one point block each -------------------------
+        {
+            f32x4 gl[2][4];
+            gemm_side_h2<PF>(img, P.wbh[0], wave, lane, gl);
+            const int c0 = wave < 2 ? wave : 2;
+            __syncthreads();
+            // D[i = input column within block c0][j = point]: four consecutive input columns per register quad
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                if (r == 1 && wave >= 2) break;
+                const int p = 32 * (wave < 2 ? r : wave - 2) + (lane & 31);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int k0 = 32 * c0 + 8 * g + 4 * h;
+                    if (k0 < NIN) {     // 64..67 is the last useful quad (67 itself is padding inside both row strides)
+                        const f32x4 st = lds4(s.stash + p * LDST + k0);
+                        f32x4 v;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[q] = gl[r][g][q] + st[q];
+                        *reinterpret_cast<f32x4*>(s.act + p * LDG + k0) = v;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+#undef QSP_WH
+#undef QSP_WBH
 }
 
 }  // namespace qsp

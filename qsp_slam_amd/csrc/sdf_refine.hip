@@ -364,6 +364,7 @@ __global__ __launch_bounds__(H2_THREADS) void k_mlp_fwd_h2(const HypState* __res
     __shared__ float Tsh[16];
     __shared__ int s_item;
     const int n_items = qctl[0];
+    float amax = 0.f;
     int h_cached = -1;
     for (;;) {
         if (threadIdx.x == 0) s_item = atomicAdd(&qctl[1], 1);
@@ -402,12 +403,13 @@ __global__ __launch_bounds__(H2_THREADS) void k_mlp_fwd_h2(const HypState* __res
             s.xin[4 * threadIdx.x + 3] = 0.f;
         }
         __syncthreads();
-        mlp_tile_h2<2>(s, P);
+        mlp_tile_h2<false, 2>(s, P, amax);
         if (threadIdx.x < TILE_P) {
             const int v = t * TILE_P + threadIdx.x;
             if (v < n) out[v] = s.y[threadIdx.x];
         }
     }
+    if (!(amax <= H2_MAX)) *P->range_flag = 1;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -659,6 +661,160 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void k_mlp_jtj(const HypState* __re
     QSP_TSK(5)
     tsk_first = false;
   }
+}
+
+// the same kernel on the split-fp16 tile: four waves per workgroup (mlp_tile_h2<true>); the six J~^T J~ tiles on waves 0..3
+// (waves 0 and 1 carry two)
+__global__ __launch_bounds__(H2_THREADS) void k_mlp_jtj_h2(const HypState* __restrict__ st,
+                                                            const ObjView* __restrict__ objs,
+                                                            const float* __restrict__ pts,
+                                                            const float* __restrict__ rays, RefineCfg cfg, const MlpParams* __restrict__ P,
+                                                            int nw_sdf, const int32_t* __restrict__ rend_rk,
+                                                            const float* __restrict__ rend_deds,
+                                                            const float* __restrict__ rend_res, int64_t rk_stride,
+                                                            const uint8_t* __restrict__ pt_active, int64_t act_stride,
+                                                            float* __restrict__ res_out, float* __restrict__ rows_out, int64_t rows_stride,
+                                                            float* __restrict__ partials, int nw_total,
+                                                            const int2* __restrict__ work, int* __restrict__ qctl,
+                                                            const float* __restrict__ c0_all) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    MlpSmem& s = *reinterpret_cast<MlpSmem*>(smem_raw);
+    __shared__ float Tsh[16];
+    __shared__ int s_item;
+    const int n_items = qctl[2];
+    float amax = 0.f;
+  for (;;) {                                   // work queue, see k_plan
+    if (threadIdx.x == 0) s_item = atomicAdd(&qctl[3], 1);
+    __syncthreads();                           // also: everybody is done with the previous item's LDS
+    const int item = s_item;
+    if (item >= n_items) break;                // the queue only grows towards n_items: every workgroup gets here
+    const int h = work[item].x, slot = work[item].y;
+    const HypState& S = st[h];
+    const ObjView ov = objs[S.obj];
+    const bool is_sdf = slot < nw_sdf;
+    const int stride = is_sdf ? nw_sdf : nw_total - nw_sdf;
+    const int j0 = is_sdf ? slot : slot - nw_sdf;
+    const int n = is_sdf ? ov.n_pts : S.n_render;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+
+    // J~^T J~ accumulators of this wave's upper-triangular tiles: tile w on every wave, tile w + 4 on waves 0, 1
+    // (tiles in the order (0,0) (0,1) (0,2) (1,1) (1,2) (2,2))
+    f32x16 hacc[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { hacc[0][i] = 0.f; hacc[1][i] = 0.f; }
+    const int ta0 = wave < 3 ? 0 : 1, tb0 = wave < 3 ? wave : 1;
+    const int ta1 = wave == 0 ? 1 : 2, tb1 = 2;
+
+    stage_code_T(s, S, Tsh);
+    for (int i = threadIdx.x; i < HID; i += H2_THREADS) {
+        s.c0[i] = c0_all[(size_t)h * 2 * HID + i];
+        s.c4[i] = c0_all[(size_t)h * 2 * HID + HID + i];
+    }
+    const float* Pc = pts + 3 * ov.pts_off;
+    const float* R = rays + 3 * ov.ray_off;
+    const int32_t* rk = rend_rk + h * rk_stride;
+    const float* deds = rend_deds + h * rk_stride;
+    const float* rres = rend_res + h * rk_stride;
+    const uint8_t* active = pt_active ? pt_active + h * act_stride : nullptr;
+    const float d_min = S.d_min, d_max = S.d_max;
+    const float hub = is_sdf ? cfg.b2 : cfg.b1;
+
+    for (int t = j0; t * TILE_P < n; t += stride) {
+        __syncthreads();
+        if (tid < TILE_P) {
+            const int v = t * TILE_P + tid;
+            float x = 0, y = 0, z = 0, sc = 0.f, rr = 0.f;
+            if (v < n) {
+                if (is_sdf) {
+                    xform(Tsh, Pc[3 * v], Pc[3 * v + 1], Pc[3 * v + 2], x, y, z);
+                    sc = (active && !active[v]) ? 0.f : 1.f;
+                } else {
+                    const int e = rk[v];
+                    const int r = e >> 6, k = e & 63;
+                    const float d = depth_at(d_min, d_max, k, cfg.n_depth);
+                    xform(Tsh, R[3 * r] * d, R[3 * r + 1] * d, R[3 * r + 2] * d, x, y, z);
+                    sc = deds[v];
+                    rr = rres[v];
+                }
+            }
+            s.xin[4 * tid + 0] = x;
+            s.xin[4 * tid + 1] = y;
+            s.xin[4 * tid + 2] = z;
+            s.xin[4 * tid + 3] = (v < n) ? 1.f : 0.f;   // row-valid flag
+            s.rscale[tid] = sc;
+            s.rres[tid] = rr;
+        }
+        __syncthreads();
+        mlp_tile_h2<true, 2>(s, P, amax);
+        // ---- Jacobian rows: J~[p] = [ s*(g_x . [I | -x^ | x]) (7) | s*g_z (64) | r~ ] -------------------------------
+        // G (gradient w.r.t. [code | xyz]) sits in s.act with row stride LDG; J~ goes behind it.
+        float* G = s.act;
+        float* Jt = s.act + TILE_P * LDG;     // [64][LDJ]
+        {
+            const int p = tid >> 2, sub = tid & 3;
+            const float valid = s.xin[4 * p + 3];
+            const float sc = s.rscale[p] * valid;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int c = sub + 4 * q;           // code column 0..63
+                Jt[p * LDJ + 7 + c] = cfg.pose_only ? 0.f : sc * G[p * LDG + c];
+            }
+            if (sub == 0) {
+                const float gx = sc * G[p * LDG + 64], gy = sc * G[p * LDG + 65], gz = sc * G[p * LDG + 66];
+                const float x = s.xin[4 * p], y = s.xin[4 * p + 1], z = s.xin[4 * p + 2];
+                // [I | -x^ | x]: columns t(3), omega(3), scale(1)   (loss_utils.py:166-185)
+                Jt[p * LDJ + 0] = gx;
+                Jt[p * LDJ + 1] = gy;
+                Jt[p * LDJ + 2] = gz;
+                Jt[p * LDJ + 3] = gz * y - gy * z;
+                Jt[p * LDJ + 4] = gx * z - gz * x;
+                Jt[p * LDJ + 5] = gy * x - gx * y;
+                Jt[p * LDJ + 6] = cfg.pose_only ? 0.f : (gx * x + gy * y + gz * z);
+                float r = is_sdf ? s.y[p] : s.rres[p];
+                float w = cfg.pose_only ? 1.f : huber_w(r, hub);
+                if (is_sdf && s.rscale[p] == 0.f) w = 0.f;      // filtered-out point (pose-only inlier mask)
+                Jt[p * LDJ + 71] = valid * (w * r);
+                if (res_out && is_sdf && valid != 0.f) res_out[h * act_stride + t * TILE_P + p] = r;
+            }
+            if (sub == 1) {
+#pragma unroll
+                for (int c = NJ; c < LDJ; ++c) Jt[p * LDJ + c] = 0.f;
+            }
+        }
+        __syncthreads();
+        if (rows_out) {   // parity-test tap: the augmented Jacobian rows exactly as the MFMA below consumes them
+            float* ro = rows_out + (int64_t)h * rows_stride * NJ + (int64_t)(is_sdf ? 0 : ov.n_pts) * NJ;
+            for (int e = tid; e < TILE_P * NJ; e += H2_THREADS) {
+                const int p = e / NJ, c = e - p * NJ;
+                const int v = t * TILE_P + p;
+                if (v < n) ro[(int64_t)v * NJ + c] = Jt[p * LDJ + c];
+            }
+        }
+        {
+            const float* A = Jt + (lane >> 5) * LDJ + 32 * ta0 + (lane & 31);
+            const float* B = Jt + (lane >> 5) * LDJ + 32 * tb0 + (lane & 31);
+#pragma unroll 8
+            for (int ks = 0; ks < TILE_P / 2; ++ks) hacc[0] = mfma32t<false>(A[2 * ks * LDJ], B[2 * ks * LDJ], hacc[0]);
+        }
+        if (wave < 2) {
+            const float* A = Jt + (lane >> 5) * LDJ + 32 * ta1 + (lane & 31);
+            const float* B = Jt + (lane >> 5) * LDJ + 32 * tb1 + (lane & 31);
+#pragma unroll 8
+            for (int ks = 0; ks < TILE_P / 2; ++ks) hacc[1] = mfma32t<false>(A[2 * ks * LDJ], B[2 * ks * LDJ], hacc[1]);
+        }
+    }
+    // partial slot [h][slot][tile][32][32]
+    {
+        float* out = partials + ((int64_t)h * nw_total + slot) * PART_FLOATS + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) out[acc_row(i, lane) * 32 + (lane & 31)] = hacc[0][i];
+        if (wave < 2) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) out[4 * 1024 + acc_row(i, lane) * 32 + (lane & 31)] = hacc[1][i];
+        }
+    }
+  }
+    if (!(amax <= H2_MAX)) *P->range_flag = 1;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -963,9 +1119,11 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void k_decode(const float* __restri
     }
 }
 
-// forward-only decode on the split-fp16 tile (four waves per workgroup)
+// decode on the split-fp16 tile (four waves per workgroup)
+template <bool GRAD>
 __global__ __launch_bounds__(H2_THREADS) void k_decode_h2(const float* __restrict__ code, const float* __restrict__ xyz, int64_t n,
-                                                          const MlpParams* __restrict__ P, float* __restrict__ y_out) {
+                                                          const MlpParams* __restrict__ P, float* __restrict__ y_out,
+                                                          float* __restrict__ grad_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     MlpSmem& s = *reinterpret_cast<MlpSmem*>(smem_raw);
     if (threadIdx.x < CODE_LEN) s.code[threadIdx.x] = code[threadIdx.x];
@@ -982,6 +1140,7 @@ __global__ __launch_bounds__(H2_THREADS) void k_decode_h2(const float* __restric
         s.c0[u] = a;
         s.c4[u] = a4;
     }
+    float amax = 0.f;
     for (int64_t t = blockIdx.x; t * TILE_P < n; t += gridDim.x) {
         __syncthreads();
         if (threadIdx.x < TILE_P) {
@@ -994,12 +1153,20 @@ __global__ __launch_bounds__(H2_THREADS) void k_decode_h2(const float* __restric
             s.xin[4 * threadIdx.x + 3] = 0.f;
         }
         __syncthreads();
-        mlp_tile_h2<2>(s, P);
+        mlp_tile_h2<GRAD, 2>(s, P, amax);
         if (threadIdx.x < TILE_P) {
             const int64_t v = t * TILE_P + threadIdx.x;
             if (v < n) y_out[v] = s.y[threadIdx.x];
         }
+        if (GRAD) {
+            for (int e = threadIdx.x; e < TILE_P * NIN; e += H2_THREADS) {
+                const int p = e / NIN, c = e % NIN;
+                const int64_t v = t * TILE_P + p;
+                if (v < n) grad_out[v * NIN + c] = s.act[p * LDG + c];
+            }
+        }
     }
+    if (!(amax <= H2_MAX)) *P->range_flag = 1;
 }
 
 // 4x4 inverse as the reference's torch.inverse calls need it (optimizer.py:123,273): Gauss-Jordan with partial pivoting in
@@ -1052,7 +1219,8 @@ struct qsp_decoder {
     int code_len = CODE_LEN;   // the caller's code length L <= 64; the tile always works on 64 (columns L..63 are zero)
     int fwd_bf3 = 0;           // QSP_DEC_OPT_FORWARD_PRECISION: forward-only passes on the split-bf16 pipe (mlp_tile_bf3)
     int jac_bf3 = 0;           // QSP_DEC_OPT_JACOBIAN_PRECISION: the forward+backward pass (mlp_tile<true, .., B3>)
-    bool fp16_ok = true;       // every weight of layers 1..7 fits fp16's range (split-fp16 planes are usable)
+    bool fp16_ok = true;       // every weight of layers 0..7 fits fp16's range (split-fp16 planes are usable)
+    int* range_flag_h = nullptr;   // host-mapped word the split-fp16 kernels set when a value left fp16's range (check_range)
 };
 
 // The family deep_sdf/deep_sdf_decoder.py:29-63 builds -- `dims` hidden layers of any width, one (or no) latent_in layer, any
@@ -1318,20 +1486,79 @@ static int pack_weights(qsp_decoder* d, const qsp_decoder_desc* desc) {
             QSP_HIP(hipMemcpy(p3d, p3.data(), p3.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
             d->P.wb3[l] = (const float4*)p3d;
         }
+        {   // split-fp16 planes of the same matrix: [col block over inputs k][slab of 16 outputs o][hi | lo'][lane][8 fp16]
+            const int KS = HID / 16;
+            std::vector<_Float16> ph((size_t)NCB * KS * 2 * 64 * 8, (_Float16)0.f);
+            for (int cb = 0; cb < NCB; ++cb)
+                for (int ks = 0; ks < KS; ++ks)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 8; ++j) {
+                            const int k = 32 * cb + (lane & 31);
+                            const int o = 16 * ks + 8 * (lane >> 5) + j;
+                            float v = 0.f;
+                            if (o < out && k < in) v = W[l][(size_t)o * in + k];
+                            if (!(fabsf(v) < 65000.f)) d->fp16_ok = false;
+                            const _Float16 hi = (_Float16)v;
+                            const size_t base = (((size_t)cb * KS + ks) * 2) * 64 * 8 + (size_t)lane * 8 + j;
+                            ph[base] = hi;
+                            ph[base + 64 * 8] = (_Float16)((v - (float)hi) * 2048.f);
+                        }
+            void* phd = nullptr;
+            QSP_HIP(hipMalloc(&phd, ph.size() * sizeof(_Float16) + 16384));
+            d->allocs.push_back(phd);
+            QSP_HIP(hipMemcpy(phd, ph.data(), ph.size() * sizeof(_Float16), hipMemcpyHostToDevice));
+            d->P.wbh[l] = (const float4*)phd;
+        }
         std::vector<float> bias(HID, 0.f);
         for (int o = 0; o < out; ++o) bias[o] = Bias[l][o];
         rc = upload(bias, (const void**)&d->P.bias[l]);
         if (rc) return rc;
     }
+    {   // layer 4's skip columns (inputs 445..511 = [code | xyz]) as their own backward matrix, packed like wbh[0]:
+        // [col block over ci = input - 445 (3 blocks, 67 used)][slab of 16 outputs o][hi | lo'][lane][8 fp16]
+        const int KS = HID / 16, in4 = in_dim[4], out4 = out_dim[4];
+        std::vector<_Float16> ph((size_t)3 * KS * 2 * 64 * 8, (_Float16)0.f);
+        for (int cb = 0; cb < 3; ++cb)
+            for (int ks = 0; ks < KS; ++ks)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int ci = 32 * cb + (lane & 31);
+                        const int o = 16 * ks + 8 * (lane >> 5) + j;
+                        float v = 0.f;
+                        if (o < out4 && ci < NIN) v = W[4][(size_t)o * in4 + SKIP_COL + ci];
+                        const _Float16 hi = (_Float16)v;
+                        const size_t base = (((size_t)cb * KS + ks) * 2) * 64 * 8 + (size_t)lane * 8 + j;
+                        ph[base] = hi;
+                        ph[base + 64 * 8] = (_Float16)((v - (float)hi) * 2048.f);
+                    }
+        void* phd = nullptr;
+        QSP_HIP(hipMalloc(&phd, ph.size() * sizeof(_Float16) + 16384));
+        d->allocs.push_back(phd);
+        QSP_HIP(hipMemcpy(phd, ph.data(), ph.size() * sizeof(_Float16), hipMemcpyHostToDevice));
+        d->P.wbh4s = (const float4*)phd;
+    }
     std::vector<float> w8(W[8].begin(), W[8].end());
     int rc = upload(w8, (const void**)&d->P.w8);
     if (rc) return rc;
     d->P.b8 = Bias[8][0];
+    QSP_HIP(hipHostMalloc((void**)&d->range_flag_h, sizeof(int), hipHostMallocMapped));
+    *d->range_flag_h = 0;
+    QSP_HIP(hipHostGetDevicePointer((void**)&d->P.range_flag, d->range_flag_h, 0));
     void* pd = nullptr;
     QSP_HIP(hipMalloc(&pd, sizeof(MlpParams)));
     d->allocs.push_back(pd);
     QSP_HIP(hipMemcpy(pd, &d->P, sizeof(MlpParams), hipMemcpyHostToDevice));
     d->Pd = (MlpParams*)pd;
+    return QSP_OK;
+}
+
+// after a synchronisation of the decoder's stream: did a split-fp16 kernel meet a value it cannot represent?
+static int check_range(qsp_decoder* d) {
+    if (d->range_flag_h && *d->range_flag_h) {
+        *d->range_flag_h = 0;
+        return qsp_fail(QSP_ERR_UNSUPPORTED, "split fp16: an activation or gradient of this decoder left fp16's range (65504); "
+                                             "use the split-bf16 or f32 precision for it");
+    }
     return QSP_OK;
 }
 
@@ -1343,7 +1570,9 @@ static int mlp_attr_once() {
     QSP_HIP(hipFuncSetAttribute((const void*)k_mlp_fwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     QSP_HIP(hipFuncSetAttribute((const void*)k_decode<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     QSP_HIP(hipFuncSetAttribute((const void*)k_mlp_fwd_h2, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    QSP_HIP(hipFuncSetAttribute((const void*)k_decode_h2, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    QSP_HIP(hipFuncSetAttribute((const void*)k_decode_h2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    QSP_HIP(hipFuncSetAttribute((const void*)k_decode_h2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    QSP_HIP(hipFuncSetAttribute((const void*)k_mlp_jtj_h2, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     QSP_HIP(hipFuncSetAttribute((const void*)k_mlp_jtj<false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     QSP_HIP(hipFuncSetAttribute((const void*)k_mlp_jtj<true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     QSP_HIP(hipFuncSetAttribute((const void*)k_decode<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
@@ -1385,7 +1614,8 @@ extern "C" int qsp_decoder_set_option(qsp_decoder* d, int32_t option, int32_t va
             d->fwd_bf3 = value;
             return QSP_OK;
         case QSP_DEC_OPT_JACOBIAN_PRECISION:
-            if (value != 0 && value != 1) return qsp_fail(QSP_ERR_INVALID, "jacobian precision: 0 (f32 MFMA) or 1 (split bf16)");
+            if (value < 0 || value > 2) return qsp_fail(QSP_ERR_INVALID, "jacobian precision: 0 (f32 MFMA), 1 (split bf16) or 2 (split fp16)");
+            if (value == 2 && !d->fp16_ok) return qsp_fail(QSP_ERR_UNSUPPORTED, "split fp16: a weight of this decoder is outside fp16's range");
             d->jac_bf3 = value;
             return QSP_OK;
         default: return qsp_fail(QSP_ERR_INVALID, "qsp_decoder_set_option: unknown option");
@@ -1396,6 +1626,7 @@ extern "C" void qsp_decoder_destroy(qsp_decoder* d) {
     if (!d) return;
     (void)hipSetDevice(d->device);
     for (void* p : d->allocs) (void)hipFree(p);
+    if (d->range_flag_h) (void)hipHostFree(d->range_flag_h);
     if (d->stream) (void)hipStreamDestroy(d->stream);
     delete d;
 }
@@ -1415,12 +1646,15 @@ static int decode_common(qsp_decoder* d, const float* code, const float* xyz, in
     QSP_HIP(hipMemcpyAsync(dx, xyz, n * 3 * sizeof(float), hipMemcpyHostToDevice, d->stream));
     const int64_t tiles = (n + TILE_P - 1) / TILE_P;
     const int grid = (int)std::min<int64_t>(tiles, 4096);
-    if (grad && d->jac_bf3)
+    if (grad && d->jac_bf3 == 2)
+        hipLaunchKernelGGL(k_decode_h2<true>, dim3(grid), dim3(H2_THREADS), sizeof(MlpSmem), d->stream, dc, dx, n, d->Pd, dy, dg);
+    else if (grad && d->jac_bf3)
         hipLaunchKernelGGL((k_decode<true, true>), dim3(grid), dim3(MLP_THREADS), sizeof(MlpSmem), d->stream, dc, dx, n, d->Pd, dy, dg);
     else if (grad)
         hipLaunchKernelGGL(k_decode<true>, dim3(grid), dim3(MLP_THREADS), sizeof(MlpSmem), d->stream, dc, dx, n, d->Pd, dy, dg);
     else if (d->fwd_bf3 == 2)
-        hipLaunchKernelGGL(k_decode_h2, dim3(grid), dim3(H2_THREADS), sizeof(MlpSmem), d->stream, dc, dx, n, d->Pd, dy);
+        hipLaunchKernelGGL(k_decode_h2<false>, dim3(grid), dim3(H2_THREADS), sizeof(MlpSmem), d->stream, dc, dx, n, d->Pd, dy,
+                           (float*)nullptr);
     else if (d->fwd_bf3)
         hipLaunchKernelGGL((k_decode<false, true>), dim3(grid), dim3(MLP_THREADS), sizeof(MlpSmem), d->stream, dc, dx, n, d->Pd, dy,
                            (float*)nullptr);
@@ -1439,6 +1673,16 @@ static int decode_common(qsp_decoder* d, const float* code, const float* xyz, in
         }
     }
     QSP_HIP(hipStreamSynchronize(d->stream));
+    {
+        const int rc = check_range(d);
+        if (rc) {
+            (void)hipFree(dc);
+            (void)hipFree(dx);
+            (void)hipFree(dy);
+            if (dg) (void)hipFree(dg);
+            return rc;
+        }
+    }
     if (grad && d->code_len != CODE_LEN) {               // [code 64 | xyz] -> [code L | xyz]
         const int L = d->code_len;
         for (int64_t i = 0; i < n; ++i) {
@@ -1706,7 +1950,12 @@ extern "C" int qsp_refine_batch_run(qsp_refine_batch* b, int32_t n_iter) {
         if (b->prof) a = next_event(b, cur);
         hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, s, 1, b->st, b->objs, nH, b->nw_sdf, nw_total - b->nw_sdf,
                            b->work_jtj, b->qctl);
-        if (b->dec->jac_bf3)
+        if (b->dec->jac_bf3 == 2)
+            hipLaunchKernelGGL(k_mlp_jtj_h2, dim3(b->n_cu), dim3(H2_THREADS), sizeof(MlpSmem), s, b->st, b->objs, b->pts,
+                               b->rays, cfg, b->dec->Pd, b->nw_sdf, b->rend_rk, b->rend_deds, b->rend_res, b->rk_stride,
+                               b->pt_active, b->act_stride, b->res_buf, b->rows, b->rows_stride, b->partials, nw_total,
+                               b->work_jtj, b->qctl, b->c0_all);
+        else if (b->dec->jac_bf3)
             hipLaunchKernelGGL(k_mlp_jtj<true>, dim3(b->n_cu), dim3(MLP_THREADS), sizeof(MlpSmem), s, b->st, b->objs, b->pts,
                                b->rays, cfg, b->dec->Pd, b->nw_sdf, b->rend_rk, b->rend_deds, b->rend_res, b->rk_stride,
                                b->pt_active, b->act_stride, b->res_buf, b->rows, b->rows_stride, b->partials, nw_total,
@@ -1728,6 +1977,10 @@ extern "C" int qsp_refine_batch_run(qsp_refine_batch* b, int32_t n_iter) {
     if (b->prof) e_end = next_event(b, cur);
     QSP_HIP(hipGetLastError());
     QSP_HIP(hipStreamSynchronize(s));
+    {
+        const int rc = check_range(b->dec);
+        if (rc) return rc;
+    }
     if (b->prof) {
         qsp_refine_profile& p = b->profile;
         memset(&p, 0, sizeof(p));

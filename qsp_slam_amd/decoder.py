@@ -43,25 +43,29 @@ class DeepSdfDecoder(object):
             self.set_precision(os.environ["QSP_PRECISION"])
         self.mac_per_point = int(sum(int(i) * int(o) for i, o in zip(in_dim, out_dim)))
 
+    PRECISIONS = {"f32": 0, "bf16x3": 1, "fp16x2": 2}
+
     def set_precision(self, name):
         """"f32": every multiply-add of the decoder on the exact-f32 matrix pipe (default).  "bf16x3": operands as three bf16
-        terms, six products per multiply-add on the bf16 matrix pipe, f32 accumulation -- float32-equivalent accuracy
-        (include/qsp_hip.h, QSP_DEC_OPT_*), ~1.5 x faster refinement."""
-        if name not in ("f32", "bf16x3"):
-            raise ValueError("precision must be 'f32' or 'bf16x3'")
-        self.set_forward_precision(name == "bf16x3")
-        self.set_jacobian_precision(name == "bf16x3")
+        terms, six products per multiply-add on the bf16 matrix pipe.  "fp16x2": operands as two fp16 terms (the second
+        pre-scaled by 2^11), three products on the fp16 matrix pipe; refuses decoders whose weights leave fp16's range and
+        fails the call if an activation or gradient does.  All accumulate in f32 and are float32-equivalent in accuracy
+        (include/qsp_hip.h, QSP_DEC_OPT_*)."""
+        if name not in self.PRECISIONS:
+            raise ValueError("precision must be one of %s" % sorted(self.PRECISIONS))
+        self.set_forward_precision(self.PRECISIONS[name])
+        self.set_jacobian_precision(self.PRECISIONS[name])
         self.precision = name
 
-    def set_forward_precision(self, split_bf16):
-        """forward-only passes (decode_sdf, mesh grid, ray samples) on the exact-f32 matrix pipe (False, default) or as three
-        bf16 terms per operand / six products on the bf16 pipe (True); see QSP_DEC_OPT_FORWARD_PRECISION in qsp_hip.h"""
-        _lib.check(_lib.lib().qsp_decoder_set_option(self.handle, 1, int(split_bf16)))     # (2: the split-fp16 forward tile)
+    def set_forward_precision(self, mode):
+        """forward-only passes (decode_sdf, mesh grid, ray samples): 0 / False = exact-f32 matrix pipe (default), 1 / True =
+        split bf16, 2 = split fp16; see QSP_DEC_OPT_FORWARD_PRECISION in qsp_hip.h"""
+        _lib.check(_lib.lib().qsp_decoder_set_option(self.handle, 1, int(mode)))
 
-    def set_jacobian_precision(self, split_bf16):
+    def set_jacobian_precision(self, mode):
         """the forward+backward pass (sdf_value_grad, the fused Jacobian / normal-equation kernel) likewise
         (QSP_DEC_OPT_JACOBIAN_PRECISION)"""
-        _lib.check(_lib.lib().qsp_decoder_set_option(self.handle, 2, 1 if split_bf16 else 0))
+        _lib.check(_lib.lib().qsp_decoder_set_option(self.handle, 2, int(mode)))
 
     def close(self):
         if getattr(self, "handle", None):
