@@ -1,6 +1,7 @@
-"""The split-bf16 decoder pipe (QSP_DEC_OPT_FORWARD_PRECISION / QSP_DEC_OPT_JACOBIAN_PRECISION = 1, csrc/sdf_mlp.hpp: three bf16
-terms per f32 operand, six products per multiply-add on the bf16 matrix pipe, f32 accumulation) is held to the SAME gates as
-the exact-f32 tile before bench.py may quote it:
+"""The split-precision decoder pipes (QSP_DEC_OPT_FORWARD_PRECISION / QSP_DEC_OPT_JACOBIAN_PRECISION, csrc/sdf_mlp.hpp) --
+"bf16x3": three bf16 terms per f32 operand, six products per multiply-add on the bf16 matrix pipe; "fp16x2": two fp16 terms
+(the second pre-scaled by 2^11), three products on the fp16 matrix pipe, four waves per workgroup; f32 accumulation in both --
+are held to the SAME gates as the exact-f32 tile before bench.py may quote them:
   * decoder value / input gradient against the reference-generated vectors at the f32 tile's tolerances;
   * every Gauss-Newton iteration of every golden case, teacher-forced from the reference's own state: K (a discrete count of
     threshold decisions on decoder outputs) exact, H, b, next state within north_star's 1e-4, dx within the f32 tile's bar;
@@ -19,20 +20,20 @@ from tests.test_oracle_sdf import JOINT_CASES, cfg_from, relerr, rows_close
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def bf3_decoder(golden_dir):
+@pytest.fixture(scope="module", params=["bf16x3", "fp16x2"])
+def bf3_decoder(golden_dir, request):
     from qsp_slam_amd import DeepSdfDecoder
     d = DeepSdfDecoder.from_npz(os.path.join(golden_dir, "decoder_8x512.npz"))
-    d.set_precision("bf16x3")
+    d.set_precision(request.param)
     yield d
     d.close()
 
 
 def test_decoder_value_and_grad_vs_reference_vectors(bf3_decoder, golden_dir):
     z = np.load(os.path.join(golden_dir, "sdf_decoder_vectors.npz"))
-    assert within("bf16x3/decoder/sdf_abs", np.abs(bf3_decoder.decode_sdf(z["code"], z["x"]) - z["sdf"]).max(), 2e-6)
+    assert within(bf3_decoder.precision + "/decoder/sdf_abs", np.abs(bf3_decoder.decode_sdf(z["code"], z["x"]) - z["sdf"]).max(), 2e-6)
     y, g = bf3_decoder.sdf_value_grad(z["code"], z["x"])
-    assert within("bf16x3/decoder/y_abs", np.abs(y - z["y"]).max(), 2e-6)
+    assert within(bf3_decoder.precision + "/decoder/y_abs", np.abs(y - z["y"]).max(), 2e-6)
     assert rows_close(g, z["grad"], tol=1e-5, max_bad=0.01)
 
 
@@ -51,7 +52,7 @@ def test_every_iteration_teacher_forced_vs_reference(bf3_decoder, golden_dir, na
         tr = batch.trace()
         T, code, loss, good = batch.get()
         assert good[0] and int(tr["K"][0]) == int(z["it_K"][i])
-        tag = "bf16x3/" + name + "/teacher_forced/"
+        tag = bf3_decoder.precision + "/" + name + "/teacher_forced/"
         assert within(tag + "H", relerr(tr["H"][0], z["it_H"][i]), 1e-4)
         assert within(tag + "b", relerr(tr["b"][0], z["it_b"][i]), 1.5e-2 if kitti else 1e-4)     # (k4 = 1e7: test_gpu_sdf.py)
         assert within(tag + "dx", relerr(tr["dx"][0], z["it_dx"][i]), 6e-3 if kitti else 2.5e-3)
@@ -128,7 +129,88 @@ def test_mesh_grid_decode_agrees_with_the_f32_pipe(bf3_decoder, golden_dir):
     code = np.zeros(64, np.float32)
     a = MeshExtractor(f32, 64, 32).extract_sdf_grid(code)
     b = MeshExtractor(bf3_decoder, 64, 32).extract_sdf_grid(code)
-    assert within("bf16x3/grid/sdf_abs_vs_f32", np.abs(a - b).max(), 5e-7)
+    assert within(bf3_decoder.precision + "/grid/sdf_abs_vs_f32", np.abs(a - b).max(), 5e-7)
     flips = (a > 0) != (b > 0)
     assert np.abs(a[flips]).max(initial=0.0) < 5e-7
     f32.close()
+
+
+# ---- split fp16 only: range guard, the decoder family, and the generic decode entry points on odd sizes ---------------------
+@pytest.fixture(scope="module")
+def h2_decoder(golden_dir):
+    from qsp_slam_amd import DeepSdfDecoder
+    d = DeepSdfDecoder.from_npz(os.path.join(golden_dir, "decoder_8x512.npz"))
+    d.set_precision("fp16x2")
+    yield d
+    d.close()
+
+
+def _scaled_decoder(golden_dir, layer, factor):
+    """the golden decoder with one layer's weight-norm gain multiplied: same function shape, larger activations / weights"""
+    from qsp_slam_amd import DeepSdfDecoder
+    z = dict(np.load(os.path.join(golden_dir, "decoder_8x512.npz")))
+    z["lin%d.weight_g" % layer] = z["lin%d.weight_g" % layer] * np.float32(factor)
+    import tempfile
+    with tempfile.NamedTemporaryFile(suffix=".npz", delete=False) as f:
+        np.savez(f.name, **z)
+        path = f.name
+    try:
+        return DeepSdfDecoder.from_npz(path)
+    finally:
+        os.unlink(path)
+
+
+def test_fp16_refuses_weights_outside_its_range(golden_dir):
+    from qsp_slam_amd._lib import QspError
+    d = _scaled_decoder(golden_dir, 2, 3e6)           # |w| of layer 2 up to ~1e5 > 65504
+    with pytest.raises(QspError):
+        d.set_precision("fp16x2")
+    d.set_precision("bf16x3")                         # the other pipes take it
+    d.close()
+
+
+def test_fp16_fails_loudly_when_an_activation_leaves_its_range(golden_dir):
+    """weights inside fp16's range but activations beyond 65504: the kernels raise the decoder's range flag and the call fails
+    (instead of returning values computed from clamped or infinite planes); the same decoder runs on the split-bf16 pipe"""
+    from qsp_slam_amd._lib import QspError
+    d = _scaled_decoder(golden_dir, 1, 2e5)
+    x = np.random.default_rng(0).uniform(-1, 1, size=(300, 3)).astype(np.float32)
+    code = np.zeros(64, np.float32)
+    ref = d.decode_sdf(code, x)
+    assert np.isfinite(ref).all()
+    d.set_precision("fp16x2")
+    with pytest.raises(QspError):
+        d.decode_sdf(code, x)
+    with pytest.raises(QspError):
+        d.sdf_value_grad(code, x)
+    d.set_precision("bf16x3")
+    assert np.abs(d.decode_sdf(code, x) - ref).max() < 1e-5
+    d.close()
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 1000])
+def test_fp16_decode_entry_points_on_ragged_sizes(h2_decoder, oracle_decoder, n):
+    rng = np.random.default_rng(n)
+    x = rng.uniform(-1, 1, size=(n, 3)).astype(np.float32)
+    code = (0.1 * rng.normal(size=64)).astype(np.float32)
+    inp = np.concatenate([np.broadcast_to(code, (n, 64)), x], -1).astype(np.float32)
+    yo, go = so.decoder_value_and_input_grad(oracle_decoder, inp)
+    y = h2_decoder.decode_sdf(code, x)
+    y2, g = h2_decoder.sdf_value_grad(code, x)
+    assert within("fp16x2/decode/y_abs_vs_oracle", np.abs(y - np.asarray(yo).reshape(-1)).max(), 2e-6)
+    assert np.array_equal(y, y2)
+    assert rows_close(g, go, tol=1e-5, max_bad=0.01)
+
+
+def test_fp16_on_the_small_decoder_of_the_family(golden_dir):
+    """4 x 256, code 32 (embedded exactly into the 8 x 512 tile): values, gradients and one joint iteration against the
+    reference-generated vectors"""
+    from qsp_slam_amd import DeepSdfDecoder
+    d = DeepSdfDecoder.from_npz(os.path.join(golden_dir, "decoder_4x256_c32.npz"))
+    d.set_precision("fp16x2")
+    z = np.load(os.path.join(golden_dir, "sdf_small_decoder_vectors.npz"))
+    assert within("fp16x2/small/sdf_abs", np.abs(d.decode_sdf(z["code"], z["x"]) - z["sdf"]).max(), 2e-6)
+    y, g = d.sdf_value_grad(z["code"], z["x"])
+    assert within("fp16x2/small/y_abs", np.abs(y - z["y"]).max(), 2e-6)
+    assert rows_close(g, z["grad"], tol=1e-5, max_bad=0.01)
+    d.close()
