@@ -82,7 +82,7 @@ struct MlpParams {
     const float4* w0x;      // [128 unit quads][3] layer-0 weights of x, y, z for four consecutive units
     const float4* wf3[8];   // split-bf16 forward weights of layers 1..7: [col block 16][slab K/16][plane hi|mid|lo][lane 64][8 bf16]
     const float4* wb3[8];   // split-bf16 backward weights of layers 0..7 (column blocks over the layer's inputs, slabs over outputs)
-    const float4* wfh[8];   // split-fp16 forward weights of layers 1..7: [col block 16][slab K/16][plane hi|lo'][lane 64][8 fp16]
+    const float4* wfh[8];   // split-fp16 forward weights: [col block 16][slab K/16][plane hi|lo'][lane 64][8 fp16]; layer 0: its xyz columns, one slab
     const float4* wbh[8];   // split-fp16 backward weights of layers 0..7 (column blocks over the layer's inputs, slabs over outputs)
     const float4* wbh4s;    // split-fp16 backward weights of layer 4's skip columns (inputs 445..511 = [code | xyz]), packed like wbh[0]
     int* range_flag;        // set by the split-fp16 kernels when a value they had to split was outside fp16's range
@@ -1252,6 +1252,31 @@ __device__ __forceinline__ float h2_mask_sel(float v, uint32_t m, int k) {      
     return __int_as_float(__float_as_int(v) & __builtin_amdgcn_sbfe((int)m, 31 - k, 1));
 }
 
+// Layer 0 as ONE slab of the same product: image columns 0..2 hold the point (3..15 zero), the packed matrix the three xyz
+// columns of W0 (its 64 code columns are folded into the per-hypothesis bias c0, the accumulators' initial value).
+__device__ __forceinline__ void gemm_l0_h2(const _Float16* __restrict__ img, const float4* __restrict__ w_, f32x16 (&acc)[2][4],
+                                           f32x16 (&acc2)[2][4], int lane) {
+    gbytes w = (gbytes)w_;
+    const uint32_t voff = 16u * lane;
+    const _Float16* b_row = img + (lane & 31) * LDH + (lane >> 5) * 16;
+    f16x8 bh[2], bl[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        bh[r] = *reinterpret_cast<const f16x8*>(b_row + r * 32 * LDH);
+        bl[r] = *reinterpret_cast<const f16x8*>(b_row + r * 32 * LDH + 8);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const f16x8 wh = as_f16x8(ldw(w + (size_t)(c * 2 + 0) * 64 * 16, voff)), wl = as_f16x8(ldw(w + (size_t)(c * 2 + 1) * 64 * 16, voff));
+#pragma unroll
+        for (int r = 0; r < 2; ++r) QSP_MFMA_H(acc2[r][c], wl, bh[r]);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) QSP_MFMA_H(acc2[r][c], wh, bl[r]);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) QSP_MFMA_H(acc[r][c], wh, bh[r]);
+    }
+}
+
 // image (64 points x 512) x a matrix packed in three column blocks (96 padded columns), as six 32x32 tiles: waves 0, 1 take
 // column blocks 0, 1 for both point blocks, waves 2, 3 column block 2 for one point block each.  out[r][g] = the lane's register
 // quad g of point block r (wave 2, 3: r = 0 only, its point block is wave - 2): columns 32 c0 + 8 g + 4 (lane >> 5) .. + 3.
@@ -1290,7 +1315,8 @@ __device__ __forceinline__ void gemm_side_h2(const _Float16* __restrict__ img, c
 // value and, with BWD, rows of d sdf / d [code | xyz] in s.act (row stride LDG) like mlp_tile<true>.  amax: running maximum of
 // the magnitudes this thread has split (the caller compares it with H2_MAX once per kernel).
 template <bool BWD, int PF, bool HAND = !BWD>
-__device__ __forceinline__ void mlp_tile_h2(MlpSmem& s, const MlpParams* __restrict__ Pm, float& amax) {
+__device__ __forceinline__ void mlp_tile_h2(MlpSmem& s, const MlpParams* __restrict__ Pm, float& amax, bool stage = true) {
+    static_assert(!(BWD && HAND), "the forward+backward tile fetches each matrix's first slabs itself (layer 7 would hand over to the wrong one)");
     int hts_n = 0;
     (void)hts_n;
     QSP_HTS()
@@ -1307,11 +1333,30 @@ __device__ __forceinline__ void mlp_tile_h2(MlpSmem& s, const MlpParams* __restr
     f32x16 acc[2][4], acc2[2][4];
     uint32_t mk[8][2][2];                                  // ReLU masks [layer][row block][column-block pair]
     _Float16* img = reinterpret_cast<_Float16*>(s.act);
-    for (int i = tid; i < HID; i += H2_THREADS) s.w8[i] = P.w8[i];
     float* bias_sh = s.stash;                              // [7][512] biases of layers 1..7 (the stash is free until layer 4's backward)
+    if (stage) {      // constants of the decoder: once per workgroup for a forward-only kernel (nothing else writes them there)
+        for (int i = tid; i < HID; i += H2_THREADS) s.w8[i] = P.w8[i];
 #pragma unroll
-    for (int l = 1; l < 8; ++l)
-        for (int i = tid; i < HID; i += H2_THREADS) bias_sh[(l - 1) * HID + i] = P.bias[l][i];
+        for (int l = 1; l < 8; ++l)
+            for (int i = tid; i < HID; i += H2_THREADS) bias_sh[(l - 1) * HID + i] = P.bias[l][i];
+    }
+    if (tid < TILE_P) {       // the point as slab 0 of the image: columns 0..2 = xyz split, 3..15 zero
+        const f32x4 x = lds4(s.xin + 4 * tid);
+        f16x8 hi, lo, z;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { hi[j] = (_Float16)0.f; lo[j] = (_Float16)0.f; z[j] = (_Float16)0.f; }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            hi[j] = (_Float16)x[j];
+            lo[j] = (_Float16)((x[j] - (float)hi[j]) * 2048.f);
+        }
+        amax = fmaxf(amax, fmaxf(fabsf(x[0]), fmaxf(fabsf(x[1]), fabsf(x[2]))));
+        _Float16* d = img + tid * LDH;
+        *reinterpret_cast<f16x8*>(d) = hi;
+        *reinterpret_cast<f16x8*>(d + 8) = lo;
+        *reinterpret_cast<f16x8*>(d + 16) = z;
+        *reinterpret_cast<f16x8*>(d + 24) = z;
+    }
     const int cb0 = 4 * wave;
     constexpr int KSH = HID / 16, KS4 = K4 / 16, CS = KSH * 2 * 64, CS4 = KS4 * 2 * 64;
 #define QSP_WH(L, KS_) (P.wfh[L] + (size_t)(cb0 * (KS_) * 2) * 64)
@@ -1319,45 +1364,10 @@ __device__ __forceinline__ void mlp_tile_h2(MlpSmem& s, const MlpParams* __restr
     WRingH<PF, 4> ring;
     if (HAND) ringh_prime(ring, QSP_WH(1, KSH), CS, lane);
     QSP_HTS()
-    // ---- layer 0 (exact f32) ---------------------------------------------------------------------------------------
-    {
-        const f32x4 x0 = lds4(s.xin + 4 * (lane & 31)), x1 = lds4(s.xin + 4 * (32 + (lane & 31)));
-        typedef const __attribute__((address_space(1))) f32x4* gq;
-        gq wx = (gq)P.w0x;
-        uint32_t m[2][2] = {{0, 0}, {0, 0}};
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int u0 = 128 * wave + 32 * c + 8 * g + 4 * h;
-                const f32x4 cq = lds4(s.c0 + u0);
-                const f32x4 w0 = wx[3 * (u0 >> 2)], w1 = wx[3 * (u0 >> 2) + 1], w2 = wx[3 * (u0 >> 2) + 2];
-#pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    const f32x4 xp = r == 0 ? x0 : x1;
-                    f32x4 v;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float x = cq[q] + w0[q] * xp.x + w1[q] * xp.y + w2[q] * xp.z;
-                        if (BWD) h2_mask_push(m[r][c >> 1], x);
-                        v[q] = x > 0.f ? x : 0.f;
-                    }
-                    h2_store4(img, 32 * r + (lane & 31), u0, v, amax);
-                }
-            }
-#pragma unroll
-        for (int r = 0; r < 2; ++r)
-#pragma unroll
-            for (int cp = 0; cp < 2; ++cp) {
-                asm volatile("" : "+v"(m[r][cp]));
-                mk[0][r][cp] = m[r][cp];
-            }
-    }
-    QSP_HTS()
     __syncthreads();
     QSP_HTS()
     // one hidden layer: accumulators start from the bias, GEMM, then (barrier) main + 2^-11 cross, ReLU, split, (barrier)
-#define QSP_FWDH(L, KS_, NL, NKS, BIASPTR)                                                                               \
+#define QSP_FWDH(L, BIASPTR, GEMM_STMT)                                                                                  \
     _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {                  \
         const f32x4 bv_ = lds4((BIASPTR) + 128 * wave + 32 * c_ + 8 * g_ + 4 * h);                                       \
         _Pragma("unroll") for (int r_ = 0; r_ < 2; ++r_) _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {              \
@@ -1367,8 +1377,7 @@ __device__ __forceinline__ void mlp_tile_h2(MlpSmem& s, const MlpParams* __restr
         __builtin_amdgcn_sched_barrier(0);                                                                               \
     }                                                                                                                    \
     QSP_HTS()                                                                                                            \
-    gemm_h2<KS_, PF, 4, 2, HAND>(img, QSP_WH(L, KS_), (KS_) * 2 * 64, (NL) > 0 ? QSP_WH((NL) > 0 ? (NL) : 1, NKS) : QSP_WBH(7), \
-                           (NKS) * 2 * 64, ring, acc, acc2, lane);                                                       \
+    GEMM_STMT;                                                                                                           \
     QSP_HTS()                                                                                                            \
     __syncthreads();                                                                                                     \
     QSP_HTS()                                                                                                            \
@@ -1395,9 +1404,11 @@ __device__ __forceinline__ void mlp_tile_h2(MlpSmem& s, const MlpParams* __restr
     QSP_HTS()                                                                                                            \
     __syncthreads();                                                                                                     \
     QSP_HTS()
-    QSP_FWDH(1, KSH, 2, KSH, bias_sh + 0 * HID)
-    QSP_FWDH(2, KSH, 3, KSH, bias_sh + 1 * HID)
-    QSP_FWDH(3, KSH, 4, KS4, bias_sh + 2 * HID)
+#define QSP_GEMMF(L, KS_, NW, NKS) gemm_h2<KS_, PF, 4, 2, HAND>(img, QSP_WH(L, KS_), (KS_) * 2 * 64, NW, (NKS) * 2 * 64, ring, acc, acc2, lane)
+    QSP_FWDH(0, s.c0, gemm_l0_h2(img, QSP_WH(0, 1), acc, acc2, lane))
+    QSP_FWDH(1, bias_sh + 0 * HID, QSP_GEMMF(1, KSH, QSP_WH(2, KSH), KSH))
+    QSP_FWDH(2, bias_sh + 1 * HID, QSP_GEMMF(2, KSH, QSP_WH(3, KSH), KSH))
+    QSP_FWDH(3, bias_sh + 2 * HID, QSP_GEMMF(3, KSH, QSP_WH(4, KS4), KS4))
     if (tid < TILE_P * 3) {        // the skip connection's xyz into columns 445..447 (zeros from layer 3's write-out until now)
         const int row = tid / 3, ci = tid - row * 3;
         const float x = s.xin[row * 4 + ci];
@@ -1408,25 +1419,27 @@ __device__ __forceinline__ void mlp_tile_h2(MlpSmem& s, const MlpParams* __restr
         amax = fmaxf(amax, fabsf(x));
     }
     __syncthreads();
-    QSP_FWDH(4, KS4, 5, KSH, s.c4)
-    QSP_FWDH(5, KSH, 6, KSH, bias_sh + 4 * HID)
-    QSP_FWDH(6, KSH, 7, KSH, bias_sh + 5 * HID)
-    QSP_FWDH(7, KSH, (BWD ? 0 : 1), KSH, bias_sh + 6 * HID)
+    QSP_FWDH(4, s.c4, QSP_GEMMF(4, KS4, QSP_WH(5, KSH), KSH))
+    QSP_FWDH(5, bias_sh + 4 * HID, QSP_GEMMF(5, KSH, QSP_WH(6, KSH), KSH))
+    QSP_FWDH(6, bias_sh + 5 * HID, QSP_GEMMF(6, KSH, QSP_WH(7, KSH), KSH))
+    QSP_FWDH(7, bias_sh + 6 * HID, QSP_GEMMF(7, KSH, QSP_WH(1, KSH), KSH))
 #undef QSP_FWDH
+#undef QSP_GEMMF
     // ---- layer 8: 512 -> 1, tanh (f32): wave = k segment of 128, lane = row; a7 = hi + 2^-11 lo' from the two planes
     // (every layer's write-out is the same code: a special case for layer 7 costs the register allocator its footing) ---------
     {
         const _Float16* a = img + lane * LDH + 16 * (16 * wave);
         const float* w = s.w8 + 128 * wave;
-        float part = 0.f;
+        float pa[4] = {0.f, 0.f, 0.f, 0.f};        // four chains: one dependent chain of 128 multiply-adds is latency-bound
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
             const f16x8 hi = *reinterpret_cast<const f16x8*>(a + 16 * g), lo = *reinterpret_cast<const f16x8*>(a + 16 * g + 8);
             const f32x4 w0 = lds4(w + 8 * g), w1 = lds4(w + 8 * g + 4);
 #pragma unroll
             for (int j = 0; j < 8; ++j)
-                part = fmaf(fmaf((float)lo[j], 0.00048828125f, (float)hi[j]), j < 4 ? w0[j] : w1[j - 4], part);
+                pa[j & 3] = fmaf(fmaf((float)lo[j], 0.00048828125f, (float)hi[j]), j < 4 ? w0[j] : w1[j - 4], pa[j & 3]);
         }
+        const float part = (pa[0] + pa[1]) + (pa[2] + pa[3]);
         s.red[wave * TILE_P + lane] = part;
     }
     __syncthreads();

@@ -364,6 +364,7 @@ __global__ __launch_bounds__(H2_THREADS) void k_mlp_fwd_h2(const HypState* __res
     __shared__ float Tsh[16];
     __shared__ int s_item;
     const int n_items = qctl[0];
+    bool staged = false;
     float amax = 0.f;
     int h_cached = -1;
     for (;;) {
@@ -403,7 +404,8 @@ __global__ __launch_bounds__(H2_THREADS) void k_mlp_fwd_h2(const HypState* __res
             s.xin[4 * threadIdx.x + 3] = 0.f;
         }
         __syncthreads();
-        mlp_tile_h2<false, 2>(s, P, amax);
+        mlp_tile_h2<false, 2>(s, P, amax, !staged);      // (the decoder's constants: staged by the first tile of the workgroup)
+        staged = true;
         if (threadIdx.x < TILE_P) {
             const int v = t * TILE_P + threadIdx.x;
             if (v < n) out[v] = s.y[threadIdx.x];
@@ -1140,6 +1142,7 @@ __global__ __launch_bounds__(H2_THREADS) void k_decode_h2(const float* __restric
         s.c0[u] = a;
         s.c4[u] = a4;
     }
+    bool staged = false;
     float amax = 0.f;
     for (int64_t t = blockIdx.x; t * TILE_P < n; t += gridDim.x) {
         __syncthreads();
@@ -1153,7 +1156,8 @@ __global__ __launch_bounds__(H2_THREADS) void k_decode_h2(const float* __restric
             s.xin[4 * threadIdx.x + 3] = 0.f;
         }
         __syncthreads();
-        mlp_tile_h2<GRAD, 2>(s, P, amax);
+        mlp_tile_h2<GRAD, 2>(s, P, amax, GRAD || !staged);
+        staged = true;
         if (threadIdx.x < TILE_P) {
             const int64_t v = t * TILE_P + threadIdx.x;
             if (v < n) y_out[v] = s.y[threadIdx.x];
@@ -1366,7 +1370,26 @@ static int pack_weights(qsp_decoder* d, const qsp_decoder_desc* desc) {
             if (!rc) rc = upload(wx, (const void**)&d->P.w0x);
             d->P.wf[0] = nullptr;
             d->P.wf3[0] = nullptr;
-            d->P.wfh[0] = nullptr;
+            if (!rc) {   // split-fp16: the xyz columns as one slab of the forward product (gemm_l0_h2): k = 0..2 used of 16
+                std::vector<_Float16> ph((size_t)16 * 2 * 64 * 8, (_Float16)0.f);
+                for (int cb = 0; cb < 16; ++cb)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 8; ++j) {
+                            const int o = 32 * cb + (lane & 31), k = 8 * (lane >> 5) + j;
+                            float v = 0.f;
+                            if (o < out && k < 3) v = W[0][(size_t)o * in + CODE_LEN + k];
+                            if (!(fabsf(v) < 65000.f)) d->fp16_ok = false;
+                            const _Float16 hi = (_Float16)v;
+                            const size_t base = ((size_t)cb * 2) * 64 * 8 + (size_t)lane * 8 + j;
+                            ph[base] = hi;
+                            ph[base + 64 * 8] = (_Float16)((v - (float)hi) * 2048.f);
+                        }
+                void* phd = nullptr;
+                QSP_HIP(hipMalloc(&phd, ph.size() * sizeof(_Float16) + 16384));
+                d->allocs.push_back(phd);
+                QSP_HIP(hipMemcpy(phd, ph.data(), ph.size() * sizeof(_Float16), hipMemcpyHostToDevice));
+                d->P.wfh[0] = (const float4*)phd;
+            }
         } else {
             // forward: B[k][o]; column blocks over o (16 blocks of 32), k-groups of 8 over K = 512.
             // Layer 4 (latent_in): K = 448 = [h3 (445) | xyz (3)]; its 64 code columns go to w4c (folded into a bias per

@@ -24,7 +24,7 @@ __global__ __launch_bounds__(H2_THREADS) void kt(const MlpParams* P, float* y, i
             s.xin[4 * threadIdx.x] = 0.1f; s.xin[4 * threadIdx.x + 1] = 0.2f; s.xin[4 * threadIdx.x + 2] = 0.3f; s.xin[4 * threadIdx.x + 3] = 0.f;
         }
         __syncthreads();
-        mlp_tile_h2<BWDV, PFV>(s, P, amax);
+        mlp_tile_h2<BWDV, PFV>(s, P, amax, BWDV || t == 0);
         if (threadIdx.x < 64) y[blockIdx.x * 64 + threadIdx.x] = s.y[threadIdx.x] + (BWDV ? s.act[threadIdx.x * LDG] : 0.f);
     }
     if (!(amax <= H2_MAX)) *P->range_flag = 1;
@@ -42,8 +42,8 @@ int main(int argc, char** argv) {
     };
     const bool shared = argc > 2 && atoi(argv[2]);      // every layer reads the same 1 MiB: the weight set fits any L2
     for (int l = 0; l < 8; ++l) {
-        P.wfh[l] = (shared && l) ? P.wfh[0] : (const float4*)dev((size_t)16 * 32 * 2 * 64 * 16, 0.f);
-        P.wbh[l] = shared ? P.wfh[0] : (const float4*)dev((size_t)16 * 32 * 2 * 64 * 16, 0.f);
+        P.wfh[l] = (shared && l > 1) ? P.wfh[1] : (const float4*)dev((size_t)16 * 32 * 2 * 64 * 16, 0.f);
+        P.wbh[l] = (shared && l) ? P.wfh[1] : (const float4*)dev((size_t)16 * 32 * 2 * 64 * 16, 0.f);
         P.bias[l] = (const float*)dev(512 * 4, 0.01f);
     }
     P.wbh4s = (const float4*)dev((size_t)3 * 32 * 2 * 64 * 16, 0.f);
