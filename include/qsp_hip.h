@@ -70,10 +70,17 @@ void qsp_decoder_destroy(qsp_decoder* dec);
  *   1            every f32 weight and activation as the exact sum of three bf16 values, six bf16 products per multiply-add on
  *                the bf16 matrix pipe with f32 accumulation (v_mfma_f32_32x32x16_bf16): float32-equivalent accuracy (2.2e-7
  *                relative on the SDF value against float64; plain f32: 1.8e-7) at up to 2.67 x the f32 pipe's rate.  Results
- *                differ from mode 0 in the last bits, as two float32 implementations with different summation orders do.
- * QSP_DEC_OPT_JACOBIAN_PRECISION selects the same for the forward+backward pass that builds the Jacobian rows and the normal
- * equations (qsp_sdf_value_grad and the fused kernel of the refinement, reconstruct/loss_utils.py:82-103): that pass has no
- * discrete decision besides the ReLU masks, so mode 1 moves H, b by float32 rounding noise only. */
+ *                differ from mode 0 in the last bits, as two float32 implementations with different summation orders do;
+ *   2            every f32 weight and activation as two fp16 values, x = hi + 2^-11 lo' (22 significand bits), three fp16
+ *                products per multiply-add on the fp16 matrix pipe with f32 accumulation (v_mfma_f32_32x32x16_f16): the same
+ *                float32-equivalent accuracy (1.8e-7) at up to 5.3 x the f32 pipe's rate.  fp16's range is the precondition:
+ *                qsp_decoder_set_option returns QSP_ERR_UNSUPPORTED for a decoder with a weight beyond +-65 000, and a call
+ *                during which an activation or a back-propagated gradient exceeded 65 504 in magnitude FAILS with
+ *                QSP_ERR_UNSUPPORTED instead of returning numbers (its outputs are then undefined; modes 0 and 1 have no such
+ *                limit).  A DeepSDF decoder's activations are O(10).
+ * QSP_DEC_OPT_JACOBIAN_PRECISION selects the same (0, 1, 2) for the forward+backward pass that builds the Jacobian rows and the
+ * normal equations (qsp_sdf_value_grad and the fused kernel of the refinement, reconstruct/loss_utils.py:82-103): that pass has
+ * no discrete decision besides the ReLU masks, so modes 1 and 2 move H, b by float32 rounding noise only. */
 enum { QSP_DEC_OPT_FORWARD_PRECISION = 1, QSP_DEC_OPT_JACOBIAN_PRECISION = 2 };
 int qsp_decoder_set_option(qsp_decoder* dec, int32_t option, int32_t value);
 
