@@ -1,6 +1,6 @@
 #!/bin/bash
-# Regenerates, on the GPU box, what profiles/ holds for the final state of round 2 (the decoder on the split-bf16 pipe, which
-# QSP_PRECISION=bf16x3 selects for the helper scripts; bench.py's default).  Output: gpurun_out/refresh2/.
+# Regenerates, on the GPU box, what profiles/ holds for the final state of round 2 (the decoder on the split-fp16 pipe, which
+# QSP_PRECISION=fp16x2 selects for the helper scripts; bench.py's default).  Output: gpurun_out/refresh2/.
 #   bash tools/refresh_profiles_r02.sh
 set -e -o pipefail
 export TMPDIR=/tmp
@@ -19,7 +19,7 @@ for w in c4 c5; do
   rm -rf $O/t_$w
 done
 echo "ba traces done"
-export QSP_PRECISION=bf16x3
+export QSP_PRECISION=fp16x2
 timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmcF -- python3 tools/refine_only.py c4 64 1 > $O/pmcF.log 2>&1
 python3 tools/pmc_summary.py $O/pmcF > $O/r02_c4_pmcF_summary.txt
 timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmcW -- python3 tools/refine_only.py c4 64 1 > $O/pmcW.log 2>&1
