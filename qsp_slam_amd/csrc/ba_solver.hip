@@ -26,6 +26,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <vector>
 
 #include "../../include/qsp_hip.h"
@@ -386,6 +387,29 @@ __global__ __launch_bounds__(64) void k_finish_sum(Dev d, int n, int slot) {
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
     if (threadIdx.x == 0) d.scal[slot] = s;
 }
+// the same sum into scal[0], published to the host-visible copy together with scal[1..3] in the same launch (one rank: no
+// reduction over ranks sits between the sum and the read-back); re-arms scal[3] like k_publish_scal
+__global__ __launch_bounds__(64) void k_finish_sum_publish(Dev d, int n, double* __restrict__ host) {
+    double s = 0;
+    for (int i = threadIdx.x; i < n; i += 64) s += d.partial[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (threadIdx.x == 0) {
+        d.scal[0] = s;
+        host[0] = s;
+        host[1] = d.scal[1];
+        host[2] = d.scal[2];
+        host[3] = d.scal[3];
+        d.scal[3] = 0.0;
+    }
+}
+
+// scal[0..3] -> the host-visible copy; scal[3] (the "a block was not positive definite" flag of a trial) is re-armed for the
+// next trial here, which saves a memset launch per trial
+__global__ void k_publish_scal(Dev d, double* __restrict__ host) {
+    if (threadIdx.x < 4) host[threadIdx.x] = d.scal[threadIdx.x];
+    if (threadIdx.x == 3) d.scal[3] = 0.0;
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // k_lin_points: edge-parallel.  A workgroup owns a chunk of consecutive landmarks whose edges (contiguous, landmark-
@@ -444,9 +468,9 @@ __device__ inline void edge_hpl(const Dev& d, const Edge& E, const Par& par, dou
     else edge_hpl_t<2>(d, E, par.delta_mono, B);
 }
 
-__global__ __launch_bounds__(256) void k_lin_points(Dev d, Par par) {
+__device__ __forceinline__ void lin_points_block(const Dev& d, const Par& par, const int bid) {
     __shared__ double sh[256][9 + 1];
-    const int p0 = d.chunk_pt[blockIdx.x], p1 = d.chunk_pt[blockIdx.x + 1];
+    const int p0 = d.chunk_pt[bid], p1 = d.chunk_pt[bid + 1];
     const int e0 = d.pt_off[p0], e1 = d.pt_off[p1];
     const int ei = e0 + threadIdx.x;
     double v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -502,8 +526,8 @@ __device__ inline void lin_pose_edge(const Dev& d, const Edge& E, double delta, 
     }
 }
 
-__global__ __launch_bounds__(256) void k_lin_poses(Dev d, Par par) {
-    const int sp = blockIdx.x;
+__device__ __forceinline__ void lin_poses_block(const Dev& d, const Par& par, const int bid) {
+    const int sp = bid;
     const int kf = d.ksp_kf[sp];
     if (d.kf_h[kf] < 0) return;
     __shared__ double sh[4][27];
@@ -533,10 +557,10 @@ __global__ __launch_bounds__(256) void k_lin_poses(Dev d, Par par) {
 // 0..35 form entry (i,j) of w Ji^T Ji, w Jj^T Jj and w Ji^T Jj, lanes 36..47 the two right-hand sides.
 // Record layout (OE_REC doubles per edge): [0,36) key-frame block, [36,72) object block, [72,78) b key-frame, [78,84) b object.
 constexpr int OE_REC = 84;
-__global__ __launch_bounds__(256) void k_lin_objedges(Dev d, Par par) {
+__device__ __forceinline__ void lin_objedges_block(const Dev& d, const Par& par, const int bid) {
     __shared__ double J[4][80];     // Ji 36 | Jj 36 | -info e r1 (6) | w
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int k = blockIdx.x * 4 + wave;
+    const int k = bid * 4 + wave;
     const bool live = k < d.n_oe && !d.oe_level[k];
     if (live && lane == 0) {
         const int kf = d.oe_kf[k], ob = d.oe_obj[k];
@@ -579,8 +603,8 @@ __global__ __launch_bounds__(256) void k_lin_objedges(Dev d, Par par) {
 }
 
 // one wave per key-frame: ordered sum of its splits, then of its camera-object edge records (vertex 0 side)
-__global__ __launch_bounds__(64) void k_lin_poses_finish(Dev d, Par par) {
-    const int kf = blockIdx.x;
+__device__ __forceinline__ void lin_poses_finish_block(const Dev& d, const Par& par, const int bid) {
+    const int kf = bid;
     const int h = d.kf_h[kf];
     if (h < 0) return;
     const int t = threadIdx.x;
@@ -606,8 +630,8 @@ __global__ __launch_bounds__(64) void k_lin_poses_finish(Dev d, Par par) {
 }
 
 // one wave per object: ordered sum of its edge records (vertex 1 side)
-__global__ __launch_bounds__(64) void k_lin_objects(Dev d, Par par) {
-    const int ob = blockIdx.x;
+__device__ __forceinline__ void lin_objects_block(const Dev& d, const Par& par, const int bid) {
+    const int ob = bid;
     const int hj = d.obj_h[ob];
     if (hj < 0) return;
     const int t = threadIdx.x;
@@ -621,6 +645,19 @@ __global__ __launch_bounds__(64) void k_lin_objects(Dev d, Par par) {
         }
     if (t < 36) d.Hdiag[36 * (size_t)hj + t] = a;
     else d.bp[6 * hj + (t - 36)] = a;
+}
+
+// buildSystem in TWO launches: the three edge passes are independent of each other (block ranges of one grid, the long
+// key-frame splits first), and so are the two per-vertex sums that consume them.
+__global__ __launch_bounds__(256) void k_lin_edges(Dev d, Par par, int nb_poses, int nb_points) {
+    const int b = blockIdx.x;
+    if (b < nb_poses) lin_poses_block(d, par, b);
+    else if (b < nb_poses + nb_points) lin_points_block(d, par, b - nb_poses);
+    else lin_objedges_block(d, par, b - nb_poses - nb_points);
+}
+__global__ __launch_bounds__(64) void k_lin_vertices(Dev d, Par par) {
+    if ((int)blockIdx.x < d.n_kf) lin_poses_finish_block(d, par, blockIdx.x);
+    else lin_objects_block(d, par, blockIdx.x - d.n_kf);
 }
 
 // max |diagonal| over all active vertices (computeLambdaInit, optimization_algorithm_levenberg.cpp:166-180)
@@ -1540,6 +1577,18 @@ __global__ __launch_bounds__(256) void k_update_poses(Dev d, Par par, int n_part
     }
 }
 
+// The outlier classification between the two rounds of LocalBundleAdjustment (src/Optimizer_util.cc:621-654) on the device:
+// level 1 = excluded from the second round.  chi2 is the value k_errors left for the last accepted estimates.
+__global__ void k_classify_levels(Dev d, double th_mono, double th_stereo, double th_obj) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < d.n_edge) {
+        double p[3];
+        se3_map(d.kf_pose + 7 * d.edge[i].kf, d.pt_xyz + 3 * d.edge[i].pt, p);
+        d.edge_level[i] = (d.edge_chi2[i] > (d.edge[i].stereo ? th_stereo : th_mono) || !(p[2] > 0.0)) ? 1 : 0;
+    }
+    if (i < d.n_oe) d.oe_level[i] = d.oe_chi2[i] > th_obj ? 1 : 0;
+}
+
 __global__ void k_depth_positive(Dev d, uint8_t* pos) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= d.n_edge) return;
@@ -1850,6 +1899,14 @@ struct qsp_ba_problem {
     // LM state that persists inside one optimize call only
     qsp_ba_stats prof{};
     bool profiling = false;
+    double* scal_host = nullptr; // pinned, device-visible copy of scal[0..3] (k_publish_scal): read back without a copy engine hop
+    double* scal_host_dev = nullptr;
+    hipEvent_t ev_scal = nullptr;
+    bool speculate = true;       // enqueue the next iteration's linearisation before waiting for a trial's verdict
+    uint8_t* lvl_host = nullptr; // pinned: edge / object-edge levels classified on the device (qsp_ba_local_joint)
+    int32_t* idx_host = nullptr; // pinned staging of the hessian indices [kf | obj | pt]
+    std::vector<int32_t> idx_uploaded;   // what the device holds (an optimize() call re-uploads only what changed)
+    std::vector<int> pose_order, pt_order;   // key-frame / object vertices and landmarks sorted by id (build_index)
     bool deterministic = false;   // qsp_ba_set_deterministic
     // landmark sharding across ranks: this rank linearises and marginalises the landmarks with
     // pt_id % world == rank (and the camera-object edges of objects with obj_id % world == rank); one SUM all-reduce of
@@ -2130,6 +2187,11 @@ extern "C" int qsp_ba_create(const qsp_ba_scene* s, int device, qsp_ba_problem**
         if (e == hipSuccess) e = hipMemset(d.edge_chi2, 0, sizeof(double) * std::max(d.n_edge, 1));
         if (e == hipSuccess) e = hipMemset(d.oe_chi2, 0, sizeof(double) * std::max(d.n_oe, 1));
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipHostMalloc((void**)&p->scal_host, 8 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent);
+        if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&p->scal_host_dev, p->scal_host, 0);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_scal, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipHostMalloc((void**)&p->lvl_host, (size_t)std::max(d.n_edge + d.n_oe, 1), hipHostMallocDefault);
+        if (e == hipSuccess) e = hipHostMalloc((void**)&p->idx_host, sizeof(int32_t) * (size_t)std::max(d.n_kf + d.n_obj + d.n_pt, 1), hipHostMallocDefault);
         const int chol_lds = (int)(sizeof(double) * CHOL_LDS_DOUBLES);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_chol_first, hipFuncAttributeMaxDynamicSharedMemorySize, chol_lds);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_chol_step, hipFuncAttributeMaxDynamicSharedMemorySize, chol_lds);
@@ -2159,6 +2221,10 @@ extern "C" void qsp_ba_destroy(qsp_ba_problem* p) {
     if (!p) return;
     (void)hipSetDevice(p->device);
     for (void* q : p->allocs) (void)hipFree(q);
+    if (p->scal_host) (void)hipHostFree(p->scal_host);
+    if (p->lvl_host) (void)hipHostFree(p->lvl_host);
+    if (p->idx_host) (void)hipHostFree(p->idx_host);
+    if (p->ev_scal) (void)hipEventDestroy(p->ev_scal);
     if (p->stream) (void)hipStreamDestroy(p->stream);
     delete p;
 }
@@ -2170,6 +2236,11 @@ extern "C" int qsp_ba_set_levels(qsp_ba_problem* p, const uint8_t* mono, const u
     if (mono) for (int e = 0; e < p->n_mono; ++e) p->edge_level_h[p->mono_pos[e]] = mono[e] ? 1 : 0;
     if (stereo) for (int e = 0; e < p->n_stereo; ++e) p->edge_level_h[p->st_pos[e]] = stereo[e] ? 1 : 0;
     for (int e = 0; e < p->d.n_oe; ++e) p->oe_level_h[e] = (obj && obj[e]) ? 1 : 0;
+    if (!mono && !stereo && !obj && p->world == 1) {     // everything active: no host array has to travel
+        if (p->d.n_edge) QSP_HIP(hipMemsetAsync(p->d.edge_level, 0, p->d.n_edge, p->stream));
+        if (p->d.n_oe) QSP_HIP(hipMemsetAsync(p->d.oe_level, 0, p->d.n_oe, p->stream));
+        return QSP_OK;
+    }
     return upload_levels(p);
 }
 
@@ -2199,24 +2270,31 @@ static void build_index(qsp_ba_problem* p) {
         if (!p->edge_level_h[e]) { ka[p->edge_h[e].kf] = 1; pa[p->edge_h[e].pt] = 1; }
     for (int e = 0; e < d.n_oe; ++e)
         if (!p->oe_level_h[e]) { ka[p->oe_kf_h[e]] = 1; oa[p->oe_obj_h[e]] = 1; }
-    std::vector<std::pair<int64_t, int>> v;
-    p->kf_h.assign(d.n_kf, -1); p->obj_h.assign(d.n_obj, -1); p->pt_h.assign(d.n_pt, -1);
-    for (int i = 0; i < d.n_kf; ++i)
-        if (ka[i] && !p->kf_fixed_h[i]) v.push_back({p->kf_id_h[i], i});
-    for (int i = 0; i < d.n_obj; ++i)
-        if (oa[i]) v.push_back({p->obj_id_h[i], d.n_kf + i});
-    std::sort(v.begin(), v.end());
-    for (size_t k = 0; k < v.size(); ++k) {
-        if (v[k].second < d.n_kf) p->kf_h[v[k].second] = (int)k;
-        else p->obj_h[v[k].second - d.n_kf] = (int)k;
+    // vertices in id order (g2o's hessian order): the argsort is a property of the problem, computed once
+    if (p->pose_order.size() != (size_t)(d.n_kf + d.n_obj)) {
+        std::vector<std::pair<int64_t, int>> v;
+        for (int i = 0; i < d.n_kf; ++i) v.push_back({p->kf_id_h[i], i});
+        for (int i = 0; i < d.n_obj; ++i) v.push_back({p->obj_id_h[i], d.n_kf + i});
+        std::sort(v.begin(), v.end());
+        p->pose_order.clear();
+        for (const auto& q : v) p->pose_order.push_back(q.second);
+        v.clear();
+        for (int i = 0; i < d.n_pt; ++i) v.push_back({p->pt_id_h[i], i});
+        std::sort(v.begin(), v.end());
+        p->pt_order.clear();
+        for (const auto& q : v) p->pt_order.push_back(q.second);
     }
-    p->n_pose = (int)v.size();
-    v.clear();
-    for (int i = 0; i < d.n_pt; ++i)
-        if (pa[i]) v.push_back({p->pt_id_h[i], i});
-    std::sort(v.begin(), v.end());
-    for (size_t k = 0; k < v.size(); ++k) p->pt_h[v[k].second] = (int)k;
-    p->n_land = (int)v.size();
+    p->kf_h.assign(d.n_kf, -1); p->obj_h.assign(d.n_obj, -1); p->pt_h.assign(d.n_pt, -1);
+    int k = 0;
+    for (int i : p->pose_order) {
+        if (i < d.n_kf) { if (ka[i] && !p->kf_fixed_h[i]) p->kf_h[i] = k++; }
+        else if (oa[i - d.n_kf]) p->obj_h[i - d.n_kf] = k++;
+    }
+    p->n_pose = k;
+    k = 0;
+    for (int i : p->pt_order)
+        if (pa[i]) p->pt_h[i] = k++;
+    p->n_land = k;
     // object elimination (k_obj_*): possible when every free key-frame precedes every object in the hessian order
     int n_kfree = 0, max_kf_h = -1, n_obj_act = 0;
     for (int i = 0; i < d.n_kf; ++i)
@@ -2229,10 +2307,23 @@ static void build_index(qsp_ba_problem* p) {
     p->dimp = ((p->dim + NB - 1) / NB) * NB;
 }
 
-static int read_scal(qsp_ba_problem* p, double* out4) {
-    QSP_HIP(hipMemcpyAsync(out4, p->d.scal, 4 * sizeof(double), hipMemcpyDeviceToHost, p->stream));
-    QSP_HIP(hipStreamSynchronize(p->stream));
+// The scalars of a trial (chi2, rho denominator, max diagonal, failure flag) reach the host through pinned memory written by a
+// one-wave kernel; the host waits on an event recorded right behind it.  (A device-to-host hipMemcpyAsync goes through the copy
+// path and sat 41 us (C4) / 124 us (C5) idle in front of every read-back, profiles/r02_ba_timeline.txt.)  Two phases so that
+// work can be enqueued between the publish and the wait.
+static int publish_scal(qsp_ba_problem* p) {
+    hipLaunchKernelGGL(k_publish_scal, dim3(1), dim3(64), 0, p->stream, p->d, p->scal_host_dev);
+    QSP_HIP(hipEventRecord(p->ev_scal, p->stream));
     return QSP_OK;
+}
+static int wait_scal(qsp_ba_problem* p, double* out4) {
+    QSP_HIP(hipEventSynchronize(p->ev_scal));
+    for (int i = 0; i < 4; ++i) out4[i] = p->scal_host[i];
+    return QSP_OK;
+}
+static int read_scal(qsp_ba_problem* p, double* out4) {
+    int rc = publish_scal(p);
+    return rc ? rc : wait_scal(p, out4);
 }
 
 static int upload_levels(qsp_ba_problem* p) {
@@ -2356,16 +2447,27 @@ extern "C" int qsp_ba_optimize(qsp_ba_problem* p, int32_t n_iter, double delta_m
     Dev& d = p->d;
     hipStream_t s = p->stream;
     build_index(p);
-    QSP_HIP(hipMemcpyAsync(d.kf_h, p->kf_h.data(), sizeof(int32_t) * d.n_kf, hipMemcpyHostToDevice, s));
-    if (d.n_obj) QSP_HIP(hipMemcpyAsync(d.obj_h, p->obj_h.data(), sizeof(int32_t) * d.n_obj, hipMemcpyHostToDevice, s));
-    if (d.n_pt) QSP_HIP(hipMemcpyAsync(d.pt_h, p->pt_h.data(), sizeof(int32_t) * d.n_pt, hipMemcpyHostToDevice, s));
+    {   // hessian indices: through pinned staging (a pageable source makes the "async" copy a synchronous staged one), and only
+        // the arrays that differ from what the device already holds (the second round of a local BA rarely changes them)
+        const size_t nk = d.n_kf, no = d.n_obj, np_ = d.n_pt;
+        if (p->idx_uploaded.size() != nk + no + np_) p->idx_uploaded.assign(nk + no + np_, INT32_MIN);
+        QSP_HIP(hipStreamSynchronize(s));              // (the staging buffer of the previous call has been consumed)
+        struct Part { const int32_t* src; int32_t* dst; size_t off, n; } parts[3] = {
+            {p->kf_h.data(), d.kf_h, 0, nk}, {p->obj_h.data(), d.obj_h, nk, no}, {p->pt_h.data(), d.pt_h, nk + no, np_}};
+        for (const Part& q : parts) {
+            if (!q.n || !memcmp(q.src, p->idx_uploaded.data() + q.off, sizeof(int32_t) * q.n)) continue;
+            memcpy(p->idx_host + q.off, q.src, sizeof(int32_t) * q.n);
+            memcpy(p->idx_uploaded.data() + q.off, q.src, sizeof(int32_t) * q.n);
+            QSP_HIP(hipMemcpyAsync(q.dst, p->idx_host + q.off, sizeof(int32_t) * q.n, hipMemcpyHostToDevice, s));
+        }
+    }
     Par par{delta_mono, delta_stereo, delta_obj, 0.0, p->dim, p->dimp, p->n_pose, p->rank == 0 ? 1 : 0,
             (p->deterministic && p->dimp > 0) ? 1 : 0, p->n_dense, p->elim ? 1 : 0};
     if (tr) { tr->n = 0; tr->result = 0; tr->n_pose_blocks = p->n_pose; tr->n_landmarks = p->n_land; }
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, evA = nullptr, evB = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (p->profiling) {
         memset(&p->prof, 0, sizeof(p->prof));
-        (void)hipEventCreate(&ev0); (void)hipEventCreate(&ev1); (void)hipEventCreate(&evA); (void)hipEventCreate(&evB);
+        (void)hipEventCreate(&ev0); (void)hipEventCreate(&ev1);
         (void)hipEventRecord(ev0, s);
     }
     const int gp = std::max(1, std::min(p->n_partial, (d.n_pt + 255) / 256));
@@ -2373,23 +2475,38 @@ extern "C" int qsp_ba_optimize(qsp_ba_problem* p, int32_t n_iter, double delta_m
     double lambda = 0, ni = 2, currentChi = 0;
     int nBad = 0, done = 0, result = 0;
     double sc[4];
+    // buildSystem of the current estimates, enqueued.  (every entry of Hdiag and bp that is read is written by
+    // k_lin_poses_finish / k_lin_objects: no memsets.)  Profiling: one event pair per call, read at the end.
+    std::vector<hipEvent_t> lin_ev;
+    auto enqueue_lin = [&](bool with_chi2) -> int {
+        if (p->profiling) {
+            hipEvent_t a = nullptr;
+            (void)hipEventCreate(&a);
+            (void)hipEventRecord(a, s);
+            lin_ev.push_back(a);
+        }
+        const int nb_e = d.n_ksplit + d.n_chunk + (d.n_oe + 3) / 4;
+        if (nb_e) hipLaunchKernelGGL(k_lin_edges, dim3(nb_e), dim3(256), 0, s, d, par, d.n_ksplit, d.n_chunk);
+        hipLaunchKernelGGL(k_lin_vertices, dim3(d.n_kf + d.n_obj), dim3(64), 0, s, d, par);
+        if (p->profiling) {
+            hipEvent_t b = nullptr;
+            (void)hipEventCreate(&b);
+            (void)hipEventRecord(b, s);
+            lin_ev.push_back(b);
+        }
+        return allreduce_gather(p, d.Hdiag, (size_t)36 * p->n_pose, d.bp, (size_t)p->dim_all, d.scal, with_chi2 ? 1 : 0);   // pose blocks, b_p, chi2
+    };
+    bool lin_ready = false;      // the system of the current estimates is already enqueued (speculated behind an accepted trial)
     for (int it = 0; it < n_iter; ++it) {
         if (stop_flag && *stop_flag) { result = 2; break; }
         // computeActiveErrors + chi2 (sparse_optimizer.cpp:61-114).  After the first iteration the state is the one the last
         // accepted trial was evaluated on -- the same kernel on the same numbers -- so its chi2 is carried over instead of
         // being recomputed and read back (an iteration never starts after a rejected trial: that ends the call).
         if (it == 0) launch_errors(p, par);
-        // buildSystem
-        if (p->profiling) (void)hipEventRecord(evA, s);
-        // (every entry of Hdiag and bp that is read is written by k_lin_poses_finish / k_lin_objects: no memsets)
-        if (d.n_chunk) hipLaunchKernelGGL(k_lin_points, dim3(d.n_chunk), dim3(256), 0, s, d, par);
-        if (d.n_ksplit) hipLaunchKernelGGL(k_lin_poses, dim3(d.n_ksplit), dim3(256), 0, s, d, par);
-        if (d.n_oe) hipLaunchKernelGGL(k_lin_objedges, dim3((d.n_oe + 3) / 4), dim3(256), 0, s, d, par);
-        hipLaunchKernelGGL(k_lin_poses_finish, dim3(d.n_kf), dim3(64), 0, s, d, par);
-        if (d.n_obj) hipLaunchKernelGGL(k_lin_objects, dim3(d.n_obj), dim3(64), 0, s, d, par);
-        if (p->profiling) (void)hipEventRecord(evB, s);
-        int rc = allreduce_gather(p, d.Hdiag, (size_t)36 * p->n_pose, d.bp, (size_t)p->dim_all, d.scal, it == 0 ? 1 : 0);   // pose blocks, b_p, chi2
+        int rc = QSP_OK;
+        if (!lin_ready) rc = enqueue_lin(it == 0);
         if (rc) return rc;
+        lin_ready = false;
         if (it == 0) {
             QSP_HIP(hipMemsetAsync(d.scal + 2, 0, sizeof(double), s));
             const int gm = std::max(1, std::min(256, (d.n_pt * 3 + p->n_pose * 6 + 255) / 256));
@@ -2398,7 +2515,7 @@ extern "C" int qsp_ba_optimize(qsp_ba_problem* p, int32_t n_iter, double delta_m
                 ncclResult_t r = rccl_api()->all_reduce(d.scal + 2, d.scal + 2, 1, ncclDouble, ncclMax, p->nccl, s);
                 if (r != ncclSuccess) return rccl_fail(r, "ncclAllReduce(max)");
             }
-            rc = read_scal(p, sc);
+            rc = read_scal(p, sc);               // (also arms scal[3] for the first trial)
             if (rc) return rc;
             if (p->world > 1 && !p->nccl) {   // callback hook (SUM only): max as a SUM over one-hot slots
                 std::vector<double> slots(p->world, 0.0);
@@ -2412,20 +2529,13 @@ extern "C" int qsp_ba_optimize(qsp_ba_problem* p, int32_t n_iter, double delta_m
             }
             currentChi = sc[0];
         }
-        if (p->profiling) {
-            float ms = 0;
-            (void)hipEventSynchronize(evB);      // (profiling only: iterations after the first have no read-back to wait on)
-            (void)hipEventElapsedTime(&ms, evA, evB);
-            p->prof.ms_linearize += ms;
-            p->prof.n_linearize++;
-        }
         const double iniChi = currentChi;
         if (it == 0) { lambda = 1e-5 * sc[2]; ni = 2; nBad = 0; }
         double rho = 0;
         int qmax = 0, accepted = 0;
         do {
             par.lambda = lambda;
-            QSP_HIP(hipMemsetAsync(d.scal + 3, 0, sizeof(double), s));
+            // (scal[3], the trial's failure flag, was re-armed by the k_publish_scal of the previous read-back)
             const bool fused = p->deterministic && p->dimp > 0 && d.n_pk > 0;
             if (!fused) {   // push (g2o: sparse_optimizer.cpp:519-527); the fused path backs up inside k_trial_stage1
                 QSP_HIP(hipMemcpyAsync(d.kf_bk, d.kf_pose, sizeof(double) * 7 * d.n_kf, hipMemcpyDeviceToDevice, s));
@@ -2481,10 +2591,29 @@ extern "C" int qsp_ba_optimize(qsp_ba_problem* p, int32_t n_iter, double delta_m
             // update (oplus) + rho denominator
             hipLaunchKernelGGL(k_update_points, dim3(gp), dim3(256), 0, s, d, par);
             hipLaunchKernelGGL(k_update_poses, dim3(1), dim3(256), 0, s, d, par, gp);
-            launch_errors(p, par);
-            rc = reduce_scalars(p);
-            if (rc) return rc;
-            rc = read_scal(p, sc);
+            if (p->world == 1) {     // chi2 sum and publish in one launch
+                const int n_tot = d.n_edge + d.n_oe;
+                const int grid = std::max(1, std::min(p->n_partial, (n_tot + 255) / 256));
+                hipLaunchKernelGGL(k_errors, dim3(grid), dim3(256), 0, s, d, par);
+                hipLaunchKernelGGL(k_finish_sum_publish, dim3(1), dim3(64), 0, s, d, grid, p->scal_host_dev);
+                QSP_HIP(hipEventRecord(p->ev_scal, s));
+            } else {
+                launch_errors(p, par);
+                rc = reduce_scalars(p);
+                if (rc) return rc;
+                rc = publish_scal(p);
+                if (rc) return rc;
+            }
+            // A trial is accepted far more often than not, and the next iteration then linearises exactly the estimates the
+            // device holds now: enqueue that system BEHIND the publish and only then wait for the verdict -- the read-back and
+            // the host's turn-around hide behind ~50 us of device work.  If the trial is rejected the speculated system (of the
+            // estimates about to be rolled back) is rebuilt after the restore.
+            const bool spec = p->speculate && it + 1 < n_iter;
+            if (spec) {
+                rc = enqueue_lin(false);
+                if (rc) return rc;
+            }
+            rc = wait_scal(p, sc);
             if (rc) return rc;
             const bool ok2 = sc[3] == 0.0;
             double tempChi = ok2 ? sc[0] : DBL_MAX;
@@ -2498,6 +2627,7 @@ extern "C" int qsp_ba_optimize(qsp_ba_problem* p, int32_t n_iter, double delta_m
                 ni = 2;
                 currentChi = tempChi;
                 accepted = 1;
+                lin_ready = spec;
             } else {
                 lambda *= ni;
                 ni *= 2;
@@ -2505,6 +2635,10 @@ extern "C" int qsp_ba_optimize(qsp_ba_problem* p, int32_t n_iter, double delta_m
                 if (d.n_obj) QSP_HIP(hipMemcpyAsync(d.obj_pose, d.obj_bk, sizeof(double) * 7 * d.n_obj, hipMemcpyDeviceToDevice, s));
                 if (d.n_pt) QSP_HIP(hipMemcpyAsync(d.pt_xyz, d.pt_bk, sizeof(double) * 3 * d.n_pt, hipMemcpyDeviceToDevice, s));
                 accepted = 0;
+                if (spec) {      // the speculated system overwrote this iteration's: rebuild it for the restored estimates
+                    rc = enqueue_lin(false);
+                    if (rc) return rc;
+                }
             }
             qmax++;
             p->prof.n_trials++;
@@ -2528,7 +2662,14 @@ extern "C" int qsp_ba_optimize(qsp_ba_problem* p, int32_t n_iter, double delta_m
         (void)hipEventRecord(ev1, s);
         hipEventSynchronize(ev1);
         (void)hipEventElapsedTime(&p->prof.ms_total, ev0, ev1);
-        (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1); (void)hipEventDestroy(evA); (void)hipEventDestroy(evB);
+        (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
+        for (size_t i = 0; i + 1 < lin_ev.size(); i += 2) {      // every system built, the speculated ones included
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, lin_ev[i], lin_ev[i + 1]);
+            p->prof.ms_linearize += ms;
+            p->prof.n_linearize++;
+        }
+        for (hipEvent_t e : lin_ev) (void)hipEventDestroy(e);
         // algorithmic bytes of one linearisation
         int64_t nm = 0, ns = 0, no = 0;
         for (int e = 0; e < d.n_edge; ++e)
@@ -2599,22 +2740,47 @@ extern "C" int qsp_ba_local_joint(qsp_ba_problem* p, const volatile uint8_t* sto
     if (!p) return qsp_fail(QSP_ERR_INVALID, "qsp_ba_local_joint: null problem");
     const float thMono = sqrtf(5.991f), thStereo = sqrtf(7.815f), thObj = sqrtf(1e3f);
     if (stop_flag && *stop_flag) return QSP_OK;                                   // :589-596
+    static const bool tm = getenv("QSP_BA_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
     int rc = qsp_ba_set_levels(p, nullptr, nullptr, nullptr);
+    const double t1s = now();
     if (!rc) rc = qsp_ba_optimize(p, 5, (double)(float)sqrt(5.991), (double)(float)sqrt(7.815), (double)thObj, stop_flag, t1);
     (void)thMono; (void)thStereo;
     if (rc) return rc;
+    const double t2s = now();
     if (stop_flag && *stop_flag) return QSP_OK;                                   // :603-610 (no write-back by the caller)
     const Dev& d = p->d;
+    double t3s = t2s;
+    if (p->world == 1) {
+        // one GPU: classify where the chi2 values are; the host needs the levels only (build_index), one byte per edge
+        const int n = std::max(std::max(d.n_edge, d.n_oe), 1);
+        hipLaunchKernelGGL(k_classify_levels, dim3((n + 255) / 256), dim3(256), 0, p->stream, d, 5.991, 7.815, 1e3);
+        if (d.n_edge) QSP_HIP(hipMemcpyAsync(p->lvl_host, d.edge_level, d.n_edge, hipMemcpyDeviceToHost, p->stream));
+        if (d.n_oe) QSP_HIP(hipMemcpyAsync(p->lvl_host + d.n_edge, d.oe_level, d.n_oe, hipMemcpyDeviceToHost, p->stream));
+        QSP_HIP(hipStreamSynchronize(p->stream));
+        t3s = now();
+        if (d.n_edge) memcpy(p->edge_level_h.data(), p->lvl_host, d.n_edge);
+        if (d.n_oe) memcpy(p->oe_level_h.data(), p->lvl_host + d.n_edge, d.n_oe);
+    } else {
     std::vector<double> cm(std::max(p->n_mono, 1)), cs(std::max(p->n_stereo, 1)), co(std::max(d.n_oe, 1));
     std::vector<uint8_t> pm(std::max(p->n_mono, 1)), ps(std::max(p->n_stereo, 1));
     rc = qsp_ba_get_edges(p, cm.data(), cs.data(), co.data(), pm.data(), ps.data());
     if (rc) return rc;
+    t3s = now();
     std::vector<uint8_t> lm(std::max(p->n_mono, 1)), ls(std::max(p->n_stereo, 1)), lo(std::max(d.n_oe, 1));
     for (int e = 0; e < p->n_mono; ++e) lm[e] = (cm[e] > 5.991 || !pm[e]) ? 1 : 0;   // :621-626
     for (int e = 0; e < p->n_stereo; ++e) ls[e] = (cs[e] > 7.815 || !ps[e]) ? 1 : 0; // :636-641
     for (int e = 0; e < d.n_oe; ++e) lo[e] = (co[e] > 1e3) ? 1 : 0;                  // :650-654
     rc = qsp_ba_set_levels(p, lm.data(), ls.data(), lo.data());
-    if (!rc) rc = qsp_ba_optimize(p, 10, 0.0, 0.0, 0.0, stop_flag, t2);              // robust kernels dropped, :628,643,655
+    if (rc) return rc;
+    }
+    const double t4s = now();
+    const double t5s = t4s;
+    rc = qsp_ba_optimize(p, 10, 0.0, 0.0, 0.0, stop_flag, t2);                       // robust kernels dropped, :628,643,655
+    if (tm)
+        fprintf(stderr, "local_joint us: set_levels %.0f  optimize(5) %.0f  get_edges %.0f  classify %.0f  set_levels %.0f  optimize(10) %.0f\n",
+                t1s - t0, t2s - t1s, t3s - t2s, t4s - t3s, t5s - t4s, now() - t5s);
     return rc;
 }
 

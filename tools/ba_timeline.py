@@ -1,0 +1,28 @@
+"""From a rocprofv3 --kernel-trace directory of tools/ba_only.py: the device timeline of the LAST local joint BA -- busy time,
+idle gaps between consecutive kernels (and which kernel follows the longest ones), per-kernel totals.
+   rocprofv3 --kernel-trace --output-format csv -d DIR -- python3 tools/ba_only.py c4 3 ;  python3 tools/ba_timeline.py DIR"""
+import csv, glob, sys, collections
+f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
+rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].split("::")[-1]) for r in csv.DictReader(open(f))]
+rows.sort()
+# one BA = from a k_errors that follows a long pause to the next long pause (> 2 ms: host-side set_state / python)
+groups, cur = [], []
+for r in rows:
+    if cur and r[0] - cur[-1][1] > 1500000:
+        groups.append(cur); cur = []
+    cur.append(r)
+groups.append(cur)
+g = [x for x in groups if len(x) > 50][-1]
+span = g[-1][1] - g[0][0]
+busy = sum(e - s for s, e, _ in g)
+gaps = collections.Counter(); gapn = collections.Counter()
+for a, b in zip(g, g[1:]):
+    gap = max(0, b[0] - a[1])
+    gaps[b[2]] += gap; gapn[b[2]] += 1
+print("kernels %d   span %.3f ms   busy %.3f ms   idle %.3f ms" % (len(g), span / 1e6, busy / 1e6, (span - busy) / 1e6))
+print("idle time in front of each kernel (total us, count, mean us):")
+for k, v in gaps.most_common(12):
+    print("  %-28s %8.1f %4d %6.1f" % (k, v / 1e3, gapn[k], v / 1e3 / gapn[k]))
+tot = collections.Counter()
+for s, e, k in g: tot[k] += e - s
+print("busy by kernel (us):", ", ".join("%s %.0f" % (k, v / 1e3) for k, v in tot.most_common(10)))
