@@ -389,15 +389,20 @@ __global__ __launch_bounds__(64) void k_finish_sum(Dev d, int n, int slot) {
 }
 // the same sum into scal[0], published to the host-visible copy together with scal[1..3] in the same launch (one rank: no
 // reduction over ranks sits between the sum and the read-back); re-arms scal[3] like k_publish_scal
-__global__ __launch_bounds__(64) void k_finish_sum_publish(Dev d, int n, double* __restrict__ host) {
+__global__ __launch_bounds__(64) void k_finish_sum_publish(Dev d, int n, double* __restrict__ host, int gp, int part_off) {
     double s = 0;
     for (int i = threadIdx.x; i < n; i += 64) s += d.partial[i];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
     if (threadIdx.x == 0) {
+        // the rho denominator: the pose block's partial, then the landmark blocks' in order (k_update_poses' summation order)
+        // (gp < 0: the update ran as two launches and k_update_poses has left the sum in scal[1])
+        double tot = gp >= 0 ? d.partial[part_off + gp] : d.scal[1];
+        for (int i = 0; i < gp; ++i) tot += d.partial[part_off + i];
         d.scal[0] = s;
+        d.scal[1] = tot;
         host[0] = s;
-        host[1] = d.scal[1];
+        host[1] = tot;
         host[2] = d.scal[2];
         host[3] = d.scal[3];
         d.scal[3] = 0.0;
@@ -1577,6 +1582,55 @@ __global__ __launch_bounds__(256) void k_update_poses(Dev d, Par par, int n_part
     }
 }
 
+// k_update_points and k_update_poses as ONE launch (one rank): blocks [0, gp) the landmarks, block gp the poses and objects; the
+// scale partials go to the second half of `partial` (k_errors reuses the first) and are summed, in k_update_poses' order, by
+// k_finish_sum_publish.
+__global__ __launch_bounds__(256) void k_update_all(Dev d, Par par, int gp, int part_off) {
+    __shared__ double sh[4];
+    double sc = 0;
+    if ((int)blockIdx.x < gp) {
+        for (int pt = blockIdx.x * 256 + threadIdx.x; pt < d.n_pt; pt += gp * 256) {
+            if (d.pt_h[pt] < 0) continue;
+            double c[3] = {d.bl[3 * (size_t)pt], d.bl[3 * (size_t)pt + 1], d.bl[3 * (size_t)pt + 2]};
+            for (int a = d.pt_off[pt]; a < d.pt_off[pt + 1]; ++a) {
+                if (d.edge_level[a]) continue;
+                const int ha = d.kf_h[d.edge[a].kf];
+                if (ha < 0) continue;
+                double B[18];
+                if (par.have_hpl) {
+                    const double* Bg = d.Hpl + 18 * (size_t)a;
+                    for (int i = 0; i < 18; ++i) B[i] = Bg[i];
+                } else {
+                    edge_hpl(d, d.edge[a], par, B);
+                }
+                for (int j = 0; j < 3; ++j)
+                    for (int i = 0; i < 6; ++i) c[j] -= B[3 * i + j] * d.xp[6 * ha + i];
+            }
+            const double* Di = d.Dinv + 9 * (size_t)pt;
+            for (int i = 0; i < 3; ++i) {
+                const double xl = Di[3 * i] * c[0] + Di[3 * i + 1] * c[1] + Di[3 * i + 2] * c[2];
+                d.pt_xyz[3 * (size_t)pt + i] += xl;
+                sc += xl * (par.lambda * xl + d.bl[3 * (size_t)pt + i]);
+            }
+        }
+    } else {
+        for (int v = threadIdx.x; v < d.n_kf + d.n_obj; v += 256) {
+            const bool is_kf = v < d.n_kf;
+            const int h = is_kf ? d.kf_h[v] : d.obj_h[v - d.n_kf];
+            if (h < 0) continue;
+            double* pose = is_kf ? d.kf_pose + 7 * v : d.obj_pose + 7 * (v - d.n_kf);
+            double dl[7], n[7];
+            se3_exp(d.xp + 6 * h, dl);
+            se3_mul(dl, pose, n);
+            for (int i = 0; i < 7; ++i) pose[i] = n[i];
+            if (par.is_root)
+                for (int i = 0; i < 6; ++i) sc += d.xp[6 * h + i] * (par.lambda * d.xp[6 * h + i] + d.bp[6 * h + i]);
+        }
+    }
+    const double s = block_sum_256(sc, sh);
+    if (threadIdx.x == 0) d.partial[part_off + blockIdx.x] = s;
+}
+
 // The outlier classification between the two rounds of LocalBundleAdjustment (src/Optimizer_util.cc:621-654) on the device:
 // level 1 = excluded from the second round.  chi2 is the value k_errors left for the last accepted estimates.
 __global__ void k_classify_levels(Dev d, double th_mono, double th_stereo, double th_obj) {
@@ -2177,7 +2231,7 @@ extern "C" int qsp_ba_create(const qsp_ba_scene* s, int device, qsp_ba_problem**
     AL(Hs, (size_t)p->dimp_max * p->dimp_max + p->dimp_max);   // + room for bs right behind the matrix
     AL(Uf, (size_t)p->dimp_max * p->dimp_max); AL(Winv, (size_t)p->dimp_max * NB); AL(ych, p->dimp_max);
     p->n_partial = 1024;
-    AL(partial, p->n_partial);
+    AL(partial, 2 * p->n_partial + 8);     // [0, n_partial): chi2 partials of k_errors / update partials; [n_partial, ..): k_update_all
     AL(scal, 8);
 #undef UP
 #undef AL
@@ -2589,15 +2643,24 @@ extern "C" int qsp_ba_optimize(qsp_ba_problem* p, int32_t n_iter, double delta_m
                 hipLaunchKernelGGL(k_schur_dinv, dim3((d.n_pt + 255) / 256), dim3(256), 0, s, d, par);   // only D^-1 is needed
             }
             // update (oplus) + rho denominator
-            hipLaunchKernelGGL(k_update_points, dim3(gp), dim3(256), 0, s, d, par);
-            hipLaunchKernelGGL(k_update_poses, dim3(1), dim3(256), 0, s, d, par, gp);
-            if (p->world == 1) {     // chi2 sum and publish in one launch
+            if (p->world == 1) {     // one rank: update in one launch; chi2 sum, rho denominator and publish in one launch
+                // (one launch only with the 6x3 blocks of this build in memory: recomputed blocks read the poses the pose
+                //  block of the same launch is rewriting)
+                const bool one = par.have_hpl != 0;
+                if (one) {
+                    hipLaunchKernelGGL(k_update_all, dim3(gp + 1), dim3(256), 0, s, d, par, gp, p->n_partial);
+                } else {
+                    hipLaunchKernelGGL(k_update_points, dim3(gp), dim3(256), 0, s, d, par);
+                    hipLaunchKernelGGL(k_update_poses, dim3(1), dim3(256), 0, s, d, par, gp);
+                }
                 const int n_tot = d.n_edge + d.n_oe;
                 const int grid = std::max(1, std::min(p->n_partial, (n_tot + 255) / 256));
                 hipLaunchKernelGGL(k_errors, dim3(grid), dim3(256), 0, s, d, par);
-                hipLaunchKernelGGL(k_finish_sum_publish, dim3(1), dim3(64), 0, s, d, grid, p->scal_host_dev);
+                hipLaunchKernelGGL(k_finish_sum_publish, dim3(1), dim3(64), 0, s, d, grid, p->scal_host_dev, one ? gp : -1, p->n_partial);
                 QSP_HIP(hipEventRecord(p->ev_scal, s));
             } else {
+                hipLaunchKernelGGL(k_update_points, dim3(gp), dim3(256), 0, s, d, par);
+                hipLaunchKernelGGL(k_update_poses, dim3(1), dim3(256), 0, s, d, par, gp);
                 launch_errors(p, par);
                 rc = reduce_scalars(p);
                 if (rc) return rc;
