@@ -26,3 +26,9 @@ for k, v in gaps.most_common(12):
 tot = collections.Counter()
 for s, e, k in g: tot[k] += e - s
 print("busy by kernel (us):", ", ".join("%s %.0f" % (k, v / 1e3) for k, v in tot.most_common(10)))
+if len(sys.argv) > 2:      # the kernels of one LM trial in order: start (us from the trial's first kernel), duration, gap in front
+    i0 = [i for i, r in enumerate(g) if r[2] == "k_trial_stage1"][int(sys.argv[2])]
+    t0 = g[i0][0]
+    for j in range(i0 - 3, i0 + 16):
+        s_, e_, k_ = g[j]
+        print("  %-24s start %8.1f  dur %6.1f  gap %6.1f" % (k_, (s_ - t0) / 1e3, (e_ - s_) / 1e3, (s_ - g[j - 1][1]) / 1e3))
