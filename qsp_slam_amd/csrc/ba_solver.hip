@@ -26,6 +26,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <vector>
 
@@ -389,7 +390,7 @@ __global__ __launch_bounds__(64) void k_finish_sum(Dev d, int n, int slot) {
 }
 // the same sum into scal[0], published to the host-visible copy together with scal[1..3] in the same launch (one rank: no
 // reduction over ranks sits between the sum and the read-back); re-arms scal[3] like k_publish_scal
-__global__ __launch_bounds__(64) void k_finish_sum_publish(Dev d, int n, double* __restrict__ host, int gp, int part_off) {
+__global__ __launch_bounds__(64) void k_finish_sum_publish(Dev d, int n, double* __restrict__ host, int gp, int part_off, double seq) {
     double s = 0;
     for (int i = threadIdx.x; i < n; i += 64) s += d.partial[i];
 #pragma unroll
@@ -406,14 +407,20 @@ __global__ __launch_bounds__(64) void k_finish_sum_publish(Dev d, int n, double*
         host[2] = d.scal[2];
         host[3] = d.scal[3];
         d.scal[3] = 0.0;
+        __threadfence_system();
+        *reinterpret_cast<volatile double*>(host + 4) = seq;
     }
 }
 
 // scal[0..3] -> the host-visible copy; scal[3] (the "a block was not positive definite" flag of a trial) is re-armed for the
 // next trial here, which saves a memset launch per trial
-__global__ void k_publish_scal(Dev d, double* __restrict__ host) {
-    if (threadIdx.x < 4) host[threadIdx.x] = d.scal[threadIdx.x];
-    if (threadIdx.x == 3) d.scal[3] = 0.0;
+__global__ void k_publish_scal(Dev d, double* __restrict__ host, double seq) {
+    if (threadIdx.x == 0) {
+        for (int i = 0; i < 4; ++i) host[i] = d.scal[i];
+        d.scal[3] = 0.0;
+        __threadfence_system();
+        *reinterpret_cast<volatile double*>(host + 4) = seq;      // the host polls this word (wait_scal)
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1955,7 +1962,7 @@ struct qsp_ba_problem {
     bool profiling = false;
     double* scal_host = nullptr; // pinned, device-visible copy of scal[0..3] (k_publish_scal): read back without a copy engine hop
     double* scal_host_dev = nullptr;
-    hipEvent_t ev_scal = nullptr;
+    double scal_seq = 0.0;       // sequence number of the last read-back enqueued
     bool speculate = true;       // enqueue the next iteration's linearisation before waiting for a trial's verdict
     uint8_t* lvl_host = nullptr; // pinned: edge / object-edge levels classified on the device (qsp_ba_local_joint)
     int32_t* idx_host = nullptr; // pinned staging of the hessian indices [kf | obj | pt]
@@ -2243,7 +2250,7 @@ extern "C" int qsp_ba_create(const qsp_ba_scene* s, int device, qsp_ba_problem**
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipHostMalloc((void**)&p->scal_host, 8 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent);
         if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&p->scal_host_dev, p->scal_host, 0);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_scal, hipEventDisableTiming);
+        if (e == hipSuccess) p->scal_host[4] = 0.0;
         if (e == hipSuccess) e = hipHostMalloc((void**)&p->lvl_host, (size_t)std::max(d.n_edge + d.n_oe, 1), hipHostMallocDefault);
         if (e == hipSuccess) e = hipHostMalloc((void**)&p->idx_host, sizeof(int32_t) * (size_t)std::max(d.n_kf + d.n_obj + d.n_pt, 1), hipHostMallocDefault);
         const int chol_lds = (int)(sizeof(double) * CHOL_LDS_DOUBLES);
@@ -2278,7 +2285,6 @@ extern "C" void qsp_ba_destroy(qsp_ba_problem* p) {
     if (p->scal_host) (void)hipHostFree(p->scal_host);
     if (p->lvl_host) (void)hipHostFree(p->lvl_host);
     if (p->idx_host) (void)hipHostFree(p->idx_host);
-    if (p->ev_scal) (void)hipEventDestroy(p->ev_scal);
     if (p->stream) (void)hipStreamDestroy(p->stream);
     delete p;
 }
@@ -2366,12 +2372,28 @@ static void build_index(qsp_ba_problem* p) {
 // path and sat 41 us (C4) / 124 us (C5) idle in front of every read-back, profiles/r02_ba_timeline.txt.)  Two phases so that
 // work can be enqueued between the publish and the wait.
 static int publish_scal(qsp_ba_problem* p) {
-    hipLaunchKernelGGL(k_publish_scal, dim3(1), dim3(64), 0, p->stream, p->d, p->scal_host_dev);
-    QSP_HIP(hipEventRecord(p->ev_scal, p->stream));
+    p->scal_seq += 1.0;
+    hipLaunchKernelGGL(k_publish_scal, dim3(1), dim3(64), 0, p->stream, p->d, p->scal_host_dev, p->scal_seq);
     return QSP_OK;
 }
+// The publishing kernel writes the sequence number of the read-back last (system-scope fence in front of it); the host polls
+// that word in coherent pinned memory and sees the scalars a few microseconds after the kernel, with no event object or
+// signal packet in the stream.  (The ~10 us in front of the kernel that follows the publish are the system-scope release of a
+// kernel that wrote host memory: they were there with an event record as well.)
 static int wait_scal(qsp_ba_problem* p, double* out4) {
-    QSP_HIP(hipEventSynchronize(p->ev_scal));
+    volatile double* seq = p->scal_host + 4;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint64_t spin = 0; *seq != p->scal_seq; ++spin) {
+        if ((spin & 0xFFFF) == 0xFFFF) {     // a faulted or wedged kernel must not hang the caller: ask the runtime now and then
+            const hipError_t e = hipStreamQuery(p->stream);
+            if (e != hipSuccess && e != hipErrorNotReady) return qsp_fail(QSP_ERR_DEVICE, hipGetErrorString(e));
+            if (e == hipSuccess && *seq != p->scal_seq)     // the stream has drained: the word is visible at the latest now
+                return qsp_fail(QSP_ERR_DEVICE, "BA scalar read-back: sequence word never arrived");
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30))
+                return qsp_fail(QSP_ERR_DEVICE, "BA scalar read-back timed out");
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
     for (int i = 0; i < 4; ++i) out4[i] = p->scal_host[i];
     return QSP_OK;
 }
@@ -2656,8 +2678,9 @@ extern "C" int qsp_ba_optimize(qsp_ba_problem* p, int32_t n_iter, double delta_m
                 const int n_tot = d.n_edge + d.n_oe;
                 const int grid = std::max(1, std::min(p->n_partial, (n_tot + 255) / 256));
                 hipLaunchKernelGGL(k_errors, dim3(grid), dim3(256), 0, s, d, par);
-                hipLaunchKernelGGL(k_finish_sum_publish, dim3(1), dim3(64), 0, s, d, grid, p->scal_host_dev, one ? gp : -1, p->n_partial);
-                QSP_HIP(hipEventRecord(p->ev_scal, s));
+                p->scal_seq += 1.0;
+                hipLaunchKernelGGL(k_finish_sum_publish, dim3(1), dim3(64), 0, s, d, grid, p->scal_host_dev, one ? gp : -1, p->n_partial,
+                                   p->scal_seq);
             } else {
                 hipLaunchKernelGGL(k_update_points, dim3(gp), dim3(256), 0, s, d, par);
                 hipLaunchKernelGGL(k_update_poses, dim3(1), dim3(256), 0, s, d, par, gp);
