@@ -56,6 +56,9 @@ FLOP_FWDBWD = 2.0 * FLOP_FWD      # forward + backward-data
 PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # same table, "Peak BF16/FP16 MFMA", dense
 PRODUCTS = {"f32": 1, "bf16x3": 6, "fp16x2": 3}     # matrix-pipe products per algorithmic multiply-add
+# what the fp16 pipe SUSTAINS with realistic operands and nothing else running (bare v_mfma_f32_32x32x16_f16 loop on every SIMD,
+# tools/micro/mfma_rate_f16.hip -> profiles/r02_mfma_rate_f16.txt): switching power draws the clock from 2.4 to 1.6 GHz
+SUSTAINED_FP16_MFMA_TFLOPS = 1668.0
 
 
 def peak_for(precision):
@@ -479,6 +482,11 @@ def main():
                          "peak_note": ("dense 16-bit MFMA peak 2500 TFLOP/s / %d products per algorithmic multiply-add"
                                        % PRODUCTS[pr] if split else "f32 MFMA peak"),
                          "matrix_pipe_TFLOPs": PRODUCTS[pr] * m["jtj"]["achieved"] if split else None,
+                         "frac_of_sustained_pipe_rate": (PRODUCTS[pr] * m["jtj"]["achieved"] / SUSTAINED_FP16_MFMA_TFLOPS
+                                                         if pr == "fp16x2" else None),
+                         "sustained_note": ("bare fp16 MFMA loop with random operands on all SIMDs: %.0f TFLOP/s at 1.6 GHz "
+                                            "(profiles/r02_mfma_rate_f16.txt); `peak` is the data-sheet figure at 2.4 GHz"
+                                            % SUSTAINED_FP16_MFMA_TFLOPS) if pr == "fp16x2" else None,
                          "effective_vs_f32_mfma_peak": m["jtj"]["achieved"] / PEAK_F32_MFMA_TFLOPS,
                          "traffic": traffic,
                          "traffic_unit": "bytes/launch, rocprofv3 PMC passes of this command (profiles/%s)" % traffic_src,
