@@ -20,10 +20,11 @@ from qsp_slam_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def gpu_decoder(golden_dir):
+@pytest.fixture(scope="module", params=["f32", "fp16x2"])     # the exact-f32 pipe and bench.py's default pipe
+def gpu_decoder(golden_dir, request):
     from qsp_slam_amd import DeepSdfDecoder
     d = DeepSdfDecoder.from_npz(os.path.join(golden_dir, "decoder_8x512.npz"))
+    d.set_precision(request.param)
     yield d
     d.close()
 
