@@ -13,6 +13,10 @@
 //   k_solve       fixed-order reduction of the tile partials, priors, damping, 71x71 solve, exp_sim3, state update
 //                 (optimizer.py:231-263)
 //
+// (plus k_c0 and k_plan: per-hypothesis bias vectors and the work queues of the two MLP kernels.)  The two MLP kernels exist
+// per decoder pipe (qsp_decoder_set_option): k_mlp_fwd<false> / k_mlp_jtj<false> on the exact-f32 matrix pipe, <true> with three
+// bf16 terms per operand, k_mlp_fwd_h2 / k_mlp_jtj_h2 with two fp16 terms (four waves per workgroup, sdf_mlp.hpp).
+//
 // The reference does the same work as ~60 small torch launches and ~10 host synchronisations per iteration,
 // per hypothesis, serially.
 #include <hip/hip_runtime.h>
