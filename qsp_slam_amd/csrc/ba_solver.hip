@@ -484,6 +484,40 @@ __device__ __forceinline__ void lin_points_block(const Dev& d, const Par& par, c
     __shared__ double sh[256][9 + 1];
     const int p0 = d.chunk_pt[bid], p1 = d.chunk_pt[bid + 1];
     const int e0 = d.pt_off[p0], e1 = d.pt_off[p1];
+    if (e1 - e0 > 256) {
+        // a chunk of ONE landmark with more than 256 observations (qsp_ba_create gives such a landmark a chunk of its own):
+        // windows of 256 edges, nine threads carry the nine running sums over the windows in edge order
+        double run = 0;
+        for (int w0 = e0; w0 < e1; w0 += 256) {
+            const int ew = w0 + threadIdx.x;
+            double v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+            if (ew < e1 && !d.edge_level[ew]) {
+                const Edge E = d.edge[ew];
+                if (E.stereo) lin_point_edge<3>(d, E, ew, par.delta_stereo, v);
+                else lin_point_edge<2>(d, E, ew, par.delta_mono, v);
+            }
+            __syncthreads();                 // (the previous window's sums have been read)
+            for (int i = 0; i < 9; ++i) sh[threadIdx.x][i] = v[i];
+            __syncthreads();
+            if (threadIdx.x < 9) {
+                const int nq = min(256, e1 - w0);
+                for (int q = 0; q < nq; ++q) run += sh[q][threadIdx.x];
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 9) sh[0][threadIdx.x] = run;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const double* a = sh[0];
+            double* H = d.Hll + 9 * (size_t)p0;
+            H[0] = a[0]; H[1] = a[1]; H[2] = a[2];
+            H[3] = a[1]; H[4] = a[3]; H[5] = a[4];
+            H[6] = a[2]; H[7] = a[4]; H[8] = a[5];
+            double* bl = d.bl + 3 * (size_t)p0;
+            bl[0] = a[6]; bl[1] = a[7]; bl[2] = a[8];
+        }
+        return;
+    }
     const int ei = e0 + threadIdx.x;
     double v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (ei < e1 && !d.edge_level[ei]) {
@@ -2169,13 +2203,15 @@ extern "C" int qsp_ba_create(const qsp_ba_scene* s, int device, qsp_ba_problem**
     {
         int begin = 0;
         for (int pt = 0; pt < d.n_pt; ++pt) {
-            if (p->pt_off_h[pt + 1] - p->pt_off_h[pt] > 256) {
-                delete p;
-                return qsp_fail(QSP_ERR_UNSUPPORTED, "qsp_ba_create: a map point with more than 256 observations");
-            }
-            if (p->pt_off_h[pt + 1] - p->pt_off_h[begin] > 256 || pt - begin >= 256) {
+            // a landmark with more than 256 observations forms a chunk of its own (the kernel walks it in windows)
+            const bool heavy = p->pt_off_h[pt + 1] - p->pt_off_h[pt] > 256;
+            if (pt > begin && (heavy || p->pt_off_h[pt + 1] - p->pt_off_h[begin] > 256 || pt - begin >= 256)) {
                 chunk_pt.push_back(pt);
                 begin = pt;
+            }
+            if (heavy && pt + 1 < d.n_pt) {
+                chunk_pt.push_back(pt + 1);
+                begin = pt + 1;
             }
         }
         chunk_pt.push_back(d.n_pt);

@@ -14,8 +14,8 @@
 //
 // The reference's two source files are compiled INTO this unit, unchanged, under the class name OptimizerG2O (they stay on
 // disk, they only leave the CMake list).  That gives the CPU pass-throughs above and the fallback: the reference's bundle
-// adjustments cannot fail, the GPU path can (no device, out of device memory, a graph outside the supported limits such as a
-// map point with more than 256 observations) -- when an OptimizerHip entry point reports an error it has left the map as it
+// adjustments cannot fail, the GPU path can (no device, out of device memory for the dense reduced system) -- when an
+// OptimizerHip entry point reports an error it has left the map as it
 // found it, the error text is logged, and the same call is handed to the g2o implementation.
 //
 // Build (in the reference tree):  copy this file to src/, replace the two entries of CMakeLists.txt:107-108 by

@@ -72,6 +72,26 @@ def test_single_stage_matches_oracle(name):
     gpu.close()
 
 
+@pytest.mark.parametrize("mode", ["deterministic", "atomic"])
+def test_landmarks_with_more_than_256_observations(mode):
+    """260 key-frames, every landmark observed by all of them (> 256 edges per landmark): the landmark pass walks such a landmark
+    in windows of 256 edges; before, qsp_ba_create refused the scene (and the drop-in Optimizer fell back to g2o)"""
+    from qsp_slam_amd.ba import BaProblem
+    sc = synth.make_ba_scene_large(11, 260, 60, obs_per_pt=260)
+    ref = bo.BaProblem(sc)
+    tr = ref.optimize(2, 0.0, 0.0, 0.0)
+    gpu = BaProblem(sc)
+    gpu.set_deterministic(mode == "deterministic")
+    tg = gpu.optimize(2, 0.0, 0.0, 0.0)
+    assert np.array_equal(tg["kf_hidx"], tr["kf_hidx"]) and np.array_equal(tg["pt_hidx"], tr["pt_hidx"])
+    assert list(tg["trials"]) == list(tr["trials"]) and list(tg["accepted"]) == list(tr["accepted"])
+    assert close(tg["chi2"], tr["chi2"], rtol=1e-8) and close(tg["lam"], tr["lam"], rtol=1e-8)
+    kf, pt, ob = gpu.state()
+    rkf, rpt, rob = ref.state()
+    assert close(kf, rkf, rtol=1e-7, atol=1e-9) and close(pt, rpt, rtol=1e-7, atol=1e-9)
+    gpu.close()
+
+
 @pytest.mark.parametrize("name", ["tiny", "mono", "c2", "two_fixed"])
 def test_local_joint_ba_two_stage_matches_oracle(name):
     """Optimizer::LocalJointBundleAdjustment schedule: same outlier set, same LM path, same estimates"""
