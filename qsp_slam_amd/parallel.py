@@ -107,9 +107,13 @@ class RcclComm(object):
         L = _lib.lib()
         self.rank, self.world, self.device = int(rank), int(world), int(device)
         ident = (C.c_uint8 * 128)()
+        raw, err = bytes(ident), None
         if self.rank == 0:
-            _lib.check(L.qsp_comm_unique_id(ident))
-        raw = bytes(ident)
+            try:
+                _lib.check(L.qsp_comm_unique_id(ident))
+                raw = bytes(ident)
+            except Exception as e:      # every rank still takes part in the exchange below: a rank 0 that raised here would
+                raw, err = b"", e       # leave the others blocked in it
         if self.world > 1:
             if exchange is None:
                 import torch.distributed as dist
@@ -118,6 +122,8 @@ class RcclComm(object):
                 raw = box[0]
             else:
                 raw = exchange(raw)
+        if len(raw) != 128:
+            raise err if err is not None else RuntimeError("RcclComm: rank 0 could not create the RCCL unique id")
         ident = (C.c_uint8 * 128).from_buffer_copy(raw)
         self.handle = C.c_void_p()
         _lib.check(L.qsp_comm_create(ident, self.rank, self.world, self.device, C.byref(self.handle)))
