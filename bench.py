@@ -359,7 +359,7 @@ def run_workload(ctx, name, steps, warmup, detailed, precision=None):
                  "ba_linearize_GBps": ba_stat["bytes_lin"] / max(lin_us, 1e-9) / 1e3,
                  "ba_linearize_frac_of_8TBps": ba_stat["bytes_lin"] / max(lin_us, 1e-9) / 1e3 / PEAK_HBM_GBPS,
                  "ba_linearize_moved_bytes": moved_lin, "ba_linearize_moved_GBps": moved_lin / max(lin_us, 1e-9) / 1e3,
-                 "ba_linearize_note": "launch-bound at the BASELINE sizes: 5 launches for a few MB; `ba_linearize_large` "
+                 "ba_linearize_note": "launch-bound at the BASELINE sizes: 2 launches for a few MB; `ba_linearize_large` "
                                       "(N = 1 only) is the same code on a graph large enough to stream"})
     if detailed:
         res["_objs"], res["_scene"], res["_hyp"], res["_T0"] = objs, scene, hyp, T0
