@@ -378,20 +378,30 @@ def latency_block(dec):
     opt = Optimizer(dec, joint_cfg(5))
     o = synth.make_object_views(3003, 1, 2000, n_fg=256, n_bg=200)[0]
     obj = dict(t_cam_obj=o["t_cam_obj"], pts=o["pts"], rays=o["rays"], depth=o["depth"])
-    for _ in range(3):
-        opt.reconstruct_object(o["t_cam_obj"], o["pts"], o["rays"], o["depth"])
     n = 20
-    t0 = time.perf_counter()
-    for _ in range(n):
-        opt.reconstruct_object(o["t_cam_obj"], o["pts"], o["rays"], o["depth"])
-    one = 1e3 * (time.perf_counter() - t0) / n
-    opt.reconstruct_objects_batched([obj], flip_sample_num=4)
-    t0 = time.perf_counter()
-    for _ in range(n):
+
+    def timed():
+        for _ in range(3):
+            opt.reconstruct_object(o["t_cam_obj"], o["pts"], o["rays"], o["depth"])
+        t0 = time.perf_counter()
+        for _ in range(n):
+            opt.reconstruct_object(o["t_cam_obj"], o["pts"], o["rays"], o["depth"])
+        one = 1e3 * (time.perf_counter() - t0) / n
         opt.reconstruct_objects_batched([obj], flip_sample_num=4)
-    four = 1e3 * (time.perf_counter() - t0) / n
-    return {"workload": "C3 stand-in: one object per call, 2000 surface points, 256+200 rays, 5 GN iterations",
-            "ms_reconstruct_object": one, "ms_four_flips_one_call": four, "calls_timed": n}
+        t0 = time.perf_counter()
+        for _ in range(n):
+            opt.reconstruct_objects_batched([obj], flip_sample_num=4)
+        return one, 1e3 * (time.perf_counter() - t0) / n
+
+    one, four = timed()
+    out = {"workload": "C3 stand-in: one object per call, 2000 surface points, 256+200 rays, 5 GN iterations",
+           "ms_reconstruct_object": one, "ms_four_flips_one_call": four, "calls_timed": n}
+    if dec.precision == "fp16x2":       # the explicit latency option: 32-point tiles in the Jacobian kernel (QSP_DEC_OPT_TILE_POINTS)
+        dec.set_tile_points(32)
+        one32, four32 = timed()
+        dec.set_tile_points(64)
+        out["tile_points_32"] = {"ms_reconstruct_object": one32, "ms_four_flips_one_call": four32}
+    return out
 
 
 def main():

@@ -80,8 +80,15 @@ void qsp_decoder_destroy(qsp_decoder* dec);
  *                limit).  A DeepSDF decoder's activations are O(10).
  * QSP_DEC_OPT_JACOBIAN_PRECISION selects the same (0, 1, 2) for the forward+backward pass that builds the Jacobian rows and the
  * normal equations (qsp_sdf_value_grad and the fused kernel of the refinement, reconstruct/loss_utils.py:82-103): that pass has
- * no discrete decision besides the ReLU masks, so modes 1 and 2 move H, b by float32 rounding noise only. */
-enum { QSP_DEC_OPT_FORWARD_PRECISION = 1, QSP_DEC_OPT_JACOBIAN_PRECISION = 2 };
+ * no discrete decision besides the ReLU masks, so modes 1 and 2 move H, b by float32 rounding noise only.
+ * QSP_DEC_OPT_TILE_POINTS (64, the default, or 32): points per workgroup tile of the Jacobian / normal-equation kernel of the
+ * refinement batches created AFTER the call (the forward pass over the ray samples keeps 64).  A single object of a few
+ * thousand surface points fills only tens of the 256 CUs with 64-point tiles; 32-point tiles spread it over twice as many work
+ * items at ~0.67 of the time each -- the latency option for the reference's one-object-per-call pattern
+ * (reconstruct/optimizer.py:96-281 called from src/LocalMapping_util.cc:705-760).  Exists on the split-fp16 pipe only (both
+ * precisions = 2; qsp_refine_batch_create returns QSP_ERR_UNSUPPORTED otherwise).  The partition of the normal-equation
+ * partial sums follows the tile size, so results are bit-reproducible per tile size, not across the two. */
+enum { QSP_DEC_OPT_FORWARD_PRECISION = 1, QSP_DEC_OPT_JACOBIAN_PRECISION = 2, QSP_DEC_OPT_TILE_POINTS = 3 };
 int qsp_decoder_set_option(qsp_decoder* dec, int32_t option, int32_t value);
 
 /* decode_sdf, reconstruct/loss_utils.py:51-79.  Host pointers: code (code_len), xyz (n,3) row-major, sdf_out (n). */

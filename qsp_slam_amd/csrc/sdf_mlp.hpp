@@ -1254,14 +1254,15 @@ __device__ __forceinline__ float h2_mask_sel(float v, uint32_t m, int k) {      
 
 // Layer 0 as ONE slab of the same product: image columns 0..2 hold the point (3..15 zero), the packed matrix the three xyz
 // columns of W0 (its 64 code columns are folded into the per-hypothesis bias c0, the accumulators' initial value).
-__device__ __forceinline__ void gemm_l0_h2(const _Float16* __restrict__ img, const float4* __restrict__ w_, f32x16 (&acc)[2][4],
-                                           f32x16 (&acc2)[2][4], int lane) {
+template <int NR>
+__device__ __forceinline__ void gemm_l0_h2(const _Float16* __restrict__ img, const float4* __restrict__ w_, f32x16 (&acc)[NR][4],
+                                           f32x16 (&acc2)[NR][4], int lane) {
     gbytes w = (gbytes)w_;
     const uint32_t voff = 16u * lane;
     const _Float16* b_row = img + (lane & 31) * LDH + (lane >> 5) * 16;
-    f16x8 bh[2], bl[2];
+    f16x8 bh[NR], bl[NR];
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
+    for (int r = 0; r < NR; ++r) {
         bh[r] = *reinterpret_cast<const f16x8*>(b_row + r * 32 * LDH);
         bl[r] = *reinterpret_cast<const f16x8*>(b_row + r * 32 * LDH + 8);
     }
@@ -1269,42 +1270,45 @@ __device__ __forceinline__ void gemm_l0_h2(const _Float16* __restrict__ img, con
     for (int c = 0; c < 4; ++c) {
         const f16x8 wh = as_f16x8(ldw(w + (size_t)(c * 2 + 0) * 64 * 16, voff)), wl = as_f16x8(ldw(w + (size_t)(c * 2 + 1) * 64 * 16, voff));
 #pragma unroll
-        for (int r = 0; r < 2; ++r) QSP_MFMA_H(acc2[r][c], wl, bh[r]);
+        for (int r = 0; r < NR; ++r) QSP_MFMA_H(acc2[r][c], wl, bh[r]);
 #pragma unroll
-        for (int r = 0; r < 2; ++r) QSP_MFMA_H(acc2[r][c], wh, bl[r]);
+        for (int r = 0; r < NR; ++r) QSP_MFMA_H(acc2[r][c], wh, bl[r]);
 #pragma unroll
-        for (int r = 0; r < 2; ++r) QSP_MFMA_H(acc[r][c], wh, bh[r]);
+        for (int r = 0; r < NR; ++r) QSP_MFMA_H(acc[r][c], wh, bh[r]);
     }
 }
 
-// image (64 points x 512) x a matrix packed in three column blocks (96 padded columns), as six 32x32 tiles: waves 0, 1 take
-// column blocks 0, 1 for both point blocks, waves 2, 3 column block 2 for one point block each.  out[r][g] = the lane's register
-// quad g of point block r (wave 2, 3: r = 0 only, its point block is wave - 2): columns 32 c0 + 8 g + 4 (lane >> 5) .. + 3.
-template <int PF>
+// image (32 NR points x 512) x a matrix packed in three column blocks (96 padded columns), as 32x32 tiles.  NR = 2 (six tiles):
+// waves 0, 1 take column blocks 0, 1 for both point blocks, waves 2, 3 column block 2 for one point block each.  NR = 1 (three
+// tiles): waves 0..2 one column block each, wave 3 idle.  side_c0 / side_row / side_count say which tiles a wave holds;
+// out[r][g] = the lane's register quad g of its r-th tile: columns 32 c0 + 8 g + 4 (lane >> 5) .. + 3.
+template <int NR> __device__ __forceinline__ int side_c0(int wave) { return NR == 2 ? (wave < 2 ? wave : 2) : wave; }
+template <int NR> __device__ __forceinline__ int side_count(int wave) { return NR == 2 ? (wave < 2 ? 2 : 1) : (wave < 3 ? 1 : 0); }
+template <int NR> __device__ __forceinline__ int side_row(int wave, int r) { return NR == 2 ? (wave < 2 ? r : wave - 2) : 0; }
+template <int PF, int NR>
 __device__ __forceinline__ void gemm_side_h2(const _Float16* __restrict__ img, const float4* __restrict__ wb, int wave, int lane,
-                                             f32x4 (&out)[2][4]) {
+                                             f32x4 (&out)[NR][4]) {
     constexpr int KSH = HID / 16, CS = KSH * 2 * 64;
-    const int c0 = wave < 2 ? wave : 2;
-    const int r0 = wave < 2 ? 0 : wave - 2;
-    const float4* w0 = wb + (size_t)(c0 * KSH * 2) * 64;
+    const int c0 = side_c0<NR>(wave);
+    const float4* w0 = wb + (size_t)((c0 < 3 ? c0 : 0) * KSH * 2) * 64;
     WRingH<PF, 1> ring0;
-    f32x16 g0[2][1], g2[2][1];
+    f32x16 g0[NR][1], g2[NR][1];
 #pragma unroll
-    for (int r = 0; r < 2; ++r)
+    for (int r = 0; r < NR; ++r)
 #pragma unroll
         for (int i = 0; i < 16; ++i) { g0[r][0][i] = 0.f; g2[r][0][i] = 0.f; }
-    if (wave < 2) {
-        gemm_h2<KSH, PF, 1, 2, false>(img, w0, CS, w0, CS, ring0, g0, g2, lane);
-    } else {
+    if (side_count<NR>(wave) == NR) {
+        gemm_h2<KSH, PF, 1, NR, false>(img, w0, CS, w0, CS, ring0, g0, g2, lane);
+    } else if (side_count<NR>(wave) == 1) {          // (NR == 2 only: one of the two point blocks)
         f32x16 g01[1][1], g21[1][1];
 #pragma unroll
         for (int i = 0; i < 16; ++i) { g01[0][0][i] = 0.f; g21[0][0][i] = 0.f; }
-        gemm_h2<KSH, PF, 1, 1, false>(img + r0 * 32 * LDH, w0, CS, w0, CS, ring0, g01, g21, lane);
+        gemm_h2<KSH, PF, 1, 1, false>(img + side_row<NR>(wave, 0) * 32 * LDH, w0, CS, w0, CS, ring0, g01, g21, lane);
         g0[0][0] = g01[0][0];
         g2[0][0] = g21[0][0];
     }
 #pragma unroll
-    for (int r = 0; r < 2; ++r)
+    for (int r = 0; r < NR; ++r)
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -1314,7 +1318,7 @@ __device__ __forceinline__ void gemm_side_h2(const _Float16* __restrict__ img, c
 // Network on the split-fp16 pipe for the tile staged in s.code / s.xin / s.c0 / s.c4, 256 threads.  On return s.y[row] = sdf
 // value and, with BWD, rows of d sdf / d [code | xyz] in s.act (row stride LDG) like mlp_tile<true>.  amax: running maximum of
 // the magnitudes this thread has split (the caller compares it with H2_MAX once per kernel).
-template <bool BWD, int PF, bool HAND = !BWD>
+template <bool BWD, int PF, bool HAND = !BWD, int NR = 2>     // NR: point blocks of 32 (tile of 64 or 32 points)
 __device__ __forceinline__ void mlp_tile_h2(MlpSmem& s, const MlpParams* __restrict__ Pm, float& amax, bool stage = true) {
     static_assert(!(BWD && HAND), "the forward+backward tile fetches each matrix's first slabs itself (layer 7 would hand over to the wrong one)");
     int hts_n = 0;
@@ -1330,8 +1334,9 @@ __device__ __forceinline__ void mlp_tile_h2(MlpSmem& s, const MlpParams* __restr
     int oz;
     asm volatile("s_mov_b32 %0, 0" : "=s"(oz));
     const MlpParams& P = Pm[oz];
-    f32x16 acc[2][4], acc2[2][4];
-    uint32_t mk[8][2][2];                                  // ReLU masks [layer][row block][column-block pair]
+    constexpr int TP = 32 * NR;
+    f32x16 acc[NR][4], acc2[NR][4];
+    uint32_t mk[8][NR][2];                                  // ReLU masks [layer][row block][column-block pair]
     _Float16* img = reinterpret_cast<_Float16*>(s.act);
     float* bias_sh = s.stash;                              // [7][512] biases of layers 1..7 (the stash is free until layer 4's backward)
     if (stage) {      // constants of the decoder: once per workgroup for a forward-only kernel (nothing else writes them there)
@@ -1340,7 +1345,7 @@ __device__ __forceinline__ void mlp_tile_h2(MlpSmem& s, const MlpParams* __restr
         for (int l = 1; l < 8; ++l)
             for (int i = tid; i < HID; i += H2_THREADS) bias_sh[(l - 1) * HID + i] = P.bias[l][i];
     }
-    if (tid < TILE_P) {       // the point as slab 0 of the image: columns 0..2 = xyz split, 3..15 zero
+    if (tid < TP) {       // the point as slab 0 of the image: columns 0..2 = xyz split, 3..15 zero
         const f32x4 x = lds4(s.xin + 4 * tid);
         f16x8 hi, lo, z;
 #pragma unroll
@@ -1370,7 +1375,7 @@ __device__ __forceinline__ void mlp_tile_h2(MlpSmem& s, const MlpParams* __restr
 #define QSP_FWDH(L, BIASPTR, GEMM_STMT)                                                                                  \
     _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {                  \
         const f32x4 bv_ = lds4((BIASPTR) + 128 * wave + 32 * c_ + 8 * g_ + 4 * h);                                       \
-        _Pragma("unroll") for (int r_ = 0; r_ < 2; ++r_) _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {              \
+        _Pragma("unroll") for (int r_ = 0; r_ < NR; ++r_) _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {             \
             acc[r_][c_][4 * g_ + q_] = bv_[q_];                                                                          \
             acc2[r_][c_][4 * g_ + q_] = 0.f;                                                                             \
         }                                                                                                                \
@@ -1382,10 +1387,10 @@ __device__ __forceinline__ void mlp_tile_h2(MlpSmem& s, const MlpParams* __restr
     __syncthreads();                                                                                                     \
     QSP_HTS()                                                                                                            \
     {                                                                                                                    \
-        uint32_t m_[2][2] = {{0, 0}, {0, 0}};                                                                            \
+        uint32_t m_[NR][2] = {};                                                                                         \
         _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {              \
             const int u0_ = 128 * wave + 32 * c_ + 8 * g_ + 4 * h;                                                       \
-            _Pragma("unroll") for (int r_ = 0; r_ < 2; ++r_) {                                                           \
+            _Pragma("unroll") for (int r_ = 0; r_ < NR; ++r_) {                                                          \
                 f32x4 v_;                                                                                                \
                 _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                       \
                     const float x_ = fmaf(acc2[r_][c_][4 * g_ + q_], 0.00048828125f, acc[r_][c_][4 * g_ + q_]);         \
@@ -1396,7 +1401,7 @@ __device__ __forceinline__ void mlp_tile_h2(MlpSmem& s, const MlpParams* __restr
             }                                                                                                            \
             __builtin_amdgcn_sched_barrier(0);     /* one register quad pair at a time: bounded temporaries */            \
         }                                                                                                                \
-        _Pragma("unroll") for (int r_ = 0; r_ < 2; ++r_) _Pragma("unroll") for (int cp_ = 0; cp_ < 2; ++cp_) {           \
+        _Pragma("unroll") for (int r_ = 0; r_ < NR; ++r_) _Pragma("unroll") for (int cp_ = 0; cp_ < 2; ++cp_) {          \
             asm volatile("" : "+v"(m_[r_][cp_]));                                                                        \
             mk[L][r_][cp_] = m_[r_][cp_];                                                                                \
         }                                                                                                                \
@@ -1404,12 +1409,12 @@ __device__ __forceinline__ void mlp_tile_h2(MlpSmem& s, const MlpParams* __restr
     QSP_HTS()                                                                                                            \
     __syncthreads();                                                                                                     \
     QSP_HTS()
-#define QSP_GEMMF(L, KS_, NW, NKS) gemm_h2<KS_, PF, 4, 2, HAND>(img, QSP_WH(L, KS_), (KS_) * 2 * 64, NW, (NKS) * 2 * 64, ring, acc, acc2, lane)
-    QSP_FWDH(0, s.c0, gemm_l0_h2(img, QSP_WH(0, 1), acc, acc2, lane))
+#define QSP_GEMMF(L, KS_, NW, NKS) gemm_h2<KS_, PF, 4, NR, HAND>(img, QSP_WH(L, KS_), (KS_) * 2 * 64, NW, (NKS) * 2 * 64, ring, acc, acc2, lane)
+    QSP_FWDH(0, s.c0, gemm_l0_h2<NR>(img, QSP_WH(0, 1), acc, acc2, lane))
     QSP_FWDH(1, bias_sh + 0 * HID, QSP_GEMMF(1, KSH, QSP_WH(2, KSH), KSH))
     QSP_FWDH(2, bias_sh + 1 * HID, QSP_GEMMF(2, KSH, QSP_WH(3, KSH), KSH))
     QSP_FWDH(3, bias_sh + 2 * HID, QSP_GEMMF(3, KSH, QSP_WH(4, KS4), KS4))
-    if (tid < TILE_P * 3) {        // the skip connection's xyz into columns 445..447 (zeros from layer 3's write-out until now)
+    if (tid < TP * 3) {        // the skip connection's xyz into columns 445..447 (zeros from layer 3's write-out until now)
         const int row = tid / 3, ci = tid - row * 3;
         const float x = s.xin[row * 4 + ci];
         const _Float16 xh = (_Float16)x;
@@ -1440,13 +1445,13 @@ __device__ __forceinline__ void mlp_tile_h2(MlpSmem& s, const MlpParams* __restr
                 pa[j & 3] = fmaf(fmaf((float)lo[j], 0.00048828125f, (float)hi[j]), j < 4 ? w0[j] : w1[j - 4], pa[j & 3]);
         }
         const float part = (pa[0] + pa[1]) + (pa[2] + pa[3]);
-        s.red[wave * TILE_P + lane] = part;
+        if (lane < TP) s.red[wave * TP + lane] = part;
     }
     __syncthreads();
-    if (tid < TILE_P) {
+    if (tid < TP) {
         float t = P.b8;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) t += s.red[q * TILE_P + tid];
+        for (int q = 0; q < 4; ++q) t += s.red[q * TP + tid];
         s.y[tid] = tanhf(t);
     }
     __syncthreads();
@@ -1457,7 +1462,7 @@ __device__ __forceinline__ void mlp_tile_h2(MlpSmem& s, const MlpParams* __restr
     if constexpr (BWD) {
         // ---- backward seed: d y / d a7 = (1 - y^2) * w8[unit] * [a7 > 0] ---------------------------------------------
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
+        for (int r = 0; r < NR; ++r) {
             const int p = 32 * r + (lane & 31);
             const float yy = s.y[p];
             const float dy = 1.f - yy * yy;
@@ -1478,13 +1483,13 @@ __device__ __forceinline__ void mlp_tile_h2(MlpSmem& s, const MlpParams* __restr
         __syncthreads();
         // ---- backward through layers 7..1: g_in = g_a . W_L, masked by layer L-1; the skip gradient of layer 4 to the stash ----
 #define QSP_BWDH(L, KS_, NWB)                                                                                            \
-    _Pragma("unroll") for (int r_ = 0; r_ < 2; ++r_) _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_)                    \
+    _Pragma("unroll") for (int r_ = 0; r_ < NR; ++r_) _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_)                   \
         _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) { acc[r_][c_][i_] = 0.f; acc2[r_][c_][i_] = 0.f; }             \
-    gemm_h2<KS_, PF, 4, 2, HAND>(img, QSP_WBH(L), CS, NWB, CS, ring, acc, acc2, lane);                                         \
+    gemm_h2<KS_, PF, 4, NR, HAND>(img, QSP_WBH(L), CS, NWB, CS, ring, acc, acc2, lane);                                         \
     __syncthreads();                                                                                                     \
     _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {                  \
         const int u0_ = 128 * wave + 32 * c_ + 8 * g_ + 4 * h;                                                           \
-        _Pragma("unroll") for (int r_ = 0; r_ < 2; ++r_) {                                                               \
+        _Pragma("unroll") for (int r_ = 0; r_ < NR; ++r_) {                                                              \
             const int p_ = 32 * r_ + (lane & 31);                                                                        \
             f32x4 v_;                                                                                                    \
             _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                           \
@@ -1502,13 +1507,13 @@ __device__ __forceinline__ void mlp_tile_h2(MlpSmem& s, const MlpParams* __restr
         QSP_BWDH(5, KSH, QSP_WBH(4))
         {   // the skip connection's gradient d y / d [code | xyz] = g_a4 . W4[:, 445:512]: its own 64 x 96 product, to the stash
             // in f32 (layer 4's write-out below masks those columns to zero like any dead unit: mk[3] has no bit set there)
-            f32x4 sk[2][4];
-            gemm_side_h2<PF>(img, P.wbh4s, wave, lane, sk);
-            const int c0 = wave < 2 ? wave : 2;
+            f32x4 sk[NR][4];
+            gemm_side_h2<PF, NR>(img, P.wbh4s, wave, lane, sk);
+            const int c0 = side_c0<NR>(wave);
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                if (r == 1 && wave >= 2) break;
-                const int p = 32 * (wave < 2 ? r : wave - 2) + (lane & 31);
+            for (int r = 0; r < NR; ++r) {
+                if (r >= side_count<NR>(wave)) break;
+                const int p = 32 * side_row<NR>(wave, r) + (lane & 31);
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int k0 = 32 * c0 + 8 * g + 4 * h;
@@ -1525,15 +1530,15 @@ __device__ __forceinline__ void mlp_tile_h2(MlpSmem& s, const MlpParams* __restr
         // ---- backward through layer 0: 67 (padded 96) input columns = 2 x 3 output tiles: waves 0, 1 take column blocks 0, 1
         // for both point blocks, waves 2, 3 column block 2 (inputs 64..66) for one point block each -------------------------
         {
-            f32x4 gl[2][4];
-            gemm_side_h2<PF>(img, P.wbh[0], wave, lane, gl);
-            const int c0 = wave < 2 ? wave : 2;
+            f32x4 gl[NR][4];
+            gemm_side_h2<PF, NR>(img, P.wbh[0], wave, lane, gl);
+            const int c0 = side_c0<NR>(wave);
             __syncthreads();
             // D[i = input column within block c0][j = point]: four consecutive input columns per register quad
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                if (r == 1 && wave >= 2) break;
-                const int p = 32 * (wave < 2 ? r : wave - 2) + (lane & 31);
+            for (int r = 0; r < NR; ++r) {
+                if (r >= side_count<NR>(wave)) break;
+                const int p = 32 * side_row<NR>(wave, r) + (lane & 31);
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int k0 = 32 * c0 + 8 * g + 4 * h;

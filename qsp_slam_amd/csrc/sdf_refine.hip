@@ -72,6 +72,7 @@ struct RefineCfg {
     int32_t pose_only;      // estimate_pose_cam_obj mode
     int32_t iter;           // current iteration index (pose-only inlier filter)
     int32_t code_len;       // the decoder's code length L <= 64: code unknowns L..63 are padding (decoupled in k_solve)
+    int32_t tile_p;         // points per MLP tile: 64, or 32 (QSP_DEC_OPT_TILE_POINTS, split-fp16 pipe only)
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -257,7 +258,8 @@ __global__ __launch_bounds__(MLP_THREADS) void k_c0(const HypState* __restrict__
 
 // mode 0: forward items (h, tile) over the valid ray samples; mode 1: jtj items (h, slot), surface slots then render slots
 __global__ __launch_bounds__(1024) void k_plan(int mode, const HypState* __restrict__ st, const ObjView* __restrict__ objs,
-                                               int n_hyp, int nw_sdf, int nw_rend, int2* __restrict__ work, int* __restrict__ qctl) {
+                                               int n_hyp, int nw_sdf, int nw_rend, int2* __restrict__ work, int* __restrict__ qctl,
+                                               int tile_p) {
     __shared__ int wsum[16];
     __shared__ int carry_sh;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -267,10 +269,10 @@ __global__ __launch_bounds__(1024) void k_plan(int mode, const HypState* __restr
         const int h = base + t;
         int n_a = 0, n_b = 0;
         if (h < n_hyp && st[h].alive) {
-            if (mode == 0) n_a = (st[h].n_valid + TILE_P - 1) / TILE_P;
+            if (mode == 0) n_a = (st[h].n_valid + tile_p - 1) / tile_p;
             else {
-                n_a = min(nw_sdf, (objs[st[h].obj].n_pts + TILE_P - 1) / TILE_P);
-                n_b = min(nw_rend, (st[h].n_render + TILE_P - 1) / TILE_P);
+                n_a = min(nw_sdf, (objs[st[h].obj].n_pts + tile_p - 1) / tile_p);
+                n_b = min(nw_rend, (st[h].n_render + tile_p - 1) / tile_p);
             }
         }
         const int cnt = n_a + n_b;
@@ -357,6 +359,7 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void k_mlp_fwd(const HypState* __re
 }
 
 // the same work queue on the split-fp16 tile: four waves per workgroup (mlp_tile_h2)
+template <int NR>      // NR point blocks of 32 per tile (QSP_DEC_OPT_TPOINTS)
 __global__ __launch_bounds__(H2_THREADS) void k_mlp_fwd_h2(const HypState* __restrict__ st,
                                                             const ObjView* __restrict__ objs,
                                                             const float* __restrict__ rays, RefineCfg cfg, const MlpParams* __restrict__ P,
@@ -368,6 +371,7 @@ __global__ __launch_bounds__(H2_THREADS) void k_mlp_fwd_h2(const HypState* __res
     __shared__ float Tsh[16];
     __shared__ int s_item;
     const int n_items = qctl[0];
+    constexpr int TP = 32 * NR;
     bool staged = false;
     float amax = 0.f;
     int h_cached = -1;
@@ -393,8 +397,8 @@ __global__ __launch_bounds__(H2_THREADS) void k_mlp_fwd_h2(const HypState* __res
         }
         const float d_min = S.d_min, d_max = S.d_max;
         __syncthreads();
-        if (threadIdx.x < TILE_P) {
-            const int v = t * TILE_P + threadIdx.x;
+        if (threadIdx.x < TP) {
+            const int v = t * TP + threadIdx.x;
             float x = 0, y = 0, z = 0;
             if (v < n) {
                 const int e = rk[v];
@@ -408,10 +412,10 @@ __global__ __launch_bounds__(H2_THREADS) void k_mlp_fwd_h2(const HypState* __res
             s.xin[4 * threadIdx.x + 3] = 0.f;
         }
         __syncthreads();
-        mlp_tile_h2<false, 2>(s, P, amax, !staged);      // (the decoder's constants: staged by the first tile of the workgroup)
+        mlp_tile_h2<false, 2, true, NR>(s, P, amax, !staged);      // (the decoder's constants: staged by the first tile of the workgroup)
         staged = true;
-        if (threadIdx.x < TILE_P) {
-            const int v = t * TILE_P + threadIdx.x;
+        if (threadIdx.x < TP) {
+            const int v = t * TP + threadIdx.x;
             if (v < n) out[v] = s.y[threadIdx.x];
         }
     }
@@ -688,6 +692,7 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void k_mlp_jtj(const HypState* __re
 
 // the same kernel on the split-fp16 tile: four waves per workgroup (mlp_tile_h2<true>); the six J~^T J~ tiles on waves 0..3
 // (waves 0 and 1 carry two)
+template <int NR>      // NR point blocks of 32 per tile (QSP_DEC_OPT_TPOINTS)
 __global__ __launch_bounds__(H2_THREADS) void k_mlp_jtj_h2(const HypState* __restrict__ st,
                                                             const ObjView* __restrict__ objs,
                                                             const float* __restrict__ pts,
@@ -705,6 +710,7 @@ __global__ __launch_bounds__(H2_THREADS) void k_mlp_jtj_h2(const HypState* __res
     __shared__ float Tsh[16];
     __shared__ int s_item;
     const int n_items = qctl[2];
+    constexpr int TP = 32 * NR, SUBS = H2_THREADS / TP;      // threads per Jacobian row
     float amax = 0.f;
   for (;;) {                                   // work queue, see k_plan
     if (threadIdx.x == 0) s_item = atomicAdd(&qctl[3], 1);
@@ -742,10 +748,10 @@ __global__ __launch_bounds__(H2_THREADS) void k_mlp_jtj_h2(const HypState* __res
     const float d_min = S.d_min, d_max = S.d_max;
     const float hub = is_sdf ? cfg.b2 : cfg.b1;
 
-    for (int t = j0; t * TILE_P < n; t += stride) {
+    for (int t = j0; t * TP < n; t += stride) {
         __syncthreads();
-        if (tid < TILE_P) {
-            const int v = t * TILE_P + tid;
+        if (tid < TP) {
+            const int v = t * TP + tid;
             float x = 0, y = 0, z = 0, sc = 0.f, rr = 0.f;
             if (v < n) {
                 if (is_sdf) {
@@ -768,18 +774,18 @@ __global__ __launch_bounds__(H2_THREADS) void k_mlp_jtj_h2(const HypState* __res
             s.rres[tid] = rr;
         }
         __syncthreads();
-        mlp_tile_h2<true, 2>(s, P, amax);
+        mlp_tile_h2<true, 2, false, NR>(s, P, amax);
         // ---- Jacobian rows: J~[p] = [ s*(g_x . [I | -x^ | x]) (7) | s*g_z (64) | r~ ] -------------------------------
         // G (gradient w.r.t. [code | xyz]) sits in s.act with row stride LDG; J~ goes behind it.
         float* G = s.act;
-        float* Jt = s.act + TILE_P * LDG;     // [64][LDJ]
+        float* Jt = s.act + TILE_P * LDG;   /* (behind the 64-row G image whatever the tile size) */     // [64][LDJ]
         {
-            const int p = tid >> 2, sub = tid & 3;
+            const int p = tid / SUBS, sub = tid % SUBS;
             const float valid = s.xin[4 * p + 3];
             const float sc = s.rscale[p] * valid;
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int c = sub + 4 * q;           // code column 0..63
+            for (int q = 0; q < CODE_LEN / SUBS; ++q) {
+                const int c = sub + SUBS * q;        // code column 0..63
                 Jt[p * LDJ + 7 + c] = cfg.pose_only ? 0.f : sc * G[p * LDG + c];
             }
             if (sub == 0) {
@@ -797,7 +803,7 @@ __global__ __launch_bounds__(H2_THREADS) void k_mlp_jtj_h2(const HypState* __res
                 float w = cfg.pose_only ? 1.f : huber_w(r, hub);
                 if (is_sdf && s.rscale[p] == 0.f) w = 0.f;      // filtered-out point (pose-only inlier mask)
                 Jt[p * LDJ + 71] = valid * (w * r);
-                if (res_out && is_sdf && valid != 0.f) res_out[h * act_stride + t * TILE_P + p] = r;
+                if (res_out && is_sdf && valid != 0.f) res_out[h * act_stride + t * TP + p] = r;
             }
             if (sub == 1) {
 #pragma unroll
@@ -807,9 +813,9 @@ __global__ __launch_bounds__(H2_THREADS) void k_mlp_jtj_h2(const HypState* __res
         __syncthreads();
         if (rows_out) {   // parity-test tap: the augmented Jacobian rows exactly as the MFMA below consumes them
             float* ro = rows_out + (int64_t)h * rows_stride * NJ + (int64_t)(is_sdf ? 0 : ov.n_pts) * NJ;
-            for (int e = tid; e < TILE_P * NJ; e += H2_THREADS) {
+            for (int e = tid; e < TP * NJ; e += H2_THREADS) {
                 const int p = e / NJ, c = e - p * NJ;
-                const int v = t * TILE_P + p;
+                const int v = t * TP + p;
                 if (v < n) ro[(int64_t)v * NJ + c] = Jt[p * LDJ + c];
             }
         }
@@ -817,13 +823,13 @@ __global__ __launch_bounds__(H2_THREADS) void k_mlp_jtj_h2(const HypState* __res
             const float* A = Jt + (lane >> 5) * LDJ + 32 * ta0 + (lane & 31);
             const float* B = Jt + (lane >> 5) * LDJ + 32 * tb0 + (lane & 31);
 #pragma unroll 8
-            for (int ks = 0; ks < TILE_P / 2; ++ks) hacc[0] = mfma32t<false>(A[2 * ks * LDJ], B[2 * ks * LDJ], hacc[0]);
+            for (int ks = 0; ks < TP / 2; ++ks) hacc[0] = mfma32t<false>(A[2 * ks * LDJ], B[2 * ks * LDJ], hacc[0]);
         }
         if (wave < 2) {
             const float* A = Jt + (lane >> 5) * LDJ + 32 * ta1 + (lane & 31);
             const float* B = Jt + (lane >> 5) * LDJ + 32 * tb1 + (lane & 31);
 #pragma unroll 8
-            for (int ks = 0; ks < TILE_P / 2; ++ks) hacc[1] = mfma32t<false>(A[2 * ks * LDJ], B[2 * ks * LDJ], hacc[1]);
+            for (int ks = 0; ks < TP / 2; ++ks) hacc[1] = mfma32t<false>(A[2 * ks * LDJ], B[2 * ks * LDJ], hacc[1]);
         }
     }
     // partial slot [h][slot][tile][32][32]
@@ -920,7 +926,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(HypState* __restrict__ 
         const ObjView o = objs[S.obj];
         atomicAdd(&counters[0], (unsigned long long)(o.n_pts + S.n_render));
         atomicAdd(&counters[1], (unsigned long long)S.n_valid);
-        atomicAdd(&counters[2], (unsigned long long)((o.n_pts + TILE_P - 1) / TILE_P + (S.n_render + TILE_P - 1) / TILE_P));
+        atomicAdd(&counters[2], (unsigned long long)((o.n_pts + cfg.tile_p - 1) / cfg.tile_p + (S.n_render + cfg.tile_p - 1) / cfg.tile_p));
         atomicAdd(&counters[3], (unsigned long long)((S.n_valid + TILE_P - 1) / TILE_P));
     }
     __shared__ double Hd[NH * (NH + 1)];  // augmented [H | b] in f64
@@ -930,9 +936,9 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(HypState* __restrict__ 
     const ObjView ov = objs[S.obj];
     const int tid = threadIdx.x;
     const float* base = partials + (int64_t)h * nw_total * PART_FLOATS;
-    const int n_sdf_slots = min(nw_sdf, (ov.n_pts + TILE_P - 1) / TILE_P);
+    const int n_sdf_slots = min(nw_sdf, (ov.n_pts + cfg.tile_p - 1) / cfg.tile_p);
     const int K = S.n_render;
-    const int n_rend_slots = min(nw_total - nw_sdf, (K + TILE_P - 1) / TILE_P);
+    const int n_rend_slots = min(nw_total - nw_sdf, (K + cfg.tile_p - 1) / cfg.tile_p);
     // number of active surface points (pose-only inlier filter; otherwise n_pts)
     if (tid == 0) n_act_sh = ov.n_pts;
     __syncthreads();
@@ -1246,6 +1252,7 @@ struct qsp_decoder {
     int fwd_bf3 = 0;           // QSP_DEC_OPT_FORWARD_PRECISION: forward-only passes on the split-bf16 pipe (mlp_tile_bf3)
     int jac_bf3 = 0;           // QSP_DEC_OPT_JACOBIAN_PRECISION: the forward+backward pass (mlp_tile<true, .., B3>)
     bool fp16_ok = true;       // every weight of layers 0..7 fits fp16's range (split-fp16 planes are usable)
+    int tile_p = 64;           // QSP_DEC_OPT_TILE_POINTS: points per MLP tile of the refinement batches created from now on
     int* range_flag_h = nullptr;   // host-mapped word the split-fp16 kernels set when a value left fp16's range (check_range)
 };
 
@@ -1614,10 +1621,11 @@ static int mlp_attr_once() {
     QSP_HIP(hipFuncSetAttribute((const void*)k_mlp_fwd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     QSP_HIP(hipFuncSetAttribute((const void*)k_mlp_fwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     QSP_HIP(hipFuncSetAttribute((const void*)k_decode<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    QSP_HIP(hipFuncSetAttribute((const void*)k_mlp_fwd_h2, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    QSP_HIP(hipFuncSetAttribute((const void*)k_mlp_fwd_h2<2>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     QSP_HIP(hipFuncSetAttribute((const void*)k_decode_h2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     QSP_HIP(hipFuncSetAttribute((const void*)k_decode_h2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    QSP_HIP(hipFuncSetAttribute((const void*)k_mlp_jtj_h2, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    QSP_HIP(hipFuncSetAttribute((const void*)k_mlp_jtj_h2<2>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    QSP_HIP(hipFuncSetAttribute((const void*)k_mlp_jtj_h2<1>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     QSP_HIP(hipFuncSetAttribute((const void*)k_scan, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * SCAN_RAYS * SCAN_LD)));
     QSP_HIP(hipFuncSetAttribute((const void*)k_mlp_jtj<false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     QSP_HIP(hipFuncSetAttribute((const void*)k_mlp_jtj<true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
@@ -1663,6 +1671,10 @@ extern "C" int qsp_decoder_set_option(qsp_decoder* d, int32_t option, int32_t va
             if (value < 0 || value > 2) return qsp_fail(QSP_ERR_INVALID, "jacobian precision: 0 (f32 MFMA), 1 (split bf16) or 2 (split fp16)");
             if (value == 2 && !d->fp16_ok) return qsp_fail(QSP_ERR_UNSUPPORTED, "split fp16: a weight of this decoder is outside fp16's range");
             d->jac_bf3 = value;
+            return QSP_OK;
+        case QSP_DEC_OPT_TILE_POINTS:
+            if (value != 32 && value != 64) return qsp_fail(QSP_ERR_INVALID, "tile points: 64 (default) or 32");
+            d->tile_p = value;
             return QSP_OK;
         default: return qsp_fail(QSP_ERR_INVALID, "qsp_decoder_set_option: unknown option");
     }
@@ -1812,6 +1824,10 @@ static int batch_create(qsp_decoder* dec, const RefineCfg& cfg, int n_iter, int3
     if (!cfg.pose_only && ((!device_fill && (!rays || !depth)) || !n_rays || !n_fg))
         return qsp_fail(QSP_ERR_INVALID, "refine batch: rays missing");
     if (cfg.n_depth < 2 || cfg.n_depth > MAX_DEPTH) return qsp_fail(QSP_ERR_INVALID, "n_depth must be in [2, 64]");
+    if (dec->tile_p == 32 && (dec->fwd_bf3 != 2 || dec->jac_bf3 != 2))
+        return qsp_fail(QSP_ERR_UNSUPPORTED, "32-point tiles (QSP_DEC_OPT_TILE_POINTS) exist on the split-fp16 pipe only: set both "
+                                             "precisions to 2 first");
+    const int tile_p = dec->tile_p;
     QSP_HIP(hipSetDevice(dec->device));
     qsp_refine_batch* b = new qsp_refine_batch();
     b->dec = dec;
@@ -1819,6 +1835,7 @@ static int batch_create(qsp_decoder* dec, const RefineCfg& cfg, int n_iter, int3
     b->code_len = dec->code_len;
     b->cfg = cfg;
     b->cfg.code_len = dec->code_len;
+    b->cfg.tile_p = dec->tile_p;
     b->n_iter_cfg = n_iter;
     b->n_obj = n_obj;
     b->n_hyp = n_hyp;
@@ -1851,7 +1868,7 @@ static int batch_create(qsp_decoder* dec, const RefineCfg& cfg, int n_iter, int3
         if (v.n_rays) memcpy(&hr[3 * v.ray_off], rays[o], sizeof(float) * 3 * v.n_rays);
         if (v.n_fg) memcpy(&hd[v.ray_off], depth[o], sizeof(float) * v.n_fg);
     }
-    b->nw_sdf = std::max(1, std::min(NW_SDF_MAX, (b->max_pts + TILE_P - 1) / TILE_P));
+    b->nw_sdf = std::max(1, std::min(NW_SDF_MAX, (b->max_pts + tile_p - 1) / tile_p));
     b->rk_stride = (int64_t)std::max(1, b->max_rays) * cfg.n_depth;
     b->ray_stride = b->max_rays + 1;
     b->act_stride = std::max(1, b->max_pts);
@@ -1977,9 +1994,9 @@ extern "C" int qsp_refine_batch_run(qsp_refine_batch* b, int32_t n_iter) {
             if (b->prof) spans.push_back({a, next_event(b, cur), 2});
             if (b->prof) a = next_event(b, cur);
             hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, s, 0, b->st, b->objs, nH, b->nw_sdf, nw_total - b->nw_sdf,
-                               b->work_fwd, b->qctl);
-            if (b->dec->fwd_bf3 == 2)
-                hipLaunchKernelGGL(k_mlp_fwd_h2, dim3(b->n_cu), dim3(H2_THREADS), sizeof(MlpSmem), s, b->st, b->objs, b->rays,
+                               b->work_fwd, b->qctl, TILE_P);     // (the forward pass keeps 64-point tiles: tens of thousands
+            if (b->dec->fwd_bf3 == 2)                                     //  of ray samples fill the chip either way)
+                hipLaunchKernelGGL(k_mlp_fwd_h2<2>, dim3(b->n_cu), dim3(H2_THREADS), sizeof(MlpSmem), s, b->st, b->objs, b->rays,
                                    cfg, b->dec->Pd, b->valid_rk, b->rk_stride, b->sdf_valid, b->work_fwd, b->qctl, b->c0_all);
             else if (b->dec->fwd_bf3)
                 hipLaunchKernelGGL(k_mlp_fwd<true>, dim3(b->n_cu), dim3(MLP_THREADS), sizeof(MlpSmem), s, b->st, b->objs, b->rays,
@@ -1995,9 +2012,14 @@ extern "C" int qsp_refine_batch_run(qsp_refine_batch* b, int32_t n_iter) {
         }
         if (b->prof) a = next_event(b, cur);
         hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, s, 1, b->st, b->objs, nH, b->nw_sdf, nw_total - b->nw_sdf,
-                           b->work_jtj, b->qctl);
-        if (b->dec->jac_bf3 == 2)
-            hipLaunchKernelGGL(k_mlp_jtj_h2, dim3(b->n_cu), dim3(H2_THREADS), sizeof(MlpSmem), s, b->st, b->objs, b->pts,
+                           b->work_jtj, b->qctl, cfg.tile_p);
+        if (b->dec->jac_bf3 == 2 && cfg.tile_p == 32)
+            hipLaunchKernelGGL(k_mlp_jtj_h2<1>, dim3(b->n_cu), dim3(H2_THREADS), sizeof(MlpSmem), s, b->st, b->objs, b->pts,
+                               b->rays, cfg, b->dec->Pd, b->nw_sdf, b->rend_rk, b->rend_deds, b->rend_res, b->rk_stride,
+                               b->pt_active, b->act_stride, b->res_buf, b->rows, b->rows_stride, b->partials, nw_total,
+                               b->work_jtj, b->qctl, b->c0_all);
+        else if (b->dec->jac_bf3 == 2)
+            hipLaunchKernelGGL(k_mlp_jtj_h2<2>, dim3(b->n_cu), dim3(H2_THREADS), sizeof(MlpSmem), s, b->st, b->objs, b->pts,
                                b->rays, cfg, b->dec->Pd, b->nw_sdf, b->rend_rk, b->rend_deds, b->rend_res, b->rk_stride,
                                b->pt_active, b->act_stride, b->res_buf, b->rows, b->rows_stride, b->partials, nw_total,
                                b->work_jtj, b->qctl, b->c0_all);

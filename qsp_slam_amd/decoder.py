@@ -67,6 +67,12 @@ class DeepSdfDecoder(object):
         (QSP_DEC_OPT_JACOBIAN_PRECISION)"""
         _lib.check(_lib.lib().qsp_decoder_set_option(self.handle, 2, int(mode)))
 
+    def set_tile_points(self, n):
+        """points per MLP tile (64 default, or 32) of the refinement batches created after the call; 32 is the latency option for
+        one object per call and exists on the "fp16x2" pipe only (QSP_DEC_OPT_TILE_POINTS in qsp_hip.h)"""
+        _lib.check(_lib.lib().qsp_decoder_set_option(self.handle, 3, int(n)))
+        self.tile_points = int(n)
+
     def close(self):
         if getattr(self, "handle", None):
             _lib.lib().qsp_decoder_destroy(self.handle)

@@ -20,11 +20,15 @@ from tests.test_oracle_sdf import JOINT_CASES, cfg_from, relerr, rows_close
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["bf16x3", "fp16x2"])
+@pytest.fixture(scope="module", params=["bf16x3", "fp16x2", "fp16x2_t32"])
 def bf3_decoder(golden_dir, request):
+    """"fp16x2_t32": the split-fp16 pipe with 32-point tiles (QSP_DEC_OPT_TILE_POINTS, the one-object latency option)"""
     from qsp_slam_amd import DeepSdfDecoder
     d = DeepSdfDecoder.from_npz(os.path.join(golden_dir, "decoder_8x512.npz"))
-    d.set_precision(request.param)
+    d.set_precision(request.param.split("_")[0])
+    if request.param.endswith("_t32"):
+        d.set_tile_points(32)
+        d.precision = request.param          # (tag of the recorded margins)
     yield d
     d.close()
 
@@ -213,4 +217,23 @@ def test_fp16_on_the_small_decoder_of_the_family(golden_dir):
     y, g = d.sdf_value_grad(z["code"], z["x"])
     assert within("fp16x2/small/y_abs", np.abs(y - z["y"]).max(), 2e-6)
     assert rows_close(g, z["grad"], tol=1e-5, max_bad=0.01)
+    d.close()
+
+
+def test_32_point_tiles_exist_on_the_split_fp16_pipe_only(golden_dir):
+    from qsp_slam_amd import DeepSdfDecoder, synth
+    from qsp_slam_amd._lib import QspError
+    from qsp_slam_amd.reconstruct.optimizer import Optimizer, RefineBatch, _joint_cfg
+    d = DeepSdfDecoder.from_npz(os.path.join(golden_dir, "decoder_8x512.npz"))
+    d.set_tile_points(32)
+    o = synth.make_object_views(5, 1, 200, n_fg=40, n_bg=10)[0]
+    opt = Optimizer(d, make_cfg(so.JointConfig()))
+    for prec in ("f32", "bf16x3"):
+        d.set_precision(prec)
+        with pytest.raises(QspError):
+            RefineBatch(d, _joint_cfg(opt), [o["pts"]], [o["rays"]], [o["depth"]], [0])
+    d.set_precision("fp16x2")
+    RefineBatch(d, _joint_cfg(opt), [o["pts"]], [o["rays"]], [o["depth"]], [0]).close()
+    with pytest.raises(QspError):
+        d.set_tile_points(48)
     d.close()
