@@ -1150,16 +1150,17 @@ __device__ __forceinline__ void ringh_prime(WRingH<PF, NCB>& R, const float4* __
 // acc / acc2 [r][c] += image rows [32 r, 32 r + 32) x slabs [0, KS) * W for NCB column blocks; w = base of the first column
 // block, consecutive column blocks `cs` float4 apart, nw / ncs the same for the next GEMM (its first PF slabs are fetched by
 // this one's last iterations).  img = the first row of row block 0.
-template <int KS, int PF, int NCB, int NR, bool HAND = true>
+template <int KS, int PF, int NCB, int NR, bool HAND = true, bool PRIMED = false>
 __device__ __forceinline__ void gemm_h2(const _Float16* __restrict__ img, const float4* __restrict__ w_, int cs,
                                         const float4* __restrict__ nw_, int ncs, WRingH<PF, NCB>& R, f32x16 (&acc)[NR][NCB],
                                         f32x16 (&acc2)[NR][NCB], int lane) {
     static_assert(KS % PF == 0 && KS >= 2 * PF, "slab count must be a multiple of the prefetch depth, at least twice it");
     static_assert(PF % 2 == 0, "the operand sets alternate between consecutive slabs");
     // HAND: this GEMM's first PF slabs were fetched by the previous one and it fetches the next one's (the ring lives across the
-    // write-out in between).  Without: fetch them here, none for the next (one exposed fetch per GEMM, 64 registers less held
-    // across the write-outs).
-    if (!HAND) ringh_prime(R, w_, cs, lane);
+    // write-out in between).  Without: fetch them here (one exposed fetch per GEMM, 64 registers less held across the
+    // write-outs) -- or, PRIMED, the caller has issued that fetch already (at the end of the preceding write-out: the ring is
+    // then live across a barrier and the accumulator initialisation only); none for the next either way.
+    if (!HAND && !PRIMED) ringh_prime(R, w_, cs, lane);
     gbytes w = (gbytes)w_;
     gbytes nw = HAND ? (gbytes)nw_ : w;         // (without: the last round's fetches land in registers nobody reads)
     if (!HAND) ncs = cs;
@@ -1367,12 +1368,12 @@ __device__ __forceinline__ void mlp_tile_h2(MlpSmem& s, const MlpParams* __restr
 #define QSP_WH(L, KS_) (P.wfh[L] + (size_t)(cb0 * (KS_) * 2) * 64)
 #define QSP_WBH(L) (P.wbh[L] + (size_t)(cb0 * KSH * 2) * 64)
     WRingH<PF, 4> ring;
-    if (HAND) ringh_prime(ring, QSP_WH(1, KSH), CS, lane);
+    ringh_prime(ring, QSP_WH(1, KSH), CS, lane);      // (layer 1's first slabs: in flight behind layer 0)
     QSP_HTS()
     __syncthreads();
     QSP_HTS()
     // one hidden layer: accumulators start from the bias, GEMM, then (barrier) main + 2^-11 cross, ReLU, split, (barrier)
-#define QSP_FWDH(L, BIASPTR, GEMM_STMT)                                                                                  \
+#define QSP_FWDH(L, BIASPTR, GEMM_STMT, PRIME_NEXT)                                                                      \
     _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {                  \
         const f32x4 bv_ = lds4((BIASPTR) + 128 * wave + 32 * c_ + 8 * g_ + 4 * h);                                       \
         _Pragma("unroll") for (int r_ = 0; r_ < NR; ++r_) _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {             \
@@ -1406,14 +1407,15 @@ __device__ __forceinline__ void mlp_tile_h2(MlpSmem& s, const MlpParams* __restr
             mk[L][r_][cp_] = m_[r_][cp_];                                                                                \
         }                                                                                                                \
     }                                                                                                                    \
+    if (!HAND) { PRIME_NEXT; }     /* the next GEMM's first slabs, behind the barrier and the accumulator initialisation */  \
     QSP_HTS()                                                                                                            \
     __syncthreads();                                                                                                     \
     QSP_HTS()
-#define QSP_GEMMF(L, KS_, NW, NKS) gemm_h2<KS_, PF, 4, NR, HAND>(img, QSP_WH(L, KS_), (KS_) * 2 * 64, NW, (NKS) * 2 * 64, ring, acc, acc2, lane)
-    QSP_FWDH(0, s.c0, gemm_l0_h2<NR>(img, QSP_WH(0, 1), acc, acc2, lane))
-    QSP_FWDH(1, bias_sh + 0 * HID, QSP_GEMMF(1, KSH, QSP_WH(2, KSH), KSH))
-    QSP_FWDH(2, bias_sh + 1 * HID, QSP_GEMMF(2, KSH, QSP_WH(3, KSH), KSH))
-    QSP_FWDH(3, bias_sh + 2 * HID, QSP_GEMMF(3, KSH, QSP_WH(4, KS4), KS4))
+#define QSP_GEMMF(L, KS_, NW, NKS) gemm_h2<KS_, PF, 4, NR, HAND, true>(img, QSP_WH(L, KS_), (KS_) * 2 * 64, NW, (NKS) * 2 * 64, ring, acc, acc2, lane)
+    QSP_FWDH(0, s.c0, gemm_l0_h2<NR>(img, QSP_WH(0, 1), acc, acc2, lane), (void)0)
+    QSP_FWDH(1, bias_sh + 0 * HID, QSP_GEMMF(1, KSH, QSP_WH(2, KSH), KSH), ringh_prime(ring, QSP_WH(2, KSH), CS, lane))
+    QSP_FWDH(2, bias_sh + 1 * HID, QSP_GEMMF(2, KSH, QSP_WH(3, KSH), KSH), ringh_prime(ring, QSP_WH(3, KSH), CS, lane))
+    QSP_FWDH(3, bias_sh + 2 * HID, QSP_GEMMF(3, KSH, QSP_WH(4, KS4), KS4), ringh_prime(ring, QSP_WH(4, KS4), CS4, lane))
     if (tid < TP * 3) {        // the skip connection's xyz into columns 445..447 (zeros from layer 3's write-out until now)
         const int row = tid / 3, ci = tid - row * 3;
         const float x = s.xin[row * 4 + ci];
@@ -1424,10 +1426,10 @@ __device__ __forceinline__ void mlp_tile_h2(MlpSmem& s, const MlpParams* __restr
         amax = fmaxf(amax, fabsf(x));
     }
     __syncthreads();
-    QSP_FWDH(4, s.c4, QSP_GEMMF(4, KS4, QSP_WH(5, KSH), KSH))
-    QSP_FWDH(5, bias_sh + 4 * HID, QSP_GEMMF(5, KSH, QSP_WH(6, KSH), KSH))
-    QSP_FWDH(6, bias_sh + 5 * HID, QSP_GEMMF(6, KSH, QSP_WH(7, KSH), KSH))
-    QSP_FWDH(7, bias_sh + 6 * HID, QSP_GEMMF(7, KSH, QSP_WH(1, KSH), KSH))
+    QSP_FWDH(4, s.c4, QSP_GEMMF(4, KS4, QSP_WH(5, KSH), KSH), ringh_prime(ring, QSP_WH(5, KSH), CS, lane))
+    QSP_FWDH(5, bias_sh + 4 * HID, QSP_GEMMF(5, KSH, QSP_WH(6, KSH), KSH), ringh_prime(ring, QSP_WH(6, KSH), CS, lane))
+    QSP_FWDH(6, bias_sh + 5 * HID, QSP_GEMMF(6, KSH, QSP_WH(7, KSH), KSH), ringh_prime(ring, QSP_WH(7, KSH), CS, lane))
+    QSP_FWDH(7, bias_sh + 6 * HID, QSP_GEMMF(7, KSH, QSP_WH(1, KSH), KSH), (void)0)
 #undef QSP_FWDH
 #undef QSP_GEMMF
     // ---- layer 8: 512 -> 1, tanh (f32): wave = k segment of 128, lane = row; a7 = hi + 2^-11 lo' from the two planes
@@ -1480,12 +1482,13 @@ __device__ __forceinline__ void mlp_tile_h2(MlpSmem& s, const MlpParams* __restr
                     h2_store4(img, p, u0, v, amax);
                 }
         }
+        ringh_prime(ring, QSP_WBH(7), CS, lane);
         __syncthreads();
         // ---- backward through layers 7..1: g_in = g_a . W_L, masked by layer L-1; the skip gradient of layer 4 to the stash ----
 #define QSP_BWDH(L, KS_, NWB)                                                                                            \
     _Pragma("unroll") for (int r_ = 0; r_ < NR; ++r_) _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_)                   \
         _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) { acc[r_][c_][i_] = 0.f; acc2[r_][c_][i_] = 0.f; }             \
-    gemm_h2<KS_, PF, 4, NR, HAND>(img, QSP_WBH(L), CS, NWB, CS, ring, acc, acc2, lane);                                         \
+    gemm_h2<KS_, PF, 4, NR, HAND, true>(img, QSP_WBH(L), CS, NWB, CS, ring, acc, acc2, lane);                                         \
     __syncthreads();                                                                                                     \
     _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {                  \
         const int u0_ = 128 * wave + 32 * c_ + 8 * g_ + 4 * h;                                                           \
@@ -1501,6 +1504,7 @@ __device__ __forceinline__ void mlp_tile_h2(MlpSmem& s, const MlpParams* __restr
         }                                                                                                                \
         __builtin_amdgcn_sched_barrier(0);                                                                               \
     }                                                                                                                    \
+    if ((L) > 1) ringh_prime(ring, NWB, CS, lane);     /* the next layer's first slabs (layer 0's product has its own ring) */ \
     __syncthreads();
         QSP_BWDH(7, KSH, QSP_WBH(6))
         QSP_BWDH(6, KSH, QSP_WBH(5))
