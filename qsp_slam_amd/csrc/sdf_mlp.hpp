@@ -1340,7 +1340,8 @@ __device__ __forceinline__ void mlp_tile_h2(MlpSmem& s, const MlpParams* __restr
     uint32_t mk[8][NR][2];                                  // ReLU masks [layer][row block][column-block pair]
     _Float16* img = reinterpret_cast<_Float16*>(s.act);
     float* bias_sh = s.stash;                              // [7][512] biases of layers 1..7 (the stash is free until layer 4's backward)
-    if (stage) {      // constants of the decoder: once per workgroup for a forward-only kernel (nothing else writes them there)
+    if (stage) {      // constants of the decoder: once per workgroup (the forward+backward tile, whose stash doubles as the bias
+                      // store, re-stages the biases itself at its end)
         for (int i = tid; i < HID; i += H2_THREADS) s.w8[i] = P.w8[i];
 #pragma unroll
         for (int l = 1; l < 8; ++l)
@@ -1534,6 +1535,14 @@ __device__ __forceinline__ void mlp_tile_h2(MlpSmem& s, const MlpParams* __restr
         // ---- backward through layer 0: 67 (padded 96) input columns = 2 x 3 output tiles: waves 0, 1 take column blocks 0, 1
         // for both point blocks, waves 2, 3 column block 2 (inputs 64..66) for one point block each -------------------------
         {
+            // the biases of layers 1..7 for the NEXT tile of this workgroup (the stash that holds them in the forward pass is
+            // about to be read for the last time): loads issued here, in flight behind the product below, stored at the very end
+            float bnext[14];
+#pragma unroll
+            for (int l = 1; l < 8; ++l)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) bnext[2 * (l - 1) + i] = P.bias[l][tid + i * H2_THREADS];
+            __builtin_amdgcn_sched_barrier(0);
             f32x4 gl[NR][4];
             gemm_side_h2<PF, NR>(img, P.wbh[0], wave, lane, gl);
             const int c0 = side_c0<NR>(wave);
@@ -1555,8 +1564,12 @@ __device__ __forceinline__ void mlp_tile_h2(MlpSmem& s, const MlpParams* __restr
                     }
                 }
             }
+            __syncthreads();
+#pragma unroll
+            for (int l = 1; l < 8; ++l)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) bias_sh[(l - 1) * HID + tid + i * H2_THREADS] = bnext[2 * (l - 1) + i];
         }
-        __syncthreads();
     }
 #undef QSP_WH
 #undef QSP_WBH

@@ -711,6 +711,7 @@ __global__ __launch_bounds__(H2_THREADS) void k_mlp_jtj_h2(const HypState* __res
     __shared__ int s_item;
     const int n_items = qctl[2];
     constexpr int TP = 32 * NR, SUBS = H2_THREADS / TP;      // threads per Jacobian row
+    bool staged = false;
     float amax = 0.f;
   for (;;) {                                   // work queue, see k_plan
     if (threadIdx.x == 0) s_item = atomicAdd(&qctl[3], 1);
@@ -774,7 +775,8 @@ __global__ __launch_bounds__(H2_THREADS) void k_mlp_jtj_h2(const HypState* __res
             s.rres[tid] = rr;
         }
         __syncthreads();
-        mlp_tile_h2<true, 2, false, NR>(s, P, amax);
+        mlp_tile_h2<true, 2, false, NR>(s, P, amax, !staged);
+        staged = true;
         // ---- Jacobian rows: J~[p] = [ s*(g_x . [I | -x^ | x]) (7) | s*g_z (64) | r~ ] -------------------------------
         // G (gradient w.r.t. [code | xyz]) sits in s.act with row stride LDG; J~ goes behind it.
         float* G = s.act;
@@ -1184,7 +1186,7 @@ __global__ __launch_bounds__(H2_THREADS) void k_decode_h2(const float* __restric
             s.xin[4 * threadIdx.x + 3] = 0.f;
         }
         __syncthreads();
-        mlp_tile_h2<GRAD, 2>(s, P, amax, GRAD || !staged);
+        mlp_tile_h2<GRAD, 2>(s, P, amax, !staged);
         staged = true;
         if (threadIdx.x < TILE_P) {
             const int64_t v = t * TILE_P + threadIdx.x;

@@ -24,7 +24,7 @@ __global__ __launch_bounds__(H2_THREADS) void kt(const MlpParams* P, float* y, i
             s.xin[4 * threadIdx.x] = 0.1f; s.xin[4 * threadIdx.x + 1] = 0.2f; s.xin[4 * threadIdx.x + 2] = 0.3f; s.xin[4 * threadIdx.x + 3] = 0.f;
         }
         __syncthreads();
-        mlp_tile_h2<BWDV, PFV>(s, P, amax, BWDV || t == 0);
+        mlp_tile_h2<BWDV, PFV>(s, P, amax, t == 0);
         if (threadIdx.x < 64) y[blockIdx.x * 64 + threadIdx.x] = s.y[threadIdx.x] + (BWDV ? s.act[threadIdx.x * LDG] : 0.f);
     }
     if (!(amax <= H2_MAX)) *P->range_flag = 1;
