@@ -546,7 +546,9 @@ __device__ __forceinline__ void lin_points_block(const Dev& d, const Par& par, c
 // reduced in a fixed tree into kpart[split]; k_lin_poses_finish adds a key-frame's splits (and its camera-object
 // edges) in order.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int KSPLIT = 2048;
+constexpr int KSPLIT = 2048;         // graphs that stream (>= KSPLIT_SMALL_BELOW edges): 4.4 TB/s on 2 M edges, 2.7 with 512
+constexpr int KSPLIT_SMALL = 512;    // BASELINE-size graphs are latency-bound: shorter per-thread edge loops (C4 BA 3.92 -> 3.80 ms)
+constexpr int KSPLIT_SMALL_BELOW = 1 << 18;
 
 template <int D>
 __device__ inline void lin_pose_edge(const Dev& d, const Edge& E, double delta, double* A /*21*/, double* b /*6*/) {
@@ -2219,12 +2221,13 @@ extern "C" int qsp_ba_create(const qsp_ba_scene* s, int device, qsp_ba_problem**
     }
     d.n_chunk = (d.n_pt == 0) ? 0 : (int)chunk_pt.size() - 1;
     std::vector<int32_t> ksp_kf, ksp_begin, ksp_end, ksp_first(d.n_kf + 1, 0);
+    const int ksplit = d.n_edge < KSPLIT_SMALL_BELOW ? KSPLIT_SMALL : KSPLIT;
     for (int k = 0; k < d.n_kf; ++k) {
         ksp_first[k] = (int)ksp_kf.size();
-        for (int b0 = kf_off[k]; b0 < kf_off[k + 1]; b0 += KSPLIT) {
+        for (int b0 = kf_off[k]; b0 < kf_off[k + 1]; b0 += ksplit) {
             ksp_kf.push_back(k);
             ksp_begin.push_back(b0);
-            ksp_end.push_back(std::min(b0 + KSPLIT, kf_off[k + 1]));
+            ksp_end.push_back(std::min(b0 + ksplit, kf_off[k + 1]));
         }
     }
     ksp_first[d.n_kf] = (int)ksp_kf.size();
