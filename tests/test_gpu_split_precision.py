@@ -164,8 +164,9 @@ def _scaled_decoder(golden_dir, layer, factor):
         os.unlink(path)
 
 
-def test_fp16_refuses_weights_outside_its_range(golden_dir):
+def test_fp16_refuses_weights_outside_its_range(golden_dir, monkeypatch):
     from qsp_slam_amd._lib import QspError
+    monkeypatch.delenv("QSP_PRECISION", raising=False)  # a session-wide default would refuse at construction
     d = _scaled_decoder(golden_dir, 2, 3e6)           # |w| of layer 2 up to ~1e5 > 65504
     with pytest.raises(QspError):
         d.set_precision("fp16x2")
@@ -173,10 +174,11 @@ def test_fp16_refuses_weights_outside_its_range(golden_dir):
     d.close()
 
 
-def test_fp16_fails_loudly_when_an_activation_leaves_its_range(golden_dir):
+def test_fp16_fails_loudly_when_an_activation_leaves_its_range(golden_dir, monkeypatch):
     """weights inside fp16's range but activations beyond 65504: the kernels raise the decoder's range flag and the call fails
     (instead of returning values computed from clamped or infinite planes); the same decoder runs on the split-bf16 pipe"""
     from qsp_slam_amd._lib import QspError
+    monkeypatch.delenv("QSP_PRECISION", raising=False)
     d = _scaled_decoder(golden_dir, 1, 2e5)
     x = np.random.default_rng(0).uniform(-1, 1, size=(300, 3)).astype(np.float32)
     code = np.zeros(64, np.float32)
