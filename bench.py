@@ -39,6 +39,10 @@ import time
 
 import numpy as np
 
+# dmabuf IPC is the only mode the host driver supports: RCCL across processes fails with the legacy mode (set before any
+# process touches the GPU; the launcher normally exports it already)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
