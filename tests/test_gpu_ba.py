@@ -402,3 +402,50 @@ def test_objects_with_smaller_vertex_ids_than_keyframes_stay_in_the_dense_system
     for x, y in zip(gpu.state(), ref.state()):
         assert close(x, y, rtol=1e-7, atol=1e-9)
     gpu.close()
+
+
+def _thinned(sc, lonely_kf=5, single_obs_pt=7, unobserved_pt=9):
+    """the scene with one free key-frame that observes nothing, one landmark seen exactly once (a rank-2 3x3 block that only
+    the damping makes invertible) and one landmark no edge touches"""
+    sc = dict(sc)
+
+    def drop(prefix, mask):
+        for k in list(sc):
+            if k.startswith(prefix + "_") and hasattr(sc[k], "shape"):
+                sc[k] = sc[k][~mask]
+    for pre in ("mono", "st"):
+        kf, pt = sc[pre + "_kf"], sc[pre + "_pt"]
+        m = (kf == lonely_kf) | (pt == unobserved_pt)
+        seen = np.nonzero((pt == single_obs_pt) & ~m)[0]
+        m[seen[1:] if pre == "mono" else seen] = True
+        drop(pre, m)
+    drop("oe", sc["oe_kf"] == lonely_kf)
+    return sc
+
+
+@pytest.mark.parametrize("mode", ["deterministic", "atomic"])
+def test_vertices_without_edges_and_single_observation_landmarks(mode):
+    """g2o keeps such vertices in the index mapping; their blocks are the damping alone (or rank deficient + damping) and the
+    increments stay finite -- same index tables, trial sequence and estimates as the oracle"""
+    from qsp_slam_amd.ba import BaProblem
+    sc = _thinned(synth.make_ba_scene(seed=77, n_kf=8, n_pt=200, n_obj=2, stereo_frac=0.3))
+    assert (sc["mono_pt"] == 7).sum() + (sc["st_pt"] == 7).sum() == 1
+    assert not ((sc["mono_kf"] == 5).any() or (sc["st_kf"] == 5).any() or (sc["oe_kf"] == 5).any())
+    ref, gpu = bo.BaProblem(sc), BaProblem(sc)
+    gpu.set_deterministic(mode == "deterministic")
+    r1, r2 = ref.local_joint_ba()
+    g1, g2 = gpu.local_joint_ba()
+    kh, oh, ph = gpu.index()
+    assert np.array_equal(kh, r2["kf_hidx"]) and np.array_equal(oh, r2["obj_hidx"]) and np.array_equal(ph, r2["pt_hidx"])
+    for g, r in ((g1, r1), (g2, r2)):
+        assert list(g["trials"]) == list(r["trials"]) and list(g["accepted"]) == list(r["accepted"])
+        # lambda's update factor is a cubic in rho = (chi2 - chi2_new) / scale: at the last step chi2 moves by 1e-5 of itself,
+        # so 1e-10 of chi2 is 1e-5 of rho (measured: 7e-6 / 1.4e-4 in the last lambda with the two Schur variants, 1e-9 before)
+        assert close(g["chi2"], r["chi2"], rtol=1e-8) and close(g["lam"][:-1], r["lam"][:-1], rtol=1e-6)
+        assert close(g["lam"][-1:], r["lam"][-1:], rtol=1e-3)
+    kf, pt, ob = gpu.state()
+    rkf, rpt, rob = ref.state()
+    assert np.array_equal(kf[5], sc["kf_pose"][5]) or close(kf[5], rkf[5], rtol=1e-9, atol=1e-12)   # nothing pulls on it
+    assert np.array_equal(pt[9], rpt[9])
+    assert close(kf, rkf, rtol=1e-7, atol=1e-9) and close(pt, rpt, rtol=1e-7, atol=1e-9) and close(ob, rob, rtol=1e-7, atol=1e-9)
+    gpu.close()
