@@ -449,3 +449,28 @@ def test_vertices_without_edges_and_single_observation_landmarks(mode):
     assert np.array_equal(pt[9], rpt[9])
     assert close(kf, rkf, rtol=1e-7, atol=1e-9) and close(pt, rpt, rtol=1e-7, atol=1e-9) and close(ob, rob, rtol=1e-7, atol=1e-9)
     gpu.close()
+
+
+def test_pose_graph_of_key_frames_and_objects_without_landmarks():
+    """no map point at all (n_pt = 0, no reprojection edge): only the camera-object edges remain; nothing of the landmark
+    side may be launched with an empty grid"""
+    from qsp_slam_amd.ba import BaProblem
+    sc = dict(synth.make_ba_scene(seed=78, n_kf=6, n_pt=40, n_obj=3, stereo_frac=0.3, obs_per_obj=4))
+    for pre in ("mono", "st"):
+        for k in list(sc):
+            if k.startswith(pre + "_") and hasattr(sc[k], "shape"):
+                sc[k] = sc[k][:0]
+    for k in ("pt_xyz", "pt_id", "gt_pt"):
+        sc[k] = sc[k][:0]
+    ref, gpu = bo.BaProblem(sc), BaProblem(sc)
+    r1, r2 = ref.local_joint_ba()
+    g1, g2 = gpu.local_joint_ba()
+    assert list(g1["trials"]) == list(r1["trials"]) and list(g1["accepted"]) == list(r1["accepted"])
+    # the second stage starts at the converged state of this small problem: chi2 moves by less than 1e-15 of itself, so whether
+    # the tenth trial of its only iteration counts as a gain is decided by the last bit on either side
+    assert list(g2["trials"]) == list(r2["trials"])
+    assert close(g1["chi2"], r1["chi2"], rtol=1e-8) and close(g2["chi2"], r2["chi2"], rtol=1e-8)
+    kf, pt, ob = gpu.state()
+    rkf, rpt, rob = ref.state()
+    assert pt.shape[0] == 0 and close(kf, rkf, rtol=1e-7, atol=1e-9) and close(ob, rob, rtol=1e-7, atol=1e-9)
+    gpu.close()
