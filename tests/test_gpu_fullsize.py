@@ -215,3 +215,30 @@ def test_c5_refinement_full_batch_kitti_weights(gpu_decoder):
     s = np.cbrt(np.linalg.det(R.astype(np.float64)))
     up = (R[:, :, 1] / s[:, None]) @ np.array([0.0, -1.0, 0.0])
     assert (up > 0.999).mean() > 0.95
+
+
+def test_ragged_batch_with_failing_objects_between_good_ones(gpu_decoder):
+    """objects of very different sizes in one batch, two of which take the reference's early exits (no surface point: NaN
+    loss, optimizer.py:168-169; rays that never come near the surface: fewer than 10 samples, :187-188): every hypothesis
+    == the same hypothesis alone, to the bit, and the failing ones do not disturb their neighbours"""
+    from tests.test_gpu_sdf import make_cfg
+    from oracle import sdf_oracle as so
+    from qsp_slam_amd.reconstruct.optimizer import Optimizer
+    sizes = [(1, 12, 0), (700, 150, 40), (0, 64, 32), (33, 20, 7), (2500, 300, 100), (180, 64, 32), (65, 31, 1)]
+    objs = [synth.make_object_views(900 + i, 1, max(m, 1), n_fg=f, n_bg=b)[0] for i, (m, f, b) in enumerate(sizes)]
+    inp = []
+    for o, (m, f, b) in zip(objs, sizes):
+        d = dict(t_cam_obj=o["t_cam_obj"], pts=o["pts"][:m], rays=o["rays"], depth=o["depth"])
+        inp.append(d)
+    inp[5]["rays"] = inp[5]["rays"] * np.array([1, 1, -1], np.float32)          # looking away from the object
+    opt = Optimizer(gpu_decoder, make_cfg(so.JointConfig(n_iter=4)))
+    batch = opt.reconstruct_objects_batched(inp, flip_sample_num=2, select=False)
+    assert not any(r.is_good for r in batch[2]) and not any(r.is_good for r in batch[5])
+    assert all(r.is_good for i in (1, 4) for r in batch[i])
+    single_opt = Optimizer(gpu_decoder, make_cfg(so.JointConfig(n_iter=4)))
+    for i, d in enumerate(inp):
+        alone = single_opt.reconstruct_objects_batched([d], flip_sample_num=2, select=False)[0]
+        for a, b in zip(alone, batch[i]):
+            assert a.is_good == b.is_good and a.loss == b.loss
+            if a.is_good:
+                assert np.array_equal(a.t_cam_obj, b.t_cam_obj) and np.array_equal(a.code, b.code)
