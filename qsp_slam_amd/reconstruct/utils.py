@@ -39,5 +39,11 @@ def get_configs(cfg_file):
 
 def get_decoder(configs, device=0):
     """reconstruct/utils.py:93-95 -> deep_sdf/workspace.py:202-224 (config_decoder): reads specs.json and
-    ModelParameters/latest.pth of configs.DeepSDF_DIR and uploads the folded weights."""
-    return DeepSdfDecoder.from_experiment_dir(configs.DeepSDF_DIR, device=device)
+    ModelParameters/latest.pth of configs.DeepSDF_DIR and uploads the folded weights.
+
+    One key the reference's JSON does not have is honoured if present: `"decoder_precision": "f32" | "bf16x3" | "fp16x2"`
+    (DeepSdfDecoder.set_precision; absent = "f32", the exact-f32 matrix pipe).  An unknown name is an error, not a fallback."""
+    dec = DeepSdfDecoder.from_experiment_dir(configs.DeepSDF_DIR, device=device)
+    if "decoder_precision" in configs:
+        dec.set_precision(configs["decoder_precision"])
+    return dec

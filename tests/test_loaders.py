@@ -69,6 +69,24 @@ def test_get_decoder_from_experiment_directory(tmp_path, golden_dir):
 
 
 @pytest.mark.gpu
+def test_get_decoder_honours_the_decoder_precision_key(tmp_path, golden_dir):
+    """`"decoder_precision"` in the JSON config selects the decoder's arithmetic pipe; absent = exact f32; unknown = error"""
+    from qsp_slam_amd import DeepSdfDecoder
+    from qsp_slam_amd.reconstruct.utils import ForceKeyErrorDict, get_decoder
+    write_experiment(str(tmp_path / "exp"), golden_dir)
+    ref = DeepSdfDecoder.from_npz(os.path.join(golden_dir, "decoder_8x512.npz"))
+    ref.set_precision("fp16x2")
+    x = np.random.default_rng(1).uniform(-1, 1, size=(200, 3)).astype(np.float32)
+    code = np.zeros(64, np.float32)
+    dec = get_decoder(ForceKeyErrorDict(DeepSDF_DIR=str(tmp_path / "exp"), decoder_precision="fp16x2"))
+    assert dec.precision == "fp16x2" and np.array_equal(dec.decode_sdf(code, x), ref.decode_sdf(code, x))
+    dec.close()
+    ref.close()
+    with pytest.raises(ValueError):
+        get_decoder(ForceKeyErrorDict(DeepSDF_DIR=str(tmp_path / "exp"), decoder_precision="fp8"))
+
+
+@pytest.mark.gpu
 def test_unsupported_decoder_family_is_refused(golden_dir):
     """what cannot be mapped exactly onto the 8 x 512 tile (csrc/sdf_refine.hip:embed_family) is QSP_ERR_UNSUPPORTED, not a
     silent fallback: a latent_in layer with more than 4 hidden layers in front of or from it on, hidden widths above 512,
