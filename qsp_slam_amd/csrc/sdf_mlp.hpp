@@ -1112,6 +1112,9 @@ __device__ __forceinline__ void h2_store4(_Float16* img, int row, int u0, f32x4 
         hi[q] = h;
         lo[q] = (QSP_H2_EXP & 2) ? h : (_Float16)((v[q] - (float)h) * 2048.f);
     }
+    // (two 8-byte stores: within a lane half rows r and r + 16 share banks, 24 % of the LDS-active cycles are such conflicts --
+    // but the LDS pipe is only 14 % busy; exchanging halves with v_permlane32_swap for ONE conflict-free 16-byte store per lane
+    // was measured 1 % slower: the write-out is bound by its VALU work, profiles/r02_c4_pmcL_summary.txt)
     _Float16* d = img + h2_at(row, u0);
     *reinterpret_cast<f16x4*>(d) = hi;
     *reinterpret_cast<f16x4*>(d + 8) = lo;
