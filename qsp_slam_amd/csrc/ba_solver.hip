@@ -1495,6 +1495,12 @@ __global__ __launch_bounds__(256) void k_chol_step(double* A, double* Uf, double
     }
 }
 
+// a wave-load of 64 consecutive doubles from a UNIFORM address: scalar base + this lane's 32-bit byte offset (one VGPR of address
+// for all loads of the kernel instead of a 64-bit pointer per load in flight)
+typedef const __attribute__((address_space(1))) char* gbytes_t;
+__device__ __forceinline__ double ld_row(const double* uniform_ptr, uint32_t voff) {
+    return *reinterpret_cast<const __attribute__((address_space(1))) double*>((gbytes_t)uniform_ptr + voff);
+}
 // backward substitution x_k = W_k^T (y_k - sum_{j>k} U_kj x_j), k = nb-1 .. 0, in ONE launch of ONE workgroup of 1024
 // threads (16 waves): y lives in LDS; at step j the waves form x_j = W_j^T y_j (4 rows each), then wave w takes the blocks
 // k = w, w+16, ... < j and subtracts U_kj x_j from y_k with a lane per row (the factor is stored transposed, so a wave-load
@@ -1507,32 +1513,49 @@ __global__ __launch_bounds__(1024) void k_chol_back(Dev d, Par par, const double
                                                    const double* __restrict__ y, double* x, int n) {
     extern __shared__ __attribute__((aligned(16))) double ysh[];       // [n] y, then [NB] x_j
     double* xj = ysh + n;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);      // uniform: block addresses stay in scalar registers
+    const uint32_t voff = 8u * lane;
     const int nb = n / NB;
     for (int i = t; i < n; i += 1024) ysh[i] = y[i];
     __syncthreads();
+    // Nothing a step LOADS from global memory depends on the step before it, only what the loads are multiplied with does: W_{j-1}'s
+    // rows are fetched while step j's blocks are being subtracted, and the first 16 columns of a wave's first block before x_j
+    // exists.  The arithmetic, and so every bit of x, is that of the plain loop (same products, same four chains, same order).
+    double wt[NB / 16];
+#pragma unroll
+    for (int i = 0; i < NB / 16; ++i) wt[i] = ld_row(Winv + (size_t)(nb - 1) * NB * NB + (wave + 16 * i) * NB, voff);
     for (int j = nb - 1; j >= 0; --j) {
+        const double* Uj = Uf + (size_t)(j * NB) * n;     // element (m, c) of block k at Uj[k * NB + c * n + m]
+        double u[16];
+        if (wave < j) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) u[c] = ld_row(Uj + wave * NB + (size_t)c * n, voff);
+        }
         {                                                 // x_j[r] = sum_q W_j[q][r] y_j[q];  Winv holds WT[r][q] = W[q][r]
-            const double* WT = Winv + (size_t)j * NB * NB;
             const double yq = ysh[j * NB + lane];
 #pragma unroll
             for (int i = 0; i < NB / 16; ++i) {
                 const int r = wave + 16 * i;
-                double v = WT[r * NB + lane] * yq;
+                double v = wt[i] * yq;
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
                 if (lane == 0) { xj[r] = v; x[j * NB + r] = v; }
             }
+            if (j > 0) {
+#pragma unroll
+                for (int i = 0; i < NB / 16; ++i) wt[i] = ld_row(Winv + (size_t)(j - 1) * NB * NB + (wave + 16 * i) * NB, voff);
+            }
         }
         __syncthreads();
         for (int k = wave; k < j; k += 16) {
-            const double* U = Uf + (size_t)(j * NB) * n + k * NB;      // element (m, c) at U[c * n + m]
             double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
 #pragma unroll 1
             for (int c0 = 0; c0 < NB; c0 += 16) {         // 16 independent wave-loads in flight, four accumulator chains
-                double u[16];
+                if (c0 > 0 || k > wave) {                 // (the first batch of the first block is already here)
 #pragma unroll
-                for (int c = 0; c < 16; ++c) u[c] = U[(size_t)(c0 + c) * n + lane];
+                    for (int c = 0; c < 16; ++c) u[c] = ld_row(Uj + k * NB + (size_t)(c0 + c) * n, voff);
+                }
 #pragma unroll
                 for (int c = 0; c < 16; c += 4) {
                     a0 += u[c + 0] * xj[c0 + c + 0];
