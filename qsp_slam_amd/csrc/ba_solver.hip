@@ -1495,6 +1495,7 @@ __global__ __launch_bounds__(256) void k_chol_step(double* A, double* Uf, double
     }
 }
 
+constexpr int CHOL_BACK_HELPERS = 4;     // workgroups on the solver's XCD that warm its L2 (k_chol_back)
 // a wave-load of 64 consecutive doubles from a UNIFORM address: scalar base + this lane's 32-bit byte offset (one VGPR of address
 // for all loads of the kernel instead of a 64-bit pointer per load in flight)
 typedef const __attribute__((address_space(1))) char* gbytes_t;
@@ -1517,6 +1518,22 @@ __global__ __launch_bounds__(1024) void k_chol_back(Dev d, Par par, const double
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);      // uniform: block addresses stay in scalar registers
     const uint32_t voff = 8u * lane;
     const int nb = n / NB;
+    if (blockIdx.x != 0) {
+        // Helpers (speed only, no result): blocks b and b + 8 are observed to share an XCD, so blocks 8, 16, .. touch one double per
+        // 128-byte line of the factor rows and diagonal inverses the solver is about to walk -- last block row first, which is the
+        // order of use -- and leave.  The solver's loads then hit its XCD's L2 instead of travelling to the memory side: one
+        // compute unit pulling 5.6 MB (C5) at ~34 GB/s is what bounds the single-workgroup form.
+        if (blockIdx.x & 7) return;
+        const int h = (int)blockIdx.x / 8 - 1, H = ((int)gridDim.x - 1) / 8;
+        double sink = 0;
+        for (int R = n - 1 - h; R >= NB; R -= H) {            // row R of block row j = R / NB: columns [0, j NB) are read
+            const double* row = Uf + (size_t)R * n;
+            for (int q = t * 16; q < (R / NB) * NB; q += 1024 * 16) sink += row[q];
+        }
+        for (size_t q = ((size_t)h * 1024 + t) * 16; q < (size_t)nb * NB * NB; q += (size_t)H * 1024 * 16) sink += Winv[q];
+        asm volatile("" ::"v"(sink));                        // (keeps the loads alive; nothing is written)
+        return;
+    }
     for (int i = t; i < n; i += 1024) ysh[i] = y[i];
     __syncthreads();
     // Nothing a step LOADS from global memory depends on the step before it, only what the loads are multiplied with does: W_{j-1}'s
@@ -2720,7 +2737,7 @@ extern "C" int qsp_ba_optimize(qsp_ba_problem* p, int32_t n_iter, double delta_m
                 for (int k = 0; k + 1 < nb; ++k)
                     hipLaunchKernelGGL(k_chol_step, dim3(nb - k - 1, nb - k - 1), dim3(256), lds, s, d.Hs, d.Uf, d.Winv, d.bs,
                                        d.ych, p->dimp, k, d.scal);
-                hipLaunchKernelGGL(k_chol_back, dim3(1), dim3(1024), sizeof(double) * (size_t)(p->dimp + NB), s, d, par, d.Uf, d.Winv,
+                hipLaunchKernelGGL(k_chol_back, dim3(1 + 8 * CHOL_BACK_HELPERS), dim3(1024), sizeof(double) * (size_t)(p->dimp + NB), s, d, par, d.Uf, d.Winv,
                                    d.ych, d.xp, p->dimp);
             } else if (d.n_pt) {
                 if (fused) { /* unreachable: fused needs dimp > 0 */ }
