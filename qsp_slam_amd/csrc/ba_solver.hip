@@ -1495,6 +1495,32 @@ __global__ __launch_bounds__(256) void k_chol_step(double* A, double* Uf, double
     }
 }
 
+// Sum over the 64 lanes of a wave on the VALU alone (DPP), result valid in lanes 48..63.  __shfl_xor goes through the LDS
+// crossbar (two ds_bpermute per double and level): 16 waves x 4 rows x 12 of them per step kept the one compute unit of
+// k_chol_back busy for 4.8 k of a step's 16 k cycles (tools/cb_stamps.py).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_term(double v) {
+    union { double d; int i[2]; } a, r;
+    a.d = v;
+    r.i[0] = __builtin_amdgcn_update_dpp(0, a.i[0], CTRL, ROW_MASK, 0xf, false);
+    r.i[1] = __builtin_amdgcn_update_dpp(0, a.i[1], CTRL, ROW_MASK, 0xf, false);
+    return r.d;                                  // lanes outside ROW_MASK keep the `old` operand: +0.0
+}
+__device__ __forceinline__ double wave_sum_dpp(double v) {
+    v += dpp_term<0xB1, 0xf>(v);                 // quad_perm [1,0,3,2]
+    v += dpp_term<0x4E, 0xf>(v);                 // quad_perm [2,3,0,1]: every lane holds its quad's sum
+    v += dpp_term<0x141, 0xf>(v);                // row_half_mirror: sums of 8
+    v += dpp_term<0x140, 0xf>(v);                // row_mirror: every lane holds its row's (16 lanes) sum
+    v += dpp_term<0x142, 0xa>(v);                // row_bcast15 into rows 1 and 3: rows 0+1, rows 2+3
+    v += dpp_term<0x143, 0xc>(v);                // row_bcast31 into rows 2 and 3: row 3 holds the total
+    return v;
+}
+#ifdef QSP_CB_STAMPS      // timing experiments only: shader-clock stamps of thread 0 at the phase boundaries of every step
+__device__ unsigned long long qsp_cb_ts[64 * 5];
+#define QSP_CBTS(j_, i_) { if (t == 0 && (j_) < 64) qsp_cb_ts[(j_) * 5 + (i_)] = __builtin_readcyclecounter(); }
+#else
+#define QSP_CBTS(j_, i_)
+#endif
 constexpr int CHOL_BACK_HELPERS = 4;     // workgroups on the solver's XCD that warm its L2 (k_chol_back)
 // a wave-load of 64 consecutive doubles from a UNIFORM address: scalar base + this lane's 32-bit byte offset (one VGPR of address
 // for all loads of the kernel instead of a 64-bit pointer per load in flight)
@@ -1512,8 +1538,9 @@ __device__ __forceinline__ double ld_row(const double* uniform_ptr, uint32_t vof
 // it is made, and every row needs three of them.  The simplest form was kept.
 __global__ __launch_bounds__(1024) void k_chol_back(Dev d, Par par, const double* __restrict__ Uf, const double* __restrict__ Winv,
                                                    const double* __restrict__ y, double* x, int n) {
-    extern __shared__ __attribute__((aligned(16))) double ysh[];       // [n] y, then [NB] x_j
+    extern __shared__ __attribute__((aligned(16))) double ysh[];       // [n] y, [NB] x_j, [n] x
     double* xj = ysh + n;
+    double* xs = xj + NB;      // the solution stays in LDS until the end: a global store per step would sit in front of its barrier
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);      // uniform: block addresses stay in scalar registers
     const uint32_t voff = 8u * lane;
@@ -1544,6 +1571,7 @@ __global__ __launch_bounds__(1024) void k_chol_back(Dev d, Par par, const double
     for (int i = 0; i < NB / 16; ++i) wt[i] = ld_row(Winv + (size_t)(nb - 1) * NB * NB + (wave + 16 * i) * NB, voff);
     for (int j = nb - 1; j >= 0; --j) {
         const double* Uj = Uf + (size_t)(j * NB) * n;     // element (m, c) of block k at Uj[k * NB + c * n + m]
+        QSP_CBTS(j, 0)
         double u[16];
         if (wave < j) {
 #pragma unroll
@@ -1554,17 +1582,17 @@ __global__ __launch_bounds__(1024) void k_chol_back(Dev d, Par par, const double
 #pragma unroll
             for (int i = 0; i < NB / 16; ++i) {
                 const int r = wave + 16 * i;
-                double v = wt[i] * yq;
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-                if (lane == 0) { xj[r] = v; x[j * NB + r] = v; }
+                const double v = wave_sum_dpp(wt[i] * yq);
+                if (lane == 63) { xj[r] = v; xs[j * NB + r] = v; }
             }
             if (j > 0) {
 #pragma unroll
                 for (int i = 0; i < NB / 16; ++i) wt[i] = ld_row(Winv + (size_t)(j - 1) * NB * NB + (wave + 16 * i) * NB, voff);
             }
         }
+        QSP_CBTS(j, 1)
         __syncthreads();
+        QSP_CBTS(j, 2)
         for (int k = wave; k < j; k += 16) {
             double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
 #pragma unroll 1
@@ -1583,10 +1611,12 @@ __global__ __launch_bounds__(1024) void k_chol_back(Dev d, Par par, const double
             }
             ysh[k * NB + lane] -= (a0 + a1) + (a2 + a3);
         }
+        QSP_CBTS(j, 3)
         __syncthreads();
+        QSP_CBTS(j, 4)
     }
-    if (par.elim) {                                       // x_o = G_o b_o - sum_e F_e^T x_k  (the dense x is complete in global memory)
-        __threadfence_block();
+    for (int i = t; i < n; i += 1024) x[i] = xs[i];       // (the last barrier of the loop has made xs complete)
+    if (par.elim) {                                       // x_o = G_o b_o - sum_e F_e^T x_k  (the dense x is complete in LDS)
         for (int i = t; i < 6 * d.n_obj; i += 1024) {
             const int ob = i / 6, c = i % 6;
             const int ho = d.obj_h[ob];
@@ -1599,7 +1629,7 @@ __global__ __launch_bounds__(1024) void k_chol_back(Dev d, Par par, const double
                 if (hk < 0) continue;
                 const double* F = d.oe_F + 36 * (size_t)e;
 #pragma unroll
-                for (int m = 0; m < 6; ++m) v -= F[6 * m + c] * x[6 * hk + m];
+                for (int m = 0; m < 6; ++m) v -= F[6 * m + c] * xs[6 * hk + m];
             }
             x[6 * ho + c] = v;
         }
@@ -2336,6 +2366,7 @@ extern "C" int qsp_ba_create(const qsp_ba_scene* s, int device, qsp_ba_problem**
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_chol_first, hipFuncAttributeMaxDynamicSharedMemorySize, chol_lds);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_chol_step, hipFuncAttributeMaxDynamicSharedMemorySize, chol_lds);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_schur_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCHUR_ROW_LDS_MAX);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_chol_back, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCHUR_ROW_LDS_MAX);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_obj_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCHUR_ROW_LDS_MAX);
         if (e != hipSuccess) rc = qsp_fail(QSP_ERR_DEVICE, hipGetErrorString(e));
     }
@@ -2699,6 +2730,8 @@ extern "C" int qsp_ba_optimize(qsp_ba_problem* p, int32_t n_iter, double delta_m
             }
             // solve
             if (p->dimp > 0) {
+                if (sizeof(double) * (size_t)(2 * p->dimp + NB) > SCHUR_ROW_LDS_MAX)     // k_chol_back keeps y and x in LDS (dimp <= 10 208)
+                    return qsp_fail(QSP_ERR_UNSUPPORTED, "qsp_ba_optimize: reduced camera system too large for the dense solver");
                 const int nprep = p->n_dense * 36 + d.n_oe * 36 + (p->dimp - p->dim);
                 const size_t row_lds = sizeof(double) * ((size_t)6 * p->dimp + 6);
                 if (fused) {
@@ -2737,7 +2770,7 @@ extern "C" int qsp_ba_optimize(qsp_ba_problem* p, int32_t n_iter, double delta_m
                 for (int k = 0; k + 1 < nb; ++k)
                     hipLaunchKernelGGL(k_chol_step, dim3(nb - k - 1, nb - k - 1), dim3(256), lds, s, d.Hs, d.Uf, d.Winv, d.bs,
                                        d.ych, p->dimp, k, d.scal);
-                hipLaunchKernelGGL(k_chol_back, dim3(1 + 8 * CHOL_BACK_HELPERS), dim3(1024), sizeof(double) * (size_t)(p->dimp + NB), s, d, par, d.Uf, d.Winv,
+                hipLaunchKernelGGL(k_chol_back, dim3(1 + 8 * CHOL_BACK_HELPERS), dim3(1024), sizeof(double) * (size_t)(2 * p->dimp + NB), s, d, par, d.Uf, d.Winv,
                                    d.ych, d.xp, p->dimp);
             } else if (d.n_pt) {
                 if (fused) { /* unreachable: fused needs dimp > 0 */ }
@@ -3055,3 +3088,9 @@ extern "C" int qsp_ba_set_deterministic(qsp_ba_problem* p, int on) {
 }
 
 #include "ellipsoid_fit.hpp"
+
+#ifdef QSP_CB_STAMPS
+extern "C" int qsp_debug_cb_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(qsp::ba::qsp_cb_ts), sizeof(unsigned long long) * 64 * 5);
+}
+#endif
