@@ -423,6 +423,79 @@ __global__ void k_publish_scal(Dev d, double* __restrict__ host, double seq) {
     }
 }
 
+// Sum over the 64 lanes of a wave on the VALU alone (DPP), result valid in lanes 48..63.  __shfl_xor goes through the LDS
+// crossbar (two ds_bpermute per double and level), which all waves of a compute unit share: in k_chol_back 16 waves x 4 rows x
+// 12 of them per step kept the LDS busy for 4.8 k of a step's 16 k cycles (tools/cb_stamps.py), in k_schur_pairs the butterfly
+// over a pair's 42 sums was 504 of them per wave.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_term(double v) {
+    union { double d; int i[2]; } a, r;
+    a.d = v;
+    r.i[0] = __builtin_amdgcn_update_dpp(0, a.i[0], CTRL, ROW_MASK, 0xf, false);
+    r.i[1] = __builtin_amdgcn_update_dpp(0, a.i[1], CTRL, ROW_MASK, 0xf, false);
+    return r.d;                                  // lanes outside ROW_MASK keep the `old` operand: +0.0
+}
+__device__ __forceinline__ double wave_sum_dpp(double v) {
+    v += dpp_term<0xB1, 0xf>(v);                 // quad_perm [1,0,3,2]
+    v += dpp_term<0x4E, 0xf>(v);                 // quad_perm [2,3,0,1]: every lane holds its quad's sum
+    v += dpp_term<0x141, 0xf>(v);                // row_half_mirror: sums of 8
+    v += dpp_term<0x140, 0xf>(v);                // row_mirror: every lane holds its row's (16 lanes) sum
+    v += dpp_term<0x142, 0xa>(v);                // row_bcast15 into rows 1 and 3: rows 0+1, rows 2+3
+    v += dpp_term<0x143, 0xc>(v);                // row_bcast31 into rows 2 and 3: row 3 holds the total
+    return v;
+}
+
+// Sums of N <= 64 values over the 64 lanes at once: at each of the six levels a lane keeps the half of the values whose index has
+// the lane's bit set like its own and adds the partner lane's copy of them, so the number of live values halves while the number
+// of lanes that contributed doubles.  Afterwards lane L holds the complete sum of value L -- 1 + 1/2 + 1/4 + .. of the work of
+// reducing every value on its own.  Partners: quad_perm (lane ^ 1, ^ 2), row_ror 4 / 8 (the lanes of a row that share lane & 3,
+// then lane & 7), v_permlane16_swap / v_permlane32_swap (lane ^ 16, ^ 32).  VALU only, fixed order.
+__device__ __forceinline__ double lane_xor16(double b, bool odd_row) {
+    union { double d; unsigned u[2]; } x, r;
+    x.d = b;
+    const auto s0 = __builtin_amdgcn_permlane16_swap(x.u[0], x.u[0], false, false);
+    const auto s1 = __builtin_amdgcn_permlane16_swap(x.u[1], x.u[1], false, false);
+    r.u[0] = odd_row ? s0[0] : s0[1];
+    r.u[1] = odd_row ? s1[0] : s1[1];
+    return r.d;
+}
+__device__ __forceinline__ double lane_xor32(double b, bool upper) {
+    union { double d; unsigned u[2]; } x, r;
+    x.d = b;
+    const auto s0 = __builtin_amdgcn_permlane32_swap(x.u[0], x.u[0], false, false);
+    const auto s1 = __builtin_amdgcn_permlane32_swap(x.u[1], x.u[1], false, false);
+    r.u[0] = upper ? s0[0] : s0[1];
+    r.u[1] = upper ? s1[0] : s1[1];
+    return r.d;
+}
+template <int LEVEL>
+__device__ __forceinline__ double lane_partner(double b, int lane) {
+    if (LEVEL == 0) return dpp_term<0xB1, 0xf>(b);            // quad_perm [1,0,3,2]
+    if (LEVEL == 1) return dpp_term<0x4E, 0xf>(b);            // quad_perm [2,3,0,1]
+    if (LEVEL == 2) return dpp_term<0x124, 0xf>(b);           // row_ror:4
+    if (LEVEL == 3) return dpp_term<0x128, 0xf>(b);           // row_ror:8
+    if (LEVEL == 4) return lane_xor16(b, (lane & 16) != 0);
+    return lane_xor32(b, (lane & 32) != 0);
+}
+template <int N, int LEVEL>
+struct LaneTranspose {
+    static __device__ __forceinline__ void run(double* v, int lane) {      // v[0..N) in, lane L ends with the sum of value L in v[0]
+        constexpr int H = (N + 1) / 2;
+        const bool bit = (lane >> LEVEL) & 1;
+#pragma unroll
+        for (int m = 0; m < H; ++m) {
+            const double lo = v[2 * m], hi = (2 * m + 1 < N) ? v[2 * m + 1] : 0.0;
+            const double keep = bit ? hi : lo, give = bit ? lo : hi;
+            v[m] = keep + lane_partner<LEVEL>(give, lane);
+        }
+        LaneTranspose<H, LEVEL + 1>::run(v, lane);
+    }
+};
+template <int N>
+struct LaneTranspose<N, 6> {
+    static __device__ __forceinline__ void run(double*, int) {}
+};
+
 // ---------------------------------------------------------------------------------------------------------------
 // k_lin_points: edge-parallel.  A workgroup owns a chunk of consecutive landmarks whose edges (contiguous, landmark-
 // major) number at most 256: thread = edge.  Each thread parks its J_p^T W J_p (6 unique)
@@ -589,13 +662,8 @@ __device__ __forceinline__ void lin_poses_block(const Dev& d, const Par& par, co
         else lin_pose_edge<2>(d, E, par.delta_mono, A, A + 21);
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int i = 0; i < 27; ++i) {
-        double v = A[i];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-        if (lane == 0) sh[wave][i] = v;
-    }
+    LaneTranspose<27, 0>::run(A, lane);                   // lane i < 27 holds the wave's sum of entry i (VALU only, fixed tree)
+    if (lane < 27) sh[wave][lane] = A[0];
     __syncthreads();
     if (threadIdx.x < 27)
         d.kpart[27 * (size_t)sp + threadIdx.x] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
@@ -1013,26 +1081,15 @@ __global__ __launch_bounds__(256) void k_schur_pairs(Dev d, Par par) {
             }
         }
     }
-#pragma unroll
-    for (int i = 0; i < 42; ++i) {
-        double v = acc[i];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-        acc[i] = v;
-    }
+    LaneTranspose<42, 0>::run(acc, lane);                 // lane L < 42 now holds the wave's sum of entry L (fixed tree, VALU only)
     if (big) {
-        if (lane == 0) {
-#pragma unroll
-            for (int i = 0; i < 42; ++i) sh[wave][i] = acc[i];
-        }
+        if (lane < 42) sh[wave][lane] = acc[0];
         __syncthreads();
         if (wave != 0) return;
     }
     // T = sum B_a D^-1 B_b^T belongs at (ha, hb); only the upper block triangle of Hs is used: transpose if ha > hb
     if (lane < 42) {
-        double v = 0;
-#pragma unroll
-        for (int e = 0; e < 42; ++e) v = (e == lane) ? acc[e] : v;
+        double v = acc[0];
         if (big) v = (sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]);
         if (lane < 36) {
             const int i = lane / 6, j = lane % 6;
@@ -1495,26 +1552,6 @@ __global__ __launch_bounds__(256) void k_chol_step(double* A, double* Uf, double
     }
 }
 
-// Sum over the 64 lanes of a wave on the VALU alone (DPP), result valid in lanes 48..63.  __shfl_xor goes through the LDS
-// crossbar (two ds_bpermute per double and level): 16 waves x 4 rows x 12 of them per step kept the one compute unit of
-// k_chol_back busy for 4.8 k of a step's 16 k cycles (tools/cb_stamps.py).
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double dpp_term(double v) {
-    union { double d; int i[2]; } a, r;
-    a.d = v;
-    r.i[0] = __builtin_amdgcn_update_dpp(0, a.i[0], CTRL, ROW_MASK, 0xf, false);
-    r.i[1] = __builtin_amdgcn_update_dpp(0, a.i[1], CTRL, ROW_MASK, 0xf, false);
-    return r.d;                                  // lanes outside ROW_MASK keep the `old` operand: +0.0
-}
-__device__ __forceinline__ double wave_sum_dpp(double v) {
-    v += dpp_term<0xB1, 0xf>(v);                 // quad_perm [1,0,3,2]
-    v += dpp_term<0x4E, 0xf>(v);                 // quad_perm [2,3,0,1]: every lane holds its quad's sum
-    v += dpp_term<0x141, 0xf>(v);                // row_half_mirror: sums of 8
-    v += dpp_term<0x140, 0xf>(v);                // row_mirror: every lane holds its row's (16 lanes) sum
-    v += dpp_term<0x142, 0xa>(v);                // row_bcast15 into rows 1 and 3: rows 0+1, rows 2+3
-    v += dpp_term<0x143, 0xc>(v);                // row_bcast31 into rows 2 and 3: row 3 holds the total
-    return v;
-}
 #ifdef QSP_CB_STAMPS      // timing experiments only: shader-clock stamps of thread 0 at the phase boundaries of every step
 __device__ unsigned long long qsp_cb_ts[64 * 5];
 #define QSP_CBTS(j_, i_) { if (t == 0 && (j_) < 64) qsp_cb_ts[(j_) * 5 + (i_)] = __builtin_readcyclecounter(); }
@@ -1579,11 +1616,14 @@ __global__ __launch_bounds__(1024) void k_chol_back(Dev d, Par par, const double
         }
         {                                                 // x_j[r] = sum_q W_j[q][r] y_j[q];  Winv holds WT[r][q] = W[q][r]
             const double yq = ysh[j * NB + lane];
+            double pr[NB / 16];
 #pragma unroll
-            for (int i = 0; i < NB / 16; ++i) {
-                const int r = wave + 16 * i;
-                const double v = wave_sum_dpp(wt[i] * yq);
-                if (lane == 63) { xj[r] = v; xs[j * NB + r] = v; }
+            for (int i = 0; i < NB / 16; ++i) pr[i] = wt[i] * yq;
+            LaneTranspose<NB / 16, 0>::run(pr, lane);         // lane i < 4 holds the sum of row wave + 16 i
+            if (lane < NB / 16) {
+                const int r = wave + 16 * lane;
+                xj[r] = pr[0];
+                xs[j * NB + r] = pr[0];
             }
             if (j > 0) {
 #pragma unroll
