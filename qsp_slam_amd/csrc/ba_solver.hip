@@ -1859,13 +1859,11 @@ __device__ inline void po_jacobian(const double* p, const double* K, bool stereo
 template <int N>
 __device__ inline void po_block_sum(double* v, double (*sh)[N], double* tot) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double w[N];
 #pragma unroll
-    for (int i = 0; i < N; ++i) {
-        double a = v[i];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
-        if (lane == 0) sh[wave][i] = a;
-    }
+    for (int i = 0; i < N; ++i) w[i] = v[i];
+    LaneTranspose<N, 0>::run(w, lane);                    // lane i < N holds the wave's sum of v[i] (VALU only: this kernel is one
+    if (lane < N) sh[wave][lane] = w[0];                  // workgroup running ~100 dependent steps, each with such a sum)
     __syncthreads();
     if (threadIdx.x < N) tot[threadIdx.x] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
     __syncthreads();
