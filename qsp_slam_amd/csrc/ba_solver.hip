@@ -1393,12 +1393,20 @@ __device__ inline bool factor_tile64(double (&S)[4][4], double (&W)[4][4], doubl
     for (int jb = 0; jb < NB / 4; ++jb) {
         double* rb = rowbuf + (jb & 1) * 8 * NB;
         if ((t >> 4) == jb) {
-            const int src = (lane & 48) | jb;
+            // the 16 lanes at work sit in wave jb / 4 at lanes 16 (jb & 3) ..; the diagonal tile's owner is lane 16 (jb & 3) + jb of it:
+            // a uniform lane index, so v_readlane (to scalar registers) replaces the ds_bpermute pair of a shuffle
+            const int src = 16 * (jb & 3) | jb;
             double D[4][4], rs[4];
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
-                for (int b = a; b < 4; ++b) D[a][b] = __shfl(S[a][b], src, 64);
+                for (int b = a; b < 4; ++b) {
+                    union { double d; int i[2]; } u, r;
+                    u.d = S[a][b];
+                    r.i[0] = __builtin_amdgcn_readlane(u.i[0], src);
+                    r.i[1] = __builtin_amdgcn_readlane(u.i[1], src);
+                    D[a][b] = r.d;
+                }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 double dd = D[q][q];
