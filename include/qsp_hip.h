@@ -87,8 +87,26 @@ void qsp_decoder_destroy(qsp_decoder* dec);
  * items at ~0.67 of the time each -- the latency option for the reference's one-object-per-call pattern
  * (reconstruct/optimizer.py:96-281 called from src/LocalMapping_util.cc:705-760).  Exists on the split-fp16 pipe only (both
  * precisions = 2; qsp_refine_batch_create returns QSP_ERR_UNSUPPORTED otherwise).  The partition of the normal-equation
- * partial sums follows the tile size, so results are bit-reproducible per tile size, not across the two. */
-enum { QSP_DEC_OPT_FORWARD_PRECISION = 1, QSP_DEC_OPT_JACOBIAN_PRECISION = 2, QSP_DEC_OPT_TILE_POINTS = 3 };
+ * partial sums follows the tile size, so results are bit-reproducible per tile size, not across the two.
+ * QSP_DEC_OPT_RENDER_SCREENING (value = margin in units of 1e-6 SDF, 0 = off, the default): the ray-sample forward pass of the
+ * refinement (reconstruct/loss.py:78) in two passes.  The render term clamps -- a sample with |sdf| >= cut_off contributes an
+ * occupancy of exactly 0 or 1 (reconstruct/loss_utils.py:40-48) -- so away from the surface only the SIGN of the value is used.
+ * Pass 1 evaluates every sample with one fp16 term per operand (a third of the matrix-pipe work, 128-point tiles); pass 2
+ * re-evaluates the samples with |s1| < cut_off + margin on the split-fp16 pipe and overwrites them.  With margin >= the
+ * largest |s1 - s3| the result (K, n_valid, H, b, every later iterate) equals the unscreened split-fp16 result BIT FOR BIT;
+ * 20 000 (0.02) is > 8 x the largest difference measured over the fixtures and the randomised sweep (profiles/r03_*).  Needs
+ * QSP_DEC_OPT_FORWARD_PRECISION = 2 (QSP_ERR_UNSUPPORTED otherwise); margins above 5 x the usual cut_off (50 000) are refused:
+ * at that point the second pass covers most samples and the option has no purpose.
+ * QSP_DEC_OPT_USE_TANH (0 / 1): NetworkSpecs.use_tanh of deep_sdf/deep_sdf_decoder.py:66-68,92-94 -- a tanh on the output
+ * layer in front of the final tanh.
+ * QSP_DEC_OPT_RANGE_FALLBACK (1, the default / 0): when a split-fp16 kernel meets an activation or gradient outside fp16's
+ * range, 1 re-runs THAT call on the exact-f32 pipe inside the library and returns its result (counted by
+ * qsp_decoder_get_counter(QSP_DEC_CNT_RANGE_FALLBACKS)); 0 fails the call with QSP_ERR_UNSUPPORTED as round 2 did. */
+enum { QSP_DEC_OPT_FORWARD_PRECISION = 1, QSP_DEC_OPT_JACOBIAN_PRECISION = 2, QSP_DEC_OPT_TILE_POINTS = 3,
+       QSP_DEC_OPT_RENDER_SCREENING = 4, QSP_DEC_OPT_USE_TANH = 5, QSP_DEC_OPT_RANGE_FALLBACK = 6 };
+enum { QSP_DEC_CNT_RANGE_FALLBACKS = 1 };
+/* process-lifetime counters of a decoder (calls that were re-run on the f32 pipe because a value left fp16's range) */
+int64_t qsp_decoder_get_counter(qsp_decoder* dec, int32_t counter);
 int qsp_decoder_set_option(qsp_decoder* dec, int32_t option, int32_t value);
 
 /* decode_sdf, reconstruct/loss_utils.py:51-79.  Host pointers: code (code_len), xyz (n,3) row-major, sdf_out (n). */
@@ -165,6 +183,9 @@ typedef struct {
     int64_t pts_jtj;         /* points through fwd+bwd (sdf points + render rows), all iterations     */
     int64_t pts_fwd;         /* points through forward only (valid ray samples), all iterations       */
     int64_t tiles_jtj, tiles_fwd;   /* 64-point tiles actually executed (incl. padding rows)          */
+    int64_t pts_band;        /* screened forward pass: samples re-evaluated by the second pass (0 when off) */
+    int32_t range_fallbacks; /* 1 if this run was repeated on the f32 pipe (QSP_DEC_OPT_RANGE_FALLBACK)     */
+    int32_t pad_;
 } qsp_refine_profile;
 int qsp_refine_batch_profile(qsp_refine_batch* b, int enable, qsp_refine_profile* out);
 

@@ -41,7 +41,8 @@ class JointCfg(C.Structure):
 class RefineProfile(C.Structure):
     _fields_ = [("ms_total", C.c_float), ("ms_mlp_jtj", C.c_float), ("ms_mlp_fwd", C.c_float),
                 ("ms_other", C.c_float), ("n_launch_jtj", C.c_int32), ("n_launch_fwd", C.c_int32),
-                ("pts_jtj", C.c_int64), ("pts_fwd", C.c_int64), ("tiles_jtj", C.c_int64), ("tiles_fwd", C.c_int64)]
+                ("pts_jtj", C.c_int64), ("pts_fwd", C.c_int64), ("tiles_jtj", C.c_int64), ("tiles_fwd", C.c_int64),
+                ("pts_band", C.c_int64), ("range_fallbacks", C.c_int32), ("pad_", C.c_int32)]
 
 
 class BaScene(C.Structure):

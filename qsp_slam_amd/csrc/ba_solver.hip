@@ -1663,7 +1663,10 @@ __global__ __launch_bounds__(1024) void k_chol_back(Dev d, Par par, const double
         __syncthreads();
         QSP_CBTS(j, 4)
     }
-    for (int i = t; i < n; i += 1024) x[i] = xs[i];       // (the last barrier of the loop has made xs complete)
+    // (the last barrier of the loop has made xs complete.)  Only the rows that were solved: with the objects eliminated their
+    // slots x[6 ho + c], ho >= n_dense, start at par.dim and would overlap the padding rows [dim, dimp) -- two writers, no
+    // barrier in between.  Nobody reads the padding rows of x.
+    for (int i = t; i < par.dim; i += 1024) x[i] = xs[i];
     if (par.elim) {                                       // x_o = G_o b_o - sum_e F_e^T x_k  (the dense x is complete in LDS)
         for (int i = t; i < 6 * d.n_obj; i += 1024) {
             const int ob = i / 6, c = i % 6;
@@ -2517,6 +2520,11 @@ static void build_index(qsp_ba_problem* p) {
         if (p->kf_h[i] >= 0) { ++n_kfree; max_kf_h = std::max(max_kf_h, p->kf_h[i]); }
     for (int i = 0; i < d.n_obj; ++i) n_obj_act += p->obj_h[i] >= 0;
     p->elim = p->elim_allowed && n_obj_act > 0 && n_kfree > 0 && max_kf_h == n_kfree - 1;
+    // k_obj_rows (the atomic mode's object update) holds a 6 x dimp row block in LDS (48 dimp bytes of the 160 KB): beyond 3413
+    // dense unknowns (~568 free key-frames) it does not fit and the objects stay in the dense system.  The atomic-free mode
+    // carries the object entries in its pair lists and has no such limit, but the mode can be switched between optimize() calls
+    // (qsp_ba_set_deterministic), so the bound is applied to both.
+    if (p->elim && sizeof(double) * (size_t)6 * (size_t)(((6 * n_kfree + NB - 1) / NB) * NB) > SCHUR_ROW_LDS_MAX) p->elim = false;
     p->n_dense = p->elim ? n_kfree : p->n_pose;
     p->dim_all = 6 * p->n_pose;
     p->dim = 6 * p->n_dense;
@@ -2693,6 +2701,8 @@ extern "C" int qsp_ba_optimize(qsp_ba_problem* p, int32_t n_iter, double delta_m
             QSP_HIP(hipMemcpyAsync(q.dst, p->idx_host + q.off, sizeof(int32_t) * q.n, hipMemcpyHostToDevice, s));
         }
     }
+    if (sizeof(double) * (size_t)(2 * p->dimp + NB) > SCHUR_ROW_LDS_MAX)     // k_chol_back keeps y and x in LDS (dimp <= 10 208):
+        return qsp_fail(QSP_ERR_UNSUPPORTED, "qsp_ba_optimize: reduced camera system too large for the dense solver");   // refused before anything is enqueued
     Par par{delta_mono, delta_stereo, delta_obj, 0.0, p->dim, p->dimp, p->n_pose, p->rank == 0 ? 1 : 0,
             (p->deterministic && p->dimp > 0) ? 1 : 0, p->n_dense, p->elim ? 1 : 0};
     if (tr) { tr->n = 0; tr->result = 0; tr->n_pose_blocks = p->n_pose; tr->n_landmarks = p->n_land; }
@@ -2776,8 +2786,6 @@ extern "C" int qsp_ba_optimize(qsp_ba_problem* p, int32_t n_iter, double delta_m
             }
             // solve
             if (p->dimp > 0) {
-                if (sizeof(double) * (size_t)(2 * p->dimp + NB) > SCHUR_ROW_LDS_MAX)     // k_chol_back keeps y and x in LDS (dimp <= 10 208)
-                    return qsp_fail(QSP_ERR_UNSUPPORTED, "qsp_ba_optimize: reduced camera system too large for the dense solver");
                 const int nprep = p->n_dense * 36 + d.n_oe * 36 + (p->dimp - p->dim);
                 const size_t row_lds = sizeof(double) * ((size_t)6 * p->dimp + 6);
                 if (fused) {
@@ -2806,6 +2814,7 @@ extern "C" int qsp_ba_optimize(qsp_ba_problem* p, int32_t n_iter, double delta_m
                     if (p->elim) {
                         hipLaunchKernelGGL(k_obj_prepare, dim3(d.n_obj), dim3(64), 0, s, d, par);
                         hipLaunchKernelGGL(k_obj_rows, dim3(d.n_kf), dim3(64), sizeof(double) * (size_t)6 * p->dimp, s, d, par);
+                        QSP_HIP(hipGetLastError());      // (a rejected launch here would leave Hs without the object terms)
                     }
                 }
                 rc = allreduce(p, d.Hs, (int64_t)p->dimp * p->dimp + p->dimp);     // reduced matrix + right-hand side

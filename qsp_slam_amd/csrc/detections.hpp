@@ -132,7 +132,8 @@ __global__ void __launch_bounds__(64) k_det_init(Inputs in, HypState* st, float*
     S.alive = 1;
     S.n_valid = S.n_render = 0;
     S.obj = d;
-    S.pad[0] = S.pad[1] = 0;
+    S.n_band = 0;
+    S.pad = 0;
 }
 
 // one thread per detection: the keep rule of :738-752 over its hypotheses, in order

@@ -86,7 +86,21 @@ struct MlpParams {
     const float4* wbh[8];   // split-fp16 backward weights of layers 0..7 (column blocks over the layer's inputs, slabs over outputs)
     const float4* wbh4s;    // split-fp16 backward weights of layer 4's skip columns (inputs 445..511 = [code | xyz]), packed like wbh[0]
     int* range_flag;        // set by the split-fp16 kernels when a value they had to split was outside fp16's range
+    int use_tanh;           // NetworkSpecs.use_tanh: tanh on the output layer in front of the final tanh (deep_sdf_decoder.py:92-94)
 };
+
+// The network's output and the seed of the backward pass from the last layer's pre-activation t (deep_sdf_decoder.py:92-94,
+// 107-108): y = tanh(t), or tanh(tanh(t)) with use_tanh; dy = d y / d t in autograd's order (the outer tanh's factor first).
+__device__ __forceinline__ float mlp_output(float t, int use_tanh, float& dy) {
+    float y = tanhf(t);
+    dy = 1.f - y * y;
+    if (use_tanh) {
+        const float y2 = tanhf(y);
+        dy = (1.f - y2 * y2) * dy;
+        y = y2;
+    }
+    return y;
+}
 
 // LDS carve (bytes): act 132096 | stash 17408 | inp 64*4*4 | code 256 | y 256 | red 2048 | row scale/res 512
 struct __attribute__((aligned(16))) MlpSmem {
@@ -101,6 +115,7 @@ struct __attribute__((aligned(16))) MlpSmem {
     float rscale[TILE_P];       // row scale of the Jacobian (1 for SDF rows, de/ds for render rows, 0 for padding)
     float rres[TILE_P];         // residual supplied by the caller (render rows)
     float w8[HID];              // last layer's weight row (read by the layer-8 dot product and the backward seed)
+    float dy[TILE_P];           // d y / d (last layer's pre-activation): the backward seed's row factor (mlp_output)
 };
 
 // The same instruction with the accumulator tile in AccVGPRs.  A kernel that fits 256 registers gets ArchVGPR accumulators from
@@ -814,7 +829,9 @@ __device__ __forceinline__ void mlp_tile(MlpSmem& s, const MlpParams* __restrict
         float t = P.b8;
 #pragma unroll
         for (int q = 0; q < 8; ++q) t += s.red[q * TILE_P + tid];
-        s.y[tid] = tanhf(t);
+        float dy_;
+        s.y[tid] = mlp_output(t, P.use_tanh, dy_);
+        s.dy[tid] = dy_;
     }
     QSP_TS()
     __syncthreads();
@@ -827,8 +844,7 @@ __device__ __forceinline__ void mlp_tile(MlpSmem& s, const MlpParams* __restrict
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const int p = 32 * r + (lane & 31);
-            const float yy = s.y[p];
-            const float dy = 1.f - yy * yy;
+            const float dy = s.dy[p];
 #pragma unroll
             for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -1051,7 +1067,9 @@ __device__ __forceinline__ void mlp_tile_bf3(MlpSmem& s, const MlpParams* __rest
         float t = P.b8;
 #pragma unroll
         for (int q = 0; q < 8; ++q) t += s.red[q * TILE_P + tid];
-        s.y[tid] = tanhf(t);
+        float dy_;
+        s.y[tid] = mlp_output(t, P.use_tanh, dy_);
+        s.dy[tid] = dy_;
     }
     __syncthreads();
 }
@@ -1458,7 +1476,9 @@ __device__ __forceinline__ void mlp_tile_h2(MlpSmem& s, const MlpParams* __restr
         float t = P.b8;
 #pragma unroll
         for (int q = 0; q < 4; ++q) t += s.red[q * TP + tid];
-        s.y[tid] = tanhf(t);
+        float dy_;
+        s.y[tid] = mlp_output(t, P.use_tanh, dy_);
+        s.dy[tid] = dy_;
     }
     __syncthreads();
     QSP_HTS()
@@ -1470,8 +1490,7 @@ __device__ __forceinline__ void mlp_tile_h2(MlpSmem& s, const MlpParams* __restr
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
             const int p = 32 * r + (lane & 31);
-            const float yy = s.y[p];
-            const float dy = 1.f - yy * yy;
+            const float dy = s.dy[p];
 #pragma unroll
             for (int c = 0; c < 4; ++c)
 #pragma unroll
@@ -1576,6 +1595,213 @@ __device__ __forceinline__ void mlp_tile_h2(MlpSmem& s, const MlpParams* __restr
     }
 #undef QSP_WH
 #undef QSP_WBH
+}
+
+// ===================================================================================================================
+// The SCREENING tile (round 3): the decoder on the fp16 matrix pipe with ONE term per operand -- x_hi . w_hi only, f32
+// accumulation -- over 128 points per workgroup.  It is not a precision mode: its values are never used as SDF values.  The render
+// term clamps (loss_utils.py:40-48, loss.py:84-122): a ray sample with |sdf| >= th contributes an occupancy of exactly 0 or 1, so
+// away from the surface only the SIGN of the value matters.  k_mlp_fwd_h1 evaluates every ray sample with this tile and keeps a
+// list of the samples with |s1| < th + margin; only those are evaluated again by the three-product tile (k_mlp_fwd_h2), whose
+// values overwrite s1.  With margin >= |s1 - s3| every clamp and every band decision -- hence K, n_valid, H, b -- equals the
+// all-three-product path's bit for bit (tests/test_gpu_screening.py); the margin is a multiple of the largest |s1 - s3| measured
+// (profiles/r03_screen_margin.txt).
+//   * one plane: the activation image is 2 bytes per value, so 128 points fit the LDS that holds 64 points of the split image
+//     -- half the weight bytes per point, and only the hi planes of the packed weights are fetched: a quarter of the split
+//     tile's weight stream per point;
+//   * one accumulator set: a wave's 128 units x 128 points are 4 x 4 tiles of v_mfma_f32_32x32x16_f16 = the 256 AccVGPRs;
+//   * a third of the matrix-pipe work per point.
+// Same packed weights (MlpParams::wfh), same lane maps, same layer-0 / skip handling as mlp_tile_h2.
+constexpr int H1_ROWS = 128;
+constexpr int LDH1 = HID + 8;     // image row stride in halfs (1040 B: 16 rows of a ds_read_b128 lane group fall on 16 different slots)
+struct __attribute__((aligned(16))) MlpSmemH1 {
+    _Float16 img[H1_ROWS * LDH1 + 64];      // (+ tail: the operand prefetch of a row's last slab reads one slab further)
+    float bias[7 * HID];                    // biases of layers 1..7
+    float c0[HID];                          // layer 0 without its xyz part, per hypothesis (k_c0)
+    float c4[HID];                          // layer 4's bias with the code part of the skip connection
+    float w8[HID];
+    float xin[H1_ROWS * 4];
+    float y[H1_ROWS];
+    float red[4 * H1_ROWS];
+};
+
+template <int PF, int NCB>
+struct WRingH1 {
+    f32x4 q[PF][NCB];       // hi plane of [slab in flight][column block]
+};
+template <int PF, int NCB>
+__device__ __forceinline__ void ringh1_prime(WRingH1<PF, NCB>& R, const float4* __restrict__ w_, int cs, int lane) {
+    gbytes w = (gbytes)w_;
+    const uint32_t voff = 16u * lane;
+#pragma unroll
+    for (int d = 0; d < PF; ++d)
+#pragma unroll
+        for (int c = 0; c < NCB; ++c) R.q[d][c] = ldw(w + ((size_t)c * cs + (d * 2) * 64) * 16, voff);
+}
+
+// acc[r][c] += image rows [32 r, 32 r + 32) x slabs [0, KS) * W_hi for NCB column blocks (packed like gemm_h2's, lo' planes
+// skipped); the last PF slabs' refills fetch the first PF slabs of the NEXT matrix (nw_, ncs).
+template <int KS, int PF, int NCB, int NR>
+__device__ __forceinline__ void gemm_h1(const _Float16* __restrict__ img, const float4* __restrict__ w_, int cs,
+                                        const float4* __restrict__ nw_, int ncs, WRingH1<PF, NCB>& R, f32x16 (&acc)[NR][NCB], int lane) {
+    static_assert(KS % PF == 0 && KS >= 2 * PF && PF % 2 == 0 && NR == NCB, "shape");
+    gbytes w = (gbytes)w_;
+    gbytes nw = (gbytes)nw_;
+    uint32_t voff = 16u * lane;
+    int b_idx = (lane & 31) * LDH1 + (lane >> 5) * 8;
+    asm volatile("" : "+v"(voff), "+v"(b_idx));
+    __builtin_amdgcn_s_waitcnt(0x0F70);      // (see gemm_h2: no spill reload may be pending at the loop header)
+    const _Float16* b_row = img + b_idx;
+    f16x8 bh[2][NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) bh[0][r] = *reinterpret_cast<const f16x8*>(b_row + r * 32 * LDH1);
+#pragma nounroll
+    for (int ks = 0; ks < KS; ks += PF) {
+        const bool more = ks + PF < KS;
+        gbytes fb = more ? w + (size_t)(ks + PF) * 2 * 64 * 16 : nw;
+        const size_t fcs = (size_t)(more ? cs : ncs) * 16;
+#pragma unroll
+        for (int d = 0; d < PF; ++d) {
+            const _Float16* nb = b_row + 16 * (ks + d + 1);
+#pragma unroll
+            for (int c = 0; c < NCB; ++c) {
+                const f16x8 wh = as_f16x8(R.q[d][c]);
+#pragma unroll
+                for (int r = 0; r < NR; ++r) acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bh[d & 1][r], acc[r][c], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                bh[(d & 1) ^ 1][c] = *reinterpret_cast<const f16x8*>(nb + c * 32 * LDH1);     // (NR == NCB: row block c of the next slab)
+                if (c > 0) R.q[d][c - 1] = ldw(fb + (c - 1) * fcs + (size_t)(d * 2) * 64 * 16, voff);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            R.q[d][NCB - 1] = ldw(fb + (NCB - 1) * fcs + (size_t)(d * 2) * 64 * 16, voff);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+// four consecutive units of one row -> fp16, one 8-byte store
+__device__ __forceinline__ void h1_store4(_Float16* img, int row, int u0, f32x4 v, float& amax) {
+    amax = fmaxf(fmaxf(amax, fabsf(v[0])), fmaxf(fabsf(v[1]), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+    asm volatile("" : "+v"(amax));
+    f16x4 hi;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) hi[q] = (_Float16)v[q];
+    *reinterpret_cast<f16x4*>(img + row * LDH1 + u0) = hi;
+}
+
+// 128 points staged in s.xin / s.c0 / s.c4 (+ the decoder's constants in s.bias / s.w8) -> s.y[row] = screening value
+template <int PF>
+__device__ __forceinline__ void mlp_tile_h1(MlpSmemH1& s, const MlpParams* __restrict__ Pm, float& amax) {
+    constexpr int NR = 4;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int h = lane >> 5;
+    int oz;
+    asm volatile("s_mov_b32 %0, 0" : "=s"(oz));
+    const MlpParams& P = Pm[oz];
+    f32x16 acc[NR][4];
+    _Float16* img = s.img;
+    if (tid < H1_ROWS) {      // the point as slab 0 of the image: columns 0..2 = xyz, 3..15 zero
+        const f32x4 x = lds4(s.xin + 4 * tid);
+        f16x8 hi, z;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { hi[j] = (_Float16)0.f; z[j] = (_Float16)0.f; }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) hi[j] = (_Float16)x[j];
+        amax = fmaxf(amax, fmaxf(fabsf(x[0]), fmaxf(fabsf(x[1]), fabsf(x[2]))));
+        _Float16* d = img + tid * LDH1;
+        *reinterpret_cast<f16x8*>(d) = hi;
+        *reinterpret_cast<f16x8*>(d + 8) = z;
+    }
+    const int cb0 = 4 * wave;
+    constexpr int KSH = HID / 16, KS4 = K4 / 16, CS = KSH * 2 * 64, CS4 = KS4 * 2 * 64;
+#define QSP_WH(L, KS_) (P.wfh[L] + (size_t)(cb0 * (KS_) * 2) * 64)
+    WRingH1<PF, 4> ring;
+    ringh1_prime(ring, QSP_WH(1, KSH), CS, lane);
+    __syncthreads();
+#define QSP_FWD1(L, BIASPTR, GEMM_STMT)                                                                                  \
+    _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {                  \
+        const f32x4 bv_ = lds4((BIASPTR) + 128 * wave + 32 * c_ + 8 * g_ + 4 * h);                                       \
+        _Pragma("unroll") for (int r_ = 0; r_ < NR; ++r_) _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_)               \
+            acc[r_][c_][4 * g_ + q_] = bv_[q_];                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                               \
+    }                                                                                                                    \
+    GEMM_STMT;                                                                                                           \
+    __syncthreads();                                                                                                     \
+    _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {                  \
+        const int u0_ = 128 * wave + 32 * c_ + 8 * g_ + 4 * h;                                                           \
+        _Pragma("unroll") for (int r_ = 0; r_ < NR; ++r_) {                                                              \
+            f32x4 v_;                                                                                                    \
+            _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                           \
+                const float x_ = acc[r_][c_][4 * g_ + q_];                                                               \
+                v_[q_] = x_ > 0.f ? x_ : 0.f;                                                                            \
+            }                                                                                                            \
+            h1_store4(img, 32 * r_ + (lane & 31), u0_, v_, amax);                                                        \
+        }                                                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                               \
+    }                                                                                                                    \
+    __syncthreads();
+#define QSP_GEMM1(L, KS_, NW, NKS) gemm_h1<KS_, PF, 4, NR>(img, QSP_WH(L, KS_), (KS_) * 2 * 64, NW, (NKS) * 2 * 64, ring, acc, lane)
+    {   // layer 0: one slab of the same product (xyz columns of W0; the code part is s.c0)
+        gbytes w = (gbytes)QSP_WH(0, 1);
+        const uint32_t voff = 16u * lane;
+        const _Float16* b_row = img + (lane & 31) * LDH1 + (lane >> 5) * 8;
+        QSP_FWD1(0, s.c0, {
+            f16x8 bh0[NR];
+            _Pragma("unroll") for (int r = 0; r < NR; ++r) bh0[r] = *reinterpret_cast<const f16x8*>(b_row + r * 32 * LDH1);
+            _Pragma("unroll") for (int c = 0; c < 4; ++c) {
+                const f16x8 wh = as_f16x8(ldw(w + (size_t)(c * 2) * 64 * 16, voff));
+                _Pragma("unroll") for (int r = 0; r < NR; ++r)
+                    acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bh0[r], acc[r][c], 0, 0, 0);
+            }
+        })
+    }
+    QSP_FWD1(1, s.bias + 0 * HID, QSP_GEMM1(1, KSH, QSP_WH(2, KSH), KSH))
+    QSP_FWD1(2, s.bias + 1 * HID, QSP_GEMM1(2, KSH, QSP_WH(3, KSH), KSH))
+    QSP_FWD1(3, s.bias + 2 * HID, QSP_GEMM1(3, KSH, QSP_WH(4, KS4), KS4))
+    if (tid < H1_ROWS) {       // the skip connection's xyz into columns 445..447 (zeros from layer 3's write-out until now)
+#pragma unroll
+        for (int ci = 0; ci < 3; ++ci) {
+            const float x = s.xin[tid * 4 + ci];
+            img[tid * LDH1 + SKIP_COL + ci] = (_Float16)x;
+        }
+    }
+    __syncthreads();
+    QSP_FWD1(4, s.c4, QSP_GEMM1(4, KS4, QSP_WH(5, KSH), KSH))
+    QSP_FWD1(5, s.bias + 4 * HID, QSP_GEMM1(5, KSH, QSP_WH(6, KSH), KSH))
+    QSP_FWD1(6, s.bias + 5 * HID, QSP_GEMM1(6, KSH, QSP_WH(7, KSH), KSH))
+    QSP_FWD1(7, s.bias + 6 * HID, QSP_GEMM1(7, KSH, QSP_WH(1, KSH), KSH))
+#undef QSP_FWD1
+#undef QSP_GEMM1
+#undef QSP_WH
+    // layer 8: 512 -> 1, tanh: wave = k segment of 128, lane = rows lane and lane + 64
+    {
+        const float* w = s.w8 + 128 * wave;
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const _Float16* a = img + (lane + 64 * rr) * LDH1 + 128 * wave;
+            float pa[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const f16x8 hi = *reinterpret_cast<const f16x8*>(a + 8 * g);
+                const f32x4 w0 = lds4(w + 8 * g), w1 = lds4(w + 8 * g + 4);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pa[j & 3] = fmaf((float)hi[j], j < 4 ? w0[j] : w1[j - 4], pa[j & 3]);
+            }
+            s.red[wave * H1_ROWS + lane + 64 * rr] = (pa[0] + pa[1]) + (pa[2] + pa[3]);
+        }
+    }
+    __syncthreads();
+    if (tid < H1_ROWS) {
+        float t = P.b8;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) t += s.red[q * H1_ROWS + tid];
+        float dy_;
+        s.y[tid] = mlp_output(t, P.use_tanh, dy_);
+    }
+    __syncthreads();
 }
 
 }  // namespace qsp

@@ -32,1211 +32,8 @@
 #include "common.hpp"
 #include "sdf_mlp.hpp"
 
-namespace qsp {
+#include "sdf_kernels.hpp"
 
-constexpr int MAX_DEPTH = 64;
-#ifndef QSP_NW_REND
-#define QSP_NW_REND 16
-#endif
-#ifndef QSP_NW_SDF_MAX
-#define QSP_NW_SDF_MAX 256      // surface slots per hypothesis: one 64-point tile per work item up to 16 k surface points
-#endif
-constexpr int NW_REND = QSP_NW_REND;     // render slots per hypothesis (work items looping over render-row tiles beyond 16 x 64 rows)
-constexpr int NW_SDF_MAX = QSP_NW_SDF_MAX;  // work items per hypothesis looping over surface-point tiles
-constexpr int NH = 71;          // 7 pose + 64 code unknowns
-constexpr int PART_FLOATS = HT_TILES * 1024;
-
-// per-hypothesis state, resident in HBM
-struct HypState {
-    float T_oc[16];     // camera -> object Sim3, row-major
-    float code[CODE_LEN];
-    float T_co[16];     // object -> camera (inverse), refreshed by k_sample
-    float scale, d_min, d_max, loss;
-    float loss_sdf, loss_render;
-    int32_t alive;      // 1 while the reference would still be iterating
-    int32_t n_valid;    // ray samples inside the unit ball
-    int32_t n_render;   // render rows K
-    int32_t obj;        // object index
-    int32_t pad[2];
-};
-
-struct ObjView {            // per-object observation extents inside the concatenated arrays
-    int64_t pts_off;        // in points
-    int64_t ray_off;        // in rays
-    int32_t n_pts, n_rays, n_fg, pad;
-};
-
-struct RefineCfg {
-    float k1, k2, k3, k4, b1, b2, lr, s_damp, cut_off;
-    int32_t n_depth;
-    int32_t pose_only;      // estimate_pose_cam_obj mode
-    int32_t iter;           // current iteration index (pose-only inlier filter)
-    int32_t code_len;       // the decoder's code length L <= 64: code unknowns L..63 are padding (decoupled in k_solve)
-    int32_t tile_p;         // points per MLP tile: 64, or 32 (QSP_DEC_OPT_TILE_POINTS, split-fp16 pipe only)
-};
-
-// ---------------------------------------------------------------------------------------------------------------
-// small device helpers
-// ---------------------------------------------------------------------------------------------------------------
-
-// torch.linspace(d_min, d_max, D)[k] in f32 (two-sided form used by ATen's kernels)
-__device__ __forceinline__ float depth_at(float d_min, float d_max, int k, int D) {
-    const float step = (d_max - d_min) / (float)(D - 1);
-    return (k < D / 2) ? d_min + step * (float)k : d_max - step * (float)(D - 1 - k);
-}
-
-__device__ __forceinline__ void xform(const float* T, float px, float py, float pz, float& x, float& y, float& z) {
-    x = px * T[0] + py * T[1] + pz * T[2] + T[3];
-    y = px * T[4] + py * T[5] + pz * T[6] + T[7];
-    z = px * T[8] + py * T[9] + pz * T[10] + T[11];
-}
-
-// 4x4 inverse, Gauss-Jordan with partial pivoting in f64 from f32 input (reference: torch.inverse in f32)
-__device__ void inv4(const float* A, float* Ainv) {
-    double a[4][8];
-    for (int i = 0; i < 4; ++i)
-        for (int j = 0; j < 4; ++j) {
-            a[i][j] = (double)A[4 * i + j];
-            a[i][4 + j] = (i == j) ? 1.0 : 0.0;
-        }
-    for (int c = 0; c < 4; ++c) {
-        int p = c;
-        double best = fabs(a[c][c]);
-        for (int r = c + 1; r < 4; ++r)
-            if (fabs(a[r][c]) > best) { best = fabs(a[r][c]); p = r; }
-        if (p != c)
-            for (int j = 0; j < 8; ++j) { double t = a[c][j]; a[c][j] = a[p][j]; a[p][j] = t; }
-        const double inv = 1.0 / a[c][c];
-        for (int j = 0; j < 8; ++j) a[c][j] *= inv;
-        for (int r = 0; r < 4; ++r)
-            if (r != c) {
-                const double f = a[r][c];
-                for (int j = 0; j < 8; ++j) a[r][j] -= f * a[c][j];
-            }
-    }
-    for (int i = 0; i < 4; ++i)
-        for (int j = 0; j < 4; ++j) Ainv[4 * i + j] = (float)a[i][4 + j];
-}
-
-__device__ __forceinline__ float det3(const float* T) {   // of the upper-left 3x3 of a row-major 4x4
-    const double a = T[0], b = T[1], c = T[2], d = T[4], e = T[5], f = T[6], g = T[8], h = T[9], i = T[10];
-    return (float)(a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g));
-}
-
-// exclusive scan of one int per thread over the block (a multiple of 64, at most 512 threads); returns the exclusive prefix,
-// total in *total
-__device__ int block_excl_scan_256(int v, int* smem /* >= 8 ints */, int* total) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int x = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int y = __shfl_up(x, o, 64);
-        if (lane >= o) x += y;
-    }
-    if (lane == 63) smem[wave] = x;
-    __syncthreads();
-    int base = 0, tot = 0;
-    const int nw = blockDim.x >> 6;
-    for (int w = 0; w < nw; ++w) {
-        if (w < wave) base += smem[w];
-        tot += smem[w];
-    }
-    __syncthreads();
-    *total = tot;
-    return base + x - v;
-}
-
-// Huber weight sqrt(rho(|r|))/|r| (loss_utils.py:236-247); |r| == 0 divides by 1
-__device__ __forceinline__ float huber_w(float r, float b) {
-    const float a = fabsf(r);
-    const float rho = (a <= b) ? a * a : 2.f * b * a - b * b;
-    return sqrtf(rho) / (a == 0.f ? 1.f : a);
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// k_sample: per-hypothesis prologue + valid ray samples (loss.py:60-74, optimizer.py:144-153)
-// ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_sample(HypState* __restrict__ st, const ObjView* __restrict__ objs,
-                                                const float* __restrict__ rays, RefineCfg cfg,
-                                                int32_t* __restrict__ valid_rk, int64_t rk_stride,
-                                                int32_t* __restrict__ ray_voff, int64_t ray_stride) {
-    const int h = blockIdx.x;
-    HypState& S = st[h];
-    if (!S.alive) return;
-    __shared__ float T[16];
-    __shared__ float dm[2];
-    __shared__ int sc[8];
-    if (threadIdx.x == 0) {
-        float Tco[16];
-        inv4(S.T_oc, Tco);
-        const float scale = powf(det3(Tco), (float)(1.0 / 3.0));
-        for (int i = 0; i < 16; ++i) S.T_co[i] = Tco[i];
-        S.scale = scale;
-        S.d_min = Tco[11] - 1.0f * scale;
-        S.d_max = Tco[11] + 1.0f * scale;
-        dm[0] = S.d_min;
-        dm[1] = S.d_max;
-        for (int i = 0; i < 16; ++i) T[i] = S.T_oc[i];
-    }
-    __syncthreads();
-    const ObjView ov = objs[S.obj];
-    const int D = cfg.n_depth;
-    const float* R = rays + 3 * ov.ray_off;
-    int32_t* rk = valid_rk + h * rk_stride;
-    int32_t* voff = ray_voff + h * ray_stride;
-    int carry = 0;
-    for (int base = 0; base < ov.n_rays; base += 256) {
-        const int r = base + threadIdx.x;
-        uint64_t mask = 0;
-        float rx = 0, ry = 0, rz = 0;
-        if (r < ov.n_rays) {
-            rx = R[3 * r], ry = R[3 * r + 1], rz = R[3 * r + 2];
-            for (int k = 0; k < D; ++k) {
-                const float d = depth_at(dm[0], dm[1], k, D);
-                float x, y, z;
-                xform(T, rx * d, ry * d, rz * d, x, y, z);
-                if (sqrtf(x * x + y * y + z * z) < 1.0f) mask |= (1ull << k);
-            }
-        }
-        const int cnt = __popcll(mask);
-        int tot;
-        const int ex = block_excl_scan_256(cnt, sc, &tot);
-        if (r < ov.n_rays) {
-            voff[r] = carry + ex;
-            int w = carry + ex;
-            for (int k = 0; k < D; ++k)
-                if (mask >> k & 1ull) rk[w++] = (r << 6) | k;
-        }
-        carry += tot;
-    }
-    if (threadIdx.x == 0) {
-        voff[ov.n_rays] = carry;
-        S.n_valid = carry;
-        S.n_render = 0;
-        if (!cfg.pose_only && carry < 10) S.alive = 0;   // loss.py:73-74 -> optimizer.py:171-172
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// staging of one tile's inputs
-// ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void stage_code_T(MlpSmem& s, const HypState& S, float* Tsh) {
-    if (threadIdx.x < CODE_LEN) s.code[threadIdx.x] = S.code[threadIdx.x];
-    if (threadIdx.x >= 64 && threadIdx.x < 80) Tsh[threadIdx.x - 64] = S.T_oc[threadIdx.x - 64];
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// Work queues of the two MLP kernels.
-// Both kernels are launched as ONE workgroup per CU and pull (hypothesis, slot) items from a list through an atomic
-// counter until it is exhausted.  Why not a (slots, hypotheses) grid: workgroup ids are dealt round-robin to the 8 XCDs, a
-// grid row holds slots with and without work (render slots beyond K, the ragged last surface slot), and for most row
-// lengths the working slots of every hypothesis fall on the same XCDs -- measured 6-40 % of the chip idle depending on
-// (slots mod 8).  A compacted list has no empty items, so whichever CU is free takes the next one.
-// Partial sums stay addressed by the LOGICAL (hypothesis, slot), so results do not depend on who processed what.
-//   qctl[0] = #items forward, qctl[1] = next forward item, qctl[2] = #items jtj, qctl[3] = next jtj item
-// ---------------------------------------------------------------------------------------------------------------
-// c0[h][u] = b0[u] + sum_k W0[u][k] code_h[k]: layer 0 without its xyz columns (see mlp_prepare), once per hypothesis
-__global__ __launch_bounds__(MLP_THREADS) void k_c0(const HypState* __restrict__ st, const MlpParams* __restrict__ Pm,
-                                                    float* __restrict__ c0_all) {
-    __shared__ float code[CODE_LEN];
-    const HypState& S = st[blockIdx.x];
-    if (!S.alive) return;
-    if (threadIdx.x < CODE_LEN) code[threadIdx.x] = S.code[threadIdx.x];
-    __syncthreads();
-    const int u = threadIdx.x;
-    const float* w = Pm->w0c + (size_t)u * CODE_LEN;
-    const float* w4 = Pm->w4c + (size_t)u * CODE_LEN;
-    float a = Pm->bias[0][u], a4 = Pm->bias[4][u];
-#pragma unroll 8
-    for (int k = 0; k < CODE_LEN; ++k) {
-        a += w[k] * code[k];
-        a4 += w4[k] * code[k];
-    }
-    c0_all[(size_t)blockIdx.x * 2 * HID + u] = a;
-    c0_all[(size_t)blockIdx.x * 2 * HID + HID + u] = a4;     // layer 4's bias with the skip connection's code part
-}
-
-// mode 0: forward items (h, tile) over the valid ray samples; mode 1: jtj items (h, slot), surface slots then render slots
-__global__ __launch_bounds__(1024) void k_plan(int mode, const HypState* __restrict__ st, const ObjView* __restrict__ objs,
-                                               int n_hyp, int nw_sdf, int nw_rend, int2* __restrict__ work, int* __restrict__ qctl,
-                                               int tile_p) {
-    __shared__ int wsum[16];
-    __shared__ int carry_sh;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    if (t == 0) carry_sh = 0;
-    __syncthreads();
-    for (int base = 0; base < n_hyp; base += 1024) {
-        const int h = base + t;
-        int n_a = 0, n_b = 0;
-        if (h < n_hyp && st[h].alive) {
-            if (mode == 0) n_a = (st[h].n_valid + tile_p - 1) / tile_p;
-            else {
-                n_a = min(nw_sdf, (objs[st[h].obj].n_pts + tile_p - 1) / tile_p);
-                n_b = min(nw_rend, (st[h].n_render + tile_p - 1) / tile_p);
-            }
-        }
-        const int cnt = n_a + n_b;
-        int inc = cnt;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int up = __shfl_up(inc, o, 64);
-            if (lane >= o) inc += up;
-        }
-        if (lane == 63) wsum[wave] = inc;
-        __syncthreads();
-        int off = carry_sh + inc - cnt;
-        for (int w = 0; w < wave; ++w) off += wsum[w];
-        for (int j = 0; j < n_a; ++j) work[off + j] = make_int2(h, j);
-        for (int j = 0; j < n_b; ++j) work[off + n_a + j] = make_int2(h, nw_sdf + j);
-        __syncthreads();
-        if (t == 1023) carry_sh = off + cnt;
-        __syncthreads();
-    }
-    if (t == 0) {
-        qctl[2 * mode] = carry_sh;
-        qctl[2 * mode + 1] = 0;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// k_mlp_fwd: decoder forward on the valid ray samples (loss.py:78)
-// ---------------------------------------------------------------------------------------------------------------
-template <bool BF3>
-__global__ __launch_bounds__(MLP_THREADS, 2) void k_mlp_fwd(const HypState* __restrict__ st,
-                                                            const ObjView* __restrict__ objs,
-                                                            const float* __restrict__ rays, RefineCfg cfg, const MlpParams* __restrict__ P,
-                                                            const int32_t* __restrict__ valid_rk, int64_t rk_stride,
-                                                            float* __restrict__ sdf_valid, const int2* __restrict__ work,
-                                                            int* __restrict__ qctl, const float* __restrict__ c0_all) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    MlpSmem& s = *reinterpret_cast<MlpSmem*>(smem_raw);
-    __shared__ float Tsh[16];
-    __shared__ int s_item;
-    const int n_items = qctl[0];
-    int h_cached = -1;
-    for (;;) {
-        if (threadIdx.x == 0) s_item = atomicAdd(&qctl[1], 1);
-        __syncthreads();                       // also: everybody is done with the previous item's LDS
-        const int item = s_item;
-        if (item >= n_items) break;            // the queue only grows towards n_items: every workgroup gets here
-        const int h = work[item].x, t = work[item].y;
-        const HypState& S = st[h];
-        const int n = S.n_valid;
-        const ObjView ov = objs[S.obj];
-        const float* R = rays + 3 * ov.ray_off;
-        const int32_t* rk = valid_rk + h * rk_stride;
-        float* out = sdf_valid + h * rk_stride;
-        if (h != h_cached) {                   // per-hypothesis staging: code, pose, layer-0 code part
-            stage_code_T(s, S, Tsh);
-            s.c0[threadIdx.x] = c0_all[(size_t)h * 2 * HID + threadIdx.x];
-            s.c4[threadIdx.x] = c0_all[(size_t)h * 2 * HID + HID + threadIdx.x];
-            h_cached = h;
-        }
-        const float d_min = S.d_min, d_max = S.d_max;
-        __syncthreads();
-        if (threadIdx.x < TILE_P) {
-            const int v = t * TILE_P + threadIdx.x;
-            float x = 0, y = 0, z = 0;
-            if (v < n) {
-                const int e = rk[v];
-                const int r = e >> 6, k = e & 63;
-                const float d = depth_at(d_min, d_max, k, cfg.n_depth);
-                xform(Tsh, R[3 * r] * d, R[3 * r + 1] * d, R[3 * r + 2] * d, x, y, z);
-            }
-            s.xin[4 * threadIdx.x + 0] = x;
-            s.xin[4 * threadIdx.x + 1] = y;
-            s.xin[4 * threadIdx.x + 2] = z;
-            s.xin[4 * threadIdx.x + 3] = 0.f;
-        }
-        __syncthreads();
-        if (BF3) mlp_tile_bf3<QSP_BF3_PF>(s, P);
-        else mlp_tile<false, 4>(s, P);
-        if (threadIdx.x < TILE_P) {
-            const int v = t * TILE_P + threadIdx.x;
-            if (v < n) out[v] = s.y[threadIdx.x];
-        }
-    }
-}
-
-// the same work queue on the split-fp16 tile: four waves per workgroup (mlp_tile_h2)
-template <int NR>      // NR point blocks of 32 per tile (QSP_DEC_OPT_TPOINTS)
-__global__ __launch_bounds__(H2_THREADS) void k_mlp_fwd_h2(const HypState* __restrict__ st,
-                                                            const ObjView* __restrict__ objs,
-                                                            const float* __restrict__ rays, RefineCfg cfg, const MlpParams* __restrict__ P,
-                                                            const int32_t* __restrict__ valid_rk, int64_t rk_stride,
-                                                            float* __restrict__ sdf_valid, const int2* __restrict__ work,
-                                                            int* __restrict__ qctl, const float* __restrict__ c0_all) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    MlpSmem& s = *reinterpret_cast<MlpSmem*>(smem_raw);
-    __shared__ float Tsh[16];
-    __shared__ int s_item;
-    const int n_items = qctl[0];
-    constexpr int TP = 32 * NR;
-    bool staged = false;
-    float amax = 0.f;
-    int h_cached = -1;
-    for (;;) {
-        if (threadIdx.x == 0) s_item = atomicAdd(&qctl[1], 1);
-        __syncthreads();                       // also: everybody is done with the previous item's LDS
-        const int item = s_item;
-        if (item >= n_items) break;            // the queue only grows towards n_items: every workgroup gets here
-        const int h = work[item].x, t = work[item].y;
-        const HypState& S = st[h];
-        const int n = S.n_valid;
-        const ObjView ov = objs[S.obj];
-        const float* R = rays + 3 * ov.ray_off;
-        const int32_t* rk = valid_rk + h * rk_stride;
-        float* out = sdf_valid + h * rk_stride;
-        if (h != h_cached) {                   // per-hypothesis staging: code, pose, layer-0 code part
-            stage_code_T(s, S, Tsh);
-            for (int i = threadIdx.x; i < HID; i += H2_THREADS) {
-                s.c0[i] = c0_all[(size_t)h * 2 * HID + i];
-                s.c4[i] = c0_all[(size_t)h * 2 * HID + HID + i];
-            }
-            h_cached = h;
-        }
-        const float d_min = S.d_min, d_max = S.d_max;
-        __syncthreads();
-        if (threadIdx.x < TP) {
-            const int v = t * TP + threadIdx.x;
-            float x = 0, y = 0, z = 0;
-            if (v < n) {
-                const int e = rk[v];
-                const int r = e >> 6, k = e & 63;
-                const float d = depth_at(d_min, d_max, k, cfg.n_depth);
-                xform(Tsh, R[3 * r] * d, R[3 * r + 1] * d, R[3 * r + 2] * d, x, y, z);
-            }
-            s.xin[4 * threadIdx.x + 0] = x;
-            s.xin[4 * threadIdx.x + 1] = y;
-            s.xin[4 * threadIdx.x + 2] = z;
-            s.xin[4 * threadIdx.x + 3] = 0.f;
-        }
-        __syncthreads();
-        mlp_tile_h2<false, 2, true, NR>(s, P, amax, !staged);      // (the decoder's constants: staged by the first tile of the workgroup)
-        staged = true;
-        if (threadIdx.x < TP) {
-            const int v = t * TP + threadIdx.x;
-            if (v < n) out[v] = s.y[threadIdx.x];
-        }
-    }
-    if (!(amax <= H2_MAX)) *P->range_flag = 1;
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// k_scan: per ray render function and its derivative (loss.py:84-141)
-// ---------------------------------------------------------------------------------------------------------------
-struct RayScan {
-    float d_u;
-    int n_emit;
-};
-
-// walks one ray; if `emit` != nullptr writes the kept rows starting at emit index `w`
-// One ray: `row` holds the SDF value of its depth sample k at row[k] (SCAN_NONE where the sample is outside the unit ball), staged
-// in LDS by the workgroup (k_scan).  Every per-sample array is indexed by the unrolled loop counter only, so it lives in
-// registers.  (Indexing them by the sample's k made them scratch memory, and reading the samples through a cursor made every
-// load wait for the one before: 110 us per launch for 456 rays.)  Same operations in the same order as the reference's rows.
-constexpr float SCAN_NONE = 1e30f;
-constexpr int SCAN_RAYS = 512;                 // rays per pass = threads of k_scan
-constexpr int SCAN_LD = MAX_DEPTH + 1;         // row stride in LDS: odd, so that the threads of a wave hit different banks
-__device__ __forceinline__ int scan_ray(const float* __restrict__ row, int ray, int D, float d_min, float d_max, float th,
-                                        float depth_obs, int32_t* e_rk, float* e_deds, float* e_res, int w) {
-    float occ[MAX_DEPTH];          // occupancy row (zeros outside the unit ball)
-    float Tl[MAX_DEPTH];           // transmittance T_l = prod_{j<=l} (1 - occ_j), then its suffix sums (loss.py:99-113)
-    uint64_t inband = 0;           // bit k: a valid sample with |sdf| < th
-    float acc = 1.f, d_u = 0.f;
-#pragma unroll
-    for (int k = 0; k < MAX_DEPTH; ++k) {
-        if (k < D) {
-            const float s = row[k];
-            float o = 0.f;
-            if (s < 0.5f * SCAN_NONE) {
-                const float c = fminf(fmaxf(s, -th), th);
-                o = 0.5f - c / (2.f * th);
-                if (s > -th && s < th) inband |= 1ull << k;
-            }
-            occ[k] = o;
-            const float d = depth_at(d_min, d_max, k, D);
-            d_u += d * (o * acc);
-            acc *= (1.f - o);
-            Tl[k] = acc;
-        }
-    }
-    d_u += (1.1f * d_max) * acc;                       // the extra far bin
-    float res = depth_obs - d_u;
-    res = fminf(fmaxf(res, -0.30f), 0.30f);
-    const float delta_d = (d_max - d_min) / (float)(D - 1);
-    const float do_ds = -1.f / (2.f * th);
-    float ssum = 0.f;                                  // suffix sums of T, walked from the far end
-#pragma unroll
-    for (int k = MAX_DEPTH - 1; k >= 0; --k)
-        if (k < D) { ssum += Tl[k]; Tl[k] = ssum; }
-    int n = 0;
-#pragma unroll
-    for (int k = 0; k < MAX_DEPTH; ++k) {              // emission in ascending k
-        if (k < D && ((inband >> k) & 1ull)) {
-            const float de_do = Tl[k] / (1.f - occ[k]);
-            if (de_do > 1e-2f) {
-                if (e_rk) {
-                    e_rk[w + n] = (ray << 6) | k;
-                    e_deds[w + n] = de_do * delta_d * do_ds;
-                    e_res[w + n] = res;
-                }
-                ++n;
-            }
-        }
-    }
-    return n;
-}
-__global__ __launch_bounds__(SCAN_RAYS) void k_scan(HypState* __restrict__ st, const ObjView* __restrict__ objs,
-                                                    const float* __restrict__ depth, RefineCfg cfg,
-                                                    const int32_t* __restrict__ valid_rk, int64_t rk_stride,
-                                                    const int32_t* __restrict__ ray_voff, int64_t ray_stride,
-                                                    const float* __restrict__ sdf_valid, int32_t* __restrict__ rend_rk,
-                                                    float* __restrict__ rend_deds, float* __restrict__ rend_res) {
-    const int h = blockIdx.x;
-    HypState& S = st[h];
-    if (!S.alive) return;
-    extern __shared__ __attribute__((aligned(16))) float rows[];     // [SCAN_RAYS][SCAN_LD]
-    __shared__ int sc[8];
-    const ObjView ov = objs[S.obj];
-    const int D = cfg.n_depth;
-    const float* dep = depth + ov.ray_off;   // depth array is stored per ray (fg entries valid)
-    const int32_t* rk = valid_rk + h * rk_stride;
-    const int32_t* voff = ray_voff + h * ray_stride;
-    const float* sdf = sdf_valid + h * rk_stride;
-    int32_t* e_rk = rend_rk + h * rk_stride;
-    float* e_deds = rend_deds + h * rk_stride;
-    float* e_res = rend_res + h * rk_stride;
-    const float d_min = S.d_min, d_max = S.d_max;
-    int carry = 0;
-    for (int base = 0; base < ov.n_rays; base += SCAN_RAYS) {        // one ray per thread: 456 rays in one pass
-        // the pass's samples into a dense [ray][k] table: coalesced reads of the (ray, k)-sorted lists, one table row per thread
-        __syncthreads();
-        for (int e = threadIdx.x; e < SCAN_RAYS * SCAN_LD; e += SCAN_RAYS) rows[e] = SCAN_NONE;
-        __syncthreads();
-        const int r_end = min(base + SCAN_RAYS, ov.n_rays);
-        const int v_beg = voff[base], v_end = voff[r_end];
-        for (int v = v_beg + threadIdx.x; v < v_end; v += SCAN_RAYS) {
-            const int e = rk[v];
-            rows[((e >> 6) - base) * SCAN_LD + (e & 63)] = sdf[v];
-        }
-        __syncthreads();
-        const int r = base + threadIdx.x;
-        int n = 0;
-        float dobs = 0.f;
-        const float* row = rows + threadIdx.x * SCAN_LD;
-        bool any = false;
-        if (r < ov.n_rays) {
-            any = voff[r + 1] > voff[r];
-            dobs = (r < ov.n_fg) ? dep[r] : 1.1f * d_max;   // optimizer.py:153
-            if (any) n = scan_ray(row, r, D, d_min, d_max, cfg.cut_off, dobs, nullptr, nullptr, nullptr, 0);
-        }
-        int tot;
-        const int ex = block_excl_scan_256(n, sc, &tot);
-        if (n > 0) scan_ray(row, r, D, d_min, d_max, cfg.cut_off, dobs, e_rk, e_deds, e_res, carry + ex);
-        carry += tot;
-    }
-    if (threadIdx.x == 0) S.n_render = carry;
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// k_mlp_jtj: surface points + kept render rows -> Jacobian rows -> J~^T J~ tile partials
-// ---------------------------------------------------------------------------------------------------------------
-template <bool B3>
-__global__ __launch_bounds__(MLP_THREADS, 2) void k_mlp_jtj(const HypState* __restrict__ st,
-                                                            const ObjView* __restrict__ objs,
-                                                            const float* __restrict__ pts,
-                                                            const float* __restrict__ rays, RefineCfg cfg, const MlpParams* __restrict__ P,
-                                                            int nw_sdf, const int32_t* __restrict__ rend_rk,
-                                                            const float* __restrict__ rend_deds,
-                                                            const float* __restrict__ rend_res, int64_t rk_stride,
-                                                            const uint8_t* __restrict__ pt_active, int64_t act_stride,
-                                                            float* __restrict__ res_out, float* __restrict__ rows_out, int64_t rows_stride,
-                                                            float* __restrict__ partials, int nw_total,
-                                                            const int2* __restrict__ work, int* __restrict__ qctl,
-                                                            const float* __restrict__ c0_all) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    MlpSmem& s = *reinterpret_cast<MlpSmem*>(smem_raw);
-    __shared__ float Tsh[16];
-    __shared__ int s_item;
-    const int n_items = qctl[2];
-    bool tsk_first = true;
-    (void)tsk_first;
-  for (;;) {                                   // work queue, see k_plan
-    QSP_TSK(0)
-    if (threadIdx.x == 0) s_item = atomicAdd(&qctl[3], 1);
-    __syncthreads();                           // also: everybody is done with the previous item's LDS
-    const int item = s_item;
-    if (item >= n_items) break;                // the queue only grows towards n_items: every workgroup gets here
-    QSP_TSK(1)
-    const int h = work[item].x, slot = work[item].y;
-    const HypState& S = st[h];
-    const ObjView ov = objs[S.obj];
-    const bool is_sdf = slot < nw_sdf;
-    const int stride = is_sdf ? nw_sdf : nw_total - nw_sdf;
-    const int j0 = is_sdf ? slot : slot - nw_sdf;
-    const int n = is_sdf ? ov.n_pts : S.n_render;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-
-    // J~^T J~ accumulator of this wave's upper-triangular tile (waves 0..5)
-    f32x16 hacc;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) hacc[i] = 0.f;
-    const int ta = (wave < 3) ? 0 : (wave < 5 ? 1 : 2);
-    const int tb = (wave < 3) ? wave : (wave < 5 ? wave - 2 : 2);
-
-    stage_code_T(s, S, Tsh);
-    s.c0[threadIdx.x] = c0_all[(size_t)h * 2 * HID + threadIdx.x];
-    s.c4[threadIdx.x] = c0_all[(size_t)h * 2 * HID + HID + threadIdx.x];
-    const float* Pc = pts + 3 * ov.pts_off;
-    const float* R = rays + 3 * ov.ray_off;
-    const int32_t* rk = rend_rk + h * rk_stride;
-    const float* deds = rend_deds + h * rk_stride;
-    const float* rres = rend_res + h * rk_stride;
-    const uint8_t* active = pt_active ? pt_active + h * act_stride : nullptr;
-    const float d_min = S.d_min, d_max = S.d_max;
-    const float hub = is_sdf ? cfg.b2 : cfg.b1;
-
-    for (int t = j0; t * TILE_P < n; t += stride) {
-        __syncthreads();
-        if (tid < TILE_P) {
-            const int v = t * TILE_P + tid;
-            float x = 0, y = 0, z = 0, sc = 0.f, rr = 0.f;
-            if (v < n) {
-                if (is_sdf) {
-                    xform(Tsh, Pc[3 * v], Pc[3 * v + 1], Pc[3 * v + 2], x, y, z);
-                    sc = (active && !active[v]) ? 0.f : 1.f;
-                } else {
-                    const int e = rk[v];
-                    const int r = e >> 6, k = e & 63;
-                    const float d = depth_at(d_min, d_max, k, cfg.n_depth);
-                    xform(Tsh, R[3 * r] * d, R[3 * r + 1] * d, R[3 * r + 2] * d, x, y, z);
-                    sc = deds[v];
-                    rr = rres[v];
-                }
-            }
-            s.xin[4 * tid + 0] = x;
-            s.xin[4 * tid + 1] = y;
-            s.xin[4 * tid + 2] = z;
-            s.xin[4 * tid + 3] = (v < n) ? 1.f : 0.f;   // row-valid flag
-            s.rscale[tid] = sc;
-            s.rres[tid] = rr;
-        }
-        __syncthreads();
-        QSP_TSK(2)
-        mlp_tile<true, 4, !B3, B3>(s, P);      // (AccVGPR accumulators leave the split-bf16 tile too few ArchVGPRs)
-        QSP_TSK(3)
-        // ---- Jacobian rows: J~[p] = [ s*(g_x . [I | -x^ | x]) (7) | s*g_z (64) | r~ ] -------------------------------
-        // G (gradient w.r.t. [code | xyz]) sits in s.act with row stride LDG; J~ goes behind it.
-        float* G = s.act;
-        float* Jt = s.act + TILE_P * LDG;     // [64][LDJ]
-        {
-            const int p = tid >> 3, sub = tid & 7;
-            const float valid = s.xin[4 * p + 3];
-            const float sc = s.rscale[p] * valid;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int c = sub + 8 * q;           // code column 0..63
-                Jt[p * LDJ + 7 + c] = cfg.pose_only ? 0.f : sc * G[p * LDG + c];
-            }
-            if (sub == 0) {
-                const float gx = sc * G[p * LDG + 64], gy = sc * G[p * LDG + 65], gz = sc * G[p * LDG + 66];
-                const float x = s.xin[4 * p], y = s.xin[4 * p + 1], z = s.xin[4 * p + 2];
-                // [I | -x^ | x]: columns t(3), omega(3), scale(1)   (loss_utils.py:166-185)
-                Jt[p * LDJ + 0] = gx;
-                Jt[p * LDJ + 1] = gy;
-                Jt[p * LDJ + 2] = gz;
-                Jt[p * LDJ + 3] = gz * y - gy * z;
-                Jt[p * LDJ + 4] = gx * z - gz * x;
-                Jt[p * LDJ + 5] = gy * x - gx * y;
-                Jt[p * LDJ + 6] = cfg.pose_only ? 0.f : (gx * x + gy * y + gz * z);
-                float r = is_sdf ? s.y[p] : s.rres[p];
-                float w = cfg.pose_only ? 1.f : huber_w(r, hub);
-                if (is_sdf && s.rscale[p] == 0.f) w = 0.f;      // filtered-out point (pose-only inlier mask)
-                Jt[p * LDJ + 71] = valid * (w * r);
-                if (res_out && is_sdf && valid != 0.f) res_out[h * act_stride + t * TILE_P + p] = r;
-            }
-            if (sub == 1) {
-#pragma unroll
-                for (int c = NJ; c < LDJ; ++c) Jt[p * LDJ + c] = 0.f;
-            }
-        }
-        __syncthreads();
-        if (rows_out) {   // parity-test tap: the augmented Jacobian rows exactly as the MFMA below consumes them
-            float* ro = rows_out + (int64_t)h * rows_stride * NJ + (int64_t)(is_sdf ? 0 : ov.n_pts) * NJ;
-            for (int e = tid; e < TILE_P * NJ; e += MLP_THREADS) {
-                const int p = e / NJ, c = e - p * NJ;
-                const int v = t * TILE_P + p;
-                if (v < n) ro[(int64_t)v * NJ + c] = Jt[p * LDJ + c];
-            }
-        }
-        if (wave < 6) {
-            const float* A = Jt + (lane >> 5) * LDJ + 32 * ta + (lane & 31);
-            const float* B = Jt + (lane >> 5) * LDJ + 32 * tb + (lane & 31);
-#pragma unroll 8
-            for (int ks = 0; ks < TILE_P / 2; ++ks) hacc = mfma32t<!B3>(A[2 * ks * LDJ], B[2 * ks * LDJ], hacc);
-            mfma_acc_settle<!B3>(hacc);
-        }
-        QSP_TSK(4)
-    }
-    // partial slot [h][slot][tile][32][32]
-    if (wave < 6) {
-        float* out = partials + ((int64_t)h * nw_total + slot) * PART_FLOATS + wave * 1024;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) out[acc_row(i, lane) * 32 + (lane & 31)] = hacc[i];
-    }
-    QSP_TSK(5)
-    tsk_first = false;
-  }
-}
-
-// the same kernel on the split-fp16 tile: four waves per workgroup (mlp_tile_h2<true>); the six J~^T J~ tiles on waves 0..3
-// (waves 0 and 1 carry two)
-template <int NR>      // NR point blocks of 32 per tile (QSP_DEC_OPT_TPOINTS)
-__global__ __launch_bounds__(H2_THREADS) void k_mlp_jtj_h2(const HypState* __restrict__ st,
-                                                            const ObjView* __restrict__ objs,
-                                                            const float* __restrict__ pts,
-                                                            const float* __restrict__ rays, RefineCfg cfg, const MlpParams* __restrict__ P,
-                                                            int nw_sdf, const int32_t* __restrict__ rend_rk,
-                                                            const float* __restrict__ rend_deds,
-                                                            const float* __restrict__ rend_res, int64_t rk_stride,
-                                                            const uint8_t* __restrict__ pt_active, int64_t act_stride,
-                                                            float* __restrict__ res_out, float* __restrict__ rows_out, int64_t rows_stride,
-                                                            float* __restrict__ partials, int nw_total,
-                                                            const int2* __restrict__ work, int* __restrict__ qctl,
-                                                            const float* __restrict__ c0_all) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    MlpSmem& s = *reinterpret_cast<MlpSmem*>(smem_raw);
-    __shared__ float Tsh[16];
-    __shared__ int s_item;
-    const int n_items = qctl[2];
-    constexpr int TP = 32 * NR, SUBS = H2_THREADS / TP;      // threads per Jacobian row
-    bool staged = false;
-    float amax = 0.f;
-  for (;;) {                                   // work queue, see k_plan
-    if (threadIdx.x == 0) s_item = atomicAdd(&qctl[3], 1);
-    __syncthreads();                           // also: everybody is done with the previous item's LDS
-    const int item = s_item;
-    if (item >= n_items) break;                // the queue only grows towards n_items: every workgroup gets here
-    const int h = work[item].x, slot = work[item].y;
-    const HypState& S = st[h];
-    const ObjView ov = objs[S.obj];
-    const bool is_sdf = slot < nw_sdf;
-    const int stride = is_sdf ? nw_sdf : nw_total - nw_sdf;
-    const int j0 = is_sdf ? slot : slot - nw_sdf;
-    const int n = is_sdf ? ov.n_pts : S.n_render;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-
-    // J~^T J~ accumulators of this wave's upper-triangular tiles: tile w on every wave, tile w + 4 on waves 0, 1
-    // (tiles in the order (0,0) (0,1) (0,2) (1,1) (1,2) (2,2))
-    f32x16 hacc[2];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { hacc[0][i] = 0.f; hacc[1][i] = 0.f; }
-    const int ta0 = wave < 3 ? 0 : 1, tb0 = wave < 3 ? wave : 1;
-    const int ta1 = wave == 0 ? 1 : 2, tb1 = 2;
-
-    stage_code_T(s, S, Tsh);
-    for (int i = threadIdx.x; i < HID; i += H2_THREADS) {
-        s.c0[i] = c0_all[(size_t)h * 2 * HID + i];
-        s.c4[i] = c0_all[(size_t)h * 2 * HID + HID + i];
-    }
-    const float* Pc = pts + 3 * ov.pts_off;
-    const float* R = rays + 3 * ov.ray_off;
-    const int32_t* rk = rend_rk + h * rk_stride;
-    const float* deds = rend_deds + h * rk_stride;
-    const float* rres = rend_res + h * rk_stride;
-    const uint8_t* active = pt_active ? pt_active + h * act_stride : nullptr;
-    const float d_min = S.d_min, d_max = S.d_max;
-    const float hub = is_sdf ? cfg.b2 : cfg.b1;
-
-    for (int t = j0; t * TP < n; t += stride) {
-        __syncthreads();
-        if (tid < TP) {
-            const int v = t * TP + tid;
-            float x = 0, y = 0, z = 0, sc = 0.f, rr = 0.f;
-            if (v < n) {
-                if (is_sdf) {
-                    xform(Tsh, Pc[3 * v], Pc[3 * v + 1], Pc[3 * v + 2], x, y, z);
-                    sc = (active && !active[v]) ? 0.f : 1.f;
-                } else {
-                    const int e = rk[v];
-                    const int r = e >> 6, k = e & 63;
-                    const float d = depth_at(d_min, d_max, k, cfg.n_depth);
-                    xform(Tsh, R[3 * r] * d, R[3 * r + 1] * d, R[3 * r + 2] * d, x, y, z);
-                    sc = deds[v];
-                    rr = rres[v];
-                }
-            }
-            s.xin[4 * tid + 0] = x;
-            s.xin[4 * tid + 1] = y;
-            s.xin[4 * tid + 2] = z;
-            s.xin[4 * tid + 3] = (v < n) ? 1.f : 0.f;   // row-valid flag
-            s.rscale[tid] = sc;
-            s.rres[tid] = rr;
-        }
-        __syncthreads();
-        mlp_tile_h2<true, 2, false, NR>(s, P, amax, !staged);
-        staged = true;
-        // ---- Jacobian rows: J~[p] = [ s*(g_x . [I | -x^ | x]) (7) | s*g_z (64) | r~ ] -------------------------------
-        // G (gradient w.r.t. [code | xyz]) sits in s.act with row stride LDG; J~ goes behind it.
-        float* G = s.act;
-        float* Jt = s.act + TILE_P * LDG;   /* (behind the 64-row G image whatever the tile size) */     // [64][LDJ]
-        {
-            const int p = tid / SUBS, sub = tid % SUBS;
-            const float valid = s.xin[4 * p + 3];
-            const float sc = s.rscale[p] * valid;
-#pragma unroll
-            for (int q = 0; q < CODE_LEN / SUBS; ++q) {
-                const int c = sub + SUBS * q;        // code column 0..63
-                Jt[p * LDJ + 7 + c] = cfg.pose_only ? 0.f : sc * G[p * LDG + c];
-            }
-            if (sub == 0) {
-                const float gx = sc * G[p * LDG + 64], gy = sc * G[p * LDG + 65], gz = sc * G[p * LDG + 66];
-                const float x = s.xin[4 * p], y = s.xin[4 * p + 1], z = s.xin[4 * p + 2];
-                // [I | -x^ | x]: columns t(3), omega(3), scale(1)   (loss_utils.py:166-185)
-                Jt[p * LDJ + 0] = gx;
-                Jt[p * LDJ + 1] = gy;
-                Jt[p * LDJ + 2] = gz;
-                Jt[p * LDJ + 3] = gz * y - gy * z;
-                Jt[p * LDJ + 4] = gx * z - gz * x;
-                Jt[p * LDJ + 5] = gy * x - gx * y;
-                Jt[p * LDJ + 6] = cfg.pose_only ? 0.f : (gx * x + gy * y + gz * z);
-                float r = is_sdf ? s.y[p] : s.rres[p];
-                float w = cfg.pose_only ? 1.f : huber_w(r, hub);
-                if (is_sdf && s.rscale[p] == 0.f) w = 0.f;      // filtered-out point (pose-only inlier mask)
-                Jt[p * LDJ + 71] = valid * (w * r);
-                if (res_out && is_sdf && valid != 0.f) res_out[h * act_stride + t * TP + p] = r;
-            }
-            if (sub == 1) {
-#pragma unroll
-                for (int c = NJ; c < LDJ; ++c) Jt[p * LDJ + c] = 0.f;
-            }
-        }
-        __syncthreads();
-        if (rows_out) {   // parity-test tap: the augmented Jacobian rows exactly as the MFMA below consumes them
-            float* ro = rows_out + (int64_t)h * rows_stride * NJ + (int64_t)(is_sdf ? 0 : ov.n_pts) * NJ;
-            for (int e = tid; e < TP * NJ; e += H2_THREADS) {
-                const int p = e / NJ, c = e - p * NJ;
-                const int v = t * TP + p;
-                if (v < n) ro[(int64_t)v * NJ + c] = Jt[p * LDJ + c];
-            }
-        }
-        {
-            const float* A = Jt + (lane >> 5) * LDJ + 32 * ta0 + (lane & 31);
-            const float* B = Jt + (lane >> 5) * LDJ + 32 * tb0 + (lane & 31);
-#pragma unroll 8
-            for (int ks = 0; ks < TP / 2; ++ks) hacc[0] = mfma32t<false>(A[2 * ks * LDJ], B[2 * ks * LDJ], hacc[0]);
-        }
-        if (wave < 2) {
-            const float* A = Jt + (lane >> 5) * LDJ + 32 * ta1 + (lane & 31);
-            const float* B = Jt + (lane >> 5) * LDJ + 32 * tb1 + (lane & 31);
-#pragma unroll 8
-            for (int ks = 0; ks < TP / 2; ++ks) hacc[1] = mfma32t<false>(A[2 * ks * LDJ], B[2 * ks * LDJ], hacc[1]);
-        }
-    }
-    // partial slot [h][slot][tile][32][32]
-    {
-        float* out = partials + ((int64_t)h * nw_total + slot) * PART_FLOATS + wave * 1024;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) out[acc_row(i, lane) * 32 + (lane & 31)] = hacc[0][i];
-        if (wave < 2) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) out[4 * 1024 + acc_row(i, lane) * 32 + (lane & 31)] = hacc[1][i];
-        }
-    }
-  }
-    if (!(amax <= H2_MAX)) *P->range_flag = 1;
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// k_solve: reduce partials, priors, damping, solve, update (optimizer.py:207-263)
-// ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int tri_tile(int a, int b) {   // tile index of block (a<=b) in the 3x3 upper triangle
-    return a == 0 ? b : (a == 1 ? 2 + b : 5);
-}
-
-__device__ void exp_sim3_dev(const float* x, float* T) {   // loss_utils.py:188-233, f32
-    const float v0 = x[0], v1 = x[1], v2 = x[2], w0 = x[3], w1 = x[4], w2 = x[5], sg = x[6];
-    const float W[9] = {0.f, -w2, w1, w2, 0.f, -w0, -w1, w0, 0.f};
-    float W2[9];
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) W2[3 * i + j] = W[3 * i] * W[j] + W[3 * i + 1] * W[3 + j] + W[3 * i + 2] * W[6 + j];
-    const float th = sqrtf(w0 * w0 + w1 * w1 + w2 * w2);
-    const float es = expf(sg);
-    float Rm[9], J[9];
-    const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-    if (th <= 1e-8f) {
-        const float c = (sg == 0.f) ? 1.f : (es - 1.f) / sg;
-        for (int i = 0; i < 9; ++i) { Rm[i] = I[i]; J[i] = c * I[i]; }
-    } else {
-        const float sn = sinf(th), cs = cosf(th);
-        const float a = es * sn, b = es * cs;
-        const float c = (sg <= 1e-8f) ? 0.f : (es - 1.f) / sg;
-        const float den = sg * sg + th * th;
-        const float k1 = (a * sg + (1.f - b) * th) / den;
-        const float k2 = c - ((b - 1.f) * sg + a * th) / den;
-        for (int i = 0; i < 9; ++i) {
-            Rm[i] = I[i] + W[i] * sn / th + W2[i] * (1.f - cs) / (th * th);
-            J[i] = c * I[i] + k1 * W[i] / th + k2 * W2[i] / (th * th);
-        }
-    }
-    for (int i = 0; i < 3; ++i) {
-        for (int j = 0; j < 3; ++j) T[4 * i + j] = es * Rm[3 * i + j];
-        T[4 * i + 3] = J[3 * i] * v0 + J[3 * i + 1] * v1 + J[3 * i + 2] * v2;
-    }
-    T[12] = T[13] = T[14] = 0.f;
-    T[15] = 1.f;
-}
-
-__device__ void exp_se3_dev(const float* x, float* T) {   // loss_utils.py:129-163, f32
-    const float v0 = x[0], v1 = x[1], v2 = x[2], w0 = x[3], w1 = x[4], w2 = x[5];
-    const float W[9] = {0.f, -w2, w1, w2, 0.f, -w0, -w1, w0, 0.f};
-    float W2[9];
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) W2[3 * i + j] = W[3 * i] * W[j] + W[3 * i + 1] * W[3 + j] + W[3 * i + 2] * W[6 + j];
-    const float th = sqrtf(w0 * w0 + w1 * w1 + w2 * w2);
-    const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-    float Rm[9], J[9];
-    if (th <= 1e-8f) {
-        for (int i = 0; i < 9; ++i) { Rm[i] = I[i]; J[i] = I[i]; }
-    } else {
-        const float sn = sinf(th), cs = cosf(th);
-        const float th2 = th * th, th3 = th2 * th;
-        for (int i = 0; i < 9; ++i) {
-            Rm[i] = I[i] + W[i] * sn / th + W2[i] * (1.f - cs) / th2;
-            J[i] = I[i] + ((1.f - cs) / th2) * W[i] + ((th - sn) / th3) * W2[i];
-        }
-    }
-    for (int i = 0; i < 3; ++i) {
-        for (int j = 0; j < 3; ++j) T[4 * i + j] = Rm[3 * i + j];
-        T[4 * i + 3] = J[3 * i] * v0 + J[3 * i + 1] * v1 + J[3 * i + 2] * v2;
-    }
-    T[12] = T[13] = T[14] = 0.f;
-    T[15] = 1.f;
-}
-
-constexpr int SOLVE_THREADS = 1024;   // latency, not throughput: more loads in flight for the partial sums, shorter row strips per pivot
-__global__ __launch_bounds__(SOLVE_THREADS) void k_solve(HypState* __restrict__ st, const ObjView* __restrict__ objs,
-                                               RefineCfg cfg, const float* __restrict__ partials, int nw_sdf,
-                                               int nw_total, const uint8_t* __restrict__ pt_active,
-                                               int64_t act_stride, float* __restrict__ trH, float* __restrict__ trb,
-                                               float* __restrict__ trdx, unsigned long long* __restrict__ counters) {
-    const int h = blockIdx.x;
-    HypState& S = st[h];
-    if (!S.alive) return;
-    if (threadIdx.x == 0 && counters) {   // work actually done this iteration (for the roofline figures)
-        const ObjView o = objs[S.obj];
-        atomicAdd(&counters[0], (unsigned long long)(o.n_pts + S.n_render));
-        atomicAdd(&counters[1], (unsigned long long)S.n_valid);
-        atomicAdd(&counters[2], (unsigned long long)((o.n_pts + cfg.tile_p - 1) / cfg.tile_p + (S.n_render + cfg.tile_p - 1) / cfg.tile_p));
-        atomicAdd(&counters[3], (unsigned long long)((S.n_valid + TILE_P - 1) / TILE_P));
-    }
-    __shared__ double Hd[NH * (NH + 1)];  // augmented [H | b] in f64
-    __shared__ float dxs[NH];
-    __shared__ float loss_sh[2];
-    __shared__ int n_act_sh;
-    const ObjView ov = objs[S.obj];
-    const int tid = threadIdx.x;
-    const float* base = partials + (int64_t)h * nw_total * PART_FLOATS;
-    const int n_sdf_slots = min(nw_sdf, (ov.n_pts + cfg.tile_p - 1) / cfg.tile_p);
-    const int K = S.n_render;
-    const int n_rend_slots = min(nw_total - nw_sdf, (K + cfg.tile_p - 1) / cfg.tile_p);
-    // number of active surface points (pose-only inlier filter; otherwise n_pts)
-    if (tid == 0) n_act_sh = ov.n_pts;
-    __syncthreads();
-    if (pt_active) {
-        __shared__ int cnt_sh;
-        if (tid == 0) cnt_sh = 0;
-        __syncthreads();
-        int c = 0;
-        for (int i = tid; i < ov.n_pts; i += SOLVE_THREADS) c += pt_active[h * act_stride + i] ? 1 : 0;
-        atomicAdd(&cnt_sh, c);
-        __syncthreads();
-        if (tid == 0) n_act_sh = cnt_sh;
-        __syncthreads();
-    }
-    const float M = (float)n_act_sh;
-    const float Kf = (float)K;
-    const int N = cfg.pose_only ? 6 : NH;
-    // Fixed-order sum of the tile partials (deterministic), then H, b in f32 exactly as optimizer.py:217-252 orders the
-    // operations; entries are promoted to f64 only for the linear solve.
-    for (int e = tid; e < NJ * NJ; e += SOLVE_THREADS) {
-        const int a = e / NJ, b = e % NJ;
-        if (a > b) continue;
-        const int off = tri_tile(a >> 5, b >> 5) * 1024 + (a & 31) * 32 + (b & 31);
-        float ss = 0.f, sr = 0.f;
-        // same left-to-right order as ever; unrolled so that 16 of the (24 KiB-strided) loads are in flight at a time
-#pragma unroll 16
-        for (int j = 0; j < n_sdf_slots; ++j) ss += base[(int64_t)j * PART_FLOATS + off];
-#pragma unroll 4
-        for (int j = 0; j < n_rend_slots; ++j) sr += base[(int64_t)(nw_sdf + j) * PART_FLOATS + off];
-        if (b < NH) {                      // normal-matrix entry
-            if (a >= N || b >= N) continue;
-            float v;
-            if (cfg.pose_only) {
-                v = ss / M;
-                if (a == b) v += 1e-2f;                        // optimizer.py:75
-            } else {
-                v = (cfg.k1 * sr) / Kf + (cfg.k2 * ss) / M;
-                if (a == b && a >= 7) v += cfg.k3;
-                // code unknowns beyond the decoder's code length have zero Jacobian columns: unit diagonal, zero right-hand
-                // side -> they stay 0 whatever k3 is and never mix into the other 7 + L unknowns
-                if (a >= 7 + cfg.code_len || b >= 7 + cfg.code_len) v = (a == b) ? 1.f : 0.f;
-            }
-            Hd[a * (N + 1) + b] = (double)v;
-            Hd[b * (N + 1) + a] = (double)v;
-        } else if (a < NH) {               // right-hand side: column 71 of J~^T J~ is J^T r~
-            if (a >= N) continue;
-            float v;
-            if (cfg.pose_only) v = -ss / M;
-            else {
-                v = -(cfg.k1 * sr) / Kf + (-(cfg.k2 * ss) / M);
-                if (a >= 7) v -= cfg.k3 * S.code[a - 7];
-                if (a >= 7 + cfg.code_len) v = 0.f;
-            }
-            Hd[a * (N + 1) + N] = (double)v;
-        } else {                           // (71,71): sum of squared robust residuals
-            loss_sh[0] = ss / M;                               // mean(robust_res^2)
-            loss_sh[1] = cfg.pose_only ? 0.f : sr / Kf;
-        }
-    }
-    __syncthreads();
-    const float loss_s = loss_sh[0], loss_r = loss_sh[1];
-    const bool bad = isnan(loss_s) || isnan(loss_r);           // optimizer.py:168-169,193-194
-    __syncthreads();
-    if (bad) {
-        if (tid == 0) S.alive = 0;
-        return;
-    }
-    if (tid == 0 && !cfg.pose_only) {
-        // rotation prior (loss.py:155-178) on the pose block, then damping (optimizer.py:240-252)
-        float rco[9];
-        const float sc = powf(det3(S.T_co), (float)(1.0 / 3.0));
-        for (int i = 0; i < 3; ++i)
-            for (int j = 0; j < 3; ++j) rco[3 * i + j] = S.T_co[4 * i + j] / sc;
-        // r_oc = inverse(r_co); for a rotation this is the transpose up to rounding -- invert generally (3x3, f64)
-        double m[9];
-        for (int i = 0; i < 9; ++i) m[i] = rco[i];
-        const double det = m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) +
-                           m[2] * (m[3] * m[7] - m[4] * m[6]);
-        float roc[9];
-        roc[0] = (float)((m[4] * m[8] - m[5] * m[7]) / det);
-        roc[1] = (float)((m[2] * m[7] - m[1] * m[8]) / det);
-        roc[2] = (float)((m[1] * m[5] - m[2] * m[4]) / det);
-        roc[3] = (float)((m[5] * m[6] - m[3] * m[8]) / det);
-        roc[4] = (float)((m[0] * m[8] - m[2] * m[6]) / det);
-        roc[5] = (float)((m[2] * m[3] - m[0] * m[5]) / det);
-        roc[6] = (float)((m[3] * m[7] - m[4] * m[6]) / det);
-        roc[7] = (float)((m[1] * m[6] - m[0] * m[7]) / det);
-        roc[8] = (float)((m[0] * m[4] - m[1] * m[3]) / det);
-        // ry = r_co e_y ; res = 1 - ry . n_g, n_g = (0,-1,0)
-        const float res_rot = 1.f - (-(rco[4]));
-        float Jr[7] = {0, 0, 0, 0, 0, 0, 0};
-        float rr = 0.f;
-        if (!(res_rot < 1e-7f)) {
-            // (r_oc n_g) x e_y with n_g = (0,-1,0): a = -r_oc[:,1]; a x e_y = (-a_z, 0, a_x)
-            const float ax = -roc[1], az = -roc[7];
-            Jr[3] = -az;
-            Jr[4] = 0.f;
-            Jr[5] = ax;
-            rr = res_rot;
-        }
-        for (int a = 0; a < 7; ++a) {
-            for (int b = 0; b < 7; ++b) {
-                float v = (float)Hd[a * (N + 1) + b];
-                v += cfg.k4 * (Jr[a] * Jr[b]);
-                if (a == b) v += 1.0f;
-                if (a == 6 && b == 6) v += cfg.s_damp;
-                Hd[a * (N + 1) + b] = (double)v;
-            }
-            float bv = (float)Hd[a * (N + 1) + N];
-            bv -= cfg.k4 * (-(Jr[a] * rr));
-            Hd[a * (N + 1) + N] = (double)bv;
-        }
-    }
-    __syncthreads();
-    if (trH) {
-        for (int e = tid; e < N * N; e += SOLVE_THREADS) trH[(int64_t)h * NH * NH + (e / N) * NH + (e % N)] = (float)Hd[(e / N) * (N + 1) + (e % N)];
-        for (int a = tid; a < N; a += SOLVE_THREADS) trb[(int64_t)h * NH + a] = (float)Hd[a * (N + 1) + N];
-    }
-    __syncthreads();
-    // Gauss-Jordan elimination in f64 on the augmented system (reference: torch.inverse(H) @ b, f32).  H is symmetric
-    // positive definite by construction (Gram matrices plus the identity damping of optimizer.py:240-252 / :75), so no
-    // pivot search is needed: one barrier per column, every (row, column strip) pair on its own thread.
-    const int STR = SOLVE_THREADS / N;         // 14 strips for the 71 x 71 system
-    for (int c = 0; c < N; ++c) {
-        const double inv = 1.0 / Hd[c * (N + 1) + c];
-        const int r = tid / STR, q = tid - r * STR;
-        if (r < N && r != c) {
-            const double f = Hd[r * (N + 1) + c] * inv;
-            for (int j = c + 1 + q; j <= N; j += STR) Hd[r * (N + 1) + j] -= f * Hd[c * (N + 1) + j];
-        }
-        __syncthreads();
-    }
-    for (int a = tid; a < N; a += SOLVE_THREADS) dxs[a] = (float)(Hd[a * (N + 1) + N] / Hd[a * (N + 1) + a]);
-    __syncthreads();
-    if (trdx)
-        for (int a = tid; a < N; a += SOLVE_THREADS) trdx[(int64_t)h * NH + a] = dxs[a];
-    if (tid == 0) {
-        float d[7], Td[16], Tn[16];
-        if (cfg.pose_only) {
-            for (int i = 0; i < 6; ++i) d[i] = dxs[i];
-            exp_se3_dev(d, Td);
-        } else {
-            for (int i = 0; i < 7; ++i) d[i] = cfg.lr * dxs[i];
-            exp_sim3_dev(d, Td);
-        }
-        for (int i = 0; i < 4; ++i)
-            for (int j = 0; j < 4; ++j) {
-                float a = 0.f;
-                for (int k = 0; k < 4; ++k) a += Td[4 * i + k] * S.T_oc[4 * k + j];
-                Tn[4 * i + j] = a;
-            }
-        for (int i = 0; i < 16; ++i) S.T_oc[i] = Tn[i];
-        S.loss_sdf = loss_s;
-        S.loss_render = loss_r;
-        S.loss = cfg.k1 * loss_r + cfg.k2 * loss_s;    // optimizer.py:203
-    }
-    if (!cfg.pose_only && tid < CODE_LEN) S.code[tid] += cfg.lr * dxs[7 + tid];
-}
-
-// pose-only inlier filter after iteration index 4 (optimizer.py:80-82): |res| <= 0.05 on the residuals of THAT iteration
-__global__ void k_inlier_filter(const HypState* __restrict__ st, const ObjView* __restrict__ objs,
-                                const float* __restrict__ res, int64_t act_stride, uint8_t* __restrict__ pt_active) {
-    const int h = blockIdx.y;
-    const ObjView ov = objs[st[h].obj];
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < ov.n_pts) {
-        const bool keep = fabsf(res[h * act_stride + i]) <= 0.05f;
-        pt_active[h * act_stride + i] = (pt_active[h * act_stride + i] && keep) ? 1 : 0;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// generic decode kernels for the API-level entry points (loss_utils.py:51-103): points already in the object frame
-// ---------------------------------------------------------------------------------------------------------------
-template <bool GRAD, bool BF3 = false>
-__global__ __launch_bounds__(MLP_THREADS, 2) void k_decode(const float* __restrict__ code, const float* __restrict__ xyz,
-                                                           int64_t n, const MlpParams* __restrict__ P, float* __restrict__ y_out,
-                                                           float* __restrict__ grad_out) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    MlpSmem& s = *reinterpret_cast<MlpSmem*>(smem_raw);
-    if (threadIdx.x < CODE_LEN) s.code[threadIdx.x] = code[threadIdx.x];
-    mlp_prepare(s, P);
-    for (int64_t t = blockIdx.x; t * TILE_P < n; t += gridDim.x) {
-        __syncthreads();
-        if (threadIdx.x < TILE_P) {
-            const int64_t v = t * TILE_P + threadIdx.x;
-            float x = 0, y = 0, z = 0;
-            if (v < n) { x = xyz[3 * v]; y = xyz[3 * v + 1]; z = xyz[3 * v + 2]; }
-            s.xin[4 * threadIdx.x + 0] = x;
-            s.xin[4 * threadIdx.x + 1] = y;
-            s.xin[4 * threadIdx.x + 2] = z;
-            s.xin[4 * threadIdx.x + 3] = 0.f;
-        }
-        __syncthreads();
-        if (BF3 && !GRAD) mlp_tile_bf3<QSP_BF3_PF>(s, P);
-        else mlp_tile<GRAD, 4, false, BF3>(s, P);
-        if (threadIdx.x < TILE_P) {
-            const int64_t v = t * TILE_P + threadIdx.x;
-            if (v < n) y_out[v] = s.y[threadIdx.x];
-        }
-        if (GRAD) {
-            for (int e = threadIdx.x; e < TILE_P * NIN; e += MLP_THREADS) {
-                const int p = e / NIN, c = e % NIN;
-                const int64_t v = t * TILE_P + p;
-                if (v < n) grad_out[v * NIN + c] = s.act[p * LDG + c];
-            }
-        }
-    }
-}
-
-// decode on the split-fp16 tile (four waves per workgroup)
-template <bool GRAD>
-__global__ __launch_bounds__(H2_THREADS) void k_decode_h2(const float* __restrict__ code, const float* __restrict__ xyz, int64_t n,
-                                                          const MlpParams* __restrict__ P, float* __restrict__ y_out,
-                                                          float* __restrict__ grad_out) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    MlpSmem& s = *reinterpret_cast<MlpSmem*>(smem_raw);
-    if (threadIdx.x < CODE_LEN) s.code[threadIdx.x] = code[threadIdx.x];
-    __syncthreads();
-    for (int u = threadIdx.x; u < HID; u += H2_THREADS) {      // mlp_prepare for 256 threads
-        const float* w = P->w0c + (size_t)u * CODE_LEN;
-        const float* w4 = P->w4c + (size_t)u * CODE_LEN;
-        float a = P->bias[0][u], a4 = P->bias[4][u];
-#pragma unroll 8
-        for (int k = 0; k < CODE_LEN; ++k) {
-            a += w[k] * s.code[k];
-            a4 += w4[k] * s.code[k];
-        }
-        s.c0[u] = a;
-        s.c4[u] = a4;
-    }
-    bool staged = false;
-    float amax = 0.f;
-    for (int64_t t = blockIdx.x; t * TILE_P < n; t += gridDim.x) {
-        __syncthreads();
-        if (threadIdx.x < TILE_P) {
-            const int64_t v = t * TILE_P + threadIdx.x;
-            float x = 0, y = 0, z = 0;
-            if (v < n) { x = xyz[3 * v]; y = xyz[3 * v + 1]; z = xyz[3 * v + 2]; }
-            s.xin[4 * threadIdx.x + 0] = x;
-            s.xin[4 * threadIdx.x + 1] = y;
-            s.xin[4 * threadIdx.x + 2] = z;
-            s.xin[4 * threadIdx.x + 3] = 0.f;
-        }
-        __syncthreads();
-        mlp_tile_h2<GRAD, 2>(s, P, amax, !staged);
-        staged = true;
-        if (threadIdx.x < TILE_P) {
-            const int64_t v = t * TILE_P + threadIdx.x;
-            if (v < n) y_out[v] = s.y[threadIdx.x];
-        }
-        if (GRAD) {
-            for (int e = threadIdx.x; e < TILE_P * NIN; e += H2_THREADS) {
-                const int p = e / NIN, c = e % NIN;
-                const int64_t v = t * TILE_P + p;
-                if (v < n) grad_out[v * NIN + c] = s.act[p * LDG + c];
-            }
-        }
-    }
-    if (!(amax <= H2_MAX)) *P->range_flag = 1;
-}
-
-// 4x4 inverse as the reference's torch.inverse calls need it (optimizer.py:123,273): Gauss-Jordan with partial pivoting in
-// double, rounded to f32.  One definition for host (set_state / get) and device (detections.hpp), no contraction, so both
-// give the same bits.
-__host__ __device__ inline void inv4_gj(const float* in, float* out) {
-#pragma clang fp contract(off)
-    double a[4][8];
-    for (int i = 0; i < 4; ++i)
-        for (int j = 0; j < 4; ++j) {
-            a[i][j] = in[4 * i + j];
-            a[i][4 + j] = i == j;
-        }
-    for (int c = 0; c < 4; ++c) {
-        int p = c;
-        for (int r = c + 1; r < 4; ++r)
-            if (fabs(a[r][c]) > fabs(a[p][c])) p = r;
-        if (p != c)
-            for (int j = 0; j < 8; ++j) {
-                const double t = a[c][j];
-                a[c][j] = a[p][j];
-                a[p][j] = t;
-            }
-        const double inv = 1.0 / a[c][c];
-        for (int j = 0; j < 8; ++j) a[c][j] *= inv;
-        for (int r = 0; r < 4; ++r)
-            if (r != c) {
-                const double f = a[r][c];
-                for (int j = 0; j < 8; ++j) a[r][j] -= f * a[c][j];
-            }
-    }
-    for (int i = 0; i < 4; ++i)
-        for (int j = 0; j < 4; ++j) out[4 * i + j] = (float)a[i][4 + j];
-}
-
-}  // namespace qsp
 
 // =================================================================================================================
 // host side
@@ -1256,6 +53,17 @@ struct qsp_decoder {
     bool fp16_ok = true;       // every weight of layers 0..7 fits fp16's range (split-fp16 planes are usable)
     int tile_p = 64;           // QSP_DEC_OPT_TILE_POINTS: points per MLP tile of the refinement batches created from now on
     int* range_flag_h = nullptr;   // host-mapped word the split-fp16 kernels set when a value left fp16's range (check_range)
+    float screen_margin = 0.f;     // QSP_DEC_OPT_RENDER_SCREENING: > 0 = two-pass ray-sample forward with this band margin
+    int range_fallback = 1;        // QSP_DEC_OPT_RANGE_FALLBACK: a call that left fp16's range is repeated on the f32 pipe
+    int64_t n_range_fallbacks = 0; // QSP_DEC_CNT_RANGE_FALLBACKS
+};
+
+// Runs the enclosed call with every decoder pass on the exact-f32 pipe (the range fallback of the split-fp16 modes).
+struct F32Override {
+    qsp_decoder* d;
+    int fwd, jac;
+    explicit F32Override(qsp_decoder* d_) : d(d_), fwd(d_->fwd_bf3), jac(d_->jac_bf3) { d->fwd_bf3 = 0; d->jac_bf3 = 0; }
+    ~F32Override() { d->fwd_bf3 = fwd; d->jac_bf3 = jac; }
 };
 
 // The family deep_sdf/deep_sdf_decoder.py:29-63 builds -- `dims` hidden layers of any width, one (or no) latent_in layer, any
@@ -1277,14 +85,23 @@ static int embed_family(const qsp_decoder_desc* desc, const std::vector<std::vec
         return qsp_fail(QSP_ERR_UNSUPPORTED, "decoder family: 2..8 hidden layers and a code of 1..64 are supported");
     int s = desc->latent_in_layer;
     const bool has_skip = s >= 0;
-    if (!has_skip) s = std::max(1, m - 4);                 // no latent_in: any split with <= 4 layers on either side
+    if (!has_skip) {   // no latent_in: any split with <= 4 layers on either side whose front part ends on a layer that fits slot 3
+        s = -1;
+        for (int c = std::max(1, m - 4); c <= std::min(4, m - 1) && s < 0; ++c)
+            if (desc->out_dim[c - 1] >= 1 && desc->out_dim[c - 1] <= SKIP_COL) s = c;
+        if (s < 0)
+            return qsp_fail(QSP_ERR_UNSUPPORTED, "decoder family: without a latent_in layer one of the hidden layers 1..4 must be "
+                                                  "at most 445 wide (it takes the place of the layer in front of the skip)");
+    }
     if (s < 1 || s > 4 || s > m - 1 || m - s > 4)
         return qsp_fail(QSP_ERR_UNSUPPORTED, "decoder family: the latent_in layer needs 1..4 hidden layers in front of it and "
                                               "at most 4 from it on");
     if (desc->in_dim[0] != L + 3 || desc->out_dim[m] != 1)
         return qsp_fail(QSP_ERR_UNSUPPORTED, "decoder family: first layer takes [code | xyz], last layer has one output");
     for (int l = 0; l < m; ++l) {
-        const int lim = (l == s - 1 && has_skip) ? SKIP_COL : HID;
+        // canonical slot 3 is 445 wide whether or not the network has a skip connection: the layer in front of slot 4 (or the
+        // identity layers that carry its output there) must fit it -- columns 445..511 of slot 4's input are [code | xyz]
+        const int lim = (l == s - 1) ? SKIP_COL : HID;
         if (desc->out_dim[l] < 1 || desc->out_dim[l] > lim)
             return qsp_fail(QSP_ERR_UNSUPPORTED, "decoder family: hidden width above 512 (445 in front of the latent_in layer)");
     }
@@ -1606,15 +423,23 @@ static int pack_weights(qsp_decoder* d, const qsp_decoder_desc* desc) {
     return QSP_OK;
 }
 
-// after a synchronisation of the decoder's stream: did a split-fp16 kernel meet a value it cannot represent?
-static int check_range(qsp_decoder* d) {
+// after a synchronisation of the decoder's stream: did a split-fp16 kernel meet a value it cannot represent?  (clears the flag)
+static bool range_hit(qsp_decoder* d) {
     if (d->range_flag_h && *d->range_flag_h) {
         *d->range_flag_h = 0;
-        return qsp_fail(QSP_ERR_UNSUPPORTED, "split fp16: an activation or gradient of this decoder left fp16's range (65504); "
-                                             "use the split-bf16 or f32 precision for it");
+        return true;
     }
-    return QSP_OK;
+    return false;
 }
+static int range_error() {
+    return qsp_fail(QSP_ERR_UNSUPPORTED, "split fp16: an activation or gradient of this decoder left fp16's range (65504); "
+                                         "use the split-bf16 or f32 precision for it, or leave QSP_DEC_OPT_RANGE_FALLBACK on");
+}
+// What a call does when range_hit(): with the fallback on (default) and a split-fp16 pass in use, the caller repeats itself
+// under an F32Override and counts it; otherwise the call fails.  The reference never fails a call for a numeric condition
+// (reconstruct/optimizer.py:161-194 returns is_good = False at worst), so neither does the default configuration.
+static bool range_should_fall_back(qsp_decoder* d) { return d->range_fallback && (d->fwd_bf3 == 2 || d->jac_bf3 == 2); }
+static int check_range(qsp_decoder* d) { return range_hit(d) ? range_error() : QSP_OK; }
 
 static int mlp_attr_once() {
     static bool done = false;
@@ -1624,6 +449,7 @@ static int mlp_attr_once() {
     QSP_HIP(hipFuncSetAttribute((const void*)k_mlp_fwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     QSP_HIP(hipFuncSetAttribute((const void*)k_decode<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     QSP_HIP(hipFuncSetAttribute((const void*)k_mlp_fwd_h2<2>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    QSP_HIP(hipFuncSetAttribute((const void*)k_mlp_fwd_h1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MlpSmemH1)));
     QSP_HIP(hipFuncSetAttribute((const void*)k_decode_h2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     QSP_HIP(hipFuncSetAttribute((const void*)k_decode_h2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     QSP_HIP(hipFuncSetAttribute((const void*)k_mlp_jtj_h2<2>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
@@ -1668,6 +494,7 @@ extern "C" int qsp_decoder_set_option(qsp_decoder* d, int32_t option, int32_t va
             if (value < 0 || value > 2) return qsp_fail(QSP_ERR_INVALID, "forward precision: 0 (f32 MFMA), 1 (split bf16) or 2 (split fp16)");
             if (value == 2 && !d->fp16_ok) return qsp_fail(QSP_ERR_UNSUPPORTED, "split fp16: a weight of this decoder is outside fp16's range");
             d->fwd_bf3 = value;
+            if (value != 2) d->screen_margin = 0.f;      // (the screened forward pass exists on the split-fp16 pipe only)
             return QSP_OK;
         case QSP_DEC_OPT_JACOBIAN_PRECISION:
             if (value < 0 || value > 2) return qsp_fail(QSP_ERR_INVALID, "jacobian precision: 0 (f32 MFMA), 1 (split bf16) or 2 (split fp16)");
@@ -1678,7 +505,34 @@ extern "C" int qsp_decoder_set_option(qsp_decoder* d, int32_t option, int32_t va
             if (value != 32 && value != 64) return qsp_fail(QSP_ERR_INVALID, "tile points: 64 (default) or 32");
             d->tile_p = value;
             return QSP_OK;
+        case QSP_DEC_OPT_RENDER_SCREENING:
+            if (value < 0 || value > 50000) return qsp_fail(QSP_ERR_UNSUPPORTED, "render screening: margin in 1e-6 units, 0 (off) .. 50000");
+            if (value > 0 && d->fwd_bf3 != 2)
+                return qsp_fail(QSP_ERR_UNSUPPORTED, "render screening exists on the split-fp16 forward pass only: set "
+                                                     "QSP_DEC_OPT_FORWARD_PRECISION to 2 first");
+            d->screen_margin = 1e-6f * (float)value;
+            return QSP_OK;
+        case QSP_DEC_OPT_USE_TANH: {
+            if (value != 0 && value != 1) return qsp_fail(QSP_ERR_INVALID, "use_tanh: 0 or 1");
+            d->P.use_tanh = value;
+            QSP_HIP(hipSetDevice(d->device));
+            QSP_HIP(hipStreamSynchronize(d->stream));
+            QSP_HIP(hipMemcpy(d->Pd, &d->P, sizeof(MlpParams), hipMemcpyHostToDevice));
+            return QSP_OK;
+        }
+        case QSP_DEC_OPT_RANGE_FALLBACK:
+            if (value != 0 && value != 1) return qsp_fail(QSP_ERR_INVALID, "range fallback: 0 or 1");
+            d->range_fallback = value;
+            return QSP_OK;
         default: return qsp_fail(QSP_ERR_INVALID, "qsp_decoder_set_option: unknown option");
+    }
+}
+
+extern "C" int64_t qsp_decoder_get_counter(qsp_decoder* d, int32_t counter) {
+    if (!d) return -1;
+    switch (counter) {
+        case QSP_DEC_CNT_RANGE_FALLBACKS: return d->n_range_fallbacks;
+        default: return -1;
     }
 }
 
@@ -1691,9 +545,7 @@ extern "C" void qsp_decoder_destroy(qsp_decoder* d) {
     delete d;
 }
 
-static int decode_common(qsp_decoder* d, const float* code, const float* xyz, int64_t n, float* y, float* grad) {
-    if (!d || !code || !xyz || n < 0 || !y) return qsp_fail(QSP_ERR_INVALID, "decode: bad argument");
-    if (n == 0) return QSP_OK;
+static int decode_once(qsp_decoder* d, const float* code, const float* xyz, int64_t n, float* y, float* grad, bool* hit) {
     QSP_HIP(hipSetDevice(d->device));
     float *dc = nullptr, *dx = nullptr, *dy = nullptr, *dg = nullptr;
     QSP_HIP(hipMalloc((void**)&dc, CODE_LEN * sizeof(float)));
@@ -1733,15 +585,13 @@ static int decode_common(qsp_decoder* d, const float* code, const float* xyz, in
         }
     }
     QSP_HIP(hipStreamSynchronize(d->stream));
-    {
-        const int rc = check_range(d);
-        if (rc) {
-            (void)hipFree(dc);
-            (void)hipFree(dx);
-            (void)hipFree(dy);
-            if (dg) (void)hipFree(dg);
-            return rc;
-        }
+    if (range_hit(d)) {
+        (void)hipFree(dc);
+        (void)hipFree(dx);
+        (void)hipFree(dy);
+        if (dg) (void)hipFree(dg);
+        *hit = true;
+        return QSP_OK;
     }
     if (grad && d->code_len != CODE_LEN) {               // [code 64 | xyz] -> [code L | xyz]
         const int L = d->code_len;
@@ -1755,6 +605,19 @@ static int decode_common(qsp_decoder* d, const float* code, const float* xyz, in
     (void)hipFree(dy);
     if (dg) (void)hipFree(dg);
     return QSP_OK;
+}
+
+static int decode_common(qsp_decoder* d, const float* code, const float* xyz, int64_t n, float* y, float* grad) {
+    if (!d || !code || !xyz || n < 0 || !y) return qsp_fail(QSP_ERR_INVALID, "decode: bad argument");
+    if (n == 0) return QSP_OK;
+    bool hit = false;
+    int rc = decode_once(d, code, xyz, n, y, grad, &hit);
+    if (rc || !hit) return rc;
+    if (!range_should_fall_back(d)) return range_error();
+    F32Override f32(d);
+    d->n_range_fallbacks++;
+    hit = false;
+    return decode_once(d, code, xyz, n, y, grad, &hit);
 }
 
 extern "C" int qsp_decode_sdf(qsp_decoder* d, const float* code, const float* xyz, int64_t n, float* sdf_out) {
@@ -1793,6 +656,9 @@ struct qsp_refine_batch {
     unsigned long long* counters = nullptr;   // [4] points/tiles processed (fwd+bwd, fwd-only)
     int2 *work_fwd = nullptr, *work_jtj = nullptr;   // work-queue items (k_plan)
     int* qctl = nullptr;            // [4] item counts / next-item counters
+    int32_t* band_idx = nullptr;    // screened forward pass: per hypothesis, indices into its valid-sample list (k_mlp_fwd_h1)
+    HypState* st_snap = nullptr;    // the hypotheses as a run found them (restored when the run is repeated on the f32 pipe)
+    uint8_t* act_snap = nullptr;    // pose-only mode: pt_active likewise
     float* c0_all = nullptr;        // [n_hyp][2][512] code part of layers 0 and 4 (bias included) per hypothesis (k_c0)
     int n_cu = 256;
     float* rows = nullptr;          // optional tap of the Jacobian rows (qsp_refine_batch_rows)
@@ -1808,7 +674,7 @@ static void batch_free(qsp_refine_batch* b) {
     (void)hipSetDevice(b->device);
     void* ptrs[] = {b->st, b->objs, b->pts, b->rays, b->depth, b->valid_rk, b->ray_voff, b->rend_rk, b->sdf_valid,
                     b->rend_deds, b->rend_res, b->partials, b->trH, b->trb, b->trdx, b->pt_active, b->res_buf, b->rows, b->counters,
-                    b->work_fwd, b->work_jtj, b->qctl, b->c0_all};
+                    b->work_fwd, b->work_jtj, b->qctl, b->c0_all, b->band_idx, b->st_snap, b->act_snap};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : b->ev) (void)hipEventDestroy(e);
@@ -1890,7 +756,8 @@ static int batch_create(qsp_decoder* dec, const RefineCfg& cfg, int n_iter, int3
     QSP_ALLOC(b->trH, sizeof(float) * (size_t)n_hyp * NH * NH);
     QSP_ALLOC(b->trb, sizeof(float) * (size_t)n_hyp * NH);
     QSP_ALLOC(b->trdx, sizeof(float) * (size_t)n_hyp * NH);
-    QSP_ALLOC(b->counters, sizeof(unsigned long long) * 4);
+    QSP_ALLOC(b->counters, sizeof(unsigned long long) * 8);
+    QSP_ALLOC(b->st_snap, sizeof(HypState) * n_hyp);
     QSP_ALLOC(b->qctl, sizeof(int) * 4);
     QSP_ALLOC(b->c0_all, sizeof(float) * (size_t)n_hyp * 2 * HID);
     QSP_ALLOC(b->work_jtj, sizeof(int2) * (size_t)n_hyp * nw_total);
@@ -1906,8 +773,10 @@ static int batch_create(qsp_decoder* dec, const RefineCfg& cfg, int n_iter, int3
         QSP_ALLOC(b->sdf_valid, sizeof(float) * (size_t)n_hyp * b->rk_stride);
         QSP_ALLOC(b->rend_deds, sizeof(float) * (size_t)n_hyp * b->rk_stride);
         QSP_ALLOC(b->rend_res, sizeof(float) * (size_t)n_hyp * b->rk_stride);
+        QSP_ALLOC(b->band_idx, sizeof(int32_t) * (size_t)n_hyp * b->rk_stride);
     } else {
         QSP_ALLOC(b->pt_active, (size_t)n_hyp * b->act_stride);
+        QSP_ALLOC(b->act_snap, (size_t)n_hyp * b->act_stride);
         QSP_ALLOC(b->res_buf, sizeof(float) * (size_t)n_hyp * b->act_stride);
     }
 #undef QSP_ALLOC
@@ -1971,10 +840,8 @@ static hipEvent_t next_event(qsp_refine_batch* b, size_t& cursor) {
     return e;
 }
 
-extern "C" int qsp_refine_batch_run(qsp_refine_batch* b, int32_t n_iter) {
-    if (!b) return qsp_fail(QSP_ERR_INVALID, "run: null batch");
-    QSP_HIP(hipSetDevice(b->dec->device));
-    if (n_iter <= 0) n_iter = b->n_iter_cfg;
+// one pass over n_iter Gauss-Newton iterations on the decoder's current pipes; *hit = a split-fp16 kernel left fp16's range
+static int run_once(qsp_refine_batch* b, int32_t n_iter, bool* hit) {
     hipStream_t s = b->dec->stream;
     const int nH = b->n_hyp;
     const int nw_total = b->nw_sdf + (b->cfg.pose_only ? 0 : NW_REND);
@@ -1982,11 +849,13 @@ extern "C" int qsp_refine_batch_run(qsp_refine_batch* b, int32_t n_iter) {
     struct Span { hipEvent_t a, b; int kind; };
     std::vector<Span> spans;
     hipEvent_t e_begin = nullptr, e_end = nullptr;
-    QSP_HIP(hipMemsetAsync(b->counters, 0, sizeof(unsigned long long) * 4, s));
+    QSP_HIP(hipMemsetAsync(b->counters, 0, sizeof(unsigned long long) * 8, s));
     if (b->prof) e_begin = next_event(b, cur);
     for (int it = 0; it < n_iter; ++it) {
         RefineCfg cfg = b->cfg;
         cfg.iter = it;
+        if (b->dec->jac_bf3 != 2) cfg.tile_p = TILE_P;      // (32-point tiles exist on the split-fp16 pipe only: the f32 repeat of a
+                                                            //  batch created for them runs 64-point tiles over the same slots)
         hipEvent_t a = nullptr;
         hipLaunchKernelGGL(k_c0, dim3(nH), dim3(MLP_THREADS), 0, s, b->st, b->dec->Pd, b->c0_all);
         if (!cfg.pose_only) {
@@ -1995,11 +864,24 @@ extern "C" int qsp_refine_batch_run(qsp_refine_batch* b, int32_t n_iter) {
                                b->ray_voff, b->ray_stride);
             if (b->prof) spans.push_back({a, next_event(b, cur), 2});
             if (b->prof) a = next_event(b, cur);
+            const bool screen = b->dec->fwd_bf3 == 2 && b->dec->screen_margin > 0.f;
             hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, s, 0, b->st, b->objs, nH, b->nw_sdf, nw_total - b->nw_sdf,
-                               b->work_fwd, b->qctl, TILE_P);     // (the forward pass keeps 64-point tiles: tens of thousands
-            if (b->dec->fwd_bf3 == 2)                                     //  of ray samples fill the chip either way)
+                               b->work_fwd, b->qctl, screen ? H1_ROWS : TILE_P);     // (the forward pass keeps 64-point tiles: tens of
+            if (screen) {                                                            //  thousands of ray samples fill the chip either way)
+                // two passes (QSP_DEC_OPT_RENDER_SCREENING): every sample on the one-product tile, then the band around the
+                // surface on the split-fp16 tile; the queue's control words and item list are reused behind the first pass
+                hipLaunchKernelGGL(k_mlp_fwd_h1, dim3(b->n_cu), dim3(H2_THREADS), sizeof(MlpSmemH1), s, b->st, b->objs, b->rays,
+                                   cfg, b->dec->Pd, b->valid_rk, b->rk_stride, b->sdf_valid, b->work_fwd, b->qctl, b->c0_all,
+                                   b->band_idx, cfg.cut_off + b->dec->screen_margin);
+                hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, s, 2, b->st, b->objs, nH, b->nw_sdf, nw_total - b->nw_sdf,
+                                   b->work_fwd, b->qctl, TILE_P);
                 hipLaunchKernelGGL(k_mlp_fwd_h2<2>, dim3(b->n_cu), dim3(H2_THREADS), sizeof(MlpSmem), s, b->st, b->objs, b->rays,
-                                   cfg, b->dec->Pd, b->valid_rk, b->rk_stride, b->sdf_valid, b->work_fwd, b->qctl, b->c0_all);
+                                   cfg, b->dec->Pd, b->valid_rk, b->rk_stride, b->sdf_valid, b->work_fwd, b->qctl, b->c0_all,
+                                   (const int32_t*)b->band_idx);
+            } else if (b->dec->fwd_bf3 == 2)
+                hipLaunchKernelGGL(k_mlp_fwd_h2<2>, dim3(b->n_cu), dim3(H2_THREADS), sizeof(MlpSmem), s, b->st, b->objs, b->rays,
+                                   cfg, b->dec->Pd, b->valid_rk, b->rk_stride, b->sdf_valid, b->work_fwd, b->qctl, b->c0_all,
+                                   (const int32_t*)nullptr);
             else if (b->dec->fwd_bf3)
                 hipLaunchKernelGGL(k_mlp_fwd<true>, dim3(b->n_cu), dim3(MLP_THREADS), sizeof(MlpSmem), s, b->st, b->objs, b->rays,
                                    cfg, b->dec->Pd, b->valid_rk, b->rk_stride, b->sdf_valid, b->work_fwd, b->qctl, b->c0_all);
@@ -2015,16 +897,15 @@ extern "C" int qsp_refine_batch_run(qsp_refine_batch* b, int32_t n_iter) {
         if (b->prof) a = next_event(b, cur);
         hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, s, 1, b->st, b->objs, nH, b->nw_sdf, nw_total - b->nw_sdf,
                            b->work_jtj, b->qctl, cfg.tile_p);
-        if (b->dec->jac_bf3 == 2 && cfg.tile_p == 32)
-            hipLaunchKernelGGL(k_mlp_jtj_h2<1>, dim3(b->n_cu), dim3(H2_THREADS), sizeof(MlpSmem), s, b->st, b->objs, b->pts,
-                               b->rays, cfg, b->dec->Pd, b->nw_sdf, b->rend_rk, b->rend_deds, b->rend_res, b->rk_stride,
-                               b->pt_active, b->act_stride, b->res_buf, b->rows, b->rows_stride, b->partials, nw_total,
-                               b->work_jtj, b->qctl, b->c0_all);
-        else if (b->dec->jac_bf3 == 2)
-            hipLaunchKernelGGL(k_mlp_jtj_h2<2>, dim3(b->n_cu), dim3(H2_THREADS), sizeof(MlpSmem), s, b->st, b->objs, b->pts,
-                               b->rays, cfg, b->dec->Pd, b->nw_sdf, b->rend_rk, b->rend_deds, b->rend_res, b->rk_stride,
-                               b->pt_active, b->act_stride, b->res_buf, b->rows, b->rows_stride, b->partials, nw_total,
-                               b->work_jtj, b->qctl, b->c0_all);
+        if (b->dec->jac_bf3 == 2) {
+            const JtjArgs ja{b->st, b->objs, b->pts, b->rays, cfg, b->dec->Pd, b->nw_sdf, nw_total, b->rend_rk, b->rend_deds, b->rend_res,
+                             b->rk_stride, b->pt_active, b->act_stride, b->res_buf, b->rows, b->rows_stride, b->partials, b->work_jtj,
+                             b->qctl, b->c0_all};
+            if (cfg.tile_p == 32)
+                hipLaunchKernelGGL(k_mlp_jtj_h2<1>, dim3(b->n_cu), dim3(H2_THREADS), sizeof(MlpSmem), s, ja);
+            else
+                hipLaunchKernelGGL(k_mlp_jtj_h2<2>, dim3(b->n_cu), dim3(H2_THREADS), sizeof(MlpSmem), s, ja);
+        }
         else if (b->dec->jac_bf3)
             hipLaunchKernelGGL(k_mlp_jtj<true>, dim3(b->n_cu), dim3(MLP_THREADS), sizeof(MlpSmem), s, b->st, b->objs, b->pts,
                                b->rays, cfg, b->dec->Pd, b->nw_sdf, b->rend_rk, b->rend_deds, b->rend_res, b->rk_stride,
@@ -2047,9 +928,9 @@ extern "C" int qsp_refine_batch_run(qsp_refine_batch* b, int32_t n_iter) {
     if (b->prof) e_end = next_event(b, cur);
     QSP_HIP(hipGetLastError());
     QSP_HIP(hipStreamSynchronize(s));
-    {
-        const int rc = check_range(b->dec);
-        if (rc) return rc;
+    if (range_hit(b->dec)) {
+        *hit = true;
+        return QSP_OK;
     }
     if (b->prof) {
         qsp_refine_profile& p = b->profile;
@@ -2062,15 +943,43 @@ extern "C" int qsp_refine_batch_run(qsp_refine_batch* b, int32_t n_iter) {
             else if (sp.kind == 1) { p.ms_mlp_fwd += ms; p.n_launch_fwd++; }
             else p.ms_other += ms;
         }
-        unsigned long long c[4];
+        unsigned long long c[8];
         QSP_HIP(hipMemcpy(c, b->counters, sizeof(c), hipMemcpyDeviceToHost));
         p.pts_jtj = (int64_t)c[0];
         p.pts_fwd = (int64_t)c[1];
         p.tiles_jtj = (int64_t)c[2];
         p.tiles_fwd = (int64_t)c[3];
+        p.pts_band = (int64_t)c[4];
     }
     return QSP_OK;
 }
+
+extern "C" int qsp_refine_batch_run(qsp_refine_batch* b, int32_t n_iter) {
+    if (!b) return qsp_fail(QSP_ERR_INVALID, "run: null batch");
+    QSP_HIP(hipSetDevice(b->dec->device));
+    if (n_iter <= 0) n_iter = b->n_iter_cfg;
+    qsp_decoder* d = b->dec;
+    const bool may_fall_back = range_should_fall_back(d);
+    if (may_fall_back) {      // the state this run starts from, in case it has to be repeated on the f32 pipe (n_hyp x 432 bytes)
+        QSP_HIP(hipMemcpyAsync(b->st_snap, b->st, sizeof(HypState) * b->n_hyp, hipMemcpyDeviceToDevice, d->stream));
+        if (b->pt_active) QSP_HIP(hipMemcpyAsync(b->act_snap, b->pt_active, (size_t)b->n_hyp * b->act_stride, hipMemcpyDeviceToDevice, d->stream));
+    }
+    bool hit = false;
+    int rc = run_once(b, n_iter, &hit);
+    if (rc || !hit) return rc;
+    if (!may_fall_back) return range_error();
+    // A value left fp16's range.  The reference accepts such a decoder (it computes in float32) and never raises for a numeric
+    // condition (reconstruct/optimizer.py:161-194), so the run is repeated from its starting state on the exact-f32 pipe.
+    QSP_HIP(hipMemcpyAsync(b->st, b->st_snap, sizeof(HypState) * b->n_hyp, hipMemcpyDeviceToDevice, d->stream));
+    if (b->pt_active) QSP_HIP(hipMemcpyAsync(b->pt_active, b->act_snap, (size_t)b->n_hyp * b->act_stride, hipMemcpyDeviceToDevice, d->stream));
+    F32Override f32(d);
+    d->n_range_fallbacks++;
+    hit = false;
+    rc = run_once(b, n_iter, &hit);
+    b->profile.range_fallbacks = 1;
+    return rc;
+}
+
 
 extern "C" int qsp_refine_batch_profile(qsp_refine_batch* b, int enable, qsp_refine_profile* out) {
     if (!b) return qsp_fail(QSP_ERR_INVALID, "profile: null batch");

@@ -104,7 +104,11 @@ def test_unsupported_decoder_family_is_refused(golden_dir):
         return [(rng.normal(size=(o, i)).astype(np.float32) * 0.05, None, np.zeros(o, np.float32)) for i, o in dims_in_out]
     wide = mlp([(67, 640), (640, 640 - 67), (640, 640), (640, 1)])           # width 640 > 512
     deep = mlp([(67, 64)] + [(64, 64)] * 9 + [(64, 1)])                       # 10 hidden layers
-    for layers, lin in ((wide, (2,)), (deep, ())):
+    # no latent_in and every candidate for the slot in front of the (absent) skip wider than 445: the slot is 445 wide with or
+    # without a skip (these used to be accepted and evaluated wrongly / written past the packed rows)
+    full4 = mlp([(67, 512), (512, 512), (512, 512), (512, 512), (512, 1)])
+    full8 = mlp([(67, 512)] + [(512, 512)] * 7 + [(512, 1)])
+    for layers, lin in ((wide, (2,)), (deep, ()), (full4, ()), (full8, ())):
         with pytest.raises(_lib.QspError) as e:
             DeepSdfDecoder(layers, latent_in=lin, code_len=64)
         assert e.value.code == _lib.QSP_ERR_UNSUPPORTED
@@ -127,7 +131,9 @@ def test_decoder_family_members_match_the_oracle():
             layers.append((w, None, (0.1 * rng.normal(size=out)).astype(np.float32)))
         return layers
     cases = [(32, [256] * 4, (2,)), (64, [128, 192, 96], ()), (8, [64, 64], (1,)),
-             (64, [512, 300, 400, 512, 256, 512, 100, 512], (4,)), (16, [200] * 7, (3,)), (64, [512] * 5, (1,))]
+             (64, [512, 300, 400, 512, 256, 512, 100, 512], (4,)), (16, [200] * 7, (3,)), (64, [512] * 5, (1,)),
+             # no latent_in, wide layers: the split goes behind the first layer that fits the 445-wide slot
+             (64, [512, 400, 512, 512], ()), (64, [512, 512, 512, 445, 512, 512, 512, 512], ()), (32, [500, 500, 300, 500, 500], ())]
     for L, dims, lin in cases:
         layers = family(L, dims, lin)
         dec = DeepSdfDecoder(layers, latent_in=lin, code_len=L)
