@@ -24,8 +24,13 @@ precision fp16x2 (default): the decoder's multiply-adds with every f32 operand a
         bf16x3: three bf16 terms, six products.  f32: the exact-f32 matrix pipe.  The other two pipes' step times are reported
         beside `value` in every default run (`f32_mfma`, `bf16x3_mfma`).
 
+screening (default with fp16x2, --screening-margin 0.01): the ray-sample forward pass of the refinement in two passes -- every
+        sample on a one-product fp16 tile (sign and rough magnitude), the samples with |s1| < cut_off + margin again on the
+        split-fp16 tile.  The render term clamps outside the band, so K, n_valid, H, b and every iterate are bit-identical to the
+        one-pass result (tests/test_gpu_screening.py); `fp16x2_unscreened` in the line is the same workload with one pass.
+
   python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c4|c5] [--scaling strong|weak] [--precision fp16x2|bf16x3|f32]
-                  [--no-sublines] [--no-cpu-baseline]
+                  [--screening-margin M] [--no-sublines] [--no-cpu-baseline]
   N > 1: one rank per GPU under torch.distributed.run (the driver's launch line); `python bench.py --gpus N` without that
   environment starts it as a child process.
 """
@@ -218,6 +223,14 @@ class Ctx(object):
                     if self.comm is not None:
                         self.comm.close()
                     self.comm = None
+                    if not args.allow_hook_fallback:
+                        # a broken primary path must not masquerade as a slow one in a scaling run: the hook costs two host
+                        # synchronisations per collective and is a different code path (qsp_ba_set_shard, not ..._rccl)
+                        print("bench.py rank %d: the library's RCCL communicator could not be created on every rank; refusing to "
+                              "fall back to the torch.distributed hook (pass --allow-hook-fallback to measure that path)"
+                              % self.rank, file=sys.stderr)
+                        dist.destroy_process_group()
+                        sys.exit(3)
                     self.comm_kind = "torch.distributed nccl hook (fallback: qsp_ba_set_shard + TorchAllreduce)"
 
     def sync_all(self):
@@ -234,7 +247,7 @@ class Ctx(object):
         return float(t.item())
 
 
-def run_workload(ctx, name, steps, warmup, detailed, precision=None):
+def run_workload(ctx, name, steps, warmup, detailed, precision=None, screening=None):
     """`steps` timed passes of workload `name` (after `warmup` untimed ones); every rank returns the same dict of whole-job
     numbers (rank 0's kernel timings)."""
     from qsp_slam_amd import DeepSdfDecoder, parallel, synth
@@ -246,6 +259,9 @@ def run_workload(ctx, name, steps, warmup, detailed, precision=None):
     flips = args.flips
     dec = DeepSdfDecoder.from_npz(os.path.join(ROOT, "tests", "golden", "decoder_8x512.npz"), device=dev)
     dec.set_precision(precision or args.precision)
+    margin = args.screening_margin if screening is None else screening
+    if dec.precision == "fp16x2" and margin > 0:
+        dec.set_render_screening(margin)     # two-pass ray-sample forward, bit-identical to the unscreened pipe (tests/test_gpu_screening.py)
     opt = Optimizer(dec, joint_cfg(w["n_iter"]))
     seed_off = 0 if strong else rank
     objs_all = synth.make_object_views(1000 + seed_off, w["n_obj"], w["n_pts"], n_fg=w["n_fg"], n_bg=w["n_bg"])
@@ -310,7 +326,7 @@ def run_workload(ctx, name, steps, warmup, detailed, precision=None):
     ctx.sync_all()
     t0 = time.perf_counter()
     prof = dict(ms_total=0.0, ms_mlp_jtj=0.0, ms_mlp_fwd=0.0, ms_other=0.0, n_jtj=0, n_fwd=0, pts_jtj=0, pts_fwd=0,
-                tiles_jtj=0, tiles_fwd=0)
+                tiles_jtj=0, tiles_fwd=0, pts_band=0, fallbacks=0)
     for _ in range(steps):
         step(record=True, lin_stats=lin_in_timed)
         if batch is not None:
@@ -325,6 +341,8 @@ def run_workload(ctx, name, steps, warmup, detailed, precision=None):
             prof["pts_fwd"] += p.pts_fwd
             prof["tiles_jtj"] += p.tiles_jtj
             prof["tiles_fwd"] += p.tiles_fwd
+            prof["pts_band"] += p.pts_band
+            prof["fallbacks"] += p.range_fallbacks
     ctx.sync_all()
     dt = ctx.allreduce(time.perf_counter() - t0, "MAX")
     n_good = 0
@@ -354,6 +372,17 @@ def run_workload(ctx, name, steps, warmup, detailed, precision=None):
         ms_ba=ba_stat["ms"] / steps, ba_lm_iterations=ba_stat["iters"] / steps, ba_lm_trials=ba_stat["trials"] / steps,
         ba_iters_per_s=ba_stat["iters"] / max(1e-3 * ba_stat["ms"], 1e-12),
         ms_gather=ba_stat["ms_gather"] / steps,
+        fallbacks=dict(range_reruns_on_f32=int(prof["fallbacks"]) + (dec.range_fallbacks if batch is None else 0),
+                       decoder_counter=dec.range_fallbacks,
+                       note="timed steps that were repeated on the exact-f32 pipe because a value left fp16's range "
+                            "(QSP_DEC_OPT_RANGE_FALLBACK); any non-zero count invalidates the line's dtype"),
+        screening=(dict(margin=margin, band_share=prof["pts_band"] / max(prof["pts_fwd"], 1),
+                        samples_per_launch=prof["pts_fwd"] / max(prof["n_fwd"], 1),
+                        band_samples_per_launch=prof["pts_band"] / max(prof["n_fwd"], 1),
+                        note="ray-sample forward in two passes: all samples on the one-product fp16 tile, the band "
+                             "|s1| < cut_off + margin again on the split-fp16 tile; K, n_valid, H, b bit-identical to the "
+                             "unscreened path (tests/test_gpu_screening.py)")
+                   if (dec.precision == "fp16x2" and margin > 0) else None),
         ba_desc="local joint BA 5+10 LM iterations: %d KF / %d map points / %d objects, %d mono + %d stereo + %d "
                 "camera-object edges" % (w["n_kf"], w["n_map"], w["n_obj"], len(scene["mono_pt"]), len(scene["st_pt"]),
                                          len(scene["oe_kf"])),
@@ -425,6 +454,11 @@ def main():
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"])
     ap.add_argument("--precision", default="fp16x2", choices=["fp16x2", "bf16x3", "f32"])
     ap.add_argument("--flips", type=int, default=4)
+    ap.add_argument("--screening-margin", type=float, default=0.01,
+                    help="fp16x2 only: band margin of the two-pass ray-sample forward (QSP_DEC_OPT_RENDER_SCREENING); 0 = one pass")
+    ap.add_argument("--allow-hook-fallback", action="store_true",
+                    help="N > 1, strong scaling: if the library's own RCCL communicator cannot be created, measure the "
+                         "torch.distributed all-reduce hook instead of exiting with an error")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sublines", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
@@ -450,7 +484,9 @@ def main():
     if not args.no_sublines:      # the other matrix pipes on the same workload, beside `value`
         for pr in ("f32", "bf16x3"):
             if pr != args.precision:
-                other[pr] = run_workload(ctx, args.workload, 1, 1, detailed=False, precision=pr)
+                other[pr] = run_workload(ctx, args.workload, 3, 1, detailed=False, precision=pr)
+        if args.precision == "fp16x2" and args.screening_margin > 0:     # the same pipe with the one-pass forward
+            other["fp16x2_unscreened"] = run_workload(ctx, args.workload, 3, 1, detailed=False, precision="fp16x2", screening=0.0)
     subs = {}
     if not args.no_sublines:
         for name in ("c2", "c5"):
@@ -517,12 +553,18 @@ def main():
                          "tile_padding_overhead": m["jtj"]["tile_padding_overhead"]},
             "kernels": m["kernels"],
         }
+        out["fallbacks"] = m["fallbacks"]
+        out["screening"] = m["screening"]
         for opr, o in other.items():
-            out[opr + "_mfma"] = {"note": "the same workload with --precision %s, 1 step" % opr,
-                                  "value": o["value"], "ms_per_step": o["ms_per_step"],
-                                  "k_mlp_jtj_TFLOPs": o["jtj"]["achieved"],
-                                  "k_mlp_jtj_frac_of_its_peak": o["jtj"]["achieved"] / peak_for(opr),
-                                  "k_mlp_fwd_TFLOPs": o["kernels"]["k_mlp_fwd_TFLOPs"]}
+            base = opr.split("_")[0]
+            out[opr + ("_mfma" if opr == base else "")] = {
+                "note": ("the same workload with --precision %s, 3 timed steps" % opr) if opr == base else
+                        "the same workload and pipe with --screening-margin 0 (every ray sample on the split-fp16 tile), 3 timed steps",
+                "value": o["value"], "ms_per_step": o["ms_per_step"],
+                "k_mlp_jtj_TFLOPs": o["jtj"]["achieved"],
+                "k_mlp_jtj_frac_of_its_peak": o["jtj"]["achieved"] / peak_for(base),
+                "k_mlp_fwd_TFLOPs": o["kernels"]["k_mlp_fwd_TFLOPs"], "ms_mlp_fwd": o["kernels"]["ms_mlp_fwd"],
+                "fallbacks": o["fallbacks"]["range_reruns_on_f32"]}
         if subs:
             out["sublines"] = subs
         if world == 1 and not args.no_extras:

@@ -112,6 +112,11 @@ int qsp_decoder_set_option(qsp_decoder* dec, int32_t option, int32_t value);
 /* decode_sdf, reconstruct/loss_utils.py:51-79.  Host pointers: code (code_len), xyz (n,3) row-major, sdf_out (n). */
 int qsp_decode_sdf(qsp_decoder* dec, const float* code, const float* xyz, int64_t n, float* sdf_out);
 
+/* Diagnostic: the values the FIRST pass of QSP_DEC_OPT_RENDER_SCREENING computes (one fp16 term per operand).  They are not
+ * SDF values of the decoder's precision and nothing in the library returns them as such; tests and tools/screen_margin.py use
+ * this entry to measure |s1 - s3|, the quantity the screening margin has to cover.  Host pointers. */
+int qsp_decode_sdf_screen(qsp_decoder* dec, const float* code, const float* xyz, int64_t n, float* s1_out);
+
 /* get_batch_sdf_jacobian, reconstruct/loss_utils.py:82-103 (out_dim = 1): y (n) and d y / d [code | xyz] (n, code_len+3),
  * without the weight gradients the reference's autograd also accumulates and never uses.  Host pointers. */
 int qsp_sdf_value_grad(qsp_decoder* dec, const float* code, const float* xyz, int64_t n, float* y, float* grad);
@@ -165,6 +170,9 @@ int qsp_refine_batch_get(qsp_refine_batch* b, float* t_cam_obj_out, float* code_
  * (sdf, render).  Any pointer may be NULL. */
 int qsp_refine_batch_trace(qsp_refine_batch* b, float* H, float* rhs, float* dx, int32_t* n_valid,
                            int32_t* n_render, float* loss_terms);
+/* ... and the rotation prior's own terms of that iteration (reconstruct/loss.py:155-178): rot4 (n_hyp,4) = J_rot (the three
+ * rotation entries 3..5 of J_sim3) and res_rot -- lets a parity test separate the decoder part of rhs from the k4-weighted one. */
+int qsp_refine_batch_trace_rot(qsp_refine_batch* b, float* rot4);
 
 /* Parity-test tap.  enable != 0 (with NULL outputs) before a run makes the fused kernel also store every augmented Jacobian
  * row it feeds to the normal equations: [d e/d xi (7) | d e/d code (64) | robust residual] = 72 floats per row.  After
@@ -359,6 +367,11 @@ int qsp_comm_create(const uint8_t* id /* [QSP_COMM_ID_BYTES] */, int32_t rank, i
 int qsp_comm_adopt(void* nccl_comm, int32_t rank, int32_t world, int device, qsp_comm** out);
 void qsp_comm_destroy(qsp_comm* c);
 void* qsp_comm_nccl(qsp_comm* c);     /* the ncclComm_t, for qsp_ba_set_shard_rccl */
+/* librccl is resolved at run time: QSP_RCCL_LIB=<path> if set (an explicit library wins; a path that does not load is an error),
+ * else the copy already mapped into the process, else librccl.so.1.  Test hook for the shared-memory stand-in of tests/stub_rccl
+ * (which lets a one-GPU box execute the RCCL-on-stream path with two ranks): collectives that ran with world > 1 on this
+ * communicator, out3 = [sum all-reduces, max all-reduces, all-gathers]; QSP_ERR_UNSUPPORTED with a real RCCL. */
+int qsp_comm_stub_counts(qsp_comm* c, int64_t* out3);
 int32_t qsp_comm_rank(qsp_comm* c);
 int32_t qsp_comm_world(qsp_comm* c);
 int qsp_comm_allreduce_f64(qsp_comm* c, double* device_buf, int64_t count, void* hip_stream);

@@ -20,7 +20,7 @@ sys.path.insert(0, ROOT)
 from oracle.ref_import import import_reference  # noqa: E402
 from qsp_slam_amd import synth  # noqa: E402
 
-GOLD = os.path.join(ROOT, "tests", "golden")
+GOLD = os.environ.get("QSP_GOLDEN_OUT", os.path.join(ROOT, "tests", "golden"))
 
 REDWOOD = dict(k1=10.0, k2=100.0, k3=2.5, k4=0.0, b1=0.2, b2=0.02, learning_rate=1.0, scale_damping=100.0,
                num_iterations=5)                       # configs/config_redwood_chair_01053.json
@@ -28,13 +28,13 @@ KITTI = dict(k1=1.0, k2=100.0, k3=0.25, k4=1e7, b1=0.20, b2=0.025, learning_rate
              num_iterations=10)                        # configs/config_kitti.json:21-41
 
 
-def ref_decoder(dec_mod, path):
+def ref_decoder(dec_mod, path, use_tanh=None):
     z = np.load(path)
     meta = ast.literal_eval(str(z["meta"]))
     dec = dec_mod.Decoder(meta["latent_size"], list(meta["dims"]), dropout=list(range(8)), dropout_prob=0.2,
                           norm_layers=list(meta["norm_layers"]), latent_in=list(meta["latent_in"]),
-                          weight_norm=meta["weight_norm"], xyz_in_all=meta["xyz_in_all"], use_tanh=meta["use_tanh"],
-                          latent_dropout=False)
+                          weight_norm=meta["weight_norm"], xyz_in_all=meta["xyz_in_all"],
+                          use_tanh=meta["use_tanh"] if use_tanh is None else use_tanh, latent_dropout=False)
     dec.load_state_dict({k: torch.from_numpy(z[k]) for k in z.files if k != "meta"})
     dec.eval()
     return dec
@@ -74,8 +74,14 @@ def run_joint_case(mods, dec, name, joint, data_type, seed, n_pts, n_fg, n_bg, c
                    it0_res_render=rr[2].reshape(-1).numpy())
     # --- the entry point itself, with harness-side taps on what it calls ------------------------------------------
     # (the taps wrap names in the *imported module's namespace*; no reference file is modified)
-    states, Hs, bs = [], [], []
+    states, Hs, bs, rots = [], [], [], []
     orig_render, orig_inv, orig_mv = opt_mod.compute_render_loss, torch.inverse, torch.mv
+    orig_rot = opt_mod.compute_rotation_loss_sim3
+
+    def tap_rot(t_obj_cam_):
+        j_, r_ = orig_rot(t_obj_cam_)
+        rots.append((j_.numpy().copy(), float(r_)))
+        return j_, r_
 
     def tap_render(decoder, rays, dobs_, t_obj_cam_, depths_, lat, th=0.01):
         r_ = orig_render(decoder, rays, dobs_, t_obj_cam_, depths_, lat, th=th)
@@ -93,10 +99,12 @@ def run_joint_case(mods, dec, name, joint, data_type, seed, n_pts, n_fg, n_bg, c
         return orig_mv(a, v)
 
     opt_mod.compute_render_loss, torch.inverse, torch.mv = tap_render, tap_inv, tap_mv
+    opt_mod.compute_rotation_loss_sim3 = tap_rot
     try:
         r = opt.reconstruct_object(obj["t_cam_obj"].copy(), obj["pts"], obj["rays"], obj["depth"])
     finally:
         opt_mod.compute_render_loss, torch.inverse, torch.mv = orig_render, orig_inv, orig_mv
+        opt_mod.compute_rotation_loss_sim3 = orig_rot
     if Hs:
         n_it = len(Hs)
         out["it_T_oc"] = np.stack([s_[0] for s_ in states[:n_it]])
@@ -106,6 +114,10 @@ def run_joint_case(mods, dec, name, joint, data_type, seed, n_pts, n_fg, n_bg, c
         out["it_b"] = np.stack(bs)
         out["it_dx"] = np.stack([(orig_inv(torch.from_numpy(H_)) @ torch.from_numpy(b_)).numpy()
                                  for H_, b_ in zip(Hs, bs)])
+        # the rotation prior's own terms (loss.py:155-178) per iteration: lets a test separate the decoder part of b from the
+        # k4-weighted one (with the KITTI weights k4 = 1e7 multiplies a float32 cancellation)
+        out["it_Jrot"] = np.stack([r_[0] for r_ in rots[:n_it]]).astype(np.float32)
+        out["it_res_rot"] = np.array([r_[1] for r_ in rots[:n_it]], np.float32)
     out["is_good"] = np.array(bool(r.is_good))
     out["loss"] = np.array(float(r.loss), dtype=np.float64)
     if r.is_good:
@@ -197,7 +209,28 @@ def main():
     print("pose-only done")
 
 
+def main_use_tanh():
+    """NetworkSpecs.use_tanh (deep_sdf_decoder.py:66-68,92-94): the SAME fitted parameters evaluated by the reference's Decoder
+    built with use_tanh=True (the state dict has no entry for it) -- decoder-level vectors and one joint refinement"""
+    mods = import_reference()
+    opt_mod, loss_mod, lu, dec_mod, utils_mod = mods
+    torch.set_num_threads(8)
+    dec = ref_decoder(dec_mod, os.path.join(GOLD, "decoder_8x512.npz"), use_tanh=True)
+    rng = np.random.default_rng(23)
+    x = rng.uniform(-0.9, 0.9, size=(300, 3)).astype(np.float32)
+    code = np.zeros(64, np.float32)
+    code[:3] = [0.2, -0.1, 0.3]
+    code[3:] = rng.normal(scale=0.05, size=61).astype(np.float32)
+    sdf = lu.decode_sdf(dec, torch.from_numpy(code), torch.from_numpy(x)).numpy()
+    y, g = lu.get_batch_sdf_jacobian(dec, torch.from_numpy(code), torch.from_numpy(x), 1)
+    np.savez_compressed(os.path.join(GOLD, "sdf_usetanh_decoder_vectors.npz"), x=x, code=code, sdf=sdf,
+                        y=y.reshape(-1).numpy(), grad=g.squeeze(1).numpy())
+    run_joint_case(mods, dec, "sdf_usetanh_joint_m400", REDWOOD, "Redwood", seed=41, n_pts=400, n_fg=128, n_bg=64)
+
+
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "small":
     main_small()
+elif __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "use_tanh":
+    main_use_tanh()
 elif __name__ == "__main__":
     main()

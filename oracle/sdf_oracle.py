@@ -23,10 +23,11 @@ F32 = np.float32
 class DecoderWeights(object):
     """Folded DeepSDF decoder: list of (W (out,in) f32, b (out,) f32) and the latent-skip layer index."""
 
-    def __init__(self, layers, latent_in, code_len):
+    def __init__(self, layers, latent_in, code_len, use_tanh=False):
         self.layers = [(np.ascontiguousarray(W, dtype=F32), np.ascontiguousarray(b, dtype=F32)) for W, b in layers]
         self.latent_in = tuple(latent_in)
         self.code_len = int(code_len)
+        self.use_tanh = bool(use_tanh)      # NetworkSpecs.use_tanh: tanh on the output layer, then the final tanh (:92-94,107-108)
 
     @property
     def mac_per_point(self):
@@ -57,11 +58,13 @@ def fold_state_dict(state, latent_in=(4,), code_len=64):
     return DecoderWeights(layers, latent_in, code_len)
 
 
-def load_decoder_npz(path):
+def load_decoder_npz(path, use_tanh=None):
     z = np.load(path, allow_pickle=False)
     meta = ast.literal_eval(str(z["meta"]))  # written by oracle/fit_decoder.py, a literal dict
     state = {k: z[k] for k in z.files if k != "meta"}
-    return fold_state_dict(state, latent_in=meta["latent_in"], code_len=meta["latent_size"])
+    dec = fold_state_dict(state, latent_in=meta["latent_in"], code_len=meta["latent_size"])
+    dec.use_tanh = bool(meta.get("use_tanh", False)) if use_tanh is None else bool(use_tanh)
+    return dec
 
 
 def decoder_forward(dec, inp, keep=False):
@@ -82,6 +85,9 @@ def decoder_forward(dec, inp, keep=False):
         else:
             h = a
     y = np.tanh(h[:, 0]).astype(F32)
+    if getattr(dec, "use_tanh", False):
+        pre.append(y) if keep else None     # (the inner tanh's output: the backward pass needs it)
+        y = np.tanh(y).astype(F32)
     return (y, pre) if keep else y
 
 
@@ -91,7 +97,11 @@ def decoder_value_and_input_grad(dec, inp):
     y, masks = decoder_forward(dec, inp, keep=True)
     n_layers = len(dec.layers)
     W_last = dec.layers[-1][0]
-    g = ((F32(1) - y * y)[:, None] * W_last[0][None, :]).astype(F32)  # d tanh
+    dy = (F32(1) - y * y).astype(F32)                                 # d tanh (the outer one with use_tanh)
+    if getattr(dec, "use_tanh", False):
+        y1 = masks.pop()                                               # tanh(t); autograd multiplies the outer factor first
+        dy = (dy * (F32(1) - y1 * y1)).astype(F32)
+    g = (dy[:, None] * W_last[0][None, :]).astype(F32)
     g_in = np.zeros_like(inp, dtype=F32)
     for l in range(n_layers - 2, -1, -1):
         W = dec.layers[l][0]

@@ -92,16 +92,17 @@ class DetectionResults(C.Structure):
 
 SYMBOLS = [
     "qsp_last_error", "qsp_version", "qsp_device_count",
-    "qsp_decoder_create", "qsp_decoder_destroy", "qsp_decoder_set_option", "qsp_decode_sdf", "qsp_sdf_value_grad",
+    "qsp_decoder_create", "qsp_decoder_destroy", "qsp_decoder_set_option", "qsp_decoder_get_counter", "qsp_decode_sdf",
+    "qsp_decode_sdf_screen", "qsp_sdf_value_grad",
     "qsp_refine_batch_create", "qsp_refine_batch_destroy", "qsp_refine_batch_set_state", "qsp_refine_batch_run",
-    "qsp_refine_batch_get", "qsp_refine_batch_trace", "qsp_refine_batch_profile", "qsp_refine_batch_rows",
+    "qsp_refine_batch_get", "qsp_refine_batch_trace", "qsp_refine_batch_trace_rot", "qsp_refine_batch_profile", "qsp_refine_batch_rows",
     "qsp_reconstruct_objects", "qsp_estimate_pose", "qsp_refine_detections",
     "qsp_mesh_extractor_create", "qsp_mesh_extractor_destroy", "qsp_mesh_extract", "qsp_mesh_from_volume", "qsp_mesh_fetch",
     "qsp_mc_tables",
     "qsp_pose_optimizer_create", "qsp_pose_optimizer_destroy", "qsp_pose_optimize", "qsp_ellipsoid_fit_planes",
     "qsp_ba_create", "qsp_ba_destroy", "qsp_ba_set_levels", "qsp_ba_optimize", "qsp_ba_local_joint",
     "qsp_ba_set_state", "qsp_ba_get_state", "qsp_ba_get_edges", "qsp_ba_get_index", "qsp_ba_profile", "qsp_ba_set_shard", "qsp_ba_set_deterministic",
-    "qsp_ba_set_shard_rccl", "qsp_ba_set_option", "qsp_comm_unique_id", "qsp_comm_create", "qsp_comm_adopt", "qsp_comm_destroy", "qsp_comm_nccl",
+    "qsp_ba_set_shard_rccl", "qsp_ba_set_option", "qsp_comm_unique_id", "qsp_comm_create", "qsp_comm_adopt", "qsp_comm_destroy", "qsp_comm_nccl", "qsp_comm_stub_counts",
     "qsp_comm_rank", "qsp_comm_world", "qsp_comm_allreduce_f64", "qsp_comm_allgather_f32",
 ]
 
@@ -122,8 +123,11 @@ def lib():
     L.qsp_decoder_create.argtypes = [C.POINTER(DecoderDesc), C.c_int, C.POINTER(vp)]
     L.qsp_decoder_destroy.argtypes = [vp]
     L.qsp_decoder_set_option.argtypes = [vp, C.c_int32, C.c_int32]
+    L.qsp_decoder_get_counter.argtypes = [vp, C.c_int32]
+    L.qsp_decoder_get_counter.restype = C.c_int64
     L.qsp_decoder_destroy.restype = None
     L.qsp_decode_sdf.argtypes = [vp, c_float_p, c_float_p, C.c_int64, c_float_p]
+    L.qsp_decode_sdf_screen.argtypes = [vp, c_float_p, c_float_p, C.c_int64, c_float_p]
     L.qsp_sdf_value_grad.argtypes = [vp, c_float_p, c_float_p, C.c_int64, c_float_p, c_float_p]
     pp_f = C.POINTER(c_float_p)
     L.qsp_refine_batch_create.argtypes = [vp, C.POINTER(JointCfg), C.c_int32, pp_f, c_int32_p, pp_f, c_int32_p, pp_f,
@@ -134,6 +138,7 @@ def lib():
     L.qsp_refine_batch_run.argtypes = [vp, C.c_int32]
     L.qsp_refine_batch_get.argtypes = [vp, c_float_p, c_float_p, c_float_p, c_uint8_p]
     L.qsp_refine_batch_trace.argtypes = [vp, c_float_p, c_float_p, c_float_p, c_int32_p, c_int32_p, c_float_p]
+    L.qsp_refine_batch_trace_rot.argtypes = [vp, c_float_p]
     L.qsp_refine_batch_profile.argtypes = [vp, C.c_int, C.POINTER(RefineProfile)]
     L.qsp_refine_batch_rows.argtypes = [vp, C.c_int, C.c_int32, c_float_p, c_float_p]
     L.qsp_reconstruct_objects.argtypes = [vp, C.POINTER(JointCfg), C.c_int32, pp_f, c_int32_p, pp_f, c_int32_p, pp_f,
@@ -176,6 +181,7 @@ def lib():
     L.qsp_comm_adopt.argtypes = [vp, C.c_int32, C.c_int32, C.c_int, C.POINTER(vp)]
     L.qsp_comm_destroy.argtypes = [vp]
     L.qsp_comm_destroy.restype = None
+    L.qsp_comm_stub_counts.argtypes = [vp, c_int64_p]
     L.qsp_comm_nccl.argtypes = [vp]
     L.qsp_comm_nccl.restype = vp
     L.qsp_comm_rank.argtypes = [vp]

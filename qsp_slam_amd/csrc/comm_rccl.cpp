@@ -9,6 +9,7 @@
 // preferred so that one process never holds two RCCL instances; a C++ embedder without PyTorch gets /opt/rocm/lib's.
 #include <dlfcn.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 
@@ -24,9 +25,21 @@ static std::string g_load_error;
 static void load_rccl() {
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     void* h = nullptr;
+    // QSP_RCCL_LIB: an explicit library wins over the copy already in the process (a site-specific RCCL build; the shared-memory
+    // stand-in of tests/stub_rccl/ that lets a one-GPU box run this file's code with two ranks).  A path that does not load is
+    // an error, not a reason to fall back silently.
+    const char* forced = getenv("QSP_RCCL_LIB");
+    if (forced && *forced) {
+        h = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+        if (!h) {
+            const char* e = dlerror();
+            g_load_error = std::string("QSP_RCCL_LIB=") + forced + " could not be loaded: " + (e ? e : "");
+            return;
+        }
+    }
     for (const char* n : names) {
-        h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);          // already in the process?
         if (h) break;
+        h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);          // already in the process?
     }
     for (int i = 0; !h && i < 3; ++i) h = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
     if (!h) {
@@ -44,6 +57,7 @@ static void load_rccl() {
     SYM(all_gather, "ncclAllGather")
     SYM(get_error_string, "ncclGetErrorString")
 #undef SYM
+    g_api.stub_counts = (decltype(g_api.stub_counts))dlsym(h, "qsp_stub_rccl_counts");      // (only tests/stub_rccl has it)
     g_api.ok = true;
 }
 
@@ -120,6 +134,17 @@ extern "C" void qsp_comm_destroy(qsp_comm* c) {
 }
 
 extern "C" void* qsp_comm_nccl(qsp_comm* c) { return c ? (void*)c->nccl : nullptr; }
+// Test hook: with the stand-in library of tests/stub_rccl (QSP_RCCL_LIB) the collectives that ran with more than one rank on this
+// communicator -- [sum all-reduces, max all-reduces, all-gathers]; QSP_ERR_UNSUPPORTED with a real RCCL.
+extern "C" int qsp_comm_stub_counts(qsp_comm* c, int64_t* out3) {
+    const RcclApi* a = rccl_api();
+    if (!c || !out3 || !a) return qsp_fail(QSP_ERR_INVALID, "qsp_comm_stub_counts: bad argument");
+    if (!a->stub_counts) return qsp_fail(QSP_ERR_UNSUPPORTED, "qsp_comm_stub_counts: the loaded librccl is not the test stand-in");
+    long long v[3] = {0, 0, 0};
+    a->stub_counts(c->nccl, v);
+    for (int i = 0; i < 3; ++i) out3[i] = v[i];
+    return QSP_OK;
+}
 extern "C" int32_t qsp_comm_rank(qsp_comm* c) { return c ? c->rank : -1; }
 extern "C" int32_t qsp_comm_world(qsp_comm* c) { return c ? c->world : 0; }
 

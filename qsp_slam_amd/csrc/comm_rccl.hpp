@@ -13,6 +13,7 @@ struct RcclApi {
     ncclResult_t (*all_reduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*all_gather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*get_error_string)(ncclResult_t) = nullptr;
+    void (*stub_counts)(ncclComm_t, long long*) = nullptr;     // tests/stub_rccl only
 };
 
 const RcclApi* rccl_api();              // nullptr when librccl cannot be resolved (qsp_last_error() then says why)

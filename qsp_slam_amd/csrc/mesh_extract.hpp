@@ -379,20 +379,14 @@ static int mesh_march(qsp_mesh_extractor* m, int64_t* n_verts, int64_t* n_faces)
                            m->flags, m->cnt, m->bsum, m->verts, m->faces);
     QSP_HIP(hipGetLastError());
     QSP_HIP(hipStreamSynchronize(s));
-    {
-        const int rc = check_range(m->dec);
-        if (rc) return rc;
-    }
     m->have_volume = true;
     if (n_verts) *n_verts = m->n_verts;
     if (n_faces) *n_faces = m->n_faces;
     return QSP_OK;
 }
 
-extern "C" int qsp_mesh_extract(qsp_mesh_extractor* m, const float* code, int64_t* n_verts, int64_t* n_faces) {
+static int mesh_decode(qsp_mesh_extractor* m, const float* code, bool* hit) {
     using namespace qsp;
-    if (!m || !code) return qsp_fail(QSP_ERR_INVALID, "qsp_mesh_extract: null argument");
-    QSP_HIP(hipSetDevice(m->dec->device));
     hipStream_t s = m->dec->stream;
     float code64[CODE_LEN] = {};                       // `code` holds the decoder's code_len entries
     memcpy(code64, code, sizeof(float) * m->dec->code_len);
@@ -410,6 +404,24 @@ extern "C" int qsp_mesh_extract(qsp_mesh_extractor* m, const float* code, int64_
         hipLaunchKernelGGL(k_decode<false>, dim3(grid), dim3(MLP_THREADS), sizeof(MlpSmem), s, m->code, m->xyz, m->n, m->dec->Pd,
                            m->sdf, (float*)nullptr);
     QSP_HIP(hipGetLastError());
+    QSP_HIP(hipStreamSynchronize(s));
+    *hit = range_hit(m->dec);
+    return QSP_OK;
+}
+
+extern "C" int qsp_mesh_extract(qsp_mesh_extractor* m, const float* code, int64_t* n_verts, int64_t* n_faces) {
+    if (!m || !code) return qsp_fail(QSP_ERR_INVALID, "qsp_mesh_extract: null argument");
+    QSP_HIP(hipSetDevice(m->dec->device));
+    bool hit = false;
+    int rc = mesh_decode(m, code, &hit);
+    if (rc) return rc;
+    if (hit) {      // a value of the grid decode left fp16's range: the volume is decoded again on the f32 pipe (or the call fails)
+        if (!range_should_fall_back(m->dec)) return range_error();
+        F32Override f32(m->dec);
+        m->dec->n_range_fallbacks++;
+        rc = mesh_decode(m, code, &hit);
+        if (rc) return rc;
+    }
     return mesh_march(m, n_verts, n_faces);
 }
 

@@ -801,13 +801,15 @@ __device__ __forceinline__ jtj_kargs_t jtj_kernargs() {
     return (jtj_kargs_t)p;
 }
 
-template <int NR>      // NR point blocks of 32 per tile (QSP_DEC_OPT_TPOINTS)
-__global__ __launch_bounds__(H2_THREADS) void k_mlp_jtj_h2(JtjArgs /* read through jtj_kernargs() only */) {
+// NW = 4: one wave of 512 registers per SIMD; NW = 8: two of 256 (mlp_tile_h2), the six J~^T J~ tiles on waves 0..5.
+template <int NR, int NW = 4>      // NR point blocks of 32 per tile (QSP_DEC_OPT_TPOINTS)
+__global__ __launch_bounds__(64 * NW) void k_mlp_jtj_h2(JtjArgs /* read through jtj_kernargs() only */) {
+    constexpr int NT = 64 * NW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     MlpSmem& s = *reinterpret_cast<MlpSmem*>(smem_raw);
     __shared__ float Tsh[16];
     __shared__ int s_item;
-    constexpr int TP = 32 * NR, SUBS = H2_THREADS / TP;      // threads per Jacobian row
+    constexpr int TP = 32 * NR, SUBS = NT / TP;      // threads per Jacobian row
     bool staged = false;
     float amax = 0.f;
     int item = -1, t = 0;       // the work item in hand and its current tile; item < 0: pop the next one (see k_plan)
@@ -839,7 +841,7 @@ __global__ __launch_bounds__(H2_THREADS) void k_mlp_jtj_h2(JtjArgs /* read throu
                 if (tid < CODE_LEN) s.code[tid] = S.code[tid];
                 if (tid >= 64 && tid < 80) Tsh[tid - 64] = S.T_oc[tid - 64];
                 const float* c0 = A->c0_all + (size_t)h * 2 * HID;
-                for (int i = tid; i < HID; i += H2_THREADS) {
+                for (int i = tid; i < HID; i += NT) {
                     s.c0[i] = c0[i];
                     s.c4[i] = c0[HID + i];
                 }
@@ -877,7 +879,7 @@ __global__ __launch_bounds__(H2_THREADS) void k_mlp_jtj_h2(JtjArgs /* read throu
         // ---- the tile: live across it are item, t, staged (scalars) and amax ---------------------------------------------------
         {
             const MlpParams* Pm = jtj_kernargs()->P;
-            mlp_tile_h2<true, 2, false, NR>(s, Pm, amax, !staged);
+            mlp_tile_h2<true, 2, false, NR, NW>(s, Pm, amax, !staged);
             staged = true;
         }
         // ---- phase 2: Jacobian rows  J~[p] = [ s*(g_x . [I | -x^ | x]) (7) | s*g_z (64) | r~ ],  J~^T J~ -----------------------
@@ -936,18 +938,18 @@ __global__ __launch_bounds__(H2_THREADS) void k_mlp_jtj_h2(JtjArgs /* read throu
             __syncthreads();
             if (A->rows_out) {   // parity-test tap: the augmented Jacobian rows exactly as the MFMA below consumes them
                 float* ro = A->rows_out + (int64_t)h * A->rows_stride * NJ + (int64_t)(is_sdf ? 0 : ov.n_pts) * NJ;
-                for (int e = tid; e < TP * NJ; e += H2_THREADS) {
+                for (int e = tid; e < TP * NJ; e += NT) {
                     const int p = e / NJ, c = e - p * NJ;
                     const int v = t * TP + p;
                     if (v < n) ro[(int64_t)v * NJ + c] = Jt[p * LDJ + c];
                 }
             }
-            // upper-triangular 32x32 tiles in the order (0,0) (0,1) (0,2) (1,1) (1,2) (2,2): tile w on every wave, tile w + 4 on
-            // waves 0, 1.  Partial slot [h][slot][tile][32][32].
+            // upper-triangular 32x32 tiles in the order (0,0) (0,1) (0,2) (1,1) (1,2) (2,2).  Four waves: tile w on every wave, tile
+            // w + 4 on waves 0, 1; eight waves: tile w on waves 0..5.  Partial slot [h][slot][tile][32][32].
             float* out = A->partials + ((int64_t)h * nw_total + slot) * PART_FLOATS + wave * 1024;
             const bool first = t == j0;
-            {
-                const int ta0 = wave < 3 ? 0 : 1, tb0 = wave < 3 ? wave : 1;
+            if (NW == 4 || wave < 6) {
+                const int ta0 = wave < 3 ? 0 : (wave < 5 ? 1 : 2), tb0 = wave < 3 ? wave : (wave < 5 ? wave - 2 : 2);
                 f32x16 hacc;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) hacc[i] = first ? 0.f : out[acc_row(i, lane) * 32 + (lane & 31)];
@@ -958,7 +960,7 @@ __global__ __launch_bounds__(H2_THREADS) void k_mlp_jtj_h2(JtjArgs /* read throu
 #pragma unroll
                 for (int i = 0; i < 16; ++i) out[acc_row(i, lane) * 32 + (lane & 31)] = hacc[i];
             }
-            if (wave < 2) {
+            if (NW == 4 && wave < 2) {
                 const int ta1 = wave == 0 ? 1 : 2, tb1 = 2;
                 f32x16 hacc;
 #pragma unroll
@@ -1050,7 +1052,8 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(HypState* __restrict__ 
                                                RefineCfg cfg, const float* __restrict__ partials, int nw_sdf,
                                                int nw_total, const uint8_t* __restrict__ pt_active,
                                                int64_t act_stride, float* __restrict__ trH, float* __restrict__ trb,
-                                               float* __restrict__ trdx, unsigned long long* __restrict__ counters) {
+                                               float* __restrict__ trdx, unsigned long long* __restrict__ counters,
+                                               float* __restrict__ trrot) {
     const int h = blockIdx.x;
     HypState& S = st[h];
     if (!S.alive) return;
@@ -1171,6 +1174,12 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(HypState* __restrict__ 
             Jr[4] = 0.f;
             Jr[5] = ax;
             rr = res_rot;
+        }
+        if (trrot) {     // parity-test tap: the rotation prior's own Jacobian and residual (loss.py:155-178)
+            trrot[4 * h + 0] = Jr[3];
+            trrot[4 * h + 1] = Jr[4];
+            trrot[4 * h + 2] = Jr[5];
+            trrot[4 * h + 3] = rr;
         }
         for (int a = 0; a < 7; ++a) {
             for (int b = 0; b < 7; ++b) {
@@ -1329,6 +1338,53 @@ __global__ __launch_bounds__(H2_THREADS) void k_decode_h2(const float* __restric
                 const int64_t v = t * TILE_P + p;
                 if (v < n) grad_out[v * NIN + c] = s.act[p * LDG + c];
             }
+        }
+    }
+    if (!(amax <= H2_MAX)) *P->range_flag = 1;
+}
+
+// the screening tile (mlp_tile_h1) on explicit query points: what the first pass of the screened forward computes, exposed for
+// the tests and the margin measurement (qsp_decode_sdf_screen) -- these are NOT SDF values of the decoder's precision
+__global__ __launch_bounds__(H2_THREADS) void k_decode_screen(const float* __restrict__ code, const float* __restrict__ xyz, int64_t n,
+                                                              const MlpParams* __restrict__ P, float* __restrict__ y_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    MlpSmemH1& s = *reinterpret_cast<MlpSmemH1*>(smem_raw);
+    float* codes = s.red;                   // (free until the first tile's layer 8)
+    if (threadIdx.x < CODE_LEN) codes[threadIdx.x] = code[threadIdx.x];
+    __syncthreads();
+    for (int u = threadIdx.x; u < HID; u += H2_THREADS) {
+        const float* w = P->w0c + (size_t)u * CODE_LEN;
+        const float* w4 = P->w4c + (size_t)u * CODE_LEN;
+        float a = P->bias[0][u], a4 = P->bias[4][u];
+#pragma unroll 8
+        for (int k = 0; k < CODE_LEN; ++k) {
+            a += w[k] * codes[k];
+            a4 += w4[k] * codes[k];
+        }
+        s.c0[u] = a;
+        s.c4[u] = a4;
+        s.w8[u] = P->w8[u];
+    }
+#pragma unroll
+    for (int l = 1; l < 8; ++l)
+        for (int i = threadIdx.x; i < HID; i += H2_THREADS) s.bias[(l - 1) * HID + i] = P->bias[l][i];
+    float amax = 0.f;
+    for (int64_t t = blockIdx.x; t * H1_ROWS < n; t += gridDim.x) {
+        __syncthreads();
+        if (threadIdx.x < H1_ROWS) {
+            const int64_t v = t * H1_ROWS + threadIdx.x;
+            float x = 0, y = 0, z = 0;
+            if (v < n) { x = xyz[3 * v]; y = xyz[3 * v + 1]; z = xyz[3 * v + 2]; }
+            s.xin[4 * threadIdx.x + 0] = x;
+            s.xin[4 * threadIdx.x + 1] = y;
+            s.xin[4 * threadIdx.x + 2] = z;
+            s.xin[4 * threadIdx.x + 3] = 0.f;
+        }
+        __syncthreads();
+        mlp_tile_h1<2>(s, P, amax);
+        if (threadIdx.x < H1_ROWS) {
+            const int64_t v = t * H1_ROWS + threadIdx.x;
+            if (v < n) y_out[v] = s.y[threadIdx.x];
         }
     }
     if (!(amax <= H2_MAX)) *P->range_flag = 1;

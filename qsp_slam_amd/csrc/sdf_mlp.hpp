@@ -1276,9 +1276,9 @@ __device__ __forceinline__ float h2_mask_sel(float v, uint32_t m, int k) {      
 
 // Layer 0 as ONE slab of the same product: image columns 0..2 hold the point (3..15 zero), the packed matrix the three xyz
 // columns of W0 (its 64 code columns are folded into the per-hypothesis bias c0, the accumulators' initial value).
-template <int NR>
-__device__ __forceinline__ void gemm_l0_h2(const _Float16* __restrict__ img, const float4* __restrict__ w_, f32x16 (&acc)[NR][4],
-                                           f32x16 (&acc2)[NR][4], int lane) {
+template <int NR, int NCB>
+__device__ __forceinline__ void gemm_l0_h2(const _Float16* __restrict__ img, const float4* __restrict__ w_, f32x16 (&acc)[NR][NCB],
+                                           f32x16 (&acc2)[NR][NCB], int lane) {
     gbytes w = (gbytes)w_;
     const uint32_t voff = 16u * lane;
     const _Float16* b_row = img + (lane & 31) * LDH + (lane >> 5) * 16;
@@ -1289,7 +1289,7 @@ __device__ __forceinline__ void gemm_l0_h2(const _Float16* __restrict__ img, con
         bl[r] = *reinterpret_cast<const f16x8*>(b_row + r * 32 * LDH + 8);
     }
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < NCB; ++c) {
         const f16x8 wh = as_f16x8(ldw(w + (size_t)(c * 2 + 0) * 64 * 16, voff)), wl = as_f16x8(ldw(w + (size_t)(c * 2 + 1) * 64 * 16, voff));
 #pragma unroll
         for (int r = 0; r < NR; ++r) QSP_MFMA_H(acc2[r][c], wl, bh[r]);
@@ -1304,14 +1304,24 @@ __device__ __forceinline__ void gemm_l0_h2(const _Float16* __restrict__ img, con
 // waves 0, 1 take column blocks 0, 1 for both point blocks, waves 2, 3 column block 2 for one point block each.  NR = 1 (three
 // tiles): waves 0..2 one column block each, wave 3 idle.  side_c0 / side_row / side_count say which tiles a wave holds;
 // out[r][g] = the lane's register quad g of its r-th tile: columns 32 c0 + 8 g + 4 (lane >> 5) .. + 3.
-template <int NR> __device__ __forceinline__ int side_c0(int wave) { return NR == 2 ? (wave < 2 ? wave : 2) : wave; }
-template <int NR> __device__ __forceinline__ int side_count(int wave) { return NR == 2 ? (wave < 2 ? 2 : 1) : (wave < 3 ? 1 : 0); }
-template <int NR> __device__ __forceinline__ int side_row(int wave, int r) { return NR == 2 ? (wave < 2 ? r : wave - 2) : 0; }
-template <int PF, int NR>
+// With eight waves (NW = 8): one tile per wave -- NR = 2: wave w < 6 holds column block w >> 1 of point block w & 1; NR = 1: waves 0..2.
+template <int NR, int NW> __device__ __forceinline__ int side_c0(int wave) {
+    if (NW == 8) return NR == 2 ? (wave < 6 ? wave >> 1 : 0) : (wave < 3 ? wave : 0);
+    return NR == 2 ? (wave < 2 ? wave : 2) : wave;
+}
+template <int NR, int NW> __device__ __forceinline__ int side_count(int wave) {
+    if (NW == 8) return NR == 2 ? (wave < 6 ? 1 : 0) : (wave < 3 ? 1 : 0);
+    return NR == 2 ? (wave < 2 ? 2 : 1) : (wave < 3 ? 1 : 0);
+}
+template <int NR, int NW> __device__ __forceinline__ int side_row(int wave, int r) {
+    if (NW == 8) return NR == 2 ? (wave & 1) : 0;
+    return NR == 2 ? (wave < 2 ? r : wave - 2) : 0;
+}
+template <int PF, int NR, int NW>
 __device__ __forceinline__ void gemm_side_h2(const _Float16* __restrict__ img, const float4* __restrict__ wb, int wave, int lane,
                                              f32x4 (&out)[NR][4]) {
     constexpr int KSH = HID / 16, CS = KSH * 2 * 64;
-    const int c0 = side_c0<NR>(wave);
+    const int c0 = side_c0<NR, NW>(wave);
     const float4* w0 = wb + (size_t)((c0 < 3 ? c0 : 0) * KSH * 2) * 64;
     WRingH<PF, 1> ring0;
     f32x16 g0[NR][1], g2[NR][1];
@@ -1319,13 +1329,13 @@ __device__ __forceinline__ void gemm_side_h2(const _Float16* __restrict__ img, c
     for (int r = 0; r < NR; ++r)
 #pragma unroll
         for (int i = 0; i < 16; ++i) { g0[r][0][i] = 0.f; g2[r][0][i] = 0.f; }
-    if (side_count<NR>(wave) == NR) {
+    if (side_count<NR, NW>(wave) == NR) {
         gemm_h2<KSH, PF, 1, NR, false>(img, w0, CS, w0, CS, ring0, g0, g2, lane);
-    } else if (side_count<NR>(wave) == 1) {          // (NR == 2 only: one of the two point blocks)
+    } else if (side_count<NR, NW>(wave) == 1) {          // (NR == 2 only: one of the two point blocks)
         f32x16 g01[1][1], g21[1][1];
 #pragma unroll
         for (int i = 0; i < 16; ++i) { g01[0][0][i] = 0.f; g21[0][0][i] = 0.f; }
-        gemm_h2<KSH, PF, 1, 1, false>(img + side_row<NR>(wave, 0) * 32 * LDH, w0, CS, w0, CS, ring0, g01, g21, lane);
+        gemm_h2<KSH, PF, 1, 1, false>(img + side_row<NR, NW>(wave, 0) * 32 * LDH, w0, CS, w0, CS, ring0, g01, g21, lane);
         g0[0][0] = g01[0][0];
         g2[0][0] = g21[0][0];
     }
@@ -1340,8 +1350,11 @@ __device__ __forceinline__ void gemm_side_h2(const _Float16* __restrict__ img, c
 // Network on the split-fp16 pipe for the tile staged in s.code / s.xin / s.c0 / s.c4, 256 threads.  On return s.y[row] = sdf
 // value and, with BWD, rows of d sdf / d [code | xyz] in s.act (row stride LDG) like mlp_tile<true>.  amax: running maximum of
 // the magnitudes this thread has split (the caller compares it with H2_MAX once per kernel).
-template <bool BWD, int PF, bool HAND = !BWD, int NR = 2>     // NR: point blocks of 32 (tile of 64 or 32 points)
+// NW: waves of the workgroup -- 4 (one per SIMD, 512 registers, 128 units x 32 NR points each) or 8 (two per SIMD, 256 registers,
+// 64 units each: while one wave of a SIMD is in a write-out, which is VALU work, the other can still be feeding the matrix pipe).
+template <bool BWD, int PF, bool HAND = !BWD, int NR = 2, int NW = 4>     // NR: point blocks of 32 (tile of 64 or 32 points)
 __device__ __forceinline__ void mlp_tile_h2(MlpSmem& s, const MlpParams* __restrict__ Pm, float& amax, bool stage = true) {
+    constexpr int NCB = 16 / NW, NT = 64 * NW;      // column blocks of 32 units per wave; threads
     static_assert(!(BWD && HAND), "the forward+backward tile fetches each matrix's first slabs itself (layer 7 would hand over to the wrong one)");
     int hts_n = 0;
     (void)hts_n;
@@ -1357,16 +1370,16 @@ __device__ __forceinline__ void mlp_tile_h2(MlpSmem& s, const MlpParams* __restr
     asm volatile("s_mov_b32 %0, 0" : "=s"(oz));
     const MlpParams& P = Pm[oz];
     constexpr int TP = 32 * NR;
-    f32x16 acc[NR][4], acc2[NR][4];
-    uint32_t mk[8][NR][2];                                  // ReLU masks [layer][row block][column-block pair]
+    f32x16 acc[NR][NCB], acc2[NR][NCB];
+    uint32_t mk[8][NR][NCB / 2];                            // ReLU masks [layer][row block][column-block pair]
     _Float16* img = reinterpret_cast<_Float16*>(s.act);
     float* bias_sh = s.stash;                              // [7][512] biases of layers 1..7 (the stash is free until layer 4's backward)
     if (stage) {      // constants of the decoder: once per workgroup (the forward+backward tile, whose stash doubles as the bias
                       // store, re-stages the biases itself at its end)
-        for (int i = tid; i < HID; i += H2_THREADS) s.w8[i] = P.w8[i];
+        for (int i = tid; i < HID; i += NT) s.w8[i] = P.w8[i];
 #pragma unroll
         for (int l = 1; l < 8; ++l)
-            for (int i = tid; i < HID; i += H2_THREADS) bias_sh[(l - 1) * HID + i] = P.bias[l][i];
+            for (int i = tid; i < HID; i += NT) bias_sh[(l - 1) * HID + i] = P.bias[l][i];
     }
     if (tid < TP) {       // the point as slab 0 of the image: columns 0..2 = xyz split, 3..15 zero
         const f32x4 x = lds4(s.xin + 4 * tid);
@@ -1385,19 +1398,23 @@ __device__ __forceinline__ void mlp_tile_h2(MlpSmem& s, const MlpParams* __restr
         *reinterpret_cast<f16x8*>(d + 16) = z;
         *reinterpret_cast<f16x8*>(d + 24) = z;
     }
-    const int cb0 = 4 * wave;
+    const int cb0 = NCB * wave;
     constexpr int KSH = HID / 16, KS4 = K4 / 16, CS = KSH * 2 * 64, CS4 = KS4 * 2 * 64;
 #define QSP_WH(L, KS_) (P.wfh[L] + (size_t)(cb0 * (KS_) * 2) * 64)
 #define QSP_WBH(L) (P.wbh[L] + (size_t)(cb0 * KSH * 2) * 64)
-    WRingH<PF, 4> ring;
+    WRingH<PF, NCB> ring;
     ringh_prime(ring, QSP_WH(1, KSH), CS, lane);      // (layer 1's first slabs: in flight behind layer 0)
     QSP_HTS()
     __syncthreads();
     QSP_HTS()
+    // (both accumulator sets stay in the Acc file until a write-out reads them, one register quad pair at a time)
+#define QSP_PIN_ACC()                                                                                                    \
+    _Pragma("unroll") for (int r_ = 0; r_ < NR; ++r_) _Pragma("unroll") for (int c_ = 0; c_ < NCB; ++c_)                 \
+        asm volatile("" : "+a"(acc[r_][c_]), "+a"(acc2[r_][c_]));
     // one hidden layer: accumulators start from the bias, GEMM, then (barrier) main + 2^-11 cross, ReLU, split, (barrier)
 #define QSP_FWDH(L, BIASPTR, GEMM_STMT, PRIME_NEXT)                                                                      \
-    _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {                  \
-        const f32x4 bv_ = lds4((BIASPTR) + 128 * wave + 32 * c_ + 8 * g_ + 4 * h);                                       \
+    _Pragma("unroll") for (int c_ = 0; c_ < NCB; ++c_) _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {                \
+        const f32x4 bv_ = lds4((BIASPTR) + 32 * NCB * wave + 32 * c_ + 8 * g_ + 4 * h);                                     \
         _Pragma("unroll") for (int r_ = 0; r_ < NR; ++r_) _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {             \
             acc[r_][c_][4 * g_ + q_] = bv_[q_];                                                                          \
             acc2[r_][c_][4 * g_ + q_] = 0.f;                                                                             \
@@ -1407,12 +1424,13 @@ __device__ __forceinline__ void mlp_tile_h2(MlpSmem& s, const MlpParams* __restr
     QSP_HTS()                                                                                                            \
     GEMM_STMT;                                                                                                           \
     QSP_HTS()                                                                                                            \
+    QSP_PIN_ACC()                                                                                                        \
     __syncthreads();                                                                                                     \
     QSP_HTS()                                                                                                            \
     {                                                                                                                    \
-        uint32_t m_[NR][2] = {};                                                                                         \
-        _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {              \
-            const int u0_ = 128 * wave + 32 * c_ + 8 * g_ + 4 * h;                                                       \
+        uint32_t m_[NR][NCB / 2] = {};                                                                                   \
+        _Pragma("unroll") for (int c_ = 0; c_ < NCB; ++c_) _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {            \
+            const int u0_ = 32 * NCB * wave + 32 * c_ + 8 * g_ + 4 * h;                                                     \
             _Pragma("unroll") for (int r_ = 0; r_ < NR; ++r_) {                                                          \
                 f32x4 v_;                                                                                                \
                 _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                       \
@@ -1424,7 +1442,7 @@ __device__ __forceinline__ void mlp_tile_h2(MlpSmem& s, const MlpParams* __restr
             }                                                                                                            \
             __builtin_amdgcn_sched_barrier(0);     /* one register quad pair at a time: bounded temporaries */            \
         }                                                                                                                \
-        _Pragma("unroll") for (int r_ = 0; r_ < NR; ++r_) _Pragma("unroll") for (int cp_ = 0; cp_ < 2; ++cp_) {          \
+        _Pragma("unroll") for (int r_ = 0; r_ < NR; ++r_) _Pragma("unroll") for (int cp_ = 0; cp_ < NCB / 2; ++cp_) {    \
             asm volatile("" : "+v"(m_[r_][cp_]));                                                                        \
             mk[L][r_][cp_] = m_[r_][cp_];                                                                                \
         }                                                                                                                \
@@ -1433,8 +1451,8 @@ __device__ __forceinline__ void mlp_tile_h2(MlpSmem& s, const MlpParams* __restr
     QSP_HTS()                                                                                                            \
     __syncthreads();                                                                                                     \
     QSP_HTS()
-#define QSP_GEMMF(L, KS_, NW, NKS) gemm_h2<KS_, PF, 4, NR, HAND, true>(img, QSP_WH(L, KS_), (KS_) * 2 * 64, NW, (NKS) * 2 * 64, ring, acc, acc2, lane)
-    QSP_FWDH(0, s.c0, gemm_l0_h2<NR>(img, QSP_WH(0, 1), acc, acc2, lane), (void)0)
+#define QSP_GEMMF(L, KS_, NXW, NKS) gemm_h2<KS_, PF, NCB, NR, HAND, true>(img, QSP_WH(L, KS_), (KS_) * 2 * 64, NXW, (NKS) * 2 * 64, ring, acc, acc2, lane)
+    QSP_FWDH(0, s.c0, (gemm_l0_h2<NR, NCB>(img, QSP_WH(0, 1), acc, acc2, lane)), (void)0)
     QSP_FWDH(1, bias_sh + 0 * HID, QSP_GEMMF(1, KSH, QSP_WH(2, KSH), KSH), ringh_prime(ring, QSP_WH(2, KSH), CS, lane))
     QSP_FWDH(2, bias_sh + 1 * HID, QSP_GEMMF(2, KSH, QSP_WH(3, KSH), KSH), ringh_prime(ring, QSP_WH(3, KSH), CS, lane))
     QSP_FWDH(3, bias_sh + 2 * HID, QSP_GEMMF(3, KSH, QSP_WH(4, KS4), KS4), ringh_prime(ring, QSP_WH(4, KS4), CS4, lane))
@@ -1454,9 +1472,10 @@ __device__ __forceinline__ void mlp_tile_h2(MlpSmem& s, const MlpParams* __restr
     QSP_FWDH(7, bias_sh + 6 * HID, QSP_GEMMF(7, KSH, QSP_WH(1, KSH), KSH), (void)0)
 #undef QSP_FWDH
 #undef QSP_GEMMF
-    // ---- layer 8: 512 -> 1, tanh (f32): wave = k segment of 128, lane = row; a7 = hi + 2^-11 lo' from the two planes
+    // ---- layer 8: 512 -> 1, tanh (f32): wave = k segment of 128 (waves 0..3 whatever NW is: the same partial sums in the same
+    // order, so the value does not depend on the number of waves), lane = row; a7 = hi + 2^-11 lo' from the two planes
     // (every layer's write-out is the same code: a special case for layer 7 costs the register allocator its footing) ---------
-    {
+    if (NW == 4 || wave < 4) {
         const _Float16* a = img + lane * LDH + 16 * (16 * wave);
         const float* w = s.w8 + 128 * wave;
         float pa[4] = {0.f, 0.f, 0.f, 0.f};        // four chains: one dependent chain of 128 multiply-adds is latency-bound
@@ -1492,10 +1511,10 @@ __device__ __forceinline__ void mlp_tile_h2(MlpSmem& s, const MlpParams* __restr
             const int p = 32 * r + (lane & 31);
             const float dy = s.dy[p];
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
+            for (int c = 0; c < NCB; ++c)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int u0 = 128 * wave + 32 * c + 8 * g + 4 * h;
+                    const int u0 = 32 * NCB * wave + 32 * c + 8 * g + 4 * h;
                     const f32x4 wv = lds4(s.w8 + u0);
                     f32x4 v;
 #pragma unroll
@@ -1509,14 +1528,15 @@ __device__ __forceinline__ void mlp_tile_h2(MlpSmem& s, const MlpParams* __restr
         __syncthreads();
         // ---- backward through layers 7..1: g_in = g_a . W_L, masked by layer L-1; the skip gradient of layer 4 to the stash ----
 #define QSP_BWDH(L, KS_, NWB)                                                                                            \
-    _Pragma("unroll") for (int r_ = 0; r_ < NR; ++r_) _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_)                   \
+    _Pragma("unroll") for (int r_ = 0; r_ < NR; ++r_) _Pragma("unroll") for (int c_ = 0; c_ < NCB; ++c_)                 \
         _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) { acc[r_][c_][i_] = 0.f; acc2[r_][c_][i_] = 0.f; }             \
-    gemm_h2<KS_, PF, 4, NR, HAND, true>(img, QSP_WBH(L), CS, NWB, CS, ring, acc, acc2, lane);                                         \
+    gemm_h2<KS_, PF, NCB, NR, HAND, true>(img, QSP_WBH(L), CS, NWB, CS, ring, acc, acc2, lane);                                       \
+    QSP_PIN_ACC()                                                                                                        \
     __syncthreads();                                                                                                     \
-    _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {                  \
-        const int u0_ = 128 * wave + 32 * c_ + 8 * g_ + 4 * h;                                                           \
+    _Pragma("unroll") for (int c_ = 0; c_ < NCB; ++c_) _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {                \
+        const int u0_ = 32 * NCB * wave + 32 * c_ + 8 * g_ + 4 * h;                                                      \
         _Pragma("unroll") for (int r_ = 0; r_ < NR; ++r_) {                                                              \
-            const int p_ = 32 * r_ + (lane & 31);                                                                        \
+            const int p_ = 32 * r_ + (lane & 31);                                                                      \
             f32x4 v_;                                                                                                    \
             _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                           \
                 const float x_ = fmaf(acc2[r_][c_][4 * g_ + q_], 0.00048828125f, acc[r_][c_][4 * g_ + q_]);             \
@@ -1535,12 +1555,12 @@ __device__ __forceinline__ void mlp_tile_h2(MlpSmem& s, const MlpParams* __restr
         {   // the skip connection's gradient d y / d [code | xyz] = g_a4 . W4[:, 445:512]: its own 64 x 96 product, to the stash
             // in f32 (layer 4's write-out below masks those columns to zero like any dead unit: mk[3] has no bit set there)
             f32x4 sk[NR][4];
-            gemm_side_h2<PF, NR>(img, P.wbh4s, wave, lane, sk);
-            const int c0 = side_c0<NR>(wave);
+            gemm_side_h2<PF, NR, NW>(img, P.wbh4s, wave, lane, sk);
+            const int c0 = side_c0<NR, NW>(wave);
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
-                if (r >= side_count<NR>(wave)) break;
-                const int p = 32 * side_row<NR>(wave, r) + (lane & 31);
+                if (r >= side_count<NR, NW>(wave)) break;
+                const int p = 32 * side_row<NR, NW>(wave, r) + (lane & 31);
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int k0 = 32 * c0 + 8 * g + 4 * h;
@@ -1559,21 +1579,22 @@ __device__ __forceinline__ void mlp_tile_h2(MlpSmem& s, const MlpParams* __restr
         {
             // the biases of layers 1..7 for the NEXT tile of this workgroup (the stash that holds them in the forward pass is
             // about to be read for the last time): loads issued here, in flight behind the product below, stored at the very end
-            float bnext[14];
+            constexpr int BPT = HID / NT;       // bias values per thread and layer
+            float bnext[7 * BPT];
 #pragma unroll
             for (int l = 1; l < 8; ++l)
 #pragma unroll
-                for (int i = 0; i < 2; ++i) bnext[2 * (l - 1) + i] = P.bias[l][tid + i * H2_THREADS];
+                for (int i = 0; i < BPT; ++i) bnext[BPT * (l - 1) + i] = P.bias[l][tid + i * NT];
             __builtin_amdgcn_sched_barrier(0);
             f32x4 gl[NR][4];
-            gemm_side_h2<PF, NR>(img, P.wbh[0], wave, lane, gl);
-            const int c0 = side_c0<NR>(wave);
+            gemm_side_h2<PF, NR, NW>(img, P.wbh[0], wave, lane, gl);
+            const int c0 = side_c0<NR, NW>(wave);
             __syncthreads();
             // D[i = input column within block c0][j = point]: four consecutive input columns per register quad
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
-                if (r >= side_count<NR>(wave)) break;
-                const int p = 32 * side_row<NR>(wave, r) + (lane & 31);
+                if (r >= side_count<NR, NW>(wave)) break;
+                const int p = 32 * side_row<NR, NW>(wave, r) + (lane & 31);
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int k0 = 32 * c0 + 8 * g + 4 * h;
@@ -1590,11 +1611,12 @@ __device__ __forceinline__ void mlp_tile_h2(MlpSmem& s, const MlpParams* __restr
 #pragma unroll
             for (int l = 1; l < 8; ++l)
 #pragma unroll
-                for (int i = 0; i < 2; ++i) bias_sh[(l - 1) * HID + tid + i * H2_THREADS] = bnext[2 * (l - 1) + i];
+                for (int i = 0; i < BPT; ++i) bias_sh[(l - 1) * HID + tid + i * NT] = bnext[BPT * (l - 1) + i];
         }
     }
 #undef QSP_WH
 #undef QSP_WBH
+#undef QSP_PIN_ACC
 }
 
 // ===================================================================================================================
@@ -1729,6 +1751,10 @@ __device__ __forceinline__ void mlp_tile_h1(MlpSmemH1& s, const MlpParams* __res
         __builtin_amdgcn_sched_barrier(0);                                                                               \
     }                                                                                                                    \
     GEMM_STMT;                                                                                                           \
+    /* the accumulators stay in the Acc file until the write-out reads them one register quad at a time: without this the */ \
+    /* register allocator forms VGPR copies of ~50 of them in the GEMM loop's latch, every iteration, and spills those     */ \
+    _Pragma("unroll") for (int r_ = 0; r_ < NR; ++r_) _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_)                   \
+        asm volatile("" : "+a"(acc[r_][c_]));                                                                            \
     __syncthreads();                                                                                                     \
     _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {                  \
         const int u0_ = 128 * wave + 32 * c_ + 8 * g_ + 4 * h;                                                           \

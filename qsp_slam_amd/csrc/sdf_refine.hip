@@ -23,8 +23,10 @@
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -33,6 +35,10 @@
 #include "sdf_mlp.hpp"
 
 #include "sdf_kernels.hpp"
+
+#ifndef QSP_JTJ_WAVES_DEFAULT
+#define QSP_JTJ_WAVES_DEFAULT 4
+#endif
 
 
 // =================================================================================================================
@@ -143,6 +149,52 @@ static int embed_family(const qsp_decoder_desc* desc, const std::vector<std::vec
     return QSP_OK;
 }
 
+// Layer gains.  A ReLU network is positively homogeneous layer by layer: with a_L' = c_L a_L the network
+//     W_L' = W_L c_L / c_{L-1},  b_L' = b_L c_L   (layer 4's [code | xyz] columns: W c_4, their input is not a hidden activation),
+//     w_8' = w_8 / c_7
+// computes the same function, and for c_L a power of two every intermediate of the f32 evaluation is the original one times a power
+// of two -- same bits in the result, forward and backward.  The split-fp16 planes hold a value in [6.1e-5, 65504] to 22 bits and
+// coarser below: a decoder whose layer gains are skewed (one layer's weights x 1e-4, the next x 1e4: the same function) would put a
+// whole layer's activations into fp16's subnormal range.  So every layer whose median row norm -- seen from the rescaled layer in
+// front of it -- is outside [2^-8, 2^8] is brought back to ~1 by such a c_L.  Decoders with ordinary gains (every golden and
+// fitted one) get c_L = 1 throughout and are packed exactly as before.
+static void equalize_gains(std::vector<std::vector<float>>& W, std::vector<std::vector<float>>& B) {
+    const int in_dim[9] = {NIN, HID, HID, HID, HID, HID, HID, HID, HID};
+    const int out_dim[9] = {HID, HID, HID, SKIP_COL, HID, HID, HID, HID, 1};
+    float c_prev = 1.f;
+    for (int l = 0; l < 8; ++l) {
+        const int in = in_dim[l], out = out_dim[l];
+        const int n_hidden = (l == 0) ? 0 : (l == 4 ? SKIP_COL : in);     // input columns that are the previous layer's activations
+        std::vector<double> norms;                  // of the rows that exist (embedded narrower layers have zero rows)
+        for (int o = 0; o < out; ++o) {
+            double ss = 0;
+            for (int k = 0; k < in; ++k) {
+                const double v = (double)W[l][(size_t)o * in + k] / (k < n_hidden ? (double)c_prev : 1.0);
+                ss += v * v;
+            }
+            if (ss > 0 && std::isfinite(ss)) norms.push_back(sqrt(ss));
+        }
+        // the MEDIAN row norm: a single outlier row must not push every other row of its layer out of fp16's normal range
+        // (an outlier beyond 65 504 is what QSP_ERR_UNSUPPORTED of the split-fp16 mode is for)
+        double m = 0;
+        if (!norms.empty()) {
+            std::nth_element(norms.begin(), norms.begin() + norms.size() / 2, norms.end());
+            m = norms[norms.size() / 2];
+        }
+        float c = 1.f;
+        if (m > 0 && (m < 0x1p-8 || m > 0x1p8)) c = (float)ldexp(1.0, -(int)lrint(log2(m)));
+        if (c != 1.f || c_prev != 1.f) {
+            for (int o = 0; o < out; ++o) {
+                for (int k = 0; k < in; ++k) W[l][(size_t)o * in + k] *= (k < n_hidden) ? c / c_prev : c;
+                B[l][o] *= c;
+            }
+        }
+        c_prev = c;
+    }
+    if (c_prev != 1.f)
+        for (int k = 0; k < HID; ++k) W[8][k] /= c_prev;
+}
+
 static inline uint16_t bf16_rne(float x) {
     uint32_t u;
     memcpy(&u, &x, 4);
@@ -192,6 +244,7 @@ static int pack_weights(qsp_decoder* d, const qsp_decoder_desc* desc) {
         if (rc) return rc;
     }
     d->code_len = desc->code_len;
+    equalize_gains(W, Bias);
     // from here on: the canonical 9-layer shape
     const int in_dim[9] = {NIN, HID, HID, HID, HID, HID, HID, HID, HID};
     const int out_dim[9] = {HID, HID, HID, SKIP_COL, HID, HID, HID, HID, 1};
@@ -441,6 +494,17 @@ static int range_error() {
 static bool range_should_fall_back(qsp_decoder* d) { return d->range_fallback && (d->fwd_bf3 == 2 || d->jac_bf3 == 2); }
 static int check_range(qsp_decoder* d) { return range_hit(d) ? range_error() : QSP_OK; }
 
+// Waves per workgroup of the split-fp16 Jacobian kernel: 4 (one 512-register wave per SIMD) or 8 (two 256-register waves per
+// SIMD).  QSP_JTJ_WAVES overrides the default for same-box A/B measurements (tools/ab_bench.sh).
+static int jtj_waves() {
+    static int w = 0;
+    if (!w) {
+        const char* e = getenv("QSP_JTJ_WAVES");
+        w = (e && atoi(e) == 8) ? 8 : ((e && atoi(e) == 4) ? 4 : QSP_JTJ_WAVES_DEFAULT);
+    }
+    return w;
+}
+
 static int mlp_attr_once() {
     static bool done = false;
     if (done) return QSP_OK;
@@ -450,10 +514,13 @@ static int mlp_attr_once() {
     QSP_HIP(hipFuncSetAttribute((const void*)k_decode<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     QSP_HIP(hipFuncSetAttribute((const void*)k_mlp_fwd_h2<2>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     QSP_HIP(hipFuncSetAttribute((const void*)k_mlp_fwd_h1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MlpSmemH1)));
+    QSP_HIP(hipFuncSetAttribute((const void*)k_decode_screen, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MlpSmemH1)));
     QSP_HIP(hipFuncSetAttribute((const void*)k_decode_h2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     QSP_HIP(hipFuncSetAttribute((const void*)k_decode_h2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    QSP_HIP(hipFuncSetAttribute((const void*)k_mlp_jtj_h2<2>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    QSP_HIP(hipFuncSetAttribute((const void*)k_mlp_jtj_h2<1>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    QSP_HIP(hipFuncSetAttribute((const void*)k_mlp_jtj_h2<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    QSP_HIP(hipFuncSetAttribute((const void*)k_mlp_jtj_h2<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    QSP_HIP(hipFuncSetAttribute((const void*)k_mlp_jtj_h2<2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    QSP_HIP(hipFuncSetAttribute((const void*)k_mlp_jtj_h2<1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     QSP_HIP(hipFuncSetAttribute((const void*)k_scan, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * SCAN_RAYS * SCAN_LD)));
     QSP_HIP(hipFuncSetAttribute((const void*)k_mlp_jtj<false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     QSP_HIP(hipFuncSetAttribute((const void*)k_mlp_jtj<true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
@@ -624,6 +691,34 @@ extern "C" int qsp_decode_sdf(qsp_decoder* d, const float* code, const float* xy
     return decode_common(d, code, xyz, n, sdf_out, nullptr);
 }
 
+// The screening tile's values on explicit points (diagnostic: tests and tools/screen_margin.py measure |s1 - s3| with it).
+extern "C" int qsp_decode_sdf_screen(qsp_decoder* d, const float* code, const float* xyz, int64_t n, float* s1_out) {
+    if (!d || !code || !xyz || n < 0 || !s1_out) return qsp_fail(QSP_ERR_INVALID, "decode_screen: bad argument");
+    if (n == 0) return QSP_OK;
+    if (!d->fp16_ok) return qsp_fail(QSP_ERR_UNSUPPORTED, "split fp16: a weight of this decoder is outside fp16's range");
+    QSP_HIP(hipSetDevice(d->device));
+    float *dc = nullptr, *dx = nullptr, *dy = nullptr;
+    QSP_HIP(hipMalloc((void**)&dc, CODE_LEN * sizeof(float)));
+    QSP_HIP(hipMalloc((void**)&dx, n * 3 * sizeof(float)));
+    QSP_HIP(hipMalloc((void**)&dy, n * sizeof(float)));
+    float code64[CODE_LEN] = {};
+    memcpy(code64, code, sizeof(float) * d->code_len);
+    hipError_t e = hipMemcpyAsync(dc, code64, CODE_LEN * sizeof(float), hipMemcpyHostToDevice, d->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dx, xyz, n * 3 * sizeof(float), hipMemcpyHostToDevice, d->stream);
+    if (e == hipSuccess) {
+        const int grid = (int)std::min<int64_t>((n + H1_ROWS - 1) / H1_ROWS, 4096);
+        hipLaunchKernelGGL(k_decode_screen, dim3(grid), dim3(H2_THREADS), sizeof(MlpSmemH1), d->stream, dc, dx, n, d->Pd, dy);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(s1_out, dy, n * sizeof(float), hipMemcpyDeviceToHost, d->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
+    (void)hipFree(dc);
+    (void)hipFree(dx);
+    (void)hipFree(dy);
+    if (e != hipSuccess) return qsp_fail(QSP_ERR_DEVICE, hipGetErrorString(e));
+    return check_range(d);
+}
+
 extern "C" int qsp_sdf_value_grad(qsp_decoder* d, const float* code, const float* xyz, int64_t n, float* y, float* grad) {
     if (!grad) return qsp_fail(QSP_ERR_INVALID, "qsp_sdf_value_grad: grad is null");
     return decode_common(d, code, xyz, n, y, grad);
@@ -650,7 +745,7 @@ struct qsp_refine_batch {
     float *pts = nullptr, *rays = nullptr, *depth = nullptr;
     int32_t *valid_rk = nullptr, *ray_voff = nullptr, *rend_rk = nullptr;
     float *sdf_valid = nullptr, *rend_deds = nullptr, *rend_res = nullptr, *partials = nullptr;
-    float *trH = nullptr, *trb = nullptr, *trdx = nullptr;
+    float *trH = nullptr, *trb = nullptr, *trdx = nullptr, *trrot = nullptr;
     uint8_t* pt_active = nullptr;   // pose-only mode
     float* res_buf = nullptr;       // pose-only mode: per-point residual of the current iteration
     unsigned long long* counters = nullptr;   // [4] points/tiles processed (fwd+bwd, fwd-only)
@@ -673,7 +768,7 @@ static void batch_free(qsp_refine_batch* b) {
     if (!b) return;
     (void)hipSetDevice(b->device);
     void* ptrs[] = {b->st, b->objs, b->pts, b->rays, b->depth, b->valid_rk, b->ray_voff, b->rend_rk, b->sdf_valid,
-                    b->rend_deds, b->rend_res, b->partials, b->trH, b->trb, b->trdx, b->pt_active, b->res_buf, b->rows, b->counters,
+                    b->rend_deds, b->rend_res, b->partials, b->trH, b->trb, b->trdx, b->trrot, b->pt_active, b->res_buf, b->rows, b->counters,
                     b->work_fwd, b->work_jtj, b->qctl, b->c0_all, b->band_idx, b->st_snap, b->act_snap};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -756,6 +851,7 @@ static int batch_create(qsp_decoder* dec, const RefineCfg& cfg, int n_iter, int3
     QSP_ALLOC(b->trH, sizeof(float) * (size_t)n_hyp * NH * NH);
     QSP_ALLOC(b->trb, sizeof(float) * (size_t)n_hyp * NH);
     QSP_ALLOC(b->trdx, sizeof(float) * (size_t)n_hyp * NH);
+    QSP_ALLOC(b->trrot, sizeof(float) * (size_t)n_hyp * 4);
     QSP_ALLOC(b->counters, sizeof(unsigned long long) * 8);
     QSP_ALLOC(b->st_snap, sizeof(HypState) * n_hyp);
     QSP_ALLOC(b->qctl, sizeof(int) * 4);
@@ -789,6 +885,7 @@ static int batch_create(qsp_decoder* dec, const RefineCfg& cfg, int n_iter, int3
         if (e == hipSuccess) e = hipMemset(b->trH, 0, sizeof(float) * (size_t)n_hyp * NH * NH);
         if (e == hipSuccess) e = hipMemset(b->trb, 0, sizeof(float) * (size_t)n_hyp * NH);
         if (e == hipSuccess) e = hipMemset(b->trdx, 0, sizeof(float) * (size_t)n_hyp * NH);
+        if (e == hipSuccess) e = hipMemset(b->trrot, 0, sizeof(float) * (size_t)n_hyp * 4);
         if (e != hipSuccess) rc = qsp_fail(QSP_ERR_DEVICE, hipGetErrorString(e));
     }
     if (rc) {
@@ -901,10 +998,15 @@ static int run_once(qsp_refine_batch* b, int32_t n_iter, bool* hit) {
             const JtjArgs ja{b->st, b->objs, b->pts, b->rays, cfg, b->dec->Pd, b->nw_sdf, nw_total, b->rend_rk, b->rend_deds, b->rend_res,
                              b->rk_stride, b->pt_active, b->act_stride, b->res_buf, b->rows, b->rows_stride, b->partials, b->work_jtj,
                              b->qctl, b->c0_all};
-            if (cfg.tile_p == 32)
-                hipLaunchKernelGGL(k_mlp_jtj_h2<1>, dim3(b->n_cu), dim3(H2_THREADS), sizeof(MlpSmem), s, ja);
+            // eight waves of 256 registers (two per SIMD) or four of 512 (one per SIMD): same arithmetic, same bits; jtj_waves()
+            if (cfg.tile_p == 32 && jtj_waves() == 8)
+                hipLaunchKernelGGL((k_mlp_jtj_h2<1, 8>), dim3(b->n_cu), dim3(512), sizeof(MlpSmem), s, ja);
+            else if (cfg.tile_p == 32)
+                hipLaunchKernelGGL((k_mlp_jtj_h2<1, 4>), dim3(b->n_cu), dim3(H2_THREADS), sizeof(MlpSmem), s, ja);
+            else if (jtj_waves() == 8)
+                hipLaunchKernelGGL((k_mlp_jtj_h2<2, 8>), dim3(b->n_cu), dim3(512), sizeof(MlpSmem), s, ja);
             else
-                hipLaunchKernelGGL(k_mlp_jtj_h2<2>, dim3(b->n_cu), dim3(H2_THREADS), sizeof(MlpSmem), s, ja);
+                hipLaunchKernelGGL((k_mlp_jtj_h2<2, 4>), dim3(b->n_cu), dim3(H2_THREADS), sizeof(MlpSmem), s, ja);
         }
         else if (b->dec->jac_bf3)
             hipLaunchKernelGGL(k_mlp_jtj<true>, dim3(b->n_cu), dim3(MLP_THREADS), sizeof(MlpSmem), s, b->st, b->objs, b->pts,
@@ -919,7 +1021,7 @@ static int run_once(qsp_refine_batch* b, int32_t n_iter, bool* hit) {
         if (b->prof) spans.push_back({a, next_event(b, cur), 0});
         if (b->prof) a = next_event(b, cur);
         hipLaunchKernelGGL(k_solve, dim3(nH), dim3(SOLVE_THREADS), 0, s, b->st, b->objs, cfg, b->partials, b->nw_sdf, nw_total,
-                           b->pt_active, b->act_stride, b->trH, b->trb, b->trdx, b->counters);
+                           b->pt_active, b->act_stride, b->trH, b->trb, b->trdx, b->counters, b->trrot);
         if (b->prof) spans.push_back({a, next_event(b, cur), 2});
         if (cfg.pose_only && it == 4)   // optimizer.py:80-82
             hipLaunchKernelGGL(k_inlier_filter, dim3((b->max_pts + 255) / 256, nH), dim3(256), 0, s, b->st, b->objs,
@@ -1025,6 +1127,13 @@ extern "C" int qsp_refine_batch_trace(qsp_refine_batch* b, float* H, float* rhs,
             }
         }
     }
+    return QSP_OK;
+}
+
+extern "C" int qsp_refine_batch_trace_rot(qsp_refine_batch* b, float* rot4) {
+    if (!b || !rot4) return qsp_fail(QSP_ERR_INVALID, "trace_rot: bad argument");
+    QSP_HIP(hipSetDevice(b->dec->device));
+    QSP_HIP(hipMemcpy(rot4, b->trrot, sizeof(float) * (size_t)b->n_hyp * 4, hipMemcpyDeviceToHost));
     return QSP_OK;
 }
 

@@ -56,6 +56,8 @@ class DeepSdfDecoder(object):
         self.set_forward_precision(self.PRECISIONS[name])
         self.set_jacobian_precision(self.PRECISIONS[name])
         self.precision = name
+        if name != "fp16x2":
+            self.render_screening = 0.0      # (the library drops the option with the pipe it belongs to)
 
     def set_forward_precision(self, mode):
         """forward-only passes (decode_sdf, mesh grid, ray samples): 0 / False = exact-f32 matrix pipe (default), 1 / True =
@@ -72,6 +74,36 @@ class DeepSdfDecoder(object):
         one object per call and exists on the "fp16x2" pipe only (QSP_DEC_OPT_TILE_POINTS in qsp_hip.h)"""
         _lib.check(_lib.lib().qsp_decoder_set_option(self.handle, 3, int(n)))
         self.tile_points = int(n)
+
+    def set_render_screening(self, margin=0.01):
+        """two-pass ray-sample forward of the refinement on the "fp16x2" pipe (QSP_DEC_OPT_RENDER_SCREENING in qsp_hip.h): every
+        sample on a one-product tile, only those with |s1| < cut_off + margin on the split-fp16 tile.  Bit-identical results to the
+        unscreened "fp16x2" path as long as margin covers |s1 - s3| (profiles/r03_screen_margin.txt); 0 / None turns it off."""
+        _lib.check(_lib.lib().qsp_decoder_set_option(self.handle, 4, int(round(1e6 * float(margin or 0.0)))))
+        self.render_screening = float(margin or 0.0)
+
+    def set_use_tanh(self, on):
+        """NetworkSpecs.use_tanh (deep_sdf/deep_sdf_decoder.py:66-68,92-94): a tanh on the output layer in front of the final one"""
+        _lib.check(_lib.lib().qsp_decoder_set_option(self.handle, 5, 1 if on else 0))
+        self.use_tanh = bool(on)
+
+    def set_range_fallback(self, on):
+        """on (default): a call during which a split-fp16 kernel met a value outside fp16's range is repeated on the f32 pipe by
+        the library and returns normally; off: that call raises QSP_ERR_UNSUPPORTED (QSP_DEC_OPT_RANGE_FALLBACK)"""
+        _lib.check(_lib.lib().qsp_decoder_set_option(self.handle, 6, 1 if on else 0))
+
+    @property
+    def range_fallbacks(self):
+        """calls of this decoder that were repeated on the f32 pipe so far"""
+        return int(_lib.lib().qsp_decoder_get_counter(self.handle, 1))
+
+    def decode_sdf_screen(self, code, x):
+        """the screening tile's values (first pass of set_render_screening) on explicit points -- diagnostic, not SDF values"""
+        x = _lib.f32c(x)
+        code = _lib.f32c(np.asarray(code)[: self.code_len])
+        out = np.empty(x.shape[0], np.float32)
+        _lib.check(_lib.lib().qsp_decode_sdf_screen(self.handle, _lib.fptr(code), _lib.fptr(x), x.shape[0], _lib.fptr(out)))
+        return out
 
     def close(self):
         if getattr(self, "handle", None):
@@ -93,6 +125,10 @@ class DeepSdfDecoder(object):
         for k, v in state.items():
             k = k[len("module."):] if k.startswith("module.") else k
             st[k] = np.asarray(v.detach().cpu().numpy() if hasattr(v, "detach") else v, dtype=np.float32)
+        norm = [k for k in st if k.startswith("bn")]
+        if norm:       # deep_sdf_decoder.py:58-63,96-102: LayerNorm in place of weight norm -- a different function, not built
+            raise _lib.QspError(_lib.QSP_ERR_UNSUPPORTED, "decoder family: LayerNorm parameters (%s ...) in the checkpoint: "
+                                "norm_layers without weight_norm is not supported" % norm[0])
         layers = []
         l = 0
         while ("lin%d.bias" % l) in st:
@@ -110,8 +146,12 @@ class DeepSdfDecoder(object):
         if not (isinstance(meta, dict) and isinstance(meta.get("latent_size"), int)
                 and all(isinstance(i, int) for i in meta.get("latent_in", ()))):
             raise ValueError("malformed decoder meta in %s" % path)
-        return cls.from_state_dict({k: z[k] for k in z.files if k != "meta"}, latent_in=meta["latent_in"],
-                                   code_len=meta["latent_size"], device=device)
+        cls.check_network_specs({k: meta[k] for k in ("xyz_in_all", "norm_layers", "weight_norm") if k in meta})
+        dec = cls.from_state_dict({k: z[k] for k in z.files if k != "meta"}, latent_in=meta["latent_in"],
+                                  code_len=meta["latent_size"], device=device)
+        if meta.get("use_tanh", False):
+            dec.set_use_tanh(True)
+        return dec
 
     @classmethod
     def from_experiment_dir(cls, experiment_directory, checkpoint="latest", device=0):
@@ -125,8 +165,30 @@ class DeepSdfDecoder(object):
         saved = torch.load(os.path.join(experiment_directory, "ModelParameters", checkpoint + ".pth"),
                            map_location="cpu")
         ns = specs["NetworkSpecs"]
-        return cls.from_state_dict(saved["model_state_dict"], latent_in=tuple(ns.get("latent_in", ())),
-                                   code_len=specs["CodeLength"], device=device)
+        cls.check_network_specs(ns)
+        dec = cls.from_state_dict(saved["model_state_dict"], latent_in=tuple(ns.get("latent_in", ())),
+                                  code_len=specs["CodeLength"], device=device)
+        if ns.get("use_tanh", False):
+            dec.set_use_tanh(True)
+        return dec
+
+    @staticmethod
+    def check_network_specs(ns):
+        """Every key of NetworkSpecs that the reference's Decoder constructor honours (deep_sdf/deep_sdf_decoder.py:9-72) is
+        either implemented or refused: a decoder is never loaded as a different function without an error.
+          dims, latent_in, weight_norm + norm_layers, use_tanh   implemented
+          dropout, dropout_prob, latent_dropout                  no effect in eval mode (F.dropout(training=False) is the identity)
+          xyz_in_all                                             refused (QSP_ERR_UNSUPPORTED)
+          norm_layers without weight_norm (LayerNorm)            refused"""
+        if ns.get("xyz_in_all", False):
+            raise _lib.QspError(_lib.QSP_ERR_UNSUPPORTED, "decoder family: xyz_in_all is not supported")
+        if ns.get("norm_layers") and not ns.get("weight_norm", False):
+            raise _lib.QspError(_lib.QSP_ERR_UNSUPPORTED, "decoder family: norm_layers without weight_norm (LayerNorm) is not supported")
+        known = {"dims", "dropout", "dropout_prob", "norm_layers", "latent_in", "weight_norm", "xyz_in_all", "use_tanh",
+                 "latent_dropout"}
+        unknown = sorted(set(ns) - known)
+        if unknown:
+            raise _lib.QspError(_lib.QSP_ERR_UNSUPPORTED, "decoder family: unknown NetworkSpecs keys %s" % unknown)
 
     # ---- entry points of reconstruct/loss_utils.py ----------------------------------------------------------------
     def decode_sdf(self, code, x):

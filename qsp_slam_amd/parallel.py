@@ -141,6 +141,14 @@ class RcclComm(object):
         _lib.check(_lib.lib().qsp_comm_allgather_f32(self.handle, int(send_ptr), int(recv_ptr), int(n_per_rank),
                                                      int(stream) or None))
 
+    def stub_counts(self):
+        """(tests) with the stand-in librccl of tests/stub_rccl: [sum all-reduces, max all-reduces, all-gathers] that ran with
+        more than one rank on this communicator; raises with a real RCCL"""
+        from . import _lib
+        out = np.zeros(3, np.int64)
+        _lib.check(_lib.lib().qsp_comm_stub_counts(self.handle, _lib.i64ptr(out)))
+        return out
+
     def close(self):
         if getattr(self, "handle", None) is not None and self.handle.value:
             from . import _lib

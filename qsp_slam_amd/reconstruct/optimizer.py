@@ -91,6 +91,12 @@ class RefineBatch(object):
                                                      _lib.i32ptr(nv), _lib.i32ptr(nr), _lib.fptr(lt)))
         return dict(H=H, b=b, dx=dx, n_valid=nv, K=nr, loss_sdf=lt[:, 0], loss_render=lt[:, 1])
 
+    def trace_rot(self):
+        """(n_hyp, 4): the rotation prior's J_rot (entries 3..5 of J_sim3) and res_rot of the last iteration (loss.py:155-178)"""
+        r = np.empty((self.n_hyp, 4), np.float32)
+        _lib.check(_lib.lib().qsp_refine_batch_trace_rot(self.handle, _lib.fptr(r)))
+        return r
+
     def enable_rows(self, enable=True):
         _lib.check(_lib.lib().qsp_refine_batch_rows(self.handle, 1 if enable else 0, 0, _lib.c_float_p(),
                                                     _lib.c_float_p()))

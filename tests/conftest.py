@@ -38,3 +38,13 @@ def golden_dir():
 def oracle_decoder():
     from oracle import sdf_oracle
     return sdf_oracle.load_decoder_npz(os.path.join(GOLDEN, "decoder_8x512.npz"))
+
+
+@pytest.fixture(scope="session")
+def sdf_isa(tmp_path_factory):
+    """the gfx950 assembly of csrc/sdf_refine.hip (device side only), compiled once per session for the static ISA tests"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_mfma_hazards as chk
+    path = str(tmp_path_factory.mktemp("isa") / "sdf_refine.s")
+    chk.compile_isa(path)
+    return path

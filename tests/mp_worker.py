@@ -3,6 +3,7 @@ ranks share device 0 of the one-GPU box, so the data-path reductions go over glo
 
   python tests/mp_worker.py <mode> <rank> <world> <port> <out.npz>
      ba      one landmark-sharded local joint BA of a fixed scene (qsp_ba_set_shard + the gloo hook)
+     ba_rccl the same BA through RcclComm + qsp_ba_set_shard_rccl (ncclAllReduce on the BA's stream) on tests/stub_rccl's librccl
      refine  object-sharded DeepSDF refinement + all_gather of the kept results (parallel.refine_objects_sharded)
 """
 import os
@@ -43,6 +44,31 @@ def main():
         np.savez(out, kf=kf, pt=pt, ob=ob, chi2_1=t1["chi2"], chi2_2=t2["chi2"], lam_1=t1["lam"], lam_2=t2["lam"],
                  trials_1=t1["trials"], trials_2=t2["trials"], mono_chi2=e["mono_chi2"], oe_chi2=e["oe_chi2"])
         p.close()
+    elif mode == "ba_rccl":
+        # the PRODUCTION path -- RcclComm + qsp_ba_set_shard_rccl: ncclAllReduce (SUM and MAX) on the BA's own stream -- with the
+        # shared-memory stand-in librccl of tests/stub_rccl (QSP_RCCL_LIB, set by the test): two ranks on one device
+        import torch
+        from qsp_slam_amd.ba import BaProblem
+        assert os.environ.get("QSP_RCCL_LIB"), "the test must select the stand-in library"
+        comm = parallel.RcclComm(rank, world, 0)              # unique id broadcast over the gloo group
+        sc = synth.make_ba_scene(**BA_SCENE)
+        p = BaProblem(sc)
+        p.set_shard_rccl(comm)
+        t1, t2 = p.local_joint_ba()
+        kf, pt, ob = p.state()
+        e = p.edges()
+        # the library's all-gather entry point with two ranks as well
+        send = torch.full((5,), float(rank + 1), dtype=torch.float32, device="cuda:0")
+        recv = torch.zeros(5 * world, dtype=torch.float32, device="cuda:0")
+        torch.cuda.synchronize()
+        comm.allgather_f32(send.data_ptr(), recv.data_ptr(), 5)
+        torch.cuda.synchronize()
+        np.savez(out, kf=kf, pt=pt, ob=ob, chi2_1=t1["chi2"], chi2_2=t2["chi2"], lam_1=t1["lam"], lam_2=t2["lam"],
+                 trials_1=t1["trials"], trials_2=t2["trials"], mono_chi2=e["mono_chi2"], oe_chi2=e["oe_chi2"],
+                 counts=comm.stub_counts(), gathered=recv.cpu().numpy())
+        p.close()
+        dist.barrier()
+        comm.close()
     elif mode == "refine":
         from qsp_slam_amd import DeepSdfDecoder
         from qsp_slam_amd.reconstruct.optimizer import Optimizer

@@ -23,10 +23,11 @@ def _free_port():
     return p
 
 
-def _run_ranks(mode, world, tmp_path):
+def _run_ranks(mode, world, tmp_path, extra_env=None):
     port = _free_port()
     outs = [str(tmp_path / ("%s_%d.npz" % (mode, r))) for r in range(world)]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.update(extra_env or {})
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "mp_worker.py"), mode, str(r), str(world),
                                str(port), outs[r]], env=env, cwd=ROOT) for r in range(world)]
     try:
@@ -62,6 +63,43 @@ def test_two_process_landmark_sharded_ba_matches_unsharded(tmp_path):
         assert close(got["lam_1"], r1["lam"], 1e-7) and close(got["lam_2"], r2["lam"], 1e-7)
         assert close(got["kf"], rkf, 1e-7, 1e-9) and close(got["pt"], rpt, 1e-7, 1e-9) and close(got["ob"], rob, 1e-7, 1e-9)
         assert close(got["mono_chi2"], re["mono_chi2"], 1e-6, 1e-9) and close(got["oe_chi2"], re["oe_chi2"], 1e-6, 1e-9)
+
+
+def _stub_rccl():
+    """tests/stub_rccl/librccl_stub.so, built here if the snapshot does not carry it"""
+    d = os.path.join(ROOT, "tests", "stub_rccl")
+    so = os.path.join(d, "librccl_stub.so")
+    if not os.path.isfile(so):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-shared", "-fPIC", "-O1", "-o", so, os.path.join(d, "stub_rccl.cpp"), "-lrt",
+                               "-lpthread"])
+    return so
+
+
+def test_two_process_rccl_on_stream_path_with_the_stub_library(tmp_path):
+    """the production collective path -- qsp_ba_set_shard_rccl, ncclAllReduce(SUM) per LM trial and
+    ncclAllReduce(MAX) for lambda's start, issued on the BA's own stream (csrc/ba_solver.hip) -- had only ever run with one rank:
+    RCCL refuses two ranks on one device.  Here two fresh processes on device 0 run it against the shared-memory stand-in
+    librccl (QSP_RCCL_LIB): the result equals the gloo-hook path's bit for bit (both sum two ranks; a + b is commutative),
+    follows the unsharded solve to 1e-7, the MAX branch ran, and the library's all-gather entry point works with two ranks."""
+    import mp_worker
+    from qsp_slam_amd import synth
+    from qsp_slam_amd.ba import BaProblem
+    sc = synth.make_ba_scene(**mp_worker.BA_SCENE)
+    ref = BaProblem(sc)
+    r1, r2 = ref.local_joint_ba()
+    rkf, rpt, rob = ref.state()
+    ref.close()
+    hook = _run_ranks("ba", 2, tmp_path)
+    rccl = _run_ranks("ba_rccl", 2, tmp_path, extra_env={"QSP_RCCL_LIB": _stub_rccl()})
+    for got, want in zip(rccl, hook):
+        for k in ("kf", "pt", "ob", "chi2_1", "chi2_2", "lam_1", "lam_2", "trials_1", "trials_2", "mono_chi2", "oe_chi2"):
+            assert np.array_equal(got[k], want[k]), k
+        assert list(got["trials_1"]) == list(r1["trials"]) and list(got["trials_2"]) == list(r2["trials"])
+        assert close(got["kf"], rkf, 1e-7, 1e-9) and close(got["pt"], rpt, 1e-7, 1e-9) and close(got["ob"], rob, 1e-7, 1e-9)
+        n_sum, n_max, n_gather = [int(v) for v in got["counts"]]
+        assert n_max >= 2                      # lambda's start, once per optimize() call: the ncclMax branch
+        assert n_sum >= 2 * int(np.sum(r1["trials"]) + np.sum(r2["trials"]))   # reduced system + scalars per LM trial, at least
+        assert n_gather >= 1 and np.array_equal(got["gathered"], np.repeat([1.0, 2.0], 5).astype(np.float32))
 
 
 def test_two_process_object_sharded_refinement_is_bit_identical(tmp_path):

@@ -1,0 +1,128 @@
+"""The screened ray-sample forward pass (QSP_DEC_OPT_RENDER_SCREENING, csrc/sdf_mlp.hpp:mlp_tile_h1 + csrc/sdf_kernels.hpp:
+k_mlp_fwd_h1): every valid ray sample on a one-product fp16 tile, only the band |s1| < cut_off + margin again on the split-fp16
+tile.  The render term clamps (reconstruct/loss_utils.py:40-48, reconstruct/loss.py:84-122), so outside the band only the sign
+of the value is used: the contract is that EVERYTHING downstream -- n_valid, K, H, b, dx, every later iterate, the final pose,
+code and loss -- equals the unscreened split-fp16 path BIT FOR BIT.  That is what these tests assert; the margin itself is
+checked against the measured |s1 - s3|."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import sdf_oracle as so
+from tests.margins import within
+from tests.test_gpu_sdf import make_cfg
+from tests.test_oracle_sdf import JOINT_CASES
+
+pytestmark = pytest.mark.gpu
+MARGIN = 0.01      # the shipped default of DeepSdfDecoder.set_render_screening / bench.py
+
+
+@pytest.fixture(scope="module")
+def dec(golden_dir):
+    from qsp_slam_amd import DeepSdfDecoder
+    d = DeepSdfDecoder.from_npz(os.path.join(golden_dir, "decoder_8x512.npz"))
+    d.set_precision("fp16x2")
+    yield d
+    d.close()
+
+
+def run_batch(dec, opt, objs, hyp, T0, code, n_iter, screening):
+    from qsp_slam_amd.reconstruct.optimizer import RefineBatch, _joint_cfg
+    dec.set_render_screening(MARGIN if screening else 0.0)
+    batch = RefineBatch(dec, _joint_cfg(opt), [o["pts"] for o in objs], [o["rays"] for o in objs], [o["depth"] for o in objs], hyp)
+    batch.profile(True)
+    batch.set_state(T0, code)
+    batch.run(n_iter)
+    out = dict(batch.trace())
+    T, c, loss, good = batch.get()
+    out.update(T=T, code=c, loss=loss, good=good, prof=batch.profile(True))
+    batch.close()
+    dec.set_render_screening(0.0)
+    return out
+
+
+def assert_same_bits(a, b, what):
+    for k in ("H", "b", "dx", "K", "n_valid", "T", "code", "loss", "good"):
+        assert np.array_equal(np.asarray(a[k]), np.asarray(b[k]), equal_nan=True), (what, k)
+
+
+def test_screening_values_are_within_an_eighth_of_the_margin(dec, golden_dir):
+    """|s1 - s3| over random points of the unit ball and codes of the training scale, and over the golden vectors: the margin
+    must be at least 8 x the largest difference seen; the measurement itself is recorded"""
+    rng = np.random.default_rng(2026)
+    worst = 0.0
+    for c in range(24):
+        x = rng.uniform(-1, 1, size=(8192, 3)).astype(np.float32)
+        code = (rng.choice([0.0, 0.05, 0.25]) * rng.normal(size=64)).astype(np.float32)
+        s3 = dec.decode_sdf(code, x)
+        s1 = dec.decode_sdf_screen(code, x)
+        assert np.isfinite(s1).all()
+        worst = max(worst, float(np.abs(s1 - s3).max()))
+    z = np.load(os.path.join(golden_dir, "sdf_decoder_vectors.npz"))
+    worst = max(worst, float(np.abs(dec.decode_sdf_screen(z["code"], z["x"]) - dec.decode_sdf(z["code"], z["x"])).max()))
+    assert within("fp16x2/screening/max_abs_s1_minus_s3", worst, MARGIN / 8)
+
+
+def test_screening_tile_ragged_sizes(dec):
+    """1, 127, 128, 129 and 1000 points through the 128-point tile: the same values whatever the tile a point lands in"""
+    rng = np.random.default_rng(5)
+    x = rng.uniform(-1, 1, size=(1000, 3)).astype(np.float32)
+    code = (0.05 * rng.normal(size=64)).astype(np.float32)
+    full = dec.decode_sdf_screen(code, x)
+    for n in (1, 127, 128, 129):
+        assert np.array_equal(dec.decode_sdf_screen(code, x[:n]), full[:n])
+    assert np.array_equal(dec.decode_sdf_screen(code, x[300:]), full[300:])
+
+
+@pytest.mark.parametrize("name", JOINT_CASES)
+def test_golden_cases_bit_identical_with_and_without_screening(dec, golden_dir, name):
+    from qsp_slam_amd.reconstruct.optimizer import Optimizer
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    opt = Optimizer(dec, make_cfg(z))
+    obj = dict(pts=z["pts"], rays=z["rays"], depth=z["depth"])
+    n_it = int(z["it_H"].shape[0]) if "it_H" in z.files else 2
+    a = run_batch(dec, opt, [obj], [0], z["t_cam_obj"][None], None, n_it, False)
+    b = run_batch(dec, opt, [obj], [0], z["t_cam_obj"][None], None, n_it, True)
+    assert_same_bits(a, b, name)
+    if a["good"][0]:
+        assert 0 < b["prof"].pts_band < b["prof"].pts_fwd and a["prof"].pts_band == 0
+
+
+def test_random_batches_bit_identical_with_and_without_screening(dec):
+    """48 hypotheses (12 objects x 4 yaw flips, random sizes, non-zero codes for a third), 3 iterations: the free-running result
+    of the screened path equals the unscreened one to the bit, and the band is a small share of the samples"""
+    import bench
+    from qsp_slam_amd import synth
+    from qsp_slam_amd.reconstruct.optimizer import Optimizer
+    rng = np.random.default_rng(77)
+    objs = []
+    for i in range(12):
+        objs += synth.make_object_views(int(rng.integers(1, 10 ** 6)), 1, int(rng.integers(50, 1500)), n_fg=int(rng.integers(16, 300)),
+                                        n_bg=int(rng.integers(0, 200)), code_scale=float(rng.choice([0.0, 0.05])))
+    T0, hyp = bench.flip_states(objs, 4)
+    code = np.zeros((len(hyp), 64), np.float32)
+    code[::3] = (0.05 * rng.normal(size=code[::3].shape)).astype(np.float32)
+    opt = Optimizer(dec, make_cfg(so.JointConfig(n_iter=3)))
+    a = run_batch(dec, opt, objs, hyp, T0, code, 3, False)
+    b = run_batch(dec, opt, objs, hyp, T0, code, 3, True)
+    assert_same_bits(a, b, "random batch")
+    share = b["prof"].pts_band / max(1, b["prof"].pts_fwd)
+    assert within("fp16x2/screening/band_share", share, 0.5)
+
+
+def test_screening_needs_the_split_fp16_forward_pass(golden_dir):
+    from qsp_slam_amd import DeepSdfDecoder, _lib
+    d = DeepSdfDecoder.from_npz(os.path.join(golden_dir, "decoder_8x512.npz"))
+    for prec in ("f32", "bf16x3"):
+        d.set_precision(prec)
+        with pytest.raises(_lib.QspError) as e:
+            d.set_render_screening(MARGIN)
+        assert e.value.code == _lib.QSP_ERR_UNSUPPORTED
+    d.set_precision("fp16x2")
+    d.set_render_screening(MARGIN)
+    with pytest.raises(_lib.QspError):
+        d.set_render_screening(0.06)           # beyond 5 x the cut-off the second pass covers most samples: refused
+    d.set_precision("f32")                     # leaving the pipe drops the option
+    assert d.render_screening == 0.0
+    d.close()

@@ -149,11 +149,18 @@ def h2_decoder(golden_dir):
     d.close()
 
 
-def _scaled_decoder(golden_dir, layer, factor):
-    """the golden decoder with one layer's weight-norm gain multiplied: same function shape, larger activations / weights"""
+def _scaled_decoder(golden_dir, layer, factor, rows=None):
+    """the golden decoder with the weight-norm gain of one layer (or of some of its rows) multiplied: same function shape,
+    larger activations / weights.  (A WHOLE layer's gain is undone by the library's exact power-of-two gain equalisation,
+    csrc/sdf_refine.hip:equalize_gains; single rows are not.)"""
     from qsp_slam_amd import DeepSdfDecoder
     z = dict(np.load(os.path.join(golden_dir, "decoder_8x512.npz")))
-    z["lin%d.weight_g" % layer] = z["lin%d.weight_g" % layer] * np.float32(factor)
+    g = z["lin%d.weight_g" % layer].copy()
+    if rows is None:
+        g *= np.float32(factor)
+    else:
+        g[rows] *= np.float32(factor)
+    z["lin%d.weight_g" % layer] = g
     import tempfile
     with tempfile.NamedTemporaryFile(suffix=".npz", delete=False) as f:
         np.savez(f.name, **z)
@@ -167,31 +174,105 @@ def _scaled_decoder(golden_dir, layer, factor):
 def test_fp16_refuses_weights_outside_its_range(golden_dir, monkeypatch):
     from qsp_slam_amd._lib import QspError
     monkeypatch.delenv("QSP_PRECISION", raising=False)  # a session-wide default would refuse at construction
-    d = _scaled_decoder(golden_dir, 2, 3e6)           # |w| of layer 2 up to ~1e5 > 65504
+    d = _scaled_decoder(golden_dir, 2, 3e6, rows=[0, 5])   # |w| of two units of layer 2 up to ~1e5 > 65504
     with pytest.raises(QspError):
         d.set_precision("fp16x2")
     d.set_precision("bf16x3")                         # the other pipes take it
     d.close()
 
 
-def test_fp16_fails_loudly_when_an_activation_leaves_its_range(golden_dir, monkeypatch):
-    """weights inside fp16's range but activations beyond 65504: the kernels raise the decoder's range flag and the call fails
-    (instead of returning values computed from clamped or infinite planes); the same decoder runs on the split-bf16 pipe"""
-    from qsp_slam_amd._lib import QspError
+def test_fp16_range_excursion_falls_back_to_f32_or_fails_loudly(golden_dir, monkeypatch):
+    """weights inside fp16's range but an activation beyond 65504: the kernels raise the decoder's range flag.  Default
+    (QSP_DEC_OPT_RANGE_FALLBACK = 1): the library repeats THAT call on its exact-f32 pipe and returns normally -- the reference
+    never fails a call for a numeric condition (reconstruct/optimizer.py:161-194) -- and counts it.  With the option off the call
+    fails with QSP_ERR_UNSUPPORTED instead of returning values computed from infinite planes (round 2's behaviour)."""
+    from qsp_slam_amd import _lib, synth
+    from qsp_slam_amd.reconstruct.optimizer import Optimizer
     monkeypatch.delenv("QSP_PRECISION", raising=False)
-    d = _scaled_decoder(golden_dir, 1, 2e5)
+    d = _scaled_decoder(golden_dir, 1, 6e5, rows=list(range(64)))    # 64 units of layer 1: weights up to 5.9e4, activations to 3e5
     x = np.random.default_rng(0).uniform(-1, 1, size=(300, 3)).astype(np.float32)
     code = np.zeros(64, np.float32)
     ref = d.decode_sdf(code, x)
+    ref_y, ref_g = d.sdf_value_grad(code, x)
     assert np.isfinite(ref).all()
     d.set_precision("fp16x2")
-    with pytest.raises(QspError):
+    assert d.range_fallbacks == 0
+    assert np.array_equal(d.decode_sdf(code, x), ref) and d.range_fallbacks == 1          # the f32 pipe's own bits
+    y, g = d.sdf_value_grad(code, x)
+    assert np.array_equal(y, ref_y) and np.array_equal(g, ref_g) and d.range_fallbacks == 2
+    # the refinement entry point: same result as a decoder that was on the f32 pipe all along, is_good, no exception
+    o = synth.make_object_views(9, 1, 300, n_fg=64, n_bg=32)[0]
+    opt = Optimizer(d, make_cfg(so.JointConfig(n_iter=2)))
+    r = opt.reconstruct_object(o["t_cam_obj"], o["pts"], o["rays"], o["depth"])
+    n_fb = d.range_fallbacks
+    assert n_fb >= 3
+    d.set_precision("f32")
+    r32 = Optimizer(d, make_cfg(so.JointConfig(n_iter=2))).reconstruct_object(o["t_cam_obj"], o["pts"], o["rays"], o["depth"])
+    assert r.is_good == r32.is_good and np.array_equal(r.t_cam_obj, r32.t_cam_obj) and np.array_equal(r.code, r32.code)
+    assert d.range_fallbacks == n_fb                  # nothing to fall back from on the f32 pipe
+    # the old contract on request
+    d.set_precision("fp16x2")
+    d.set_range_fallback(False)
+    with pytest.raises(_lib.QspError) as e:
         d.decode_sdf(code, x)
-    with pytest.raises(QspError):
+    assert e.value.code == _lib.QSP_ERR_UNSUPPORTED
+    with pytest.raises(_lib.QspError):
         d.sdf_value_grad(code, x)
+    d.set_range_fallback(True)
     d.set_precision("bf16x3")
     assert np.abs(d.decode_sdf(code, x) - ref).max() < 1e-5
     d.close()
+
+
+def test_fp16_low_end_of_the_range_skewed_layer_gains(golden_dir, monkeypatch):
+    """the golden decoder with one layer's gain x 1e-4 and the next layer's x 1e4 is the same function, but
+    as given it puts a whole layer's activations at ~1e-4 x O(1), where x_hi is an fp16 subnormal.  The library's exact
+    power-of-two gain equalisation (equalize_gains) brings the layer back before the planes are packed: the skewed decoder meets
+    the same 2e-6 / 1e-5 decoder gates on the split-fp16 pipe, gradients of magnitude 1e-6..1e-8 included; and a skew by exact
+    powers of two gives the unskewed decoder's bits on the f32 and split-bf16 pipes (on the split-fp16 pipe to 2e-7: the few
+    activations below fp16's smallest normal number round differently when the layer is rescaled by a power of two)."""
+    from qsp_slam_amd import DeepSdfDecoder
+    monkeypatch.delenv("QSP_PRECISION", raising=False)
+    gold = os.path.join(golden_dir, "decoder_8x512.npz")
+    z = np.load(os.path.join(golden_dir, "sdf_decoder_vectors.npz"))
+    od = so.load_decoder_npz(gold)
+
+    def skewed(down, up, layer):
+        layers = []
+        for l, (W, b) in enumerate(od.layers):
+            W, b = W.copy(), b.copy()
+            if l == layer:
+                W *= np.float32(down)
+                b *= np.float32(down)
+            if l == layer + 1:
+                W[:, :od.layers[layer][0].shape[0]] *= np.float32(up)      # (the columns fed by layer `layer`, not a skip's)
+            layers.append((W, None, b))
+        return DeepSdfDecoder(layers, latent_in=od.latent_in, code_len=od.code_len)
+
+    base = skewed(1.0, 1.0, 0)           # (the same folded weights as the skewed ones: numpy's fold, not the library's)
+    for layer in (1, 3, 5):
+        d = skewed(1e-4, 1e4, layer)
+        p2 = skewed(2.0 ** -13, 2.0 ** 13, layer)
+        for prec in ("fp16x2", "bf16x3", "f32"):
+            d.set_precision(prec)
+            p2.set_precision(prec)
+            base.set_precision(prec)
+            tag = "%s/skew_layer%d/" % (prec, layer)
+            assert within(tag + "sdf_abs", np.abs(d.decode_sdf(z["code"], z["x"]) - z["sdf"]).max(), 2e-6)
+            y, g = d.sdf_value_grad(z["code"], z["x"])
+            assert within(tag + "y_abs", np.abs(y - z["y"]).max(), 2e-6)
+            assert rows_close(g, z["grad"], tol=1e-5, max_bad=0.01)
+            yb, gb = base.sdf_value_grad(z["code"], z["x"])
+            y2, g2 = p2.sdf_value_grad(z["code"], z["x"])
+            if prec == "fp16x2":      # (activations below 6.1e-5 are fp16 subnormals: their rounding is not scale invariant)
+                assert within(tag + "pow2_skew_y_abs", np.abs(y2 - yb).max(), 2e-7)
+                assert rows_close(g2, gb, tol=2e-6, max_bad=0.01)
+            else:
+                assert np.array_equal(y2, yb) and np.array_equal(g2, gb), (prec, layer)
+        assert d.range_fallbacks == 0
+        d.close()
+        p2.close()
+    base.close()
 
 
 @pytest.mark.parametrize("n", [1, 63, 64, 65, 1000])
