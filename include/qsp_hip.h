@@ -97,15 +97,21 @@ void qsp_decoder_destroy(qsp_decoder* dec);
  * 20 000 (0.02) is > 8 x the largest difference measured over the fixtures and the randomised sweep (profiles/r03_*).  Needs
  * QSP_DEC_OPT_FORWARD_PRECISION = 2 (QSP_ERR_UNSUPPORTED otherwise); margins above 5 x the usual cut_off (50 000) are refused:
  * at that point the second pass covers most samples and the option has no purpose.
+ * QSP_DEC_OPT_SCREENING_MIN_SAMPLES (-1, the default, or a count): a run is screened only when its batch holds more ray samples
+ * (rays x depth samples, summed over the hypotheses) than this; -1 = more than two rounds of 64-point tiles over the chip.  A
+ * batch that fits one round -- one object per call -- is one tile deep either way and faster in one pass.  The result is the
+ * same bits whichever way a run goes.  0 = always screen (tests).
  * QSP_DEC_OPT_USE_TANH (0 / 1): NetworkSpecs.use_tanh of deep_sdf/deep_sdf_decoder.py:66-68,92-94 -- a tanh on the output
  * layer in front of the final tanh.
  * QSP_DEC_OPT_RANGE_FALLBACK (1, the default / 0): when a split-fp16 kernel meets an activation or gradient outside fp16's
  * range, 1 re-runs THAT call on the exact-f32 pipe inside the library and returns its result (counted by
  * qsp_decoder_get_counter(QSP_DEC_CNT_RANGE_FALLBACKS)); 0 fails the call with QSP_ERR_UNSUPPORTED as round 2 did. */
 enum { QSP_DEC_OPT_FORWARD_PRECISION = 1, QSP_DEC_OPT_JACOBIAN_PRECISION = 2, QSP_DEC_OPT_TILE_POINTS = 3,
-       QSP_DEC_OPT_RENDER_SCREENING = 4, QSP_DEC_OPT_USE_TANH = 5, QSP_DEC_OPT_RANGE_FALLBACK = 6 };
-enum { QSP_DEC_CNT_RANGE_FALLBACKS = 1 };
-/* process-lifetime counters of a decoder (calls that were re-run on the f32 pipe because a value left fp16's range) */
+       QSP_DEC_OPT_RENDER_SCREENING = 4, QSP_DEC_OPT_USE_TANH = 5, QSP_DEC_OPT_RANGE_FALLBACK = 6,
+       QSP_DEC_OPT_SCREENING_MIN_SAMPLES = 7 };
+enum { QSP_DEC_CNT_RANGE_FALLBACKS = 1, QSP_DEC_CNT_ARENA_REUSED = 2, QSP_DEC_CNT_ARENA_CREATED = 3 };
+/* lifetime counters of a decoder: calls that were re-run on the f32 pipe because a value left fp16's range; calls of
+ * qsp_reconstruct_objects that refilled the decoder's resident batch / that had to (re)allocate it */
 int64_t qsp_decoder_get_counter(qsp_decoder* dec, int32_t counter);
 int qsp_decoder_set_option(qsp_decoder* dec, int32_t option, int32_t value);
 
@@ -197,8 +203,11 @@ typedef struct {
 } qsp_refine_profile;
 int qsp_refine_batch_profile(qsp_refine_batch* b, int enable, qsp_refine_profile* out);
 
-/* One-shot convenience with the reference's per-call semantics, batched over hypotheses:
- * create + set_state + run + get + destroy.  Optimizer.reconstruct_object, reconstruct/optimizer.py:96-281. */
+/* One-shot entry point with the reference's per-call semantics, batched over hypotheses: fill + set_state + run + get on a
+ * batch that stays resident with the decoder (sized by the high-water mark of the calls so far: no device allocation per call
+ * once it has settled; released by qsp_decoder_destroy).  Optimizer.reconstruct_object, reconstruct/optimizer.py:96-281, as
+ * src/LocalMapping_util.cc:705-760 calls it -- one object (x its yaw flips) per call.  Results do not depend on what the
+ * resident batch held before. */
 int qsp_reconstruct_objects(qsp_decoder* dec, const qsp_joint_cfg* cfg, int32_t n_obj,
                             const float* const* pts, const int32_t* n_pts,
                             const float* const* rays, const int32_t* n_rays,

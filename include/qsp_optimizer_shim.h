@@ -18,6 +18,8 @@
 #ifndef QSP_OPTIMIZER_SHIM_H
 #define QSP_OPTIMIZER_SHIM_H
 
+#include <atomic>
+#include <cstdlib>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -97,8 +99,24 @@ struct Marks {
     }
 };
 
+// Process-wide count of library calls that failed, i.e. of entry points that then ran (or will run) on the reference's g2o code
+// instead.  A deployment that must not silently run on the CPU asserts `qsp_shim::fallback_count() == 0` (or sets
+// QSP_SHIM_NO_FALLBACK=1, which turns the first failure into std::abort() after the message below).
+inline std::atomic<long>& fallback_counter() {
+    static std::atomic<long> n{0};
+    return n;
+}
+inline long fallback_count() { return fallback_counter().load(); }
+inline void reset_fallback_count() { fallback_counter().store(0); }
+
 inline int report(const char* where, int rc) {
-    if (rc != QSP_OK) std::fprintf(stderr, "[qsp_hip] %s failed (%d): %s\n", where, rc, qsp_last_error());
+    if (rc != QSP_OK) {
+        fallback_counter().fetch_add(1);
+        std::fprintf(stderr, "[qsp_hip] %s failed (%d): %s -- this call falls back to the reference's g2o path (fallback #%ld)\n",
+                     where, rc, qsp_last_error(), fallback_count());
+        const char* strict = std::getenv("QSP_SHIM_NO_FALLBACK");
+        if (strict && *strict == '1') std::abort();
+    }
     return rc;
 }
 

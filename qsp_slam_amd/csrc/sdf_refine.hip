@@ -37,7 +37,7 @@
 #include "sdf_kernels.hpp"
 
 #ifndef QSP_JTJ_WAVES_DEFAULT
-#define QSP_JTJ_WAVES_DEFAULT 4
+#define QSP_JTJ_WAVES_DEFAULT 8
 #endif
 
 
@@ -60,8 +60,14 @@ struct qsp_decoder {
     int tile_p = 64;           // QSP_DEC_OPT_TILE_POINTS: points per MLP tile of the refinement batches created from now on
     int* range_flag_h = nullptr;   // host-mapped word the split-fp16 kernels set when a value left fp16's range (check_range)
     float screen_margin = 0.f;     // QSP_DEC_OPT_RENDER_SCREENING: > 0 = two-pass ray-sample forward with this band margin
+    int64_t screen_min_samples = -1;   // QSP_DEC_OPT_SCREENING_MIN_SAMPLES: -1 = more than two rounds of 64-point tiles over the chip
     int range_fallback = 1;        // QSP_DEC_OPT_RANGE_FALLBACK: a call that left fp16's range is repeated on the f32 pipe
     int64_t n_range_fallbacks = 0; // QSP_DEC_CNT_RANGE_FALLBACKS
+    // qsp_reconstruct_objects keeps ONE resident batch per decoder, sized by the high-water mark of the calls so far: the
+    // reference's call pattern is one object per call (src/LocalMapping_util.cc:705-760), and creating / destroying ~25 device
+    // buffers per call cost ~0.5 ms of a 3 ms call
+    struct qsp_refine_batch* arena = nullptr;
+    int64_t n_arena_reuse = 0, n_arena_create = 0;
 };
 
 // Runs the enclosed call with every decoder pass on the exact-f32 pipe (the range fallback of the split-fp16 modes).
@@ -579,6 +585,10 @@ extern "C" int qsp_decoder_set_option(qsp_decoder* d, int32_t option, int32_t va
                                                      "QSP_DEC_OPT_FORWARD_PRECISION to 2 first");
             d->screen_margin = 1e-6f * (float)value;
             return QSP_OK;
+        case QSP_DEC_OPT_SCREENING_MIN_SAMPLES:
+            if (value < -1) return qsp_fail(QSP_ERR_INVALID, "screening threshold: -1 (automatic) or a sample count >= 0");
+            d->screen_min_samples = value;
+            return QSP_OK;
         case QSP_DEC_OPT_USE_TANH: {
             if (value != 0 && value != 1) return qsp_fail(QSP_ERR_INVALID, "use_tanh: 0 or 1");
             d->P.use_tanh = value;
@@ -599,13 +609,18 @@ extern "C" int64_t qsp_decoder_get_counter(qsp_decoder* d, int32_t counter) {
     if (!d) return -1;
     switch (counter) {
         case QSP_DEC_CNT_RANGE_FALLBACKS: return d->n_range_fallbacks;
+        case QSP_DEC_CNT_ARENA_REUSED: return d->n_arena_reuse;
+        case QSP_DEC_CNT_ARENA_CREATED: return d->n_arena_create;
         default: return -1;
     }
 }
 
+static void batch_free(struct qsp_refine_batch* b);
 extern "C" void qsp_decoder_destroy(qsp_decoder* d) {
     if (!d) return;
     (void)hipSetDevice(d->device);
+    if (d->arena) batch_free(d->arena);
+    d->arena = nullptr;
     for (void* p : d->allocs) (void)hipFree(p);
     if (d->range_flag_h) (void)hipHostFree(d->range_flag_h);
     if (d->stream) (void)hipStreamDestroy(d->stream);
@@ -735,6 +750,10 @@ struct qsp_refine_batch {
     int n_iter_cfg = 5;
     int n_obj = 0, n_hyp = 0;
     int max_pts = 0, max_rays = 0;
+    // capacities the device buffers were allocated for (qsp_refine_batch_reload refills a batch whose capacities suffice)
+    int cap_obj = 0, cap_hyp = 0;
+    int64_t cap_pts_total = 0, cap_rays_total = 0;
+    int tile_p_created = 64;
     int nw_sdf = 1;
     int64_t rk_stride = 0, ray_stride = 0, act_stride = 0;
     std::vector<ObjView> objs_h;
@@ -777,10 +796,77 @@ static void batch_free(qsp_refine_batch* b) {
     (void)hipGetLastError();   // errors are ignored here; do not leave one behind for the next call's launch check
 }
 
+// Capacities of a batch: what its device buffers are allocated for.  A batch created for given inputs has exactly their extents;
+// the resident batch of qsp_reconstruct_objects (the decoder's arena) is created with head-room and refilled by batch_fill.
+struct BatchCaps {
+    int obj = 0, hyp = 0, max_pts = 0, max_rays = 0;
+    int64_t pts_total = 0, rays_total = 0;
+};
+
+static int batch_validate(const RefineCfg& cfg, int32_t n_obj, const int32_t* n_pts, const int32_t* n_rays, const int32_t* n_fg,
+                          int32_t n_hyp, const int32_t* hyp_obj, BatchCaps* need) {
+    BatchCaps c;
+    c.obj = n_obj;
+    c.hyp = n_hyp;
+    for (int o = 0; o < n_obj; ++o) {
+        const int nr = cfg.pose_only ? 0 : n_rays[o];
+        const int nf = cfg.pose_only ? 0 : n_fg[o];
+        if (n_pts[o] < 0 || nr < 0 || nf < 0 || nf > nr || nr >= (1 << 25)) return qsp_fail(QSP_ERR_INVALID, "refine batch: bad per-object counts");
+        c.pts_total += n_pts[o];
+        c.rays_total += nr;
+        c.max_pts = std::max(c.max_pts, (int)n_pts[o]);
+        c.max_rays = std::max(c.max_rays, nr);
+    }
+    for (int h = 0; h < n_hyp; ++h)
+        if (hyp_obj[h] < 0 || hyp_obj[h] >= n_obj) return qsp_fail(QSP_ERR_INVALID, "refine batch: hyp_obj out of range");
+    *need = c;
+    return QSP_OK;
+}
+
+// (re)fills a batch whose capacities suffice: object extents, observations, hypothesis -> object map.  Strides, slot counts
+// and buffer sizes stay those of the capacities; every per-object quantity the kernels use comes from the ObjView table.
+static int batch_fill(qsp_refine_batch* b, int32_t n_obj, const float* const* pts, const int32_t* n_pts, const float* const* rays,
+                      const int32_t* n_rays, const float* const* depth, const int32_t* n_fg, int32_t n_hyp, const int32_t* hyp_obj,
+                      bool device_fill) {
+    const RefineCfg& cfg = b->cfg;
+    b->n_obj = n_obj;
+    b->n_hyp = n_hyp;
+    b->objs_h.resize(n_obj);
+    int64_t po = 0, ro = 0;
+    for (int o = 0; o < n_obj; ++o) {
+        const int nr = cfg.pose_only ? 0 : n_rays[o];
+        const int nf = cfg.pose_only ? 0 : n_fg[o];
+        b->objs_h[o] = ObjView{po, ro, n_pts[o], nr, nf, 0};
+        po += n_pts[o];
+        ro += nr;
+    }
+    b->hyp_obj.assign(hyp_obj, hyp_obj + n_hyp);
+    std::vector<float> hp((size_t)std::max<int64_t>(po, 1) * 3), hr((size_t)std::max<int64_t>(ro, 1) * 3),
+        hd((size_t)std::max<int64_t>(ro, 1), 0.f);
+    for (int o = 0; o < n_obj && !device_fill; ++o) {
+        const ObjView& v = b->objs_h[o];
+        if (v.n_pts) memcpy(&hp[3 * v.pts_off], pts[o], sizeof(float) * 3 * v.n_pts);
+        if (v.n_rays) memcpy(&hr[3 * v.ray_off], rays[o], sizeof(float) * 3 * v.n_rays);
+        if (v.n_fg) memcpy(&hd[v.ray_off], depth[o], sizeof(float) * v.n_fg);
+    }
+    hipError_t e = hipMemcpy(b->objs, b->objs_h.data(), sizeof(ObjView) * n_obj, hipMemcpyHostToDevice);
+    if (e == hipSuccess && !device_fill) e = hipMemcpy(b->pts, hp.data(), hp.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess && !device_fill) e = hipMemcpy(b->rays, hr.data(), hr.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = device_fill ? hipMemset(b->depth, 0, hd.size() * sizeof(float))
+                                         : hipMemcpy(b->depth, hd.data(), hd.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) return qsp_fail(QSP_ERR_DEVICE, hipGetErrorString(e));
+    return QSP_OK;
+}
+
+static bool batch_fits(const qsp_refine_batch* b, const BatchCaps& need) {
+    return need.obj <= b->cap_obj && need.hyp <= b->cap_hyp && need.max_pts <= b->max_pts && need.max_rays <= b->max_rays &&
+           need.pts_total <= b->cap_pts_total && need.rays_total <= b->cap_rays_total;
+}
+
 static int batch_create(qsp_decoder* dec, const RefineCfg& cfg, int n_iter, int32_t n_obj, const float* const* pts,
                         const int32_t* n_pts, const float* const* rays, const int32_t* n_rays,
                         const float* const* depth, const int32_t* n_fg, int32_t n_hyp, const int32_t* hyp_obj,
-                        qsp_refine_batch** out, bool device_fill = false) {
+                        qsp_refine_batch** out, bool device_fill = false, const BatchCaps* caps_in = nullptr) {
     // device_fill: only the extents are given, the observation arrays are written by a kernel (detections.hpp)
     if (!dec || !out || n_obj <= 0 || n_hyp <= 0 || (!pts && !device_fill) || !n_pts || !hyp_obj)
         return qsp_fail(QSP_ERR_INVALID, "refine batch: bad argument");
@@ -790,6 +876,12 @@ static int batch_create(qsp_decoder* dec, const RefineCfg& cfg, int n_iter, int3
     if (dec->tile_p == 32 && (dec->fwd_bf3 != 2 || dec->jac_bf3 != 2))
         return qsp_fail(QSP_ERR_UNSUPPORTED, "32-point tiles (QSP_DEC_OPT_TILE_POINTS) exist on the split-fp16 pipe only: set both "
                                              "precisions to 2 first");
+    BatchCaps need;
+    {
+        const int rc = batch_validate(cfg, n_obj, n_pts, n_rays, n_fg, n_hyp, hyp_obj, &need);
+        if (rc) return rc;
+    }
+    BatchCaps caps = caps_in ? *caps_in : need;      // (caps_in >= need, the caller's business)
     const int tile_p = dec->tile_p;
     QSP_HIP(hipSetDevice(dec->device));
     qsp_refine_batch* b = new qsp_refine_batch();
@@ -799,38 +891,16 @@ static int batch_create(qsp_decoder* dec, const RefineCfg& cfg, int n_iter, int3
     b->cfg = cfg;
     b->cfg.code_len = dec->code_len;
     b->cfg.tile_p = dec->tile_p;
+    b->tile_p_created = dec->tile_p;
     b->n_iter_cfg = n_iter;
-    b->n_obj = n_obj;
-    b->n_hyp = n_hyp;
-    b->objs_h.resize(n_obj);
-    int64_t po = 0, ro = 0;
-    for (int o = 0; o < n_obj; ++o) {
-        const int nr = cfg.pose_only ? 0 : n_rays[o];
-        const int nf = cfg.pose_only ? 0 : n_fg[o];
-        if (n_pts[o] < 0 || nr < 0 || nf < 0 || nf > nr || nr >= (1 << 25)) {
-            delete b;
-            return qsp_fail(QSP_ERR_INVALID, "refine batch: bad per-object counts");
-        }
-        b->objs_h[o] = ObjView{po, ro, n_pts[o], nr, nf, 0};
-        po += n_pts[o];
-        ro += nr;
-        b->max_pts = std::max(b->max_pts, (int)n_pts[o]);
-        b->max_rays = std::max(b->max_rays, nr);
-    }
-    b->hyp_obj.assign(hyp_obj, hyp_obj + n_hyp);
-    for (int h = 0; h < n_hyp; ++h)
-        if (hyp_obj[h] < 0 || hyp_obj[h] >= n_obj) {
-            delete b;
-            return qsp_fail(QSP_ERR_INVALID, "refine batch: hyp_obj out of range");
-        }
-    std::vector<float> hp((size_t)std::max<int64_t>(po, 1) * 3), hr((size_t)std::max<int64_t>(ro, 1) * 3),
-        hd((size_t)std::max<int64_t>(ro, 1), 0.f);
-    for (int o = 0; o < n_obj && !device_fill; ++o) {
-        const ObjView& v = b->objs_h[o];
-        if (v.n_pts) memcpy(&hp[3 * v.pts_off], pts[o], sizeof(float) * 3 * v.n_pts);
-        if (v.n_rays) memcpy(&hr[3 * v.ray_off], rays[o], sizeof(float) * 3 * v.n_rays);
-        if (v.n_fg) memcpy(&hd[v.ray_off], depth[o], sizeof(float) * v.n_fg);
-    }
+    b->cap_obj = caps.obj;
+    b->cap_hyp = caps.hyp;
+    b->cap_pts_total = caps.pts_total;
+    b->cap_rays_total = caps.rays_total;
+    b->max_pts = caps.max_pts;
+    b->max_rays = caps.max_rays;
+    const int64_t cp = std::max<int64_t>(caps.pts_total, 1), cr = std::max<int64_t>(caps.rays_total, 1);
+    const int cap_hyp = caps.hyp;
     b->nw_sdf = std::max(1, std::min(NW_SDF_MAX, (b->max_pts + tile_p - 1) / tile_p));
     b->rk_stride = (int64_t)std::max(1, b->max_rays) * cfg.n_depth;
     b->ray_stride = b->max_rays + 1;
@@ -842,52 +912,48 @@ static int batch_create(qsp_decoder* dec, const RefineCfg& cfg, int n_iter, int3
         hipError_t e_ = hipMalloc((void**)&(ptr), (size_t)(bytes));                           \
         if (e_ != hipSuccess) rc = qsp_fail(QSP_ERR_DEVICE, hipGetErrorString(e_));           \
     }
-    QSP_ALLOC(b->st, sizeof(HypState) * n_hyp);
-    QSP_ALLOC(b->objs, sizeof(ObjView) * n_obj);
-    QSP_ALLOC(b->pts, hp.size() * sizeof(float));
-    QSP_ALLOC(b->rays, hr.size() * sizeof(float));
-    QSP_ALLOC(b->depth, hd.size() * sizeof(float));
-    QSP_ALLOC(b->partials, sizeof(float) * (size_t)n_hyp * nw_total * PART_FLOATS);
-    QSP_ALLOC(b->trH, sizeof(float) * (size_t)n_hyp * NH * NH);
-    QSP_ALLOC(b->trb, sizeof(float) * (size_t)n_hyp * NH);
-    QSP_ALLOC(b->trdx, sizeof(float) * (size_t)n_hyp * NH);
-    QSP_ALLOC(b->trrot, sizeof(float) * (size_t)n_hyp * 4);
+    QSP_ALLOC(b->st, sizeof(HypState) * cap_hyp);
+    QSP_ALLOC(b->objs, sizeof(ObjView) * caps.obj);
+    QSP_ALLOC(b->pts, cp * 3 * sizeof(float));
+    QSP_ALLOC(b->rays, cr * 3 * sizeof(float));
+    QSP_ALLOC(b->depth, cr * sizeof(float));
+    QSP_ALLOC(b->partials, sizeof(float) * (size_t)cap_hyp * nw_total * PART_FLOATS);
+    QSP_ALLOC(b->trH, sizeof(float) * (size_t)cap_hyp * NH * NH);
+    QSP_ALLOC(b->trb, sizeof(float) * (size_t)cap_hyp * NH);
+    QSP_ALLOC(b->trdx, sizeof(float) * (size_t)cap_hyp * NH);
+    QSP_ALLOC(b->trrot, sizeof(float) * (size_t)cap_hyp * 4);
     QSP_ALLOC(b->counters, sizeof(unsigned long long) * 8);
-    QSP_ALLOC(b->st_snap, sizeof(HypState) * n_hyp);
+    QSP_ALLOC(b->st_snap, sizeof(HypState) * cap_hyp);
     QSP_ALLOC(b->qctl, sizeof(int) * 4);
-    QSP_ALLOC(b->c0_all, sizeof(float) * (size_t)n_hyp * 2 * HID);
-    QSP_ALLOC(b->work_jtj, sizeof(int2) * (size_t)n_hyp * nw_total);
-    if (!cfg.pose_only) QSP_ALLOC(b->work_fwd, sizeof(int2) * (size_t)n_hyp * ((b->rk_stride + TILE_P - 1) / TILE_P));
+    QSP_ALLOC(b->c0_all, sizeof(float) * (size_t)cap_hyp * 2 * HID);
+    QSP_ALLOC(b->work_jtj, sizeof(int2) * (size_t)cap_hyp * nw_total);
+    if (!cfg.pose_only) QSP_ALLOC(b->work_fwd, sizeof(int2) * (size_t)cap_hyp * ((b->rk_stride + TILE_P - 1) / TILE_P));
     {
         int ncu = 0;
         if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dec->device) == hipSuccess && ncu > 0) b->n_cu = ncu;
     }
     if (!cfg.pose_only) {
-        QSP_ALLOC(b->valid_rk, sizeof(int32_t) * (size_t)n_hyp * b->rk_stride);
-        QSP_ALLOC(b->ray_voff, sizeof(int32_t) * (size_t)n_hyp * b->ray_stride);
-        QSP_ALLOC(b->rend_rk, sizeof(int32_t) * (size_t)n_hyp * b->rk_stride);
-        QSP_ALLOC(b->sdf_valid, sizeof(float) * (size_t)n_hyp * b->rk_stride);
-        QSP_ALLOC(b->rend_deds, sizeof(float) * (size_t)n_hyp * b->rk_stride);
-        QSP_ALLOC(b->rend_res, sizeof(float) * (size_t)n_hyp * b->rk_stride);
-        QSP_ALLOC(b->band_idx, sizeof(int32_t) * (size_t)n_hyp * b->rk_stride);
+        QSP_ALLOC(b->valid_rk, sizeof(int32_t) * (size_t)cap_hyp * b->rk_stride);
+        QSP_ALLOC(b->ray_voff, sizeof(int32_t) * (size_t)cap_hyp * b->ray_stride);
+        QSP_ALLOC(b->rend_rk, sizeof(int32_t) * (size_t)cap_hyp * b->rk_stride);
+        QSP_ALLOC(b->sdf_valid, sizeof(float) * (size_t)cap_hyp * b->rk_stride);
+        QSP_ALLOC(b->rend_deds, sizeof(float) * (size_t)cap_hyp * b->rk_stride);
+        QSP_ALLOC(b->rend_res, sizeof(float) * (size_t)cap_hyp * b->rk_stride);
+        QSP_ALLOC(b->band_idx, sizeof(int32_t) * (size_t)cap_hyp * b->rk_stride);
     } else {
-        QSP_ALLOC(b->pt_active, (size_t)n_hyp * b->act_stride);
-        QSP_ALLOC(b->act_snap, (size_t)n_hyp * b->act_stride);
-        QSP_ALLOC(b->res_buf, sizeof(float) * (size_t)n_hyp * b->act_stride);
+        QSP_ALLOC(b->pt_active, (size_t)cap_hyp * b->act_stride);
+        QSP_ALLOC(b->act_snap, (size_t)cap_hyp * b->act_stride);
+        QSP_ALLOC(b->res_buf, sizeof(float) * (size_t)cap_hyp * b->act_stride);
     }
 #undef QSP_ALLOC
     if (!rc) {
-        hipError_t e = hipMemcpy(b->objs, b->objs_h.data(), sizeof(ObjView) * n_obj, hipMemcpyHostToDevice);
-        if (e == hipSuccess && !device_fill) e = hipMemcpy(b->pts, hp.data(), hp.size() * sizeof(float), hipMemcpyHostToDevice);
-        if (e == hipSuccess && !device_fill) e = hipMemcpy(b->rays, hr.data(), hr.size() * sizeof(float), hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = device_fill ? hipMemset(b->depth, 0, hd.size() * sizeof(float))
-                                             : hipMemcpy(b->depth, hd.data(), hd.size() * sizeof(float), hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemset(b->trH, 0, sizeof(float) * (size_t)n_hyp * NH * NH);
-        if (e == hipSuccess) e = hipMemset(b->trb, 0, sizeof(float) * (size_t)n_hyp * NH);
-        if (e == hipSuccess) e = hipMemset(b->trdx, 0, sizeof(float) * (size_t)n_hyp * NH);
-        if (e == hipSuccess) e = hipMemset(b->trrot, 0, sizeof(float) * (size_t)n_hyp * 4);
+        hipError_t e = hipMemset(b->trH, 0, sizeof(float) * (size_t)cap_hyp * NH * NH);
+        if (e == hipSuccess) e = hipMemset(b->trb, 0, sizeof(float) * (size_t)cap_hyp * NH);
+        if (e == hipSuccess) e = hipMemset(b->trdx, 0, sizeof(float) * (size_t)cap_hyp * NH);
+        if (e == hipSuccess) e = hipMemset(b->trrot, 0, sizeof(float) * (size_t)cap_hyp * 4);
         if (e != hipSuccess) rc = qsp_fail(QSP_ERR_DEVICE, hipGetErrorString(e));
     }
+    if (!rc) rc = batch_fill(b, n_obj, pts, n_pts, rays, n_rays, depth, n_fg, n_hyp, hyp_obj, device_fill);
     if (rc) {
         batch_free(b);
         return rc;
@@ -961,7 +1027,13 @@ static int run_once(qsp_refine_batch* b, int32_t n_iter, bool* hit) {
                                b->ray_voff, b->ray_stride);
             if (b->prof) spans.push_back({a, next_event(b, cur), 2});
             if (b->prof) a = next_event(b, cur);
-            const bool screen = b->dec->fwd_bf3 == 2 && b->dec->screen_margin > 0.f;
+            // Two passes pay when the one-pass kernel would need more than one round of 64-point tiles over the chip; a batch that
+            // fits one round (a single object per call) is faster in one pass: one tile deep either way, without the second
+            // launch.  Both give the same bits, so the choice is free.  (~half of the ray samples are inside the unit ball.)
+            int64_t ub_samples = 0;
+            for (int h = 0; h < nH; ++h) ub_samples += (int64_t)b->objs_h[b->hyp_obj[h]].n_rays * cfg.n_depth;
+            const int64_t min_samples = b->dec->screen_min_samples >= 0 ? b->dec->screen_min_samples : 2 * (int64_t)b->n_cu * TILE_P;
+            const bool screen = b->dec->fwd_bf3 == 2 && b->dec->screen_margin > 0.f && ub_samples > min_samples;
             hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, s, 0, b->st, b->objs, nH, b->nw_sdf, nw_total - b->nw_sdf,
                                b->work_fwd, b->qctl, screen ? H1_ROWS : TILE_P);     // (the forward pass keeps 64-point tiles: tens of
             if (screen) {                                                            //  thousands of ray samples fill the chip either way)
@@ -1142,7 +1214,7 @@ extern "C" int qsp_refine_batch_rows(qsp_refine_batch* b, int enable, int32_t hy
     QSP_HIP(hipSetDevice(b->dec->device));
     if (enable && !b->rows) {
         b->rows_stride = b->act_stride + b->rk_stride;
-        QSP_HIP(hipMalloc((void**)&b->rows, sizeof(float) * (size_t)b->n_hyp * b->rows_stride * NJ));
+        QSP_HIP(hipMalloc((void**)&b->rows, sizeof(float) * (size_t)b->cap_hyp * b->rows_stride * NJ));
     }
     if (!enable && b->rows) {
         (void)hipFree(b->rows);
@@ -1168,13 +1240,59 @@ extern "C" int qsp_reconstruct_objects(qsp_decoder* dec, const qsp_joint_cfg* cf
                                        const float* const* depth, const int32_t* n_fg, int32_t n_hyp,
                                        const int32_t* hyp_obj, const float* t_cam_obj, const float* code,
                                        float* t_cam_obj_out, float* code_out, float* loss_out, uint8_t* is_good_out) {
-    qsp_refine_batch* b = nullptr;
-    int rc = qsp_refine_batch_create(dec, cfg, n_obj, pts, n_pts, rays, n_rays, depth, n_fg, n_hyp, hyp_obj, &b);
+    if (!dec || !cfg) return qsp_fail(QSP_ERR_INVALID, "qsp_reconstruct_objects: null argument");
+    if (cfg->code_len != dec->code_len) return qsp_fail(QSP_ERR_INVALID, "code_len of the optimizer config differs from the decoder's");
+    if (n_obj <= 0 || n_hyp <= 0 || !pts || !n_pts || !rays || !n_rays || !depth || !n_fg || !hyp_obj)
+        return qsp_fail(QSP_ERR_INVALID, "refine batch: bad argument");
+    const RefineCfg c{cfg->k1, cfg->k2, cfg->k3, cfg->k4, cfg->b1, cfg->b2, cfg->lr, cfg->s_damp, cfg->cut_off, cfg->n_depth, 0, 0,
+                      dec->code_len};
+    BatchCaps need;
+    int rc = batch_validate(c, n_obj, n_pts, n_rays, n_fg, n_hyp, hyp_obj, &need);
     if (rc) return rc;
+    // The decoder's resident batch: reused when the call fits its capacities and the quantities its strides were derived from
+    // (depth samples, tile size) are the same; the weights of the cost terms are launch arguments and simply replaced.  Otherwise
+    // it is rebuilt with a quarter of head-room over the larger of (this call, what it held): a high-water mark, so a sequence
+    // of objects of varying size settles after a few calls.  Results do not depend on the capacities (tests/test_gpu_latency.py).
+    qsp_refine_batch* b = dec->arena;
+    if (b && (b->cfg.n_depth != c.n_depth || b->tile_p_created != dec->tile_p || b->cfg.pose_only || !batch_fits(b, need))) {
+        BatchCaps grow = need;
+        grow.obj = std::max(need.obj, b->cap_obj);
+        grow.hyp = std::max(need.hyp, b->cap_hyp);
+        grow.max_pts = std::max(need.max_pts, b->max_pts);
+        grow.max_rays = std::max(need.max_rays, b->max_rays);
+        grow.pts_total = std::max(need.pts_total, b->cap_pts_total);
+        grow.rays_total = std::max(need.rays_total, b->cap_rays_total);
+        need = grow;
+        batch_free(b);
+        b = dec->arena = nullptr;
+    }
+    if (!b) {
+        BatchCaps caps = need;
+        caps.hyp = std::max(caps.hyp, 4);           // (one object x its four yaw flips: the other call shape of the reference)
+        caps.max_pts += caps.max_pts / 4;
+        caps.max_rays += caps.max_rays / 4;
+        caps.pts_total += caps.pts_total / 4;
+        caps.rays_total += caps.rays_total / 4;
+        caps.pts_total = std::max<int64_t>(caps.pts_total, (int64_t)caps.max_pts);
+        caps.rays_total = std::max<int64_t>(caps.rays_total, (int64_t)caps.max_rays);
+        rc = batch_create(dec, c, cfg->n_iter, n_obj, pts, n_pts, rays, n_rays, depth, n_fg, n_hyp, hyp_obj, &b, false, &caps);
+        if (rc) return rc;
+        dec->arena = b;
+        dec->n_arena_create++;
+    } else {
+        QSP_HIP(hipSetDevice(dec->device));
+        const int tile_p = b->cfg.tile_p;
+        b->cfg = c;
+        b->cfg.code_len = dec->code_len;
+        b->cfg.tile_p = tile_p;
+        b->n_iter_cfg = cfg->n_iter;
+        rc = batch_fill(b, n_obj, pts, n_pts, rays, n_rays, depth, n_fg, n_hyp, hyp_obj, false);
+        if (rc) return rc;
+        dec->n_arena_reuse++;
+    }
     rc = qsp_refine_batch_set_state(b, t_cam_obj, code);
     if (!rc) rc = qsp_refine_batch_run(b, 0);
     if (!rc) rc = qsp_refine_batch_get(b, t_cam_obj_out, code_out, loss_out, is_good_out);
-    qsp_refine_batch_destroy(b);
     return rc;
 }
 

@@ -75,6 +75,11 @@ class DeepSdfDecoder(object):
         _lib.check(_lib.lib().qsp_decoder_set_option(self.handle, 3, int(n)))
         self.tile_points = int(n)
 
+    def set_screening_min_samples(self, n=-1):
+        """a run is screened only when its batch holds more than n ray samples; -1 = automatic (more than two rounds of 64-point
+        tiles over the chip), 0 = always (QSP_DEC_OPT_SCREENING_MIN_SAMPLES)"""
+        _lib.check(_lib.lib().qsp_decoder_set_option(self.handle, 7, int(n)))
+
     def set_render_screening(self, margin=0.01):
         """two-pass ray-sample forward of the refinement on the "fp16x2" pipe (QSP_DEC_OPT_RENDER_SCREENING in qsp_hip.h): every
         sample on a one-product tile, only those with |s1| < cut_off + margin on the split-fp16 tile.  Bit-identical results to the
@@ -96,6 +101,12 @@ class DeepSdfDecoder(object):
     def range_fallbacks(self):
         """calls of this decoder that were repeated on the f32 pipe so far"""
         return int(_lib.lib().qsp_decoder_get_counter(self.handle, 1))
+
+    @property
+    def arena_stats(self):
+        """(calls of qsp_reconstruct_objects that refilled the decoder's resident batch, calls that had to (re)allocate it)"""
+        L = _lib.lib()
+        return int(L.qsp_decoder_get_counter(self.handle, 2)), int(L.qsp_decoder_get_counter(self.handle, 3))
 
     def decode_sdf_screen(self, code, x):
         """the screening tile's values (first pass of set_render_screening) on explicit points -- diagnostic, not SDF values"""

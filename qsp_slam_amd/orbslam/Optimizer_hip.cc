@@ -141,3 +141,8 @@ int Optimizer::OptimizeSim3(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint
 }
 
 }  // namespace ORB_SLAM2
+
+// For embedders that only see the reference-shaped Optimizer.h: how many library calls have failed in this process, i.e. how many
+// entry points ran on the reference's g2o path instead of the GPU (0 in a healthy deployment; QSP_SHIM_NO_FALLBACK=1 makes the
+// first one fatal).  include/qsp_optimizer_shim.h:fallback_count.
+extern "C" long qsp_optimizer_fallback_count(void) { return ORB_SLAM2::qsp_shim::fallback_count(); }

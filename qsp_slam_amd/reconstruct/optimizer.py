@@ -36,6 +36,33 @@ def _flip_rotation(T, k, flip_angle):
     return Tk
 
 
+def _reconstruct_objects(decoder, cfg, pts, rays, depth, hyp_obj, t_cam_obj, code):
+    """qsp_reconstruct_objects: one call = fill + set_state + run + get on the batch that stays resident with the decoder (no device
+    allocation per call once its capacities have settled) -- the reference's call pattern, src/LocalMapping_util.cc:705-760"""
+    n_hyp = len(hyp_obj)
+    L = decoder.code_len
+    pts = [_lib.f32c(p).reshape(-1, 3) for p in pts]
+    rays = [_lib.f32c(r).reshape(-1, 3) for r in rays]
+    depth = [_lib.f32c(d).reshape(-1) for d in depth]
+    n_pts = np.array([p.shape[0] for p in pts], np.int32)
+    n_rays = np.array([r.shape[0] for r in rays], np.int32)
+    n_fg = np.array([d.shape[0] for d in depth], np.int32)
+    hyp = np.ascontiguousarray(hyp_obj, dtype=np.int32)
+    pp, rp, dp = _lib.ptr_array(pts), _lib.ptr_array(rays), _lib.ptr_array(depth)
+    T0 = _lib.f32c(t_cam_obj).reshape(n_hyp, 16)
+    c0 = None if code is None else _lib.f32c(code).reshape(n_hyp, L)
+    T = np.empty((n_hyp, 4, 4), np.float32)
+    c = np.empty((n_hyp, L), np.float32)
+    loss = np.empty(n_hyp, np.float32)
+    good = np.empty(n_hyp, np.uint8)
+    _lib.check(_lib.lib().qsp_reconstruct_objects(
+        decoder.handle, C.byref(cfg), len(pts), C.cast(pp, C.POINTER(_lib.c_float_p)), _lib.i32ptr(n_pts),
+        C.cast(rp, C.POINTER(_lib.c_float_p)), _lib.i32ptr(n_rays), C.cast(dp, C.POINTER(_lib.c_float_p)), _lib.i32ptr(n_fg),
+        n_hyp, _lib.i32ptr(hyp), _lib.fptr(T0), _lib.fptr(c0) if c0 is not None else _lib.c_float_p(), _lib.fptr(T), _lib.fptr(c),
+        _lib.fptr(loss), _lib.u8ptr(good)))
+    return T, c, loss, good.astype(bool)
+
+
 class RefineBatch(object):
     """Thin owner of a qsp_refine_batch* (resident device batch)."""
 
@@ -176,14 +203,9 @@ class Optimizer(object):
                 c0 = o.get("code")
                 codes.append(np.zeros(self.code_len, np.float32) if c0 is None
                              else np.asarray(c0, np.float32)[: self.code_len])
-        batch = RefineBatch(self.decoder, _joint_cfg(self), [o["pts"] for o in objects], [o["rays"] for o in objects],
-                            [o["depth"] for o in objects], hyp_obj)
-        try:
-            batch.set_state(np.stack(T0), np.stack(codes) if any_code else None)
-            batch.run(0)
-            T, code, loss, good = batch.get()
-        finally:
-            batch.close()
+        T, code, loss, good = _reconstruct_objects(self.decoder, _joint_cfg(self), [o["pts"] for o in objects],
+                                                   [o["rays"] for o in objects], [o["depth"] for o in objects], hyp_obj,
+                                                   np.stack(T0), np.stack(codes) if any_code else None)
         out = []
         for i in range(n_obj):
             res = []

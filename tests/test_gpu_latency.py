@@ -1,0 +1,80 @@
+"""The reference's call pattern is ONE object per call (src/LocalMapping_util.cc:705-760 -> Optimizer.reconstruct_object).  The
+library's one-shot entry point (qsp_reconstruct_objects) keeps one batch resident with the decoder, sized by the high-water mark
+of the calls so far, and refills it instead of allocating ~25 device buffers per call.  What a call returns must not depend on
+what the resident batch held before or on its capacities: every call here is compared, bit for bit, with a fresh batch created
+for exactly that call."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import sdf_oracle as so
+from tests.test_gpu_sdf import make_cfg
+
+pytestmark = pytest.mark.gpu
+
+
+def fresh(dec, opt, o, T0, code=None):
+    from qsp_slam_amd.reconstruct.optimizer import RefineBatch, _joint_cfg
+    b = RefineBatch(dec, _joint_cfg(opt), [o["pts"]], [o["rays"]], [o["depth"]], [0] * len(T0))
+    b.set_state(T0, code)
+    b.run(0)
+    out = b.get()
+    b.close()
+    return out
+
+
+@pytest.mark.parametrize("prec", ["f32", "fp16x2", "fp16x2_t32"])
+def test_resident_batch_is_reused_and_results_do_not_depend_on_it(golden_dir, prec):
+    import bench
+    from qsp_slam_amd import DeepSdfDecoder, synth
+    from qsp_slam_amd.reconstruct.optimizer import Optimizer
+    dec = DeepSdfDecoder.from_npz(os.path.join(golden_dir, "decoder_8x512.npz"))
+    dec.set_precision(prec.split("_")[0])
+    if prec.endswith("t32"):
+        dec.set_tile_points(32)
+    opt = Optimizer(dec, make_cfg(so.JointConfig(n_iter=2)))
+    # sizes going up, down, to zero rays in the ball, and up beyond the capacity again
+    shapes = [(300, 64, 32), (1200, 200, 100), (150, 20, 4), (1100, 256, 200), (2500, 256, 200), (40, 16, 0)]
+    for i, (m, n_fg, n_bg) in enumerate(shapes):
+        o = synth.make_object_views(700 + i, 1, m, n_fg=n_fg, n_bg=n_bg)[0]
+        r = opt.reconstruct_object(o["t_cam_obj"], o["pts"], o["rays"], o["depth"])
+        T, code, loss, good = fresh(dec, opt, o, o["t_cam_obj"][None])
+        assert bool(r.is_good) == bool(good[0]) and np.float32(r.loss) == loss[0], (prec, i)
+        if r.is_good:
+            assert np.array_equal(r.t_cam_obj, T[0]) and np.array_equal(r.code, code[0]), (prec, i)
+        # the four yaw flips of the same object as one call, through the same resident batch
+        sel = opt.reconstruct_objects_batched([dict(t_cam_obj=o["t_cam_obj"], pts=o["pts"], rays=o["rays"], depth=o["depth"])],
+                                              flip_sample_num=4, select=False)[0]
+        T0, _ = bench.flip_states([o], 4)
+        T4, code4, loss4, good4 = fresh(dec, opt, o, T0)
+        for k in range(4):
+            assert bool(sel[k].is_good) == bool(good4[k])
+            if sel[k].is_good:
+                assert np.array_equal(sel[k].t_cam_obj, T4[k]) and np.array_equal(sel[k].code, code4[k]), (prec, i, k)
+    reused, created = dec.arena_stats
+    assert created <= 4 and reused >= 8, (reused, created)       # a high-water mark: it settles
+    dec.close()
+
+
+def test_an_initial_code_and_a_failure_through_the_resident_batch(golden_dir):
+    """the code argument and the reference's failure exit (fewer than 10 ray samples in the unit ball -> is_good False, no
+    exception) survive the reuse; a good call after a failed one is unaffected by it"""
+    from qsp_slam_amd import DeepSdfDecoder, synth
+    from qsp_slam_amd.reconstruct.optimizer import Optimizer
+    dec = DeepSdfDecoder.from_npz(os.path.join(golden_dir, "decoder_8x512.npz"))
+    opt = Optimizer(dec, make_cfg(so.JointConfig(n_iter=2)))
+    o = synth.make_object_views(11, 1, 400, n_fg=100, n_bg=50)[0]
+    code0 = (0.05 * np.random.default_rng(3).normal(size=64)).astype(np.float32)
+    good1 = opt.reconstruct_object(o["t_cam_obj"], o["pts"], o["rays"], o["depth"], code=code0)
+    bad = dict(o)
+    bad["rays"] = o["rays"].copy()
+    bad["rays"][:, 0] += 3.0                      # every ray misses the unit ball
+    rb = opt.reconstruct_object(bad["t_cam_obj"], bad["pts"], bad["rays"], bad["depth"])
+    assert not rb.is_good and rb.t_cam_obj is None
+    good2 = opt.reconstruct_object(o["t_cam_obj"], o["pts"], o["rays"], o["depth"], code=code0)
+    assert good1.is_good and good2.is_good
+    assert np.array_equal(good1.t_cam_obj, good2.t_cam_obj) and np.array_equal(good1.code, good2.code) and good1.loss == good2.loss
+    T, code, loss, good = fresh(dec, opt, o, o["t_cam_obj"][None], code0[None])
+    assert np.array_equal(good1.t_cam_obj, T[0]) and np.array_equal(good1.code, code[0])
+    dec.close()

@@ -23,6 +23,7 @@ def dec(golden_dir):
     from qsp_slam_amd import DeepSdfDecoder
     d = DeepSdfDecoder.from_npz(os.path.join(golden_dir, "decoder_8x512.npz"))
     d.set_precision("fp16x2")
+    d.set_screening_min_samples(0)        # (the library screens large batches only: force it for the small ones here)
     yield d
     d.close()
 
@@ -125,4 +126,23 @@ def test_screening_needs_the_split_fp16_forward_pass(golden_dir):
         d.set_render_screening(0.06)           # beyond 5 x the cut-off the second pass covers most samples: refused
     d.set_precision("f32")                     # leaving the pipe drops the option
     assert d.render_screening == 0.0
+    d.close()
+
+
+def test_small_batches_run_in_one_pass_large_ones_in_two(golden_dir):
+    """the automatic choice (QSP_DEC_OPT_SCREENING_MIN_SAMPLES = -1): one object per call fits one round of tiles and is not
+    screened; a batch of 24 hypotheses is; both give the bits of the unscreened pipe (asserted above for forced screening)"""
+    import bench
+    from qsp_slam_amd import DeepSdfDecoder, synth
+    from qsp_slam_amd.reconstruct.optimizer import Optimizer
+    d = DeepSdfDecoder.from_npz(os.path.join(golden_dir, "decoder_8x512.npz"))
+    d.set_precision("fp16x2")
+    opt = Optimizer(d, make_cfg(so.JointConfig(n_iter=2)))
+    objs = synth.make_object_views(31, 6, 500, n_fg=256, n_bg=200)
+    T0, hyp = bench.flip_states(objs, 4)
+    one = run_batch(d, opt, objs[:1], [0], T0[:1], None, 2, True)
+    many = run_batch(d, opt, objs, hyp, T0, None, 2, True)
+    assert one["prof"].pts_band == 0 and many["prof"].pts_band > 0
+    ref = run_batch(d, opt, objs, hyp, T0, None, 2, False)
+    assert_same_bits(many, ref, "auto")
     d.close()

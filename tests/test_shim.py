@@ -428,6 +428,7 @@ def test_dropin_optimizer_class_routes_hot_path_to_the_library_and_loop_closing_
     assert [l.split()[0] for l in log] == ["g2o:OptimizeSim3", "g2o:OptimizeEssentialGraph"]
     assert log[0].split()[1:] == ["5", "10"] and log[1].split()[1] == "2"
     assert "[qsp_hip]" not in err
+    assert out["fallbacks"] == "0"                                  # the counter a deployment asserts on
 
 
 @pytest.mark.parametrize("fail", ["create", "local", "optimize", "pose"])
@@ -450,3 +451,17 @@ def test_dropin_falls_back_to_g2o_when_the_gpu_path_reports_an_error(fail):
     else:
         assert "g2o:PoseOptimization" not in names
     assert "g2o:OptimizeSim3" in names
+    assert int(out["fallbacks"]) >= 1 and "falls back to the reference's g2o path" in err     # counted and said, not silent
+
+
+def test_dropin_fallback_can_be_made_fatal():
+    """QSP_SHIM_NO_FALLBACK=1: a deployment that must not run on the CPU unnoticed turns the first failed library call into an
+    abort (after the message) instead of a g2o run"""
+    m = make_map(seed=21, n_kf=7, n_pt=80, n_obj=2)
+    with tempfile.TemporaryDirectory() as tmp:
+        exe = build_dropin(tmp)
+        write_scene(m, os.path.join(tmp, "scene.bin"))
+        env = dict(os.environ, QSP_G2O_LOG=os.path.join(tmp, "g2o.log"), QSP_STUB_FAIL="local", QSP_SHIM_NO_FALLBACK="1")
+        r = subprocess.run([exe, os.path.join(tmp, "scene.bin"), os.path.join(tmp, "out.txt")], env=env, capture_output=True, text=True)
+        assert r.returncode != 0 and "[qsp_hip] qsp_ba_local_joint failed" in r.stderr
+        assert not os.path.exists(os.path.join(tmp, "g2o.log")) or "g2o:LocalJointBundleAdjustment" not in open(os.path.join(tmp, "g2o.log")).read()
