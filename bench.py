@@ -169,7 +169,7 @@ def cpu_baseline(w, objs, scene, n_hyp, budget_s=20.0):
 def pmc_traffic(workload, kernel):
     """Memory-side bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of this same command
     (PMC counters cannot be read from inside the process); None when the workload was not profiled."""
-    for name in ("r02_traffic.json", "r01_traffic.json"):
+    for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 return json.load(f)[workload][kernel]["bytes_per_launch"], name
@@ -567,6 +567,22 @@ def main():
                 "fallbacks": o["fallbacks"]["range_reruns_on_f32"]}
         if subs:
             out["sublines"] = subs
+        # The BA's own roofline line.  Its bandwidth kernel is the linearisation (J^T J build); at the BASELINE sizes that is a few
+        # MB behind two launches, so the headline is the largest BASELINE graph, C5 (200 KF / 160 k edges), with the bytes the
+        # kernels actually move; the same code on a graph large enough to stream is quoted beside it.
+        c5 = subs.get("c5") if args.workload != "c5" else {"ba_linearize_us": m["kernels"]["ba_linearize_us"],
+                                                            "ba_linearize_moved_GBps": m["kernels"]["ba_linearize_moved_GBps"],
+                                                            "ba_linearize_algorithmic_GBps": m["kernels"]["ba_linearize_GBps"],
+                                                            "ms_ba": m["ms_ba"]}
+        if c5:
+            out["ba_roofline"] = {"bound": "hbm", "kernel": "k_lin_edges + k_lin_vertices (BA linearisation, J^T J build)",
+                                  "workload": "C5: 200 KF / 20000 map points / 256 objects", "unit": "GB/s",
+                                  "achieved": c5["ba_linearize_moved_GBps"], "achieved_basis": "bytes the two kernels read and write",
+                                  "peak": PEAK_HBM_GBPS, "frac": c5["ba_linearize_moved_GBps"] / PEAK_HBM_GBPS,
+                                  "algorithmic_GBps": c5["ba_linearize_algorithmic_GBps"], "us_per_linearisation": c5["ba_linearize_us"],
+                                  "ms_local_joint_ba": c5["ms_ba"],
+                                  "note": "latency-bound at every BASELINE size (two launches for <= 30 MB); see "
+                                          "kernels.ba_linearize_large for the streaming regime of the same kernels"}
         if world == 1 and not args.no_extras:
             from qsp_slam_amd import synth
             from qsp_slam_amd.ba import BaProblem

@@ -28,6 +28,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <thread>
 #include <vector>
 
 #include "../../include/qsp_hip.h"
@@ -2548,6 +2549,9 @@ static int wait_scal(qsp_ba_problem* p, double* out4) {
     volatile double* seq = p->scal_host + 4;
     const auto t0 = std::chrono::steady_clock::now();
     for (uint64_t spin = 0; *seq != p->scal_seq; ++spin) {
+        // the word normally arrives within tens of microseconds; past ~0.5 ms of spinning (a slow peer rank in a sharded run, a
+        // preempted process) the core is handed back between polls instead of being burnt for up to the timeout
+        if (spin > 0xFFFF) std::this_thread::yield();
         if ((spin & 0xFFFF) == 0xFFFF) {     // a faulted or wedged kernel must not hang the caller: ask the runtime now and then
             const hipError_t e = hipStreamQuery(p->stream);
             if (e != hipSuccess && e != hipErrorNotReady) return qsp_fail(QSP_ERR_DEVICE, hipGetErrorString(e));

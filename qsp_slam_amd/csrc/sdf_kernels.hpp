@@ -138,13 +138,31 @@ __device__ __forceinline__ float huber_w(float r, float b) {
 __global__ __launch_bounds__(256) void k_sample(HypState* __restrict__ st, const ObjView* __restrict__ objs,
                                                 const float* __restrict__ rays, RefineCfg cfg,
                                                 int32_t* __restrict__ valid_rk, int64_t rk_stride,
-                                                int32_t* __restrict__ ray_voff, int64_t ray_stride) {
+                                                int32_t* __restrict__ ray_voff, int64_t ray_stride,
+                                                const MlpParams* __restrict__ Pm, float* __restrict__ c0_all) {
     const int h = blockIdx.x;
     HypState& S = st[h];
     if (!S.alive) return;
     __shared__ float T[16];
     __shared__ float dm[2];
     __shared__ int sc[8];
+    __shared__ float code_sh[CODE_LEN];
+    if (threadIdx.x < CODE_LEN) code_sh[threadIdx.x] = S.code[threadIdx.x];
+    __syncthreads();
+    // the per-hypothesis bias vectors of layers 0 and 4 (k_c0's arithmetic, folded in here: one launch less per iteration; the other
+    // waves work on it while thread 0 inverts the pose)
+    for (int u = threadIdx.x; u < HID; u += 256) {
+        const float* w = Pm->w0c + (size_t)u * CODE_LEN;
+        const float* w4 = Pm->w4c + (size_t)u * CODE_LEN;
+        float a = Pm->bias[0][u], a4 = Pm->bias[4][u];
+#pragma unroll 8
+        for (int k = 0; k < CODE_LEN; ++k) {
+            a += w[k] * code_sh[k];
+            a4 += w4[k] * code_sh[k];
+        }
+        c0_all[(size_t)h * 2 * HID + u] = a;
+        c0_all[(size_t)h * 2 * HID + HID + u] = a4;
+    }
     if (threadIdx.x == 0) {
         float Tco[16];
         inv4(S.T_oc, Tco);
@@ -1099,8 +1117,9 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(HypState* __restrict__ 
         if (a > b) continue;
         const int off = tri_tile(a >> 5, b >> 5) * 1024 + (a & 31) * 32 + (b & 31);
         float ss = 0.f, sr = 0.f;
-        // same left-to-right order as ever; unrolled so that 16 of the (24 KiB-strided) loads are in flight at a time
-#pragma unroll 16
+        // same left-to-right order as ever; unrolled so that 32 of the (24 KiB-strided) loads are in flight at a time (a single
+        // object's 2 k points are 63 slots of 32-point tiles: two batches instead of four in front of every entry)
+#pragma unroll 32
         for (int j = 0; j < n_sdf_slots; ++j) ss += base[(int64_t)j * PART_FLOATS + off];
 #pragma unroll 4
         for (int j = 0; j < n_rend_slots; ++j) sr += base[(int64_t)(nw_sdf + j) * PART_FLOATS + off];

@@ -511,6 +511,15 @@ static int jtj_waves() {
     return w;
 }
 
+static int jtj_waves_t32() {
+    static int w = 0;
+    if (!w) {
+        const char* e = getenv("QSP_JTJ_WAVES_T32");
+        w = (e && atoi(e) == 8) ? 8 : 4;
+    }
+    return w;
+}
+
 static int mlp_attr_once() {
     static bool done = false;
     if (done) return QSP_OK;
@@ -1020,11 +1029,11 @@ static int run_once(qsp_refine_batch* b, int32_t n_iter, bool* hit) {
         if (b->dec->jac_bf3 != 2) cfg.tile_p = TILE_P;      // (32-point tiles exist on the split-fp16 pipe only: the f32 repeat of a
                                                             //  batch created for them runs 64-point tiles over the same slots)
         hipEvent_t a = nullptr;
-        hipLaunchKernelGGL(k_c0, dim3(nH), dim3(MLP_THREADS), 0, s, b->st, b->dec->Pd, b->c0_all);
-        if (!cfg.pose_only) {
+        if (cfg.pose_only) hipLaunchKernelGGL(k_c0, dim3(nH), dim3(MLP_THREADS), 0, s, b->st, b->dec->Pd, b->c0_all);
+        if (!cfg.pose_only) {      // (k_sample also forms the bias vectors k_c0 forms in pose-only mode)
             if (b->prof) a = next_event(b, cur);
             hipLaunchKernelGGL(k_sample, dim3(nH), dim3(256), 0, s, b->st, b->objs, b->rays, cfg, b->valid_rk, b->rk_stride,
-                               b->ray_voff, b->ray_stride);
+                               b->ray_voff, b->ray_stride, b->dec->Pd, b->c0_all);
             if (b->prof) spans.push_back({a, next_event(b, cur), 2});
             if (b->prof) a = next_event(b, cur);
             // Two passes pay when the one-pass kernel would need more than one round of 64-point tiles over the chip; a batch that
@@ -1071,7 +1080,9 @@ static int run_once(qsp_refine_batch* b, int32_t n_iter, bool* hit) {
                              b->rk_stride, b->pt_active, b->act_stride, b->res_buf, b->rows, b->rows_stride, b->partials, b->work_jtj,
                              b->qctl, b->c0_all};
             // eight waves of 256 registers (two per SIMD) or four of 512 (one per SIMD): same arithmetic, same bits; jtj_waves()
-            if (cfg.tile_p == 32 && jtj_waves() == 8)
+            // (32-point tiles are the latency option -- one tile deep: there the four-wave form is the shorter chain, 180 us
+            //  against 248 per tile; QSP_JTJ_WAVES_T32=8 selects the other for measurements)
+            if (cfg.tile_p == 32 && jtj_waves_t32() == 8)
                 hipLaunchKernelGGL((k_mlp_jtj_h2<1, 8>), dim3(b->n_cu), dim3(512), sizeof(MlpSmem), s, ja);
             else if (cfg.tile_p == 32)
                 hipLaunchKernelGGL((k_mlp_jtj_h2<1, 4>), dim3(b->n_cu), dim3(H2_THREADS), sizeof(MlpSmem), s, ja);

@@ -39,8 +39,13 @@ class DeepSdfDecoder(object):
         self.code_len = int(code_len)
         self.device = int(device)
         self.precision = "f32"
+        self.render_screening = 0.0
         if os.environ.get("QSP_PRECISION"):        # e.g. to run a whole test session on the split-bf16 pipe
             self.set_precision(os.environ["QSP_PRECISION"])
+            if self.precision == "fp16x2" and os.environ.get("QSP_SCREENING"):
+                # ... or on the screened split-fp16 pipe, every batch in two passes whatever its size (QSP_SCREENING = margin)
+                self.set_render_screening(float(os.environ["QSP_SCREENING"]))
+                self.set_screening_min_samples(0)
         self.mac_per_point = int(sum(int(i) * int(o) for i, o in zip(in_dim, out_dim)))
 
     PRECISIONS = {"f32": 0, "bf16x3": 1, "fp16x2": 2}

@@ -477,3 +477,28 @@ def test_pose_graph_of_key_frames_and_objects_without_landmarks():
     rkf, rpt, rob = ref.state()
     assert pt.shape[0] == 0 and close(kf, rkf, rtol=1e-7, atol=1e-9) and close(ob, rob, rtol=1e-7, atol=1e-9)
     gpu.close()
+
+
+@pytest.mark.parametrize("n_kf", [560, 620])
+def test_many_keyframes_with_objects_in_the_atomic_mode(n_kf):
+    """k_obj_rows, the atomic mode's object update, keeps a 6 x dimp row block in LDS (48 dimp bytes of 160 KB):
+    beyond ~568 free key-frames it does not fit, and the launch used to be issued anyway (rejected, unchecked: Hs without the
+    object terms).  Now build_index leaves the objects in the dense system above that size.  560 key-frames: the eliminated
+    form at the edge of its LDS budget; 620: the guarded form.  Each against the atomic-free mode (pair lists, no LDS row
+    blocks) on the same graph: same LM path, chi2 and estimates to rounding."""
+    from qsp_slam_amd.ba import BaProblem
+    sc = synth.make_ba_scene_large(17, n_kf, 4000, obs_per_pt=8, n_obj=3)
+    runs = []
+    for det in (False, True):
+        g = BaProblem(sc)
+        g.set_deterministic(det)
+        t = g.optimize(2, DM, DS, DO)
+        runs.append((t, g.state()))
+        g.close()
+    (ta, sa), (td, sd) = runs
+    assert ta["n_pose_blocks"] == td["n_pose_blocks"] and ta["n_pose_blocks"] >= n_kf - 2 + 3
+    assert list(ta["trials"]) == list(td["trials"]) and list(ta["accepted"]) == list(td["accepted"])
+    assert close(ta["chi2"], td["chi2"], rtol=1e-8) and close(ta["lam"], td["lam"], rtol=1e-7)
+    for x, y in zip(sa, sd):
+        assert close(x, y, rtol=1e-7, atol=1e-9)
+    assert float(ta["chi2"][-1]) < float(ta["chi2"][0]) or len(ta["chi2"]) == 1      # (and the step did reduce the cost)

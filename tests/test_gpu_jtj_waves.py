@@ -44,7 +44,7 @@ def test_four_and_eight_wave_kernels_give_the_same_bits(tmp_path):
     res = {}
     for waves in ("4", "8"):
         path = str(tmp_path / ("w%s.npz" % waves))
-        env = dict(os.environ, QSP_JTJ_WAVES=waves)
+        env = dict(os.environ, QSP_JTJ_WAVES=waves, QSP_JTJ_WAVES_T32=waves)
         subprocess.run([sys.executable, "-c", CHILD, ROOT, path], check=True, env=env, timeout=600)
         res[waves] = np.load(path)
     assert sorted(res["4"].files) == sorted(res["8"].files)

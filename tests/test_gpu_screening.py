@@ -137,6 +137,7 @@ def test_small_batches_run_in_one_pass_large_ones_in_two(golden_dir):
     from qsp_slam_amd.reconstruct.optimizer import Optimizer
     d = DeepSdfDecoder.from_npz(os.path.join(golden_dir, "decoder_8x512.npz"))
     d.set_precision("fp16x2")
+    d.set_screening_min_samples(-1)      # (a session run with QSP_SCREENING in the environment forces two passes: back to automatic)
     opt = Optimizer(d, make_cfg(so.JointConfig(n_iter=2)))
     objs = synth.make_object_views(31, 6, 500, n_fg=256, n_bg=200)
     T0, hyp = bench.flip_states(objs, 4)

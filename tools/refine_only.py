@@ -10,8 +10,7 @@ w = bench.WORKLOADS[name]
 n_obj = int(sys.argv[2]) if len(sys.argv) > 2 else w["n_obj"]
 iters = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 dec = DeepSdfDecoder.from_npz(os.path.join(ROOT, "tests", "golden", "decoder_8x512.npz"))
-if os.environ.get("QSP_SCREENING") and dec.precision == "fp16x2":      # the bench default: two-pass ray-sample forward
-    dec.set_render_screening(float(os.environ["QSP_SCREENING"]))
+# (QSP_PRECISION=fp16x2 QSP_SCREENING=0.01 in the environment select the bench default: DeepSdfDecoder reads them itself)
 objs = synth.make_object_views(1000, n_obj, w["n_pts"], n_fg=w["n_fg"], n_bg=w["n_bg"])
 opt = Optimizer(dec, bench.joint_cfg(iters))
 T0, hyp = bench.flip_states(objs, 4)

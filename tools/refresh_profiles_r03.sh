@@ -31,5 +31,18 @@ python3 tools/pmc_summary.py $O/pmcH > $O/r03_c4_pmcH_summary.txt
 rm -rf $O/pmcF $O/pmcW $O/pmcH
 unset QSP_PRECISION QSP_SCREENING
 echo "pmc done"
+# evidence for the screened pipe (bench.py's default): the margin it has to cover, the randomised parity sweep and the WHOLE GPU
+# suite with every decoder of the session on it (every batch screened whatever its size), next to the default-pipe suite
+timeout -k 10 300 python3 tools/screen_margin.py 0.01 > $O/r03_screen_margin.txt 2> $O/screen_margin.err
+QSP_PRECISION=fp16x2 QSP_SCREENING=0.01 timeout -k 10 400 python3 tools/parity_sweep.py 120 > $O/r03_parity_sweep_fp16x2_screened.txt 2>&1
+timeout -k 10 300 python3 tools/parity_report.py $O/r03_parity.json > $O/parity.log 2>&1
+QSP_MARGINS_OUT=$O/r03_test_margins.json timeout -k 10 900 python3 -m pytest tests -m gpu -q > $O/tests.log 2>&1 || true
+tail -3 $O/tests.log
+QSP_PRECISION=fp16x2 QSP_SCREENING=0.01 QSP_MARGINS_OUT=$O/r03_test_margins_fp16x2_screened.json timeout -k 10 900 python3 -m pytest tests -m gpu -q > $O/tests_fp16x2.log 2>&1 || true
+tail -3 $O/tests_fp16x2.log
+timeout -k 10 120 python3 tools/lat_calls.py fp16x2 > $O/r03_latency.txt 2>&1
+timeout -k 10 120 python3 tools/lat_calls.py fp16x2 32 >> $O/r03_latency.txt 2>&1
+timeout -k 10 120 python3 tools/lat_calls.py f32 >> $O/r03_latency.txt 2>&1
+cat $O/r03_latency.txt
 cat $O/r03_c4_pmc_clock_w4.txt $O/r03_c4_pmc_clock_w8.txt
 grep -A1 "k_mlp_jtj\|k_mlp_fwd" $O/r03_c4_pmcF_summary.txt $O/r03_c4_pmcW_summary.txt || true
