@@ -431,7 +431,8 @@ __global__ __launch_bounds__(H2_THREADS) void k_mlp_fwd_h2(const HypState* __res
 // work item; writes the screening value and appends the samples with |s1| < band_th (or NaN) to the hypothesis's band list.
 // The order of a band list depends on which workgroup finished first; nothing downstream does: the second pass writes each
 // listed sample's value to its own slot, and a sample's value does not depend on its position in a tile.
-__global__ __launch_bounds__(H2_THREADS) void k_mlp_fwd_h1(HypState* __restrict__ st, const ObjView* __restrict__ objs,
+template <int NW>      // waves per workgroup: 4 x 512 registers or 8 x 256 (mlp_tile_h1)
+__global__ __launch_bounds__(64 * NW) void k_mlp_fwd_h1(HypState* __restrict__ st, const ObjView* __restrict__ objs,
                                                             const float* __restrict__ rays, RefineCfg cfg, const MlpParams* __restrict__ P,
                                                             const int32_t* __restrict__ valid_rk, int64_t rk_stride,
                                                             float* __restrict__ sdf_valid, const int2* __restrict__ work,
@@ -446,10 +447,10 @@ __global__ __launch_bounds__(H2_THREADS) void k_mlp_fwd_h1(HypState* __restrict_
     int h_cached = -1;
     {   // the decoder's constants, once per workgroup
         const MlpParams& Pp = *P;
-        for (int i = threadIdx.x; i < HID; i += H2_THREADS) s.w8[i] = Pp.w8[i];
+        for (int i = threadIdx.x; i < HID; i += 64 * NW) s.w8[i] = Pp.w8[i];
 #pragma unroll
         for (int l = 1; l < 8; ++l)
-            for (int i = threadIdx.x; i < HID; i += H2_THREADS) s.bias[(l - 1) * HID + i] = Pp.bias[l][i];
+            for (int i = threadIdx.x; i < HID; i += 64 * NW) s.bias[(l - 1) * HID + i] = Pp.bias[l][i];
     }
     for (;;) {
         if (threadIdx.x == 0) s_item = atomicAdd(&qctl[1], 1);
@@ -465,7 +466,7 @@ __global__ __launch_bounds__(H2_THREADS) void k_mlp_fwd_h1(HypState* __restrict_
         float* out = sdf_valid + h * rk_stride;
         if (h != h_cached) {                   // per-hypothesis staging: pose, code parts of layers 0 and 4
             if (threadIdx.x >= 64 && threadIdx.x < 80) Tsh[threadIdx.x - 64] = S.T_oc[threadIdx.x - 64];
-            for (int i = threadIdx.x; i < HID; i += H2_THREADS) {
+            for (int i = threadIdx.x; i < HID; i += 64 * NW) {
                 s.c0[i] = c0_all[(size_t)h * 2 * HID + i];
                 s.c4[i] = c0_all[(size_t)h * 2 * HID + HID + i];
             }
@@ -488,7 +489,7 @@ __global__ __launch_bounds__(H2_THREADS) void k_mlp_fwd_h1(HypState* __restrict_
             s.xin[4 * threadIdx.x + 3] = 0.f;
         }
         __syncthreads();
-        mlp_tile_h1<2>(s, P, amax);
+        mlp_tile_h1<2, NW>(s, P, amax);
         if (threadIdx.x < H1_ROWS) {           // (waves 0 and 1, all lanes)
             const int v = t * H1_ROWS + threadIdx.x;
             bool in = false;
@@ -1364,14 +1365,15 @@ __global__ __launch_bounds__(H2_THREADS) void k_decode_h2(const float* __restric
 
 // the screening tile (mlp_tile_h1) on explicit query points: what the first pass of the screened forward computes, exposed for
 // the tests and the margin measurement (qsp_decode_sdf_screen) -- these are NOT SDF values of the decoder's precision
-__global__ __launch_bounds__(H2_THREADS) void k_decode_screen(const float* __restrict__ code, const float* __restrict__ xyz, int64_t n,
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_decode_screen(const float* __restrict__ code, const float* __restrict__ xyz, int64_t n,
                                                               const MlpParams* __restrict__ P, float* __restrict__ y_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     MlpSmemH1& s = *reinterpret_cast<MlpSmemH1*>(smem_raw);
     float* codes = s.red;                   // (free until the first tile's layer 8)
     if (threadIdx.x < CODE_LEN) codes[threadIdx.x] = code[threadIdx.x];
     __syncthreads();
-    for (int u = threadIdx.x; u < HID; u += H2_THREADS) {
+    for (int u = threadIdx.x; u < HID; u += 64 * NW) {
         const float* w = P->w0c + (size_t)u * CODE_LEN;
         const float* w4 = P->w4c + (size_t)u * CODE_LEN;
         float a = P->bias[0][u], a4 = P->bias[4][u];
@@ -1386,7 +1388,7 @@ __global__ __launch_bounds__(H2_THREADS) void k_decode_screen(const float* __res
     }
 #pragma unroll
     for (int l = 1; l < 8; ++l)
-        for (int i = threadIdx.x; i < HID; i += H2_THREADS) s.bias[(l - 1) * HID + i] = P->bias[l][i];
+        for (int i = threadIdx.x; i < HID; i += 64 * NW) s.bias[(l - 1) * HID + i] = P->bias[l][i];
     float amax = 0.f;
     for (int64_t t = blockIdx.x; t * H1_ROWS < n; t += gridDim.x) {
         __syncthreads();
@@ -1400,7 +1402,7 @@ __global__ __launch_bounds__(H2_THREADS) void k_decode_screen(const float* __res
             s.xin[4 * threadIdx.x + 3] = 0.f;
         }
         __syncthreads();
-        mlp_tile_h1<2>(s, P, amax);
+        mlp_tile_h1<2, NW>(s, P, amax);
         if (threadIdx.x < H1_ROWS) {
             const int64_t v = t * H1_ROWS + threadIdx.x;
             if (v < n) y_out[v] = s.y[threadIdx.x];

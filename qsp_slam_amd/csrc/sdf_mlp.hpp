@@ -1666,7 +1666,8 @@ __device__ __forceinline__ void ringh1_prime(WRingH1<PF, NCB>& R, const float4* 
 template <int KS, int PF, int NCB, int NR>
 __device__ __forceinline__ void gemm_h1(const _Float16* __restrict__ img, const float4* __restrict__ w_, int cs,
                                         const float4* __restrict__ nw_, int ncs, WRingH1<PF, NCB>& R, f32x16 (&acc)[NR][NCB], int lane) {
-    static_assert(KS % PF == 0 && KS >= 2 * PF && PF % 2 == 0 && NR == NCB, "shape");
+    static_assert(KS % PF == 0 && KS >= 2 * PF && PF % 2 == 0 && NR % NCB == 0, "shape");
+    constexpr int RPC = NR / NCB;          // row blocks of the next slab's operands read behind each column block's MFMAs
     gbytes w = (gbytes)w_;
     gbytes nw = (gbytes)nw_;
     uint32_t voff = 16u * lane;
@@ -1691,7 +1692,9 @@ __device__ __forceinline__ void gemm_h1(const _Float16* __restrict__ img, const 
 #pragma unroll
                 for (int r = 0; r < NR; ++r) acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bh[d & 1][r], acc[r][c], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                bh[(d & 1) ^ 1][c] = *reinterpret_cast<const f16x8*>(nb + c * 32 * LDH1);     // (NR == NCB: row block c of the next slab)
+#pragma unroll
+                for (int rr = 0; rr < RPC; ++rr)
+                    bh[(d & 1) ^ 1][c * RPC + rr] = *reinterpret_cast<const f16x8*>(nb + (c * RPC + rr) * 32 * LDH1);
                 if (c > 0) R.q[d][c - 1] = ldw(fb + (c - 1) * fcs + (size_t)(d * 2) * 64 * 16, voff);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -1711,10 +1714,11 @@ __device__ __forceinline__ void h1_store4(_Float16* img, int row, int u0, f32x4 
     *reinterpret_cast<f16x4*>(img + row * LDH1 + u0) = hi;
 }
 
-// 128 points staged in s.xin / s.c0 / s.c4 (+ the decoder's constants in s.bias / s.w8) -> s.y[row] = screening value
-template <int PF>
+// 128 points staged in s.xin / s.c0 / s.c4 (+ the decoder's constants in s.bias / s.w8) -> s.y[row] = screening value.
+// NW waves: 4 (one per SIMD, 128 units each) or 8 (two per SIMD, 64 units each: a wave's write-out overlaps the other's GEMM).
+template <int PF, int NW = 4>
 __device__ __forceinline__ void mlp_tile_h1(MlpSmemH1& s, const MlpParams* __restrict__ Pm, float& amax) {
-    constexpr int NR = 4;
+    constexpr int NR = 4, NCB = 16 / NW;
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1723,7 +1727,7 @@ __device__ __forceinline__ void mlp_tile_h1(MlpSmemH1& s, const MlpParams* __res
     int oz;
     asm volatile("s_mov_b32 %0, 0" : "=s"(oz));
     const MlpParams& P = Pm[oz];
-    f32x16 acc[NR][4];
+    f32x16 acc[NR][NCB];
     _Float16* img = s.img;
     if (tid < H1_ROWS) {      // the point as slab 0 of the image: columns 0..2 = xyz, 3..15 zero
         const f32x4 x = lds4(s.xin + 4 * tid);
@@ -1737,31 +1741,31 @@ __device__ __forceinline__ void mlp_tile_h1(MlpSmemH1& s, const MlpParams* __res
         *reinterpret_cast<f16x8*>(d) = hi;
         *reinterpret_cast<f16x8*>(d + 8) = z;
     }
-    const int cb0 = 4 * wave;
+    const int cb0 = NCB * wave;
     constexpr int KSH = HID / 16, KS4 = K4 / 16, CS = KSH * 2 * 64, CS4 = KS4 * 2 * 64;
 #define QSP_WH(L, KS_) (P.wfh[L] + (size_t)(cb0 * (KS_) * 2) * 64)
-    WRingH1<PF, 4> ring;
+    WRingH1<PF, NCB> ring;
     ringh1_prime(ring, QSP_WH(1, KSH), CS, lane);
     __syncthreads();
 #define QSP_FWD1(L, BIASPTR, GEMM_STMT)                                                                                  \
-    _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {                  \
-        const f32x4 bv_ = lds4((BIASPTR) + 128 * wave + 32 * c_ + 8 * g_ + 4 * h);                                       \
+    _Pragma("unroll") for (int c_ = 0; c_ < NCB; ++c_) _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {                \
+        const f32x4 bv_ = lds4((BIASPTR) + 32 * NCB * wave + 32 * c_ + 8 * g_ + 4 * h);                                  \
         _Pragma("unroll") for (int r_ = 0; r_ < NR; ++r_) _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_)               \
-            acc[r_][c_][4 * g_ + q_] = bv_[q_];                                                                          \
+            acc[r_][c_][4 * g_ + q_] = bv_[q_];                                                                        \
         __builtin_amdgcn_sched_barrier(0);                                                                               \
     }                                                                                                                    \
     GEMM_STMT;                                                                                                           \
     /* the accumulators stay in the Acc file until the write-out reads them one register quad at a time: without this the */ \
     /* register allocator forms VGPR copies of ~50 of them in the GEMM loop's latch, every iteration, and spills those     */ \
-    _Pragma("unroll") for (int r_ = 0; r_ < NR; ++r_) _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_)                   \
-        asm volatile("" : "+a"(acc[r_][c_]));                                                                            \
+    _Pragma("unroll") for (int r_ = 0; r_ < NR; ++r_) _Pragma("unroll") for (int c_ = 0; c_ < NCB; ++c_)                 \
+        asm volatile("" : "+a"(acc[r_][c_]));                                                                          \
     __syncthreads();                                                                                                     \
-    _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {                  \
-        const int u0_ = 128 * wave + 32 * c_ + 8 * g_ + 4 * h;                                                           \
+    _Pragma("unroll") for (int c_ = 0; c_ < NCB; ++c_) _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {                \
+        const int u0_ = 32 * NCB * wave + 32 * c_ + 8 * g_ + 4 * h;                                                      \
         _Pragma("unroll") for (int r_ = 0; r_ < NR; ++r_) {                                                              \
             f32x4 v_;                                                                                                    \
             _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                           \
-                const float x_ = acc[r_][c_][4 * g_ + q_];                                                               \
+                const float x_ = acc[r_][c_][4 * g_ + q_];                                                             \
                 v_[q_] = x_ > 0.f ? x_ : 0.f;                                                                            \
             }                                                                                                            \
             h1_store4(img, 32 * r_ + (lane & 31), u0_, v_, amax);                                                        \
@@ -1769,7 +1773,7 @@ __device__ __forceinline__ void mlp_tile_h1(MlpSmemH1& s, const MlpParams* __res
         __builtin_amdgcn_sched_barrier(0);                                                                               \
     }                                                                                                                    \
     __syncthreads();
-#define QSP_GEMM1(L, KS_, NW, NKS) gemm_h1<KS_, PF, 4, NR>(img, QSP_WH(L, KS_), (KS_) * 2 * 64, NW, (NKS) * 2 * 64, ring, acc, lane)
+#define QSP_GEMM1(L, KS_, NXW, NKS) gemm_h1<KS_, PF, NCB, NR>(img, QSP_WH(L, KS_), (KS_) * 2 * 64, NXW, (NKS) * 2 * 64, ring, acc, lane)
     {   // layer 0: one slab of the same product (xyz columns of W0; the code part is s.c0)
         gbytes w = (gbytes)QSP_WH(0, 1);
         const uint32_t voff = 16u * lane;
@@ -1777,7 +1781,7 @@ __device__ __forceinline__ void mlp_tile_h1(MlpSmemH1& s, const MlpParams* __res
         QSP_FWD1(0, s.c0, {
             f16x8 bh0[NR];
             _Pragma("unroll") for (int r = 0; r < NR; ++r) bh0[r] = *reinterpret_cast<const f16x8*>(b_row + r * 32 * LDH1);
-            _Pragma("unroll") for (int c = 0; c < 4; ++c) {
+            _Pragma("unroll") for (int c = 0; c < NCB; ++c) {
                 const f16x8 wh = as_f16x8(ldw(w + (size_t)(c * 2) * 64 * 16, voff));
                 _Pragma("unroll") for (int r = 0; r < NR; ++r)
                     acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bh0[r], acc[r][c], 0, 0, 0);
@@ -1802,8 +1806,9 @@ __device__ __forceinline__ void mlp_tile_h1(MlpSmemH1& s, const MlpParams* __res
 #undef QSP_FWD1
 #undef QSP_GEMM1
 #undef QSP_WH
-    // layer 8: 512 -> 1, tanh: wave = k segment of 128, lane = rows lane and lane + 64
-    {
+    // layer 8: 512 -> 1, tanh: wave = k segment of 128 (waves 0..3 whatever NW is: same partial sums, same order), lane = rows
+    // lane and lane + 64
+    if (NW == 4 || wave < 4) {
         const float* w = s.w8 + 128 * wave;
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr) {

@@ -39,6 +39,9 @@
 #ifndef QSP_JTJ_WAVES_DEFAULT
 #define QSP_JTJ_WAVES_DEFAULT 8
 #endif
+#ifndef QSP_SCREEN_WAVES_DEFAULT
+#define QSP_SCREEN_WAVES_DEFAULT 4
+#endif
 
 
 // =================================================================================================================
@@ -511,6 +514,15 @@ static int jtj_waves() {
     return w;
 }
 
+// ... and of the screening pass (QSP_SCREEN_WAVES; same values either way)
+static int screen_waves() {
+    static int w = 0;
+    if (!w) {
+        const char* e = getenv("QSP_SCREEN_WAVES");
+        w = (e && atoi(e) == 8) ? 8 : ((e && atoi(e) == 4) ? 4 : QSP_SCREEN_WAVES_DEFAULT);
+    }
+    return w;
+}
 static int jtj_waves_t32() {
     static int w = 0;
     if (!w) {
@@ -528,8 +540,10 @@ static int mlp_attr_once() {
     QSP_HIP(hipFuncSetAttribute((const void*)k_mlp_fwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     QSP_HIP(hipFuncSetAttribute((const void*)k_decode<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     QSP_HIP(hipFuncSetAttribute((const void*)k_mlp_fwd_h2<2>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    QSP_HIP(hipFuncSetAttribute((const void*)k_mlp_fwd_h1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MlpSmemH1)));
-    QSP_HIP(hipFuncSetAttribute((const void*)k_decode_screen, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MlpSmemH1)));
+    QSP_HIP(hipFuncSetAttribute((const void*)k_mlp_fwd_h1<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MlpSmemH1)));
+    QSP_HIP(hipFuncSetAttribute((const void*)k_mlp_fwd_h1<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MlpSmemH1)));
+    QSP_HIP(hipFuncSetAttribute((const void*)k_decode_screen<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MlpSmemH1)));
+    QSP_HIP(hipFuncSetAttribute((const void*)k_decode_screen<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MlpSmemH1)));
     QSP_HIP(hipFuncSetAttribute((const void*)k_decode_h2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     QSP_HIP(hipFuncSetAttribute((const void*)k_decode_h2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     QSP_HIP(hipFuncSetAttribute((const void*)k_mlp_jtj_h2<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
@@ -731,7 +745,10 @@ extern "C" int qsp_decode_sdf_screen(qsp_decoder* d, const float* code, const fl
     if (e == hipSuccess) e = hipMemcpyAsync(dx, xyz, n * 3 * sizeof(float), hipMemcpyHostToDevice, d->stream);
     if (e == hipSuccess) {
         const int grid = (int)std::min<int64_t>((n + H1_ROWS - 1) / H1_ROWS, 4096);
-        hipLaunchKernelGGL(k_decode_screen, dim3(grid), dim3(H2_THREADS), sizeof(MlpSmemH1), d->stream, dc, dx, n, d->Pd, dy);
+        if (screen_waves() == 8)
+            hipLaunchKernelGGL(k_decode_screen<8>, dim3(grid), dim3(512), sizeof(MlpSmemH1), d->stream, dc, dx, n, d->Pd, dy);
+        else
+            hipLaunchKernelGGL(k_decode_screen<4>, dim3(grid), dim3(H2_THREADS), sizeof(MlpSmemH1), d->stream, dc, dx, n, d->Pd, dy);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(s1_out, dy, n * sizeof(float), hipMemcpyDeviceToHost, d->stream);
@@ -1048,9 +1065,14 @@ static int run_once(qsp_refine_batch* b, int32_t n_iter, bool* hit) {
             if (screen) {                                                            //  thousands of ray samples fill the chip either way)
                 // two passes (QSP_DEC_OPT_RENDER_SCREENING): every sample on the one-product tile, then the band around the
                 // surface on the split-fp16 tile; the queue's control words and item list are reused behind the first pass
-                hipLaunchKernelGGL(k_mlp_fwd_h1, dim3(b->n_cu), dim3(H2_THREADS), sizeof(MlpSmemH1), s, b->st, b->objs, b->rays,
-                                   cfg, b->dec->Pd, b->valid_rk, b->rk_stride, b->sdf_valid, b->work_fwd, b->qctl, b->c0_all,
-                                   b->band_idx, cfg.cut_off + b->dec->screen_margin);
+                if (screen_waves() == 8)
+                    hipLaunchKernelGGL(k_mlp_fwd_h1<8>, dim3(b->n_cu), dim3(512), sizeof(MlpSmemH1), s, b->st, b->objs, b->rays,
+                                       cfg, b->dec->Pd, b->valid_rk, b->rk_stride, b->sdf_valid, b->work_fwd, b->qctl, b->c0_all,
+                                       b->band_idx, cfg.cut_off + b->dec->screen_margin);
+                else
+                    hipLaunchKernelGGL(k_mlp_fwd_h1<4>, dim3(b->n_cu), dim3(H2_THREADS), sizeof(MlpSmemH1), s, b->st, b->objs, b->rays,
+                                       cfg, b->dec->Pd, b->valid_rk, b->rk_stride, b->sdf_valid, b->work_fwd, b->qctl, b->c0_all,
+                                       b->band_idx, cfg.cut_off + b->dec->screen_margin);
                 hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, s, 2, b->st, b->objs, nH, b->nw_sdf, nw_total - b->nw_sdf,
                                    b->work_fwd, b->qctl, TILE_P);
                 hipLaunchKernelGGL(k_mlp_fwd_h2<2>, dim3(b->n_cu), dim3(H2_THREADS), sizeof(MlpSmem), s, b->st, b->objs, b->rays,

@@ -1,6 +1,7 @@
 """The split-fp16 Jacobian kernel exists with four waves of 512 registers per workgroup and with eight of 256 (csrc/sdf_mlp.hpp:
-mlp_tile_h2<.., NW>): the same arithmetic in the same order, so the two must give the same bits.  Each variant is selected per
-process (QSP_JTJ_WAVES), so the comparison runs the same seeded batch in two child processes."""
+mlp_tile_h2<.., NW>), and so does the screening pass of the render forward (mlp_tile_h1<.., NW>): the same arithmetic in the same
+order, so the two must give the same bits.  Each variant is selected per process (QSP_JTJ_WAVES, QSP_JTJ_WAVES_T32,
+QSP_SCREEN_WAVES), so the comparison runs the same seeded batch in two child processes."""
 import os
 import subprocess
 import sys
@@ -22,6 +23,8 @@ from qsp_slam_amd.reconstruct.optimizer import Optimizer, RefineBatch, _joint_cf
 from tests.test_gpu_sdf import make_cfg
 dec = DeepSdfDecoder.from_npz(os.path.join(sys.argv[1], "tests", "golden", "decoder_8x512.npz"))
 dec.set_precision("fp16x2")
+dec.set_render_screening(0.01)          # (the screening pass has the two forms as well: QSP_SCREEN_WAVES)
+dec.set_screening_min_samples(0)
 out = {}
 for tile in (64, 32):
     dec.set_tile_points(tile)
@@ -44,7 +47,7 @@ def test_four_and_eight_wave_kernels_give_the_same_bits(tmp_path):
     res = {}
     for waves in ("4", "8"):
         path = str(tmp_path / ("w%s.npz" % waves))
-        env = dict(os.environ, QSP_JTJ_WAVES=waves, QSP_JTJ_WAVES_T32=waves)
+        env = dict(os.environ, QSP_JTJ_WAVES=waves, QSP_JTJ_WAVES_T32=waves, QSP_SCREEN_WAVES=waves)
         subprocess.run([sys.executable, "-c", CHILD, ROOT, path], check=True, env=env, timeout=600)
         res[waves] = np.load(path)
     assert sorted(res["4"].files) == sorted(res["8"].files)

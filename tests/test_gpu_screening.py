@@ -147,3 +147,33 @@ def test_small_batches_run_in_one_pass_large_ones_in_two(golden_dir):
     ref = run_batch(d, opt, objs, hyp, T0, None, 2, False)
     assert_same_bits(many, ref, "auto")
     d.close()
+
+
+@pytest.mark.parametrize("which", ["use_tanh", "small_4x256_c32"])
+def test_screening_is_bit_identical_on_other_members_of_the_decoder_family(golden_dir, which):
+    """the same contract with NetworkSpecs.use_tanh (the screening value is tanh(tanh(.)) like the real one) and with the embedded
+    4 x 256 / code 32 decoder (39 unknowns): screened == one pass, bit for bit, on the reference-generated joint cases"""
+    from qsp_slam_amd import DeepSdfDecoder
+    from qsp_slam_amd.reconstruct.optimizer import Optimizer
+    if which == "use_tanh":
+        d = DeepSdfDecoder.from_npz(os.path.join(golden_dir, "decoder_8x512.npz"))
+        d.set_use_tanh(True)
+        z = np.load(os.path.join(golden_dir, "sdf_usetanh_joint_m400.npz"))
+        L = 64
+    else:
+        d = DeepSdfDecoder.from_npz(os.path.join(golden_dir, "decoder_4x256_c32.npz"))
+        z = np.load(os.path.join(golden_dir, "sdf_small_joint_m400.npz"))
+        L = 32
+    d.set_precision("fp16x2")
+    d.set_screening_min_samples(0)
+    opt = Optimizer(d, make_cfg(z, code_len=L))
+    obj = dict(pts=z["pts"], rays=z["rays"], depth=z["depth"])
+    a = run_batch(d, opt, [obj], [0], z["t_cam_obj"][None], None, 3, False)
+    b = run_batch(d, opt, [obj], [0], z["t_cam_obj"][None], None, 3, True)
+    assert_same_bits(a, b, which)
+    assert a["good"][0] and 0 < b["prof"].pts_band < b["prof"].pts_fwd
+    x = np.random.default_rng(1).uniform(-1, 1, size=(4096, 3)).astype(np.float32)
+    code = np.zeros(L, np.float32)
+    assert within("fp16x2/screening/%s_max_abs_s1_minus_s3" % which, np.abs(d.decode_sdf_screen(code, x) - d.decode_sdf(code, x)).max(),
+                  MARGIN / 8)
+    d.close()

@@ -14,8 +14,10 @@ BUDGET = {
     "qsp::k_mlp_jtj_h2<2, 8>": (32, 128, 0),
     "qsp::k_mlp_jtj_h2<1, 8>": (0, 0, 0),
     "qsp::k_mlp_fwd_h2<2>": (24, 96, 0),
-    "qsp::k_mlp_fwd_h1": (0, 0, 0),
-    "qsp::k_decode_screen": (0, 0, 0),
+    "qsp::k_mlp_fwd_h1<4>": (0, 0, 0),
+    "qsp::k_mlp_fwd_h1<8>": (20, 80, 0),
+    "qsp::k_decode_screen<4>": (0, 0, 0),
+    "qsp::k_decode_screen<8>": (20, 80, 0),
     "qsp::k_decode_h2<false>": (24, 96, 0),
     "qsp::k_decode_h2<true>": (40, 160, 0),
     "qsp::k_mlp_fwd<false>": (0, 0, 0),
