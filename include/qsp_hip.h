@@ -101,6 +101,10 @@ void qsp_decoder_destroy(qsp_decoder* dec);
  * (rays x depth samples, summed over the hypotheses) than this; -1 = more than two rounds of 64-point tiles over the chip.  A
  * batch that fits one round -- one object per call -- is one tile deep either way and faster in one pass.  The result is the
  * same bits whichever way a run goes.  0 = always screen (tests).
+ * QSP_DEC_OPT_NARROW_TILE (1 / 0): decoders much smaller than the 8 x 512 shape they are embedded in (e.g. 4 x 256 / code 32: less
+ * than half of its multiply-adds) run the NARROW form of the split-fp16 tile by default -- identity slots, all-zero k-slabs and
+ * all-zero column blocks are skipped, exactly; 0 evaluates the embedded form at the full shape's cost (measurements, tests);
+ * QSP_DEC_CNT_NARROW_TILE says which is in use.  Other pipes (f32, split bf16) always run the embedded form.
  * QSP_DEC_OPT_USE_TANH (0 / 1): NetworkSpecs.use_tanh of deep_sdf/deep_sdf_decoder.py:66-68,92-94 -- a tanh on the output
  * layer in front of the final tanh.
  * QSP_DEC_OPT_RANGE_FALLBACK (1, the default / 0): when a split-fp16 kernel meets an activation or gradient outside fp16's
@@ -108,8 +112,8 @@ void qsp_decoder_destroy(qsp_decoder* dec);
  * qsp_decoder_get_counter(QSP_DEC_CNT_RANGE_FALLBACKS)); 0 fails the call with QSP_ERR_UNSUPPORTED as round 2 did. */
 enum { QSP_DEC_OPT_FORWARD_PRECISION = 1, QSP_DEC_OPT_JACOBIAN_PRECISION = 2, QSP_DEC_OPT_TILE_POINTS = 3,
        QSP_DEC_OPT_RENDER_SCREENING = 4, QSP_DEC_OPT_USE_TANH = 5, QSP_DEC_OPT_RANGE_FALLBACK = 6,
-       QSP_DEC_OPT_SCREENING_MIN_SAMPLES = 7 };
-enum { QSP_DEC_CNT_RANGE_FALLBACKS = 1, QSP_DEC_CNT_ARENA_REUSED = 2, QSP_DEC_CNT_ARENA_CREATED = 3 };
+       QSP_DEC_OPT_SCREENING_MIN_SAMPLES = 7, QSP_DEC_OPT_NARROW_TILE = 8 };
+enum { QSP_DEC_CNT_RANGE_FALLBACKS = 1, QSP_DEC_CNT_ARENA_REUSED = 2, QSP_DEC_CNT_ARENA_CREATED = 3, QSP_DEC_CNT_NARROW_TILE = 4 };
 /* lifetime counters of a decoder: calls that were re-run on the f32 pipe because a value left fp16's range; calls of
  * qsp_reconstruct_objects that refilled the decoder's resident batch / that had to (re)allocate it */
 int64_t qsp_decoder_get_counter(qsp_decoder* dec, int32_t counter);

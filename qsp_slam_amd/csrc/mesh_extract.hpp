@@ -395,8 +395,10 @@ static int mesh_decode(qsp_mesh_extractor* m, const float* code, bool* hit) {
     const int64_t tiles = (m->n + TILE_P - 1) / TILE_P;
     const int grid = (int)std::min<int64_t>(tiles, 4096);
     if (m->dec->fwd_bf3 == 2)
-        hipLaunchKernelGGL(k_decode_h2<false>, dim3(grid), dim3(H2_THREADS), sizeof(MlpSmem), s, m->code, m->xyz, m->n, m->dec->Pd, m->sdf,
-                           (float*)nullptr);
+        if (m->dec->P.narrow) hipLaunchKernelGGL((k_decode_h2<false, true>), dim3(grid), dim3(H2_THREADS), sizeof(MlpSmem), s, m->code, m->xyz, m->n,
+                                                 m->dec->Pd, m->sdf, (float*)nullptr);
+        else hipLaunchKernelGGL((k_decode_h2<false, false>), dim3(grid), dim3(H2_THREADS), sizeof(MlpSmem), s, m->code, m->xyz, m->n, m->dec->Pd,
+                                m->sdf, (float*)nullptr);
     else if (m->dec->fwd_bf3)
         hipLaunchKernelGGL((k_decode<false, true>), dim3(grid), dim3(MLP_THREADS), sizeof(MlpSmem), s, m->code, m->xyz, m->n,
                            m->dec->Pd, m->sdf, (float*)nullptr);

@@ -360,8 +360,9 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void k_mlp_fwd(const HypState* __re
 }
 
 // the same work queue on the split-fp16 tile: four waves per workgroup (mlp_tile_h2)
-template <int NR>      // NR point blocks of 32 per tile (QSP_DEC_OPT_TPOINTS)
-__global__ __launch_bounds__(H2_THREADS) void k_mlp_fwd_h2(const HypState* __restrict__ st,
+// NARROW: mlp_tile_h2's form for small decoders, run with NW = 8 waves so that the column blocks that exist spread over all SIMDs
+template <int NR, bool NARROW = false, int NW = 4>      // NR point blocks of 32 per tile (QSP_DEC_OPT_TPOINTS)
+__global__ __launch_bounds__(64 * NW) void k_mlp_fwd_h2(const HypState* __restrict__ st,
                                                             const ObjView* __restrict__ objs,
                                                             const float* __restrict__ rays, RefineCfg cfg, const MlpParams* __restrict__ P,
                                                             const int32_t* __restrict__ valid_rk, int64_t rk_stride,
@@ -394,7 +395,7 @@ __global__ __launch_bounds__(H2_THREADS) void k_mlp_fwd_h2(const HypState* __res
         float* out = sdf_valid + h * rk_stride;
         if (h != h_cached) {                   // per-hypothesis staging: code, pose, layer-0 code part
             stage_code_T(s, S, Tsh);
-            for (int i = threadIdx.x; i < HID; i += H2_THREADS) {
+            for (int i = threadIdx.x; i < HID; i += 64 * NW) {
                 s.c0[i] = c0_all[(size_t)h * 2 * HID + i];
                 s.c4[i] = c0_all[(size_t)h * 2 * HID + HID + i];
             }
@@ -417,7 +418,7 @@ __global__ __launch_bounds__(H2_THREADS) void k_mlp_fwd_h2(const HypState* __res
             s.xin[4 * threadIdx.x + 3] = 0.f;
         }
         __syncthreads();
-        mlp_tile_h2<false, 2, true, NR>(s, P, amax, !staged);      // (the decoder's constants: staged by the first tile of the workgroup)
+        mlp_tile_h2<false, 2, !NARROW, NR, NW, NARROW>(s, P, amax, !staged);      // (the decoder's constants: staged by the first tile of the workgroup)
         staged = true;
         if (threadIdx.x < TP) {
             const int v = t * TP + threadIdx.x;
@@ -821,7 +822,7 @@ __device__ __forceinline__ jtj_kargs_t jtj_kernargs() {
 }
 
 // NW = 4: one wave of 512 registers per SIMD; NW = 8: two of 256 (mlp_tile_h2), the six J~^T J~ tiles on waves 0..5.
-template <int NR, int NW = 4>      // NR point blocks of 32 per tile (QSP_DEC_OPT_TPOINTS)
+template <int NR, int NW = 4, bool NARROW = false>      // NR point blocks of 32 per tile (QSP_DEC_OPT_TPOINTS)
 __global__ __launch_bounds__(64 * NW) void k_mlp_jtj_h2(JtjArgs /* read through jtj_kernargs() only */) {
     constexpr int NT = 64 * NW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -898,7 +899,7 @@ __global__ __launch_bounds__(64 * NW) void k_mlp_jtj_h2(JtjArgs /* read through 
         // ---- the tile: live across it are item, t, staged (scalars) and amax ---------------------------------------------------
         {
             const MlpParams* Pm = jtj_kernargs()->P;
-            mlp_tile_h2<true, 2, false, NR, NW>(s, Pm, amax, !staged);
+            mlp_tile_h2<true, 2, false, NR, NW, NARROW>(s, Pm, amax, !staged);
             staged = true;
         }
         // ---- phase 2: Jacobian rows  J~[p] = [ s*(g_x . [I | -x^ | x]) (7) | s*g_z (64) | r~ ],  J~^T J~ -----------------------
@@ -1312,7 +1313,7 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void k_decode(const float* __restri
 }
 
 // decode on the split-fp16 tile (four waves per workgroup)
-template <bool GRAD>
+template <bool GRAD, bool NARROW = false>
 __global__ __launch_bounds__(H2_THREADS) void k_decode_h2(const float* __restrict__ code, const float* __restrict__ xyz, int64_t n,
                                                           const MlpParams* __restrict__ P, float* __restrict__ y_out,
                                                           float* __restrict__ grad_out) {
@@ -1346,7 +1347,7 @@ __global__ __launch_bounds__(H2_THREADS) void k_decode_h2(const float* __restric
             s.xin[4 * threadIdx.x + 3] = 0.f;
         }
         __syncthreads();
-        mlp_tile_h2<GRAD, 2>(s, P, amax, !staged);
+        mlp_tile_h2<GRAD, 2, !GRAD && !NARROW, 2, 4, NARROW>(s, P, amax, !staged);
         staged = true;
         if (threadIdx.x < TILE_P) {
             const int64_t v = t * TILE_P + threadIdx.x;

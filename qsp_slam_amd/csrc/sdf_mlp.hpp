@@ -87,6 +87,15 @@ struct MlpParams {
     const float4* wbh4s;    // split-fp16 backward weights of layer 4's skip columns (inputs 445..511 = [code | xyz]), packed like wbh[0]
     int* range_flag;        // set by the split-fp16 kernels when a value they had to split was outside fp16's range
     int use_tanh;           // NetworkSpecs.use_tanh: tanh on the output layer in front of the final tanh (deep_sdf_decoder.py:92-94)
+    // Narrow decoders (a member of the family embedded into the 8 x 512 shape, e.g. 4 x 256 / code 32): what the NARROW form of the
+    // split-fp16 tile may skip, exactly -- identity slots, all-zero k-slabs, all-zero column blocks (pack_weights fills these from
+    // the embedded matrices; `narrow` = the decoder is small enough for the skipping to pay).
+    int narrow;
+    uint8_t skip[8];        // slot l is an identity layer of the embedding
+    uint8_t ks_in[8];       // slabs of 16 input columns that carry weights (slot 4: of its [h3] part), even, >= 4
+    uint8_t ks_out[8];      // slabs of 16 outputs that exist (the contraction length of the slot's backward product), even, >= 4
+    uint8_t ncb_in[8];      // column blocks of 32 inputs that exist (the width of the slot's backward product)
+    uint8_t ncb_out[8];     // column blocks of 32 outputs that exist
 };
 
 // The network's output and the seed of the backward pass from the last layer's pre-activation t (deep_sdf_decoder.py:92-94,
@@ -1171,10 +1180,12 @@ __device__ __forceinline__ void ringh_prime(WRingH<PF, NCB>& R, const float4* __
 // acc / acc2 [r][c] += image rows [32 r, 32 r + 32) x slabs [0, KS) * W for NCB column blocks; w = base of the first column
 // block, consecutive column blocks `cs` float4 apart, nw / ncs the same for the next GEMM (its first PF slabs are fetched by
 // this one's last iterations).  img = the first row of row block 0.
-template <int KS, int PF, int NCB, int NR, bool HAND = true, bool PRIMED = false>
+template <int KS, int PF, int NCB, int NR, bool HAND = true, bool PRIMED = false, bool RT = false>
 __device__ __forceinline__ void gemm_h2(const _Float16* __restrict__ img, const float4* __restrict__ w_, int cs,
                                         const float4* __restrict__ nw_, int ncs, WRingH<PF, NCB>& R, f32x16 (&acc)[NR][NCB],
-                                        f32x16 (&acc2)[NR][NCB], int lane) {
+                                        f32x16 (&acc2)[NR][NCB], int lane, int ks_run = KS) {
+    // RT: only the first ks_run slabs (a multiple of PF, at least 2 PF) carry weights -- narrow decoders
+    const int ks_end = RT ? ks_run : KS;
     static_assert(KS % PF == 0 && KS >= 2 * PF, "slab count must be a multiple of the prefetch depth, at least twice it");
     static_assert(PF % 2 == 0, "the operand sets alternate between consecutive slabs");
     // HAND: this GEMM's first PF slabs were fetched by the previous one and it fetches the next one's (the ring lives across the
@@ -1220,9 +1231,9 @@ __device__ __forceinline__ void gemm_h2(const _Float16* __restrict__ img, const 
 #define QSP_MFMA_H(acc_, a_, b_) asm volatile("" : "+a"(acc_) : "v"(a_), "v"(b_))
 #endif
 #pragma nounroll
-    for (int ks = 0; ks < KS; ks += PF) {
+    for (int ks = 0; ks < ks_end; ks += PF) {
         // fragments to fetch during this round: slabs ks + PF.. of this matrix, or the first PF slabs of the next one
-        const bool more = ks + PF < KS;
+        const bool more = ks + PF < ks_end;
         gbytes fb = more ? w + (size_t)(ks + PF) * 2 * 64 * 16 : nw;
         const size_t fcs = (size_t)(more ? cs : ncs) * 16;
 #pragma unroll
@@ -1300,6 +1311,33 @@ __device__ __forceinline__ void gemm_l0_h2(const _Float16* __restrict__ img, con
     }
 }
 
+// One slab of a packed matrix against one slab of the image: img_slab = the slab's first half of row 0, w = the slab's hi fragment
+// of this wave's first column block, consecutive column blocks cs float4 apart.  (Narrow decoders: the xyz slab of the latent_in
+// layer, which sits behind a gap of all-zero slabs.)
+template <int NR, int NCB>
+__device__ __forceinline__ void gemm_slab_h2(const _Float16* __restrict__ img_slab, const float4* __restrict__ w_, int cs,
+                                             f32x16 (&acc)[NR][NCB], f32x16 (&acc2)[NR][NCB], int lane) {
+    gbytes w = (gbytes)w_;
+    const uint32_t voff = 16u * lane;
+    const _Float16* b_row = img_slab + (lane & 31) * LDH + (lane >> 5) * 16;
+    f16x8 bh[NR], bl[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        bh[r] = *reinterpret_cast<const f16x8*>(b_row + r * 32 * LDH);
+        bl[r] = *reinterpret_cast<const f16x8*>(b_row + r * 32 * LDH + 8);
+    }
+#pragma unroll
+    for (int c = 0; c < NCB; ++c) {
+        const f16x8 wh = as_f16x8(ldw(w + ((size_t)c * cs + 0) * 16, voff)), wl = as_f16x8(ldw(w + ((size_t)c * cs + 64) * 16, voff));
+#pragma unroll
+        for (int r = 0; r < NR; ++r) QSP_MFMA_H(acc2[r][c], wl, bh[r]);
+#pragma unroll
+        for (int r = 0; r < NR; ++r) QSP_MFMA_H(acc2[r][c], wh, bl[r]);
+#pragma unroll
+        for (int r = 0; r < NR; ++r) QSP_MFMA_H(acc[r][c], wh, bh[r]);
+    }
+}
+
 // image (32 NR points x 512) x a matrix packed in three column blocks (96 padded columns), as 32x32 tiles.  NR = 2 (six tiles):
 // waves 0, 1 take column blocks 0, 1 for both point blocks, waves 2, 3 column block 2 for one point block each.  NR = 1 (three
 // tiles): waves 0..2 one column block each, wave 3 idle.  side_c0 / side_row / side_count say which tiles a wave holds;
@@ -1317,9 +1355,9 @@ template <int NR, int NW> __device__ __forceinline__ int side_row(int wave, int 
     if (NW == 8) return NR == 2 ? (wave & 1) : 0;
     return NR == 2 ? (wave < 2 ? r : wave - 2) : 0;
 }
-template <int PF, int NR, int NW>
+template <int PF, int NR, int NW, bool RT = false>
 __device__ __forceinline__ void gemm_side_h2(const _Float16* __restrict__ img, const float4* __restrict__ wb, int wave, int lane,
-                                             f32x4 (&out)[NR][4]) {
+                                             f32x4 (&out)[NR][4], int ks_run = HID / 16) {
     constexpr int KSH = HID / 16, CS = KSH * 2 * 64;
     const int c0 = side_c0<NR, NW>(wave);
     const float4* w0 = wb + (size_t)((c0 < 3 ? c0 : 0) * KSH * 2) * 64;
@@ -1330,12 +1368,12 @@ __device__ __forceinline__ void gemm_side_h2(const _Float16* __restrict__ img, c
 #pragma unroll
         for (int i = 0; i < 16; ++i) { g0[r][0][i] = 0.f; g2[r][0][i] = 0.f; }
     if (side_count<NR, NW>(wave) == NR) {
-        gemm_h2<KSH, PF, 1, NR, false>(img, w0, CS, w0, CS, ring0, g0, g2, lane);
+        gemm_h2<KSH, PF, 1, NR, false, false, RT>(img, w0, CS, w0, CS, ring0, g0, g2, lane, ks_run);
     } else if (side_count<NR, NW>(wave) == 1) {          // (NR == 2 only: one of the two point blocks)
         f32x16 g01[1][1], g21[1][1];
 #pragma unroll
         for (int i = 0; i < 16; ++i) { g01[0][0][i] = 0.f; g21[0][0][i] = 0.f; }
-        gemm_h2<KSH, PF, 1, 1, false>(img + side_row<NR, NW>(wave, 0) * 32 * LDH, w0, CS, w0, CS, ring0, g01, g21, lane);
+        gemm_h2<KSH, PF, 1, 1, false, false, RT>(img + side_row<NR, NW>(wave, 0) * 32 * LDH, w0, CS, w0, CS, ring0, g01, g21, lane, ks_run);
         g0[0][0] = g01[0][0];
         g2[0][0] = g21[0][0];
     }
@@ -1352,10 +1390,18 @@ __device__ __forceinline__ void gemm_side_h2(const _Float16* __restrict__ img, c
 // the magnitudes this thread has split (the caller compares it with H2_MAX once per kernel).
 // NW: waves of the workgroup -- 4 (one per SIMD, 512 registers, 128 units x 32 NR points each) or 8 (two per SIMD, 256 registers,
 // 64 units each: while one wave of a SIMD is in a write-out, which is VALU work, the other can still be feeding the matrix pipe).
-template <bool BWD, int PF, bool HAND = !BWD, int NR = 2, int NW = 4>     // NR: point blocks of 32 (tile of 64 or 32 points)
+// NARROW: the form for decoders much smaller than the 8 x 512 shape they are embedded in (MlpParams::narrow): identity slots are
+// skipped (a ReLU output passes through relu(1 . h) unchanged, and in the backward pass the identity's mask is the producing
+// layer's own), the k-loops stop behind the last slab that carries weights, and a wave whose column blocks do not exist runs a
+// zero-trip GEMM (its write-out stores relu(0) = 0: every column of the image is rewritten by every executed layer, as in the
+// full-width form, so nothing the caller's epilogue left in the image survives).  Everything skipped is a product with an exact zero, so the values are those of the embedded form
+// (up to the f32 rounding of x_hi + 2^-11 x_lo' that an identity layer applies to a few values and the skip does not).  Every
+// GEMM fetches its own first slabs (no hand-over: what follows a layer depends on the decoder).
+template <bool BWD, int PF, bool HAND = !BWD, int NR = 2, int NW = 4, bool NARROW = false>     // NR: point blocks of 32
 __device__ __forceinline__ void mlp_tile_h2(MlpSmem& s, const MlpParams* __restrict__ Pm, float& amax, bool stage = true) {
     constexpr int NCB = 16 / NW, NT = 64 * NW;      // column blocks of 32 units per wave; threads
     static_assert(!(BWD && HAND), "the forward+backward tile fetches each matrix's first slabs itself (layer 7 would hand over to the wrong one)");
+    static_assert(!(NARROW && HAND), "the narrow form has no hand-over");
     int hts_n = 0;
     (void)hts_n;
     QSP_HTS()
@@ -1403,7 +1449,7 @@ __device__ __forceinline__ void mlp_tile_h2(MlpSmem& s, const MlpParams* __restr
 #define QSP_WH(L, KS_) (P.wfh[L] + (size_t)(cb0 * (KS_) * 2) * 64)
 #define QSP_WBH(L) (P.wbh[L] + (size_t)(cb0 * KSH * 2) * 64)
     WRingH<PF, NCB> ring;
-    ringh_prime(ring, QSP_WH(1, KSH), CS, lane);      // (layer 1's first slabs: in flight behind layer 0)
+    if (!NARROW) ringh_prime(ring, QSP_WH(1, KSH), CS, lane);      // (layer 1's first slabs: in flight behind layer 0)
     QSP_HTS()
     __syncthreads();
     QSP_HTS()
@@ -1413,6 +1459,14 @@ __device__ __forceinline__ void mlp_tile_h2(MlpSmem& s, const MlpParams* __restr
         asm volatile("" : "+a"(acc[r_][c_]), "+a"(acc2[r_][c_]));
     // one hidden layer: accumulators start from the bias, GEMM, then (barrier) main + 2^-11 cross, ReLU, split, (barrier)
 #define QSP_FWDH(L, BIASPTR, GEMM_STMT, PRIME_NEXT)                                                                      \
+  if (NARROW && P.skip[L]) {       /* identity slot: the activations stand; its ReLU mask is the producing layer's */      \
+    if (BWD) {                                                                                                           \
+        _Pragma("unroll") for (int r_ = 0; r_ < NR; ++r_) _Pragma("unroll") for (int cp_ = 0; cp_ < NCB / 2; ++cp_)      \
+            mk[L][r_][cp_] = mk[(L) > 0 ? (L) - 1 : 0][r_][cp_];                                                         \
+    }                                                                                                                    \
+  } else {                                                                                                               \
+    /* (narrow: a wave whose column blocks do not exist runs a zero-trip GEMM and writes relu(0) = 0: straight-line code) */  \
+    const bool act_ = !NARROW || cb0 < (int)P.ncb_out[L];                                                                 \
     _Pragma("unroll") for (int c_ = 0; c_ < NCB; ++c_) _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {                \
         const f32x4 bv_ = lds4((BIASPTR) + 32 * NCB * wave + 32 * c_ + 8 * g_ + 4 * h);                                     \
         _Pragma("unroll") for (int r_ = 0; r_ < NR; ++r_) _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {             \
@@ -1447,12 +1501,21 @@ __device__ __forceinline__ void mlp_tile_h2(MlpSmem& s, const MlpParams* __restr
             mk[L][r_][cp_] = m_[r_][cp_];                                                                                \
         }                                                                                                                \
     }                                                                                                                    \
-    if (!HAND) { PRIME_NEXT; }     /* the next GEMM's first slabs, behind the barrier and the accumulator initialisation */  \
+    if (!HAND && !NARROW) { PRIME_NEXT; }     /* the next GEMM's first slabs, behind the barrier and the accumulator initialisation */  \
     QSP_HTS()                                                                                                            \
     __syncthreads();                                                                                                     \
-    QSP_HTS()
-#define QSP_GEMMF(L, KS_, NXW, NKS) gemm_h2<KS_, PF, NCB, NR, HAND, true>(img, QSP_WH(L, KS_), (KS_) * 2 * 64, NXW, (NKS) * 2 * 64, ring, acc, acc2, lane)
-    QSP_FWDH(0, s.c0, (gemm_l0_h2<NR, NCB>(img, QSP_WH(0, 1), acc, acc2, lane)), (void)0)
+    QSP_HTS()                                                                                                            \
+  }
+#define QSP_GEMMF(L, KS_, NXW, NKS)                                                                                     \
+    if constexpr (NARROW) {                                                                                              \
+        gemm_h2<KS_, PF, NCB, NR, false, false, true>(img, QSP_WH(L, KS_), (KS_) * 2 * 64, QSP_WH(L, KS_), (KS_) * 2 * 64, ring, acc, \
+                                                      acc2, lane, act_ ? (int)P.ks_in[L] : 0);                           \
+        if ((L) == 4 && act_ && (int)P.ks_in[4] < KS4)      /* the xyz slab of the latent_in layer, behind the all-zero slabs */ \
+            gemm_slab_h2<NR, NCB>(img + 32 * (KS4 - 1), QSP_WH(4, KS4) + (size_t)((KS4 - 1) * 2) * 64, CS4, acc, acc2, lane); \
+    } else {                                                                                                             \
+        gemm_h2<KS_, PF, NCB, NR, HAND, true>(img, QSP_WH(L, KS_), (KS_) * 2 * 64, NXW, (NKS) * 2 * 64, ring, acc, acc2, lane); \
+    }
+    QSP_FWDH(0, s.c0, (gemm_l0_h2<NR, NCB>(img, QSP_WH(0, 1), acc, acc2, lane)), (void)0)      // (narrow: every wave -- zero weights beyond the width)
     QSP_FWDH(1, bias_sh + 0 * HID, QSP_GEMMF(1, KSH, QSP_WH(2, KSH), KSH), ringh_prime(ring, QSP_WH(2, KSH), CS, lane))
     QSP_FWDH(2, bias_sh + 1 * HID, QSP_GEMMF(2, KSH, QSP_WH(3, KSH), KSH), ringh_prime(ring, QSP_WH(3, KSH), CS, lane))
     QSP_FWDH(3, bias_sh + 2 * HID, QSP_GEMMF(3, KSH, QSP_WH(4, KS4), KS4), ringh_prime(ring, QSP_WH(4, KS4), CS4, lane))
@@ -1524,13 +1587,19 @@ __device__ __forceinline__ void mlp_tile_h2(MlpSmem& s, const MlpParams* __restr
                     h2_store4(img, p, u0, v, amax);
                 }
         }
-        ringh_prime(ring, QSP_WBH(7), CS, lane);
+        if (!NARROW) ringh_prime(ring, QSP_WBH(7), CS, lane);
         __syncthreads();
         // ---- backward through layers 7..1: g_in = g_a . W_L, masked by layer L-1; the skip gradient of layer 4 to the stash ----
 #define QSP_BWDH(L, KS_, NWB)                                                                                            \
+  if (!(NARROW && P.skip[L])) {        /* (an identity slot passes the gradient on: its mask is applied by the layer below) */ \
+    const bool act_ = !NARROW || cb0 < (int)P.ncb_in[L];                                                                  \
     _Pragma("unroll") for (int r_ = 0; r_ < NR; ++r_) _Pragma("unroll") for (int c_ = 0; c_ < NCB; ++c_)                 \
         _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) { acc[r_][c_][i_] = 0.f; acc2[r_][c_][i_] = 0.f; }             \
-    gemm_h2<KS_, PF, NCB, NR, HAND, true>(img, QSP_WBH(L), CS, NWB, CS, ring, acc, acc2, lane);                                       \
+    if constexpr (NARROW)                                                                                                \
+        gemm_h2<KS_, PF, NCB, NR, false, false, true>(img, QSP_WBH(L), CS, QSP_WBH(L), CS, ring, acc, acc2, lane,             \
+                                                      act_ ? min((int)P.ks_out[L], KS_) : 0);                            \
+    else                                                                                                                 \
+        gemm_h2<KS_, PF, NCB, NR, HAND, true>(img, QSP_WBH(L), CS, NWB, CS, ring, acc, acc2, lane);                        \
     QSP_PIN_ACC()                                                                                                        \
     __syncthreads();                                                                                                     \
     _Pragma("unroll") for (int c_ = 0; c_ < NCB; ++c_) _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {                \
@@ -1547,15 +1616,16 @@ __device__ __forceinline__ void mlp_tile_h2(MlpSmem& s, const MlpParams* __restr
         }                                                                                                                \
         __builtin_amdgcn_sched_barrier(0);                                                                               \
     }                                                                                                                    \
-    if ((L) > 1) ringh_prime(ring, NWB, CS, lane);     /* the next layer's first slabs (layer 0's product has its own ring) */ \
-    __syncthreads();
+    if (!NARROW && (L) > 1) ringh_prime(ring, NWB, CS, lane);     /* the next layer's first slabs (layer 0's product has its own ring) */ \
+    __syncthreads();                                                                                                     \
+  }
         QSP_BWDH(7, KSH, QSP_WBH(6))
         QSP_BWDH(6, KSH, QSP_WBH(5))
         QSP_BWDH(5, KSH, QSP_WBH(4))
         {   // the skip connection's gradient d y / d [code | xyz] = g_a4 . W4[:, 445:512]: its own 64 x 96 product, to the stash
             // in f32 (layer 4's write-out below masks those columns to zero like any dead unit: mk[3] has no bit set there)
             f32x4 sk[NR][4];
-            gemm_side_h2<PF, NR, NW>(img, P.wbh4s, wave, lane, sk);
+            gemm_side_h2<PF, NR, NW, NARROW>(img, P.wbh4s, wave, lane, sk, NARROW ? (int)P.ks_out[4] : KSH);
             const int c0 = side_c0<NR, NW>(wave);
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
@@ -1587,7 +1657,7 @@ __device__ __forceinline__ void mlp_tile_h2(MlpSmem& s, const MlpParams* __restr
                 for (int i = 0; i < BPT; ++i) bnext[BPT * (l - 1) + i] = P.bias[l][tid + i * NT];
             __builtin_amdgcn_sched_barrier(0);
             f32x4 gl[NR][4];
-            gemm_side_h2<PF, NR, NW>(img, P.wbh[0], wave, lane, gl);
+            gemm_side_h2<PF, NR, NW, NARROW>(img, P.wbh[0], wave, lane, gl, NARROW ? (int)P.ks_out[0] : KSH);
             const int c0 = side_c0<NR, NW>(wave);
             __syncthreads();
             // D[i = input column within block c0][j = point]: four consecutive input columns per register quad

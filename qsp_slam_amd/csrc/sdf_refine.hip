@@ -62,6 +62,7 @@ struct qsp_decoder {
     bool fp16_ok = true;       // every weight of layers 0..7 fits fp16's range (split-fp16 planes are usable)
     int tile_p = 64;           // QSP_DEC_OPT_TILE_POINTS: points per MLP tile of the refinement batches created from now on
     int* range_flag_h = nullptr;   // host-mapped word the split-fp16 kernels set when a value left fp16's range (check_range)
+    bool narrow_capable = false;   // the decoder is small enough for the NARROW tile (narrow_tables); QSP_DEC_OPT_NARROW_TILE toggles its use
     float screen_margin = 0.f;     // QSP_DEC_OPT_RENDER_SCREENING: > 0 = two-pass ray-sample forward with this band margin
     int64_t screen_min_samples = -1;   // QSP_DEC_OPT_SCREENING_MIN_SAMPLES: -1 = more than two rounds of 64-point tiles over the chip
     int range_fallback = 1;        // QSP_DEC_OPT_RANGE_FALLBACK: a call that left fp16's range is repeated on the f32 pipe
@@ -94,7 +95,7 @@ struct F32Override {
 // Needs: at most 4 hidden layers before and at most 4 from the latent_in layer on, widths <= 512 (<= 445 in front of the skip).
 // Cost: the arithmetic of the full 8 x 512 tile whatever the network's own size.
 static int embed_family(const qsp_decoder_desc* desc, const std::vector<std::vector<float>>& W,
-                        std::vector<std::vector<float>>& Wc, std::vector<std::vector<float>>& Bc) {
+                        std::vector<std::vector<float>>& Wc, std::vector<std::vector<float>>& Bc, std::vector<int>& src) {
     const int nl = desc->n_layers, m = nl - 1, L = desc->code_len;
     if (nl < 3 || nl > 9 || L < 1 || L > CODE_LEN)
         return qsp_fail(QSP_ERR_UNSUPPORTED, "decoder family: 2..8 hidden layers and a code of 1..64 are supported");
@@ -128,7 +129,7 @@ static int embed_family(const qsp_decoder_desc* desc, const std::vector<std::vec
     auto out_c = [](int c) { return c == 8 ? 1 : (c == 3 ? SKIP_COL : HID); };
     Wc.assign(9, std::vector<float>());
     Bc.assign(9, std::vector<float>());
-    std::vector<int> src(9, -1);                            // canonical slot -> source layer (-1: identity)
+    src.assign(9, -1);                                      // canonical slot -> source layer (-1: identity)
     for (int l = 0; l < s; ++l) src[l] = l;
     for (int l = s; l < m; ++l) src[4 + (l - s)] = l;
     src[8] = m;
@@ -204,6 +205,45 @@ static void equalize_gains(std::vector<std::vector<float>>& W, std::vector<std::
         for (int k = 0; k < HID; ++k) W[8][k] /= c_prev;
 }
 
+// What the NARROW form of the split-fp16 tile may skip (MlpParams::skip / ks_in / ks_out / ncb_in / ncb_out), read off the embedded
+// matrices themselves: a slot is skipped when embed_family made it an identity; an input slab / output block "exists" up to the
+// last column / row that carries a non-zero weight or bias.  `narrow` is set when the multiply-adds that remain are less than
+// half of the full shape's: only then the narrow kernels (no hand-over of weight fragments between layers, idle waves) pay.
+static void narrow_tables(qsp_decoder* d, const std::vector<std::vector<float>>& W, const std::vector<std::vector<float>>& B,
+                          const std::vector<int>& src) {
+    const int in_dim[9] = {NIN, HID, HID, HID, HID, HID, HID, HID, HID};
+    const int out_dim[9] = {HID, HID, HID, SKIP_COL, HID, HID, HID, HID, 1};
+    auto even4 = [](int v, int cap) { v = std::max(4, (v + 1) & ~1); return std::min(v, cap); };
+    double macs = 0, full = 0;
+    for (int l = 0; l < 8; ++l) {
+        const int in = in_dim[l], out = out_dim[l];
+        const int n_hidden = (l == 0) ? 0 : (l == 4 ? SKIP_COL : in);        // input columns that are hidden activations
+        int w_out = 0, w_in = 0;
+        for (int o = 0; o < out; ++o) {
+            bool any = B[l][o] != 0.f;
+            for (int k = 0; k < in; ++k)
+                if (W[l][(size_t)o * in + k] != 0.f) {
+                    any = true;
+                    if (k < n_hidden) w_in = std::max(w_in, k + 1);
+                }
+            if (any) w_out = o + 1;
+        }
+        const bool skip = src[l] < 0;
+        d->P.skip[l] = skip ? 1 : 0;
+        const int ks_cap = (l == 4) ? K4 / 16 : HID / 16;
+        int ks_in = even4((w_in + 15) / 16, ks_cap);
+        if (l == 4 && ks_in >= K4 / 16 - 1) ks_in = K4 / 16;               // (the xyz slab is the last one: no gap left to skip)
+        d->P.ks_in[l] = (uint8_t)ks_in;
+        d->P.ks_out[l] = (uint8_t)even4((w_out + 15) / 16, HID / 16);
+        d->P.ncb_in[l] = (uint8_t)std::max(1, (w_in + 31) / 32);
+        d->P.ncb_out[l] = (uint8_t)std::max(1, (w_out + 31) / 32);
+        full += (double)in * out;
+        if (!skip) macs += (double)(l == 0 ? in : 16 * ks_in + (l == 4 ? NIN : 0)) * (32.0 * d->P.ncb_out[l]);
+    }
+    d->narrow_capable = macs < 0.5 * full;
+    d->P.narrow = d->narrow_capable ? 1 : 0;
+}
+
 static inline uint16_t bf16_rne(float x) {
     uint32_t u;
     memcpy(&u, &x, 4);
@@ -248,12 +288,14 @@ static int pack_weights(qsp_decoder* d, const qsp_decoder_desc* desc) {
         d->mac_per_point += (double)in * out;
     }
     std::vector<std::vector<float>> W, Bias;
+    std::vector<int> slot_src;
     {
-        const int rc = embed_family(desc, Wsrc, W, Bias);
+        const int rc = embed_family(desc, Wsrc, W, Bias, slot_src);
         if (rc) return rc;
     }
     d->code_len = desc->code_len;
     equalize_gains(W, Bias);
+    narrow_tables(d, W, Bias, slot_src);
     // from here on: the canonical 9-layer shape
     const int in_dim[9] = {NIN, HID, HID, HID, HID, HID, HID, HID, HID};
     const int out_dim[9] = {HID, HID, HID, SKIP_COL, HID, HID, HID, HID, 1};
@@ -539,13 +581,18 @@ static int mlp_attr_once() {
     QSP_HIP(hipFuncSetAttribute((const void*)k_mlp_fwd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     QSP_HIP(hipFuncSetAttribute((const void*)k_mlp_fwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     QSP_HIP(hipFuncSetAttribute((const void*)k_decode<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    QSP_HIP(hipFuncSetAttribute((const void*)k_mlp_fwd_h2<2>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    QSP_HIP(hipFuncSetAttribute((const void*)k_mlp_fwd_h2<2, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    QSP_HIP(hipFuncSetAttribute((const void*)k_mlp_fwd_h2<2, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    QSP_HIP(hipFuncSetAttribute((const void*)k_mlp_jtj_h2<2, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    QSP_HIP(hipFuncSetAttribute((const void*)k_mlp_jtj_h2<1, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    QSP_HIP(hipFuncSetAttribute((const void*)k_decode_h2<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    QSP_HIP(hipFuncSetAttribute((const void*)k_decode_h2<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     QSP_HIP(hipFuncSetAttribute((const void*)k_mlp_fwd_h1<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MlpSmemH1)));
     QSP_HIP(hipFuncSetAttribute((const void*)k_mlp_fwd_h1<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MlpSmemH1)));
     QSP_HIP(hipFuncSetAttribute((const void*)k_decode_screen<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MlpSmemH1)));
     QSP_HIP(hipFuncSetAttribute((const void*)k_decode_screen<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MlpSmemH1)));
-    QSP_HIP(hipFuncSetAttribute((const void*)k_decode_h2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    QSP_HIP(hipFuncSetAttribute((const void*)k_decode_h2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    QSP_HIP(hipFuncSetAttribute((const void*)k_decode_h2<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    QSP_HIP(hipFuncSetAttribute((const void*)k_decode_h2<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     QSP_HIP(hipFuncSetAttribute((const void*)k_mlp_jtj_h2<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     QSP_HIP(hipFuncSetAttribute((const void*)k_mlp_jtj_h2<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     QSP_HIP(hipFuncSetAttribute((const void*)k_mlp_jtj_h2<2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
@@ -612,6 +659,15 @@ extern "C" int qsp_decoder_set_option(qsp_decoder* d, int32_t option, int32_t va
             if (value < -1) return qsp_fail(QSP_ERR_INVALID, "screening threshold: -1 (automatic) or a sample count >= 0");
             d->screen_min_samples = value;
             return QSP_OK;
+        case QSP_DEC_OPT_NARROW_TILE: {
+            if (value != 0 && value != 1) return qsp_fail(QSP_ERR_INVALID, "narrow tile: 0 or 1");
+            if (value && !d->narrow_capable) return qsp_fail(QSP_ERR_UNSUPPORTED, "narrow tile: this decoder fills most of the 8 x 512 shape");
+            d->P.narrow = value;
+            QSP_HIP(hipSetDevice(d->device));
+            QSP_HIP(hipStreamSynchronize(d->stream));
+            QSP_HIP(hipMemcpy(d->Pd, &d->P, sizeof(MlpParams), hipMemcpyHostToDevice));
+            return QSP_OK;
+        }
         case QSP_DEC_OPT_USE_TANH: {
             if (value != 0 && value != 1) return qsp_fail(QSP_ERR_INVALID, "use_tanh: 0 or 1");
             d->P.use_tanh = value;
@@ -634,6 +690,7 @@ extern "C" int64_t qsp_decoder_get_counter(qsp_decoder* d, int32_t counter) {
         case QSP_DEC_CNT_RANGE_FALLBACKS: return d->n_range_fallbacks;
         case QSP_DEC_CNT_ARENA_REUSED: return d->n_arena_reuse;
         case QSP_DEC_CNT_ARENA_CREATED: return d->n_arena_create;
+        case QSP_DEC_CNT_NARROW_TILE: return d->P.narrow ? 1 : 0;
         default: return -1;
     }
 }
@@ -664,14 +721,17 @@ static int decode_once(qsp_decoder* d, const float* code, const float* xyz, int6
     const int64_t tiles = (n + TILE_P - 1) / TILE_P;
     const int grid = (int)std::min<int64_t>(tiles, 4096);
     if (grad && d->jac_bf3 == 2)
-        hipLaunchKernelGGL(k_decode_h2<true>, dim3(grid), dim3(H2_THREADS), sizeof(MlpSmem), d->stream, dc, dx, n, d->Pd, dy, dg);
+        if (d->P.narrow) hipLaunchKernelGGL((k_decode_h2<true, true>), dim3(grid), dim3(H2_THREADS), sizeof(MlpSmem), d->stream, dc, dx, n, d->Pd, dy, dg);
+        else hipLaunchKernelGGL((k_decode_h2<true, false>), dim3(grid), dim3(H2_THREADS), sizeof(MlpSmem), d->stream, dc, dx, n, d->Pd, dy, dg);
     else if (grad && d->jac_bf3)
         hipLaunchKernelGGL((k_decode<true, true>), dim3(grid), dim3(MLP_THREADS), sizeof(MlpSmem), d->stream, dc, dx, n, d->Pd, dy, dg);
     else if (grad)
         hipLaunchKernelGGL(k_decode<true>, dim3(grid), dim3(MLP_THREADS), sizeof(MlpSmem), d->stream, dc, dx, n, d->Pd, dy, dg);
     else if (d->fwd_bf3 == 2)
-        hipLaunchKernelGGL(k_decode_h2<false>, dim3(grid), dim3(H2_THREADS), sizeof(MlpSmem), d->stream, dc, dx, n, d->Pd, dy,
-                           (float*)nullptr);
+        if (d->P.narrow) hipLaunchKernelGGL((k_decode_h2<false, true>), dim3(grid), dim3(H2_THREADS), sizeof(MlpSmem), d->stream, dc, dx, n, d->Pd, dy,
+                                            (float*)nullptr);
+        else hipLaunchKernelGGL((k_decode_h2<false, false>), dim3(grid), dim3(H2_THREADS), sizeof(MlpSmem), d->stream, dc, dx, n, d->Pd, dy,
+                                (float*)nullptr);
     else if (d->fwd_bf3)
         hipLaunchKernelGGL((k_decode<false, true>), dim3(grid), dim3(MLP_THREADS), sizeof(MlpSmem), d->stream, dc, dx, n, d->Pd, dy,
                            (float*)nullptr);
@@ -1059,7 +1119,8 @@ static int run_once(qsp_refine_batch* b, int32_t n_iter, bool* hit) {
             int64_t ub_samples = 0;
             for (int h = 0; h < nH; ++h) ub_samples += (int64_t)b->objs_h[b->hyp_obj[h]].n_rays * cfg.n_depth;
             const int64_t min_samples = b->dec->screen_min_samples >= 0 ? b->dec->screen_min_samples : 2 * (int64_t)b->n_cu * TILE_P;
-            const bool screen = b->dec->fwd_bf3 == 2 && b->dec->screen_margin > 0.f && ub_samples > min_samples;
+            // (a narrow decoder's one-pass forward on the NARROW tile is cheaper than the full-width screening pass: not screened)
+            const bool screen = b->dec->fwd_bf3 == 2 && b->dec->screen_margin > 0.f && ub_samples > min_samples && !b->dec->P.narrow;
             hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, s, 0, b->st, b->objs, nH, b->nw_sdf, nw_total - b->nw_sdf,
                                b->work_fwd, b->qctl, screen ? H1_ROWS : TILE_P);     // (the forward pass keeps 64-point tiles: tens of
             if (screen) {                                                            //  thousands of ray samples fill the chip either way)
@@ -1075,11 +1136,15 @@ static int run_once(qsp_refine_batch* b, int32_t n_iter, bool* hit) {
                                        b->band_idx, cfg.cut_off + b->dec->screen_margin);
                 hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, s, 2, b->st, b->objs, nH, b->nw_sdf, nw_total - b->nw_sdf,
                                    b->work_fwd, b->qctl, TILE_P);
-                hipLaunchKernelGGL(k_mlp_fwd_h2<2>, dim3(b->n_cu), dim3(H2_THREADS), sizeof(MlpSmem), s, b->st, b->objs, b->rays,
+                hipLaunchKernelGGL((k_mlp_fwd_h2<2, false, 4>), dim3(b->n_cu), dim3(H2_THREADS), sizeof(MlpSmem), s, b->st, b->objs, b->rays,
                                    cfg, b->dec->Pd, b->valid_rk, b->rk_stride, b->sdf_valid, b->work_fwd, b->qctl, b->c0_all,
                                    (const int32_t*)b->band_idx);
-            } else if (b->dec->fwd_bf3 == 2)
-                hipLaunchKernelGGL(k_mlp_fwd_h2<2>, dim3(b->n_cu), dim3(H2_THREADS), sizeof(MlpSmem), s, b->st, b->objs, b->rays,
+            } else if (b->dec->fwd_bf3 == 2 && b->dec->P.narrow)
+                hipLaunchKernelGGL((k_mlp_fwd_h2<2, true, 8>), dim3(b->n_cu), dim3(512), sizeof(MlpSmem), s, b->st, b->objs, b->rays,
+                                   cfg, b->dec->Pd, b->valid_rk, b->rk_stride, b->sdf_valid, b->work_fwd, b->qctl, b->c0_all,
+                                   (const int32_t*)nullptr);
+            else if (b->dec->fwd_bf3 == 2)
+                hipLaunchKernelGGL((k_mlp_fwd_h2<2, false, 4>), dim3(b->n_cu), dim3(H2_THREADS), sizeof(MlpSmem), s, b->st, b->objs, b->rays,
                                    cfg, b->dec->Pd, b->valid_rk, b->rk_stride, b->sdf_valid, b->work_fwd, b->qctl, b->c0_all,
                                    (const int32_t*)nullptr);
             else if (b->dec->fwd_bf3)
@@ -1104,7 +1169,11 @@ static int run_once(qsp_refine_batch* b, int32_t n_iter, bool* hit) {
             // eight waves of 256 registers (two per SIMD) or four of 512 (one per SIMD): same arithmetic, same bits; jtj_waves()
             // (32-point tiles are the latency option -- one tile deep: there the four-wave form is the shorter chain, 180 us
             //  against 248 per tile; QSP_JTJ_WAVES_T32=8 selects the other for measurements)
-            if (cfg.tile_p == 32 && jtj_waves_t32() == 8)
+            if (b->dec->P.narrow && cfg.tile_p == 32)      // narrow decoders: eight waves, so that the column blocks that exist
+                hipLaunchKernelGGL((k_mlp_jtj_h2<1, 8, true>), dim3(b->n_cu), dim3(512), sizeof(MlpSmem), s, ja);   // spread over all SIMDs
+            else if (b->dec->P.narrow)
+                hipLaunchKernelGGL((k_mlp_jtj_h2<2, 8, true>), dim3(b->n_cu), dim3(512), sizeof(MlpSmem), s, ja);
+            else if (cfg.tile_p == 32 && jtj_waves_t32() == 8)
                 hipLaunchKernelGGL((k_mlp_jtj_h2<1, 8>), dim3(b->n_cu), dim3(512), sizeof(MlpSmem), s, ja);
             else if (cfg.tile_p == 32)
                 hipLaunchKernelGGL((k_mlp_jtj_h2<1, 4>), dim3(b->n_cu), dim3(H2_THREADS), sizeof(MlpSmem), s, ja);

@@ -108,6 +108,15 @@ class DeepSdfDecoder(object):
         return int(_lib.lib().qsp_decoder_get_counter(self.handle, 1))
 
     @property
+    def narrow_tile(self):
+        """True when the split-fp16 kernels run their NARROW form for this decoder (much smaller than the 8 x 512 shape it is embedded
+        in: identity slots, all-zero slabs and column blocks skipped -- QSP_DEC_OPT_NARROW_TILE)"""
+        return bool(_lib.lib().qsp_decoder_get_counter(self.handle, 4))
+
+    def set_narrow_tile(self, on):
+        _lib.check(_lib.lib().qsp_decoder_set_option(self.handle, 8, 1 if on else 0))
+
+    @property
     def arena_stats(self):
         """(calls of qsp_reconstruct_objects that refilled the decoder's resident batch, calls that had to (re)allocate it)"""
         L = _lib.lib()

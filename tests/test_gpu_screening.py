@@ -165,6 +165,15 @@ def test_screening_is_bit_identical_on_other_members_of_the_decoder_family(golde
         z = np.load(os.path.join(golden_dir, "sdf_small_joint_m400.npz"))
         L = 32
     d.set_precision("fp16x2")
+    if which != "use_tanh":
+        # a narrow decoder's one-pass forward on the NARROW tile is cheaper than the full-width screening pass: the library does
+        # not screen it.  The embedded form of the same decoder is screened like any other.
+        assert d.narrow_tile
+        d.set_screening_min_samples(0)
+        opt0 = Optimizer(d, make_cfg(z, code_len=L))
+        o0 = dict(pts=z["pts"], rays=z["rays"], depth=z["depth"])
+        assert run_batch(d, opt0, [o0], [0], z["t_cam_obj"][None], None, 1, True)["prof"].pts_band == 0
+        d.set_narrow_tile(False)
     d.set_screening_min_samples(0)
     opt = Optimizer(d, make_cfg(z, code_len=L))
     obj = dict(pts=z["pts"], rays=z["rays"], depth=z["depth"])

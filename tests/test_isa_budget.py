@@ -9,17 +9,22 @@ import subprocess
 
 # kernel (demangled prefix) -> (max spilled VGPRs, max scratch bytes per lane, max spilled SGPRs)
 BUDGET = {
-    "qsp::k_mlp_jtj_h2<2, 4>": (32, 128, 0),
-    "qsp::k_mlp_jtj_h2<1, 4>": (0, 0, 0),
-    "qsp::k_mlp_jtj_h2<2, 8>": (32, 128, 0),
-    "qsp::k_mlp_jtj_h2<1, 8>": (0, 0, 0),
-    "qsp::k_mlp_fwd_h2<2>": (24, 96, 0),
+    "qsp::k_mlp_jtj_h2<2, 4, false>": (32, 128, 0),
+    "qsp::k_mlp_jtj_h2<1, 4, false>": (0, 0, 0),
+    "qsp::k_mlp_jtj_h2<2, 8, false>": (32, 128, 0),
+    "qsp::k_mlp_jtj_h2<1, 8, false>": (0, 0, 0),
+    "qsp::k_mlp_jtj_h2<2, 8, true>": (72, 200, 0),       # the NARROW forms: runtime slab counts and skipped slots cost the allocator
+    "qsp::k_mlp_jtj_h2<1, 8, true>": (8, 32, 0),         # some of its footing; they run a fraction of the full shape's work
+    "qsp::k_mlp_fwd_h2<2, false, 4>": (24, 96, 0),
+    "qsp::k_mlp_fwd_h2<2, true, 8>": (64, 160, 0),
     "qsp::k_mlp_fwd_h1<4>": (0, 0, 0),
     "qsp::k_mlp_fwd_h1<8>": (20, 80, 0),
     "qsp::k_decode_screen<4>": (0, 0, 0),
     "qsp::k_decode_screen<8>": (20, 80, 0),
-    "qsp::k_decode_h2<false>": (24, 96, 0),
-    "qsp::k_decode_h2<true>": (40, 160, 0),
+    "qsp::k_decode_h2<false, false>": (24, 96, 0),
+    "qsp::k_decode_h2<true, false>": (40, 160, 0),
+    "qsp::k_decode_h2<false, true>": (64, 160, 0),
+    "qsp::k_decode_h2<true, true>": (80, 200, 4),
     "qsp::k_mlp_fwd<false>": (0, 0, 0),
     "qsp::k_mlp_fwd<true>": (48, 192, 0),
     "qsp::k_mlp_jtj<false>": (72, 224, 152),
