@@ -93,7 +93,7 @@ def test_narrow_and_embedded_forms_agree_and_the_narrow_one_is_faster(small):
     assert within("fp16x2_narrow/vs_embedded/H", relerr(ta["H"], tb["H"]), 2e-5)
     assert within("fp16x2_narrow/vs_embedded/b", relerr(ta["b"], tb["b"]), 2e-5)
     assert within("fp16x2_narrow/vs_embedded/T_final_3_iterations", relerr(sa[0], sb[0]), 2e-2)
-    assert within("fp16x2_narrow/narrow_over_embedded_time", ms[True] / ms[False], 0.4)    # i.e. at least 2.5 x faster
+    assert within("fp16x2_narrow/narrow_over_embedded_time", ms[True] / ms[False], 0.5)    # measured 0.29 (3.5 x); the bar leaves room for a noisy box
 
 
 def test_random_narrow_members_of_the_family_vs_the_oracle():
