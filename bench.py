@@ -343,6 +343,8 @@ def run_workload(ctx, name, steps, warmup, detailed, precision=None, screening=N
             prof["tiles_fwd"] += p.tiles_fwd
             prof["pts_band"] += p.pts_band
             prof["fallbacks"] += p.range_fallbacks
+            prof["screen_fallbacks"] = prof.get("screen_fallbacks", 0) + p.screen_fallbacks
+            prof["screen_max_diff"] = max(prof.get("screen_max_diff", 0.0), p.screen_max_diff)
     ctx.sync_all()
     dt = ctx.allreduce(time.perf_counter() - t0, "MAX")
     n_good = 0
@@ -374,9 +376,11 @@ def run_workload(ctx, name, steps, warmup, detailed, precision=None, screening=N
         ms_gather=ba_stat["ms_gather"] / steps,
         fallbacks=dict(range_reruns_on_f32=int(prof["fallbacks"]) + (dec.range_fallbacks if batch is None else 0),
                        decoder_counter=dec.range_fallbacks,
+                       screened_runs_repeated_in_one_pass=int(prof.get("screen_fallbacks", 0)),
                        note="timed steps that were repeated on the exact-f32 pipe because a value left fp16's range "
                             "(QSP_DEC_OPT_RANGE_FALLBACK); any non-zero count invalidates the line's dtype"),
-        screening=(dict(margin=margin, band_share=prof["pts_band"] / max(prof["pts_fwd"], 1),
+        screening=(dict(margin=margin, max_abs_s1_minus_s3_on_band=float(prof.get("screen_max_diff", 0.0)),
+                        band_share=prof["pts_band"] / max(prof["pts_fwd"], 1),
                         samples_per_launch=prof["pts_fwd"] / max(prof["n_fwd"], 1),
                         band_samples_per_launch=prof["pts_band"] / max(prof["n_fwd"], 1),
                         note="ray-sample forward in two passes: all samples on the one-product fp16 tile, the band "

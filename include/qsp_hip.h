@@ -96,7 +96,11 @@ void qsp_decoder_destroy(qsp_decoder* dec);
  * largest |s1 - s3| the result (K, n_valid, H, b, every later iterate) equals the unscreened split-fp16 result BIT FOR BIT;
  * 20 000 (0.02) is > 8 x the largest difference measured over the fixtures and the randomised sweep (profiles/r03_*).  Needs
  * QSP_DEC_OPT_FORWARD_PRECISION = 2 (QSP_ERR_UNSUPPORTED otherwise); margins above 5 x the usual cut_off (50 000) are refused:
- * at that point the second pass covers most samples and the option has no purpose.
+ * at that point the second pass covers most samples and the option has no purpose.  The premise is checked on every run: the
+ * second pass has both values of each band sample in hand and keeps the largest |s1 - s3|; a run in which it exceeds HALF the
+ * margin is repeated from its starting state in one pass (qsp_decoder_get_counter(QSP_DEC_CNT_SCREEN_FALLBACKS) counts them,
+ * qsp_refine_profile.screen_max_diff / .screen_fallbacks report the last run), so a decoder whose screening values are worse
+ * than the fixtures' costs time, not bits.
  * QSP_DEC_OPT_SCREENING_MIN_SAMPLES (-1, the default, or a count): a run is screened only when its batch holds more ray samples
  * (rays x depth samples, summed over the hypotheses) than this; -1 = more than two rounds of 64-point tiles over the chip.  A
  * batch that fits one round -- one object per call -- is one tile deep either way and faster in one pass.  The result is the
@@ -113,7 +117,8 @@ void qsp_decoder_destroy(qsp_decoder* dec);
 enum { QSP_DEC_OPT_FORWARD_PRECISION = 1, QSP_DEC_OPT_JACOBIAN_PRECISION = 2, QSP_DEC_OPT_TILE_POINTS = 3,
        QSP_DEC_OPT_RENDER_SCREENING = 4, QSP_DEC_OPT_USE_TANH = 5, QSP_DEC_OPT_RANGE_FALLBACK = 6,
        QSP_DEC_OPT_SCREENING_MIN_SAMPLES = 7, QSP_DEC_OPT_NARROW_TILE = 8 };
-enum { QSP_DEC_CNT_RANGE_FALLBACKS = 1, QSP_DEC_CNT_ARENA_REUSED = 2, QSP_DEC_CNT_ARENA_CREATED = 3, QSP_DEC_CNT_NARROW_TILE = 4 };
+enum { QSP_DEC_CNT_RANGE_FALLBACKS = 1, QSP_DEC_CNT_ARENA_REUSED = 2, QSP_DEC_CNT_ARENA_CREATED = 3, QSP_DEC_CNT_NARROW_TILE = 4,
+       QSP_DEC_CNT_SCREEN_FALLBACKS = 5 };
 /* lifetime counters of a decoder: calls that were re-run on the f32 pipe because a value left fp16's range; calls of
  * qsp_reconstruct_objects that refilled the decoder's resident batch / that had to (re)allocate it */
 int64_t qsp_decoder_get_counter(qsp_decoder* dec, int32_t counter);
@@ -203,6 +208,8 @@ typedef struct {
     int64_t tiles_jtj, tiles_fwd;   /* 64-point tiles actually executed (incl. padding rows)          */
     int64_t pts_band;        /* screened forward pass: samples re-evaluated by the second pass (0 when off) */
     int32_t range_fallbacks; /* 1 if this run was repeated on the f32 pipe (QSP_DEC_OPT_RANGE_FALLBACK)     */
+    int32_t screen_fallbacks;/* 1 if this run was repeated in one pass (screening self-check, QSP_DEC_OPT_RENDER_SCREENING) */
+    float screen_max_diff;   /* largest |s1 - s3| the second pass saw on a band sample (0 when not screened)                 */
     int32_t pad_;
 } qsp_refine_profile;
 int qsp_refine_batch_profile(qsp_refine_batch* b, int enable, qsp_refine_profile* out);

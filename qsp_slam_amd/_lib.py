@@ -42,7 +42,8 @@ class RefineProfile(C.Structure):
     _fields_ = [("ms_total", C.c_float), ("ms_mlp_jtj", C.c_float), ("ms_mlp_fwd", C.c_float),
                 ("ms_other", C.c_float), ("n_launch_jtj", C.c_int32), ("n_launch_fwd", C.c_int32),
                 ("pts_jtj", C.c_int64), ("pts_fwd", C.c_int64), ("tiles_jtj", C.c_int64), ("tiles_fwd", C.c_int64),
-                ("pts_band", C.c_int64), ("range_fallbacks", C.c_int32), ("pad_", C.c_int32)]
+                ("pts_band", C.c_int64), ("range_fallbacks", C.c_int32), ("screen_fallbacks", C.c_int32),
+                ("screen_max_diff", C.c_float), ("pad_", C.c_int32)]
 
 
 class BaScene(C.Structure):

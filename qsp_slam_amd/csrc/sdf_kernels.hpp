@@ -368,9 +368,11 @@ __global__ __launch_bounds__(64 * NW) void k_mlp_fwd_h2(const HypState* __restri
                                                             const int32_t* __restrict__ valid_rk, int64_t rk_stride,
                                                             float* __restrict__ sdf_valid, const int2* __restrict__ work,
                                                             int* __restrict__ qctl, const float* __restrict__ c0_all,
-                                                            const int32_t* __restrict__ band_idx) {
+                                                            const int32_t* __restrict__ band_idx, unsigned int* __restrict__ screen_dmax) {
     // band_idx != nullptr: second pass of the screened forward -- the tiles run over the hypothesis's band list (indices into
-    // its valid-sample list written by k_mlp_fwd_h1) and overwrite those samples' screening values
+    // its valid-sample list written by k_mlp_fwd_h1) and overwrite those samples' screening values.  On the way the largest
+    // |s1 - s3| over the band samples is kept (*screen_dmax, the bits of a non-negative float): the quantity the screening margin
+    // has to cover, measured on every run -- the host repeats a run unscreened if it ever comes near the margin.
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     MlpSmem& s = *reinterpret_cast<MlpSmem*>(smem_raw);
     __shared__ float Tsh[16];
@@ -378,7 +380,7 @@ __global__ __launch_bounds__(64 * NW) void k_mlp_fwd_h2(const HypState* __restri
     const int n_items = qctl[0];
     constexpr int TP = 32 * NR;
     bool staged = false;
-    float amax = 0.f;
+    float amax = 0.f, dmax = 0.f;
     int h_cached = -1;
     for (;;) {
         if (threadIdx.x == 0) s_item = atomicAdd(&qctl[1], 1);
@@ -422,8 +424,18 @@ __global__ __launch_bounds__(64 * NW) void k_mlp_fwd_h2(const HypState* __restri
         staged = true;
         if (threadIdx.x < TP) {
             const int v = t * TP + threadIdx.x;
-            if (v < n) out[sel ? sel[v] : v] = s.y[threadIdx.x];
+            if (v < n) {
+                const int idx = sel ? sel[v] : v;
+                const float y = s.y[threadIdx.x];
+                if (sel) dmax = fmaxf(dmax, fabsf(out[idx] - y));      // (out[idx] still holds the screening value s1)
+                out[idx] = y;
+            }
         }
+    }
+    if (band_idx && screen_dmax && threadIdx.x < 64) {      // the first wave holds every row's difference (TP <= 64)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, o, 64));
+        if (threadIdx.x == 0 && dmax > 0.f) atomicMax(screen_dmax, __float_as_uint(dmax));
     }
     if (!(amax <= H2_MAX)) *P->range_flag = 1;
 }

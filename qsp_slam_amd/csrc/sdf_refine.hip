@@ -67,6 +67,7 @@ struct qsp_decoder {
     int64_t screen_min_samples = -1;   // QSP_DEC_OPT_SCREENING_MIN_SAMPLES: -1 = more than two rounds of 64-point tiles over the chip
     int range_fallback = 1;        // QSP_DEC_OPT_RANGE_FALLBACK: a call that left fp16's range is repeated on the f32 pipe
     int64_t n_range_fallbacks = 0; // QSP_DEC_CNT_RANGE_FALLBACKS
+    int64_t n_screen_fallbacks = 0;    // QSP_DEC_CNT_SCREEN_FALLBACKS: runs repeated in one pass by the screening self-check
     // qsp_reconstruct_objects keeps ONE resident batch per decoder, sized by the high-water mark of the calls so far: the
     // reference's call pattern is one object per call (src/LocalMapping_util.cc:705-760), and creating / destroying ~25 device
     // buffers per call cost ~0.5 ms of a 3 ms call
@@ -691,6 +692,7 @@ extern "C" int64_t qsp_decoder_get_counter(qsp_decoder* d, int32_t counter) {
         case QSP_DEC_CNT_ARENA_REUSED: return d->n_arena_reuse;
         case QSP_DEC_CNT_ARENA_CREATED: return d->n_arena_create;
         case QSP_DEC_CNT_NARROW_TILE: return d->P.narrow ? 1 : 0;
+        case QSP_DEC_CNT_SCREEN_FALLBACKS: return d->n_screen_fallbacks;
         default: return -1;
     }
 }
@@ -1089,8 +1091,13 @@ static hipEvent_t next_event(qsp_refine_batch* b, size_t& cursor) {
     return e;
 }
 
-// one pass over n_iter Gauss-Newton iterations on the decoder's current pipes; *hit = a split-fp16 kernel left fp16's range
-static int run_once(qsp_refine_batch* b, int32_t n_iter, bool* hit) {
+// the screened forward is trusted while the largest |s1 - s3| it sees on a band sample stays below this share of the margin
+constexpr float SCREEN_TRUST = 0.5f;
+
+// one pass over n_iter Gauss-Newton iterations on the decoder's current pipes; *hit = a split-fp16 kernel left fp16's range,
+// *screen_hit = the screened forward saw |s1 - s3| above half its margin on a band sample (the margin's premise is in doubt)
+static int run_once(qsp_refine_batch* b, int32_t n_iter, bool* hit, bool* screen_hit) {
+    bool screened_any = false;
     hipStream_t s = b->dec->stream;
     const int nH = b->n_hyp;
     const int nw_total = b->nw_sdf + (b->cfg.pose_only ? 0 : NW_REND);
@@ -1138,15 +1145,16 @@ static int run_once(qsp_refine_batch* b, int32_t n_iter, bool* hit) {
                                    b->work_fwd, b->qctl, TILE_P);
                 hipLaunchKernelGGL((k_mlp_fwd_h2<2, false, 4>), dim3(b->n_cu), dim3(H2_THREADS), sizeof(MlpSmem), s, b->st, b->objs, b->rays,
                                    cfg, b->dec->Pd, b->valid_rk, b->rk_stride, b->sdf_valid, b->work_fwd, b->qctl, b->c0_all,
-                                   (const int32_t*)b->band_idx);
+                                   (const int32_t*)b->band_idx, (unsigned int*)(b->counters + 5));
+                screened_any = true;
             } else if (b->dec->fwd_bf3 == 2 && b->dec->P.narrow)
                 hipLaunchKernelGGL((k_mlp_fwd_h2<2, true, 8>), dim3(b->n_cu), dim3(512), sizeof(MlpSmem), s, b->st, b->objs, b->rays,
                                    cfg, b->dec->Pd, b->valid_rk, b->rk_stride, b->sdf_valid, b->work_fwd, b->qctl, b->c0_all,
-                                   (const int32_t*)nullptr);
+                                   (const int32_t*)nullptr, (unsigned int*)nullptr);
             else if (b->dec->fwd_bf3 == 2)
                 hipLaunchKernelGGL((k_mlp_fwd_h2<2, false, 4>), dim3(b->n_cu), dim3(H2_THREADS), sizeof(MlpSmem), s, b->st, b->objs, b->rays,
                                    cfg, b->dec->Pd, b->valid_rk, b->rk_stride, b->sdf_valid, b->work_fwd, b->qctl, b->c0_all,
-                                   (const int32_t*)nullptr);
+                                   (const int32_t*)nullptr, (unsigned int*)nullptr);
             else if (b->dec->fwd_bf3)
                 hipLaunchKernelGGL(k_mlp_fwd<true>, dim3(b->n_cu), dim3(MLP_THREADS), sizeof(MlpSmem), s, b->st, b->objs, b->rays,
                                    cfg, b->dec->Pd, b->valid_rk, b->rk_stride, b->sdf_valid, b->work_fwd, b->qctl, b->c0_all);
@@ -1208,9 +1216,21 @@ static int run_once(qsp_refine_batch* b, int32_t n_iter, bool* hit) {
         *hit = true;
         return QSP_OK;
     }
+    float dmax = 0.f;
+    if (screened_any) {      // (8 bytes, behind the synchronisation above; a one-object call is never screened and skips it)
+        unsigned long long w = 0;
+        QSP_HIP(hipMemcpy(&w, b->counters + 5, sizeof(w), hipMemcpyDeviceToHost));
+        const unsigned int bits = (unsigned int)w;
+        memcpy(&dmax, &bits, sizeof(dmax));
+        if (!(dmax <= SCREEN_TRUST * b->dec->screen_margin)) {
+            *screen_hit = true;
+            return QSP_OK;
+        }
+    }
     if (b->prof) {
         qsp_refine_profile& p = b->profile;
         memset(&p, 0, sizeof(p));
+        p.screen_max_diff = dmax;
         (void)hipEventElapsedTime(&p.ms_total, e_begin, e_end);
         for (const Span& sp : spans) {
             float ms = 0;
@@ -1240,19 +1260,46 @@ extern "C" int qsp_refine_batch_run(qsp_refine_batch* b, int32_t n_iter) {
         QSP_HIP(hipMemcpyAsync(b->st_snap, b->st, sizeof(HypState) * b->n_hyp, hipMemcpyDeviceToDevice, d->stream));
         if (b->pt_active) QSP_HIP(hipMemcpyAsync(b->act_snap, b->pt_active, (size_t)b->n_hyp * b->act_stride, hipMemcpyDeviceToDevice, d->stream));
     }
-    bool hit = false;
-    int rc = run_once(b, n_iter, &hit);
-    if (rc || !hit) return rc;
+    // (the screened forward is a split-fp16 feature; its self-check needs the same snapshot)
+    const bool may_screen = d->fwd_bf3 == 2 && d->screen_margin > 0.f;
+    if (may_screen && !may_fall_back) {
+        QSP_HIP(hipMemcpyAsync(b->st_snap, b->st, sizeof(HypState) * b->n_hyp, hipMemcpyDeviceToDevice, d->stream));
+        if (b->pt_active) QSP_HIP(hipMemcpyAsync(b->act_snap, b->pt_active, (size_t)b->n_hyp * b->act_stride, hipMemcpyDeviceToDevice, d->stream));
+    }
+    auto restore = [&]() -> int {
+        QSP_HIP(hipMemcpyAsync(b->st, b->st_snap, sizeof(HypState) * b->n_hyp, hipMemcpyDeviceToDevice, d->stream));
+        if (b->pt_active) QSP_HIP(hipMemcpyAsync(b->pt_active, b->act_snap, (size_t)b->n_hyp * b->act_stride, hipMemcpyDeviceToDevice, d->stream));
+        return QSP_OK;
+    };
+    bool hit = false, screen_hit = false;
+    int rc = run_once(b, n_iter, &hit, &screen_hit);
+    if (rc || (!hit && !screen_hit)) return rc;
+    int screen_fallbacks = 0;
+    if (screen_hit) {
+        // The band samples' two values differ by more than half the margin: the premise "no sample outside the band could have
+        // crossed the cut-off" no longer has its safety factor.  Repeat from the starting state in one pass (the path the
+        // screened one is bit-identical to when the premise holds).
+        if ((rc = restore())) return rc;
+        const float margin = d->screen_margin;
+        d->screen_margin = 0.f;
+        d->n_screen_fallbacks++;
+        screen_fallbacks = 1;
+        hit = screen_hit = false;
+        rc = run_once(b, n_iter, &hit, &screen_hit);
+        d->screen_margin = margin;
+        b->profile.screen_fallbacks = 1;
+        if (rc || !hit) return rc;
+    }
     if (!may_fall_back) return range_error();
     // A value left fp16's range.  The reference accepts such a decoder (it computes in float32) and never raises for a numeric
     // condition (reconstruct/optimizer.py:161-194), so the run is repeated from its starting state on the exact-f32 pipe.
-    QSP_HIP(hipMemcpyAsync(b->st, b->st_snap, sizeof(HypState) * b->n_hyp, hipMemcpyDeviceToDevice, d->stream));
-    if (b->pt_active) QSP_HIP(hipMemcpyAsync(b->pt_active, b->act_snap, (size_t)b->n_hyp * b->act_stride, hipMemcpyDeviceToDevice, d->stream));
+    if ((rc = restore())) return rc;
     F32Override f32(d);
     d->n_range_fallbacks++;
-    hit = false;
-    rc = run_once(b, n_iter, &hit);
+    hit = screen_hit = false;
+    rc = run_once(b, n_iter, &hit, &screen_hit);
     b->profile.range_fallbacks = 1;
+    b->profile.screen_fallbacks = screen_fallbacks;
     return rc;
 }
 

@@ -108,6 +108,11 @@ class DeepSdfDecoder(object):
         return int(_lib.lib().qsp_decoder_get_counter(self.handle, 1))
 
     @property
+    def screen_fallbacks(self):
+        """runs the screening self-check repeated in one pass so far (|s1 - s3| on a band sample above half the margin)"""
+        return int(_lib.lib().qsp_decoder_get_counter(self.handle, 5))
+
+    @property
     def narrow_tile(self):
         """True when the split-fp16 kernels run their NARROW form for this decoder (much smaller than the 8 x 512 shape it is embedded
         in: identity slots, all-zero slabs and column blocks skipped -- QSP_DEC_OPT_NARROW_TILE)"""

@@ -112,6 +112,46 @@ def test_random_batches_bit_identical_with_and_without_screening(dec):
     assert within("fp16x2/screening/band_share", share, 0.5)
 
 
+def test_every_screened_run_measures_its_own_premise(dec, golden_dir):
+    """the second pass holds both values of each band sample: the largest |s1 - s3| of the run is reported and sits well below
+    half the margin (the library's trust threshold), so no run of the fixtures is repeated"""
+    from qsp_slam_amd.reconstruct.optimizer import Optimizer
+    z = np.load(os.path.join(golden_dir, "sdf_joint_kitti_m250.npz"))
+    opt = Optimizer(dec, make_cfg(z))
+    obj = dict(pts=z["pts"], rays=z["rays"], depth=z["depth"])
+    before = dec.screen_fallbacks
+    b = run_batch(dec, opt, [obj], [0], z["t_cam_obj"][None], None, int(z["it_H"].shape[0]), True)
+    assert b["prof"].pts_band > 0 and b["prof"].screen_fallbacks == 0 and dec.screen_fallbacks == before
+    assert within("fp16x2/screening/run_max_abs_s1_minus_s3", b["prof"].screen_max_diff, MARGIN / 8)
+    assert b["prof"].screen_max_diff > 0
+
+
+def test_a_margin_the_screening_values_do_not_honour_costs_time_not_bits(dec, golden_dir):
+    """margin 1e-4 is below twice the fixtures' |s1 - s3| (~2.6e-4): the premise of the screened pass fails its self-check, the run
+    is repeated in one pass from its starting state and the result is the unscreened one, bit for bit"""
+    from qsp_slam_amd.reconstruct.optimizer import Optimizer, RefineBatch, _joint_cfg
+    z = np.load(os.path.join(golden_dir, "sdf_joint_kitti_m250.npz"))
+    opt = Optimizer(dec, make_cfg(z))
+    obj = dict(pts=z["pts"], rays=z["rays"], depth=z["depth"])
+    n_it = int(z["it_H"].shape[0])
+    a = run_batch(dec, opt, [obj], [0], z["t_cam_obj"][None], None, n_it, False)
+    before = dec.screen_fallbacks
+    dec.set_render_screening(1e-4)
+    batch = RefineBatch(dec, _joint_cfg(opt), [obj["pts"]], [obj["rays"]], [obj["depth"]], [0])
+    batch.profile(True)
+    batch.set_state(z["t_cam_obj"][None], None)
+    batch.run(n_it)
+    out = dict(batch.trace())
+    T, c, loss, good = batch.get()
+    out.update(T=T, code=c, loss=loss, good=good)
+    prof = batch.profile(True)
+    batch.close()
+    dec.set_render_screening(0.0)
+    assert prof.screen_fallbacks == 1 and dec.screen_fallbacks == before + 1
+    assert prof.pts_band == 0          # (the profile is the repeated, one-pass run's)
+    assert_same_bits(a, out, "self-check fallback")
+
+
 def test_screening_needs_the_split_fp16_forward_pass(golden_dir):
     from qsp_slam_amd import DeepSdfDecoder, _lib
     d = DeepSdfDecoder.from_npz(os.path.join(golden_dir, "decoder_8x512.npz"))
