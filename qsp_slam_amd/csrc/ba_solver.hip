@@ -1352,8 +1352,10 @@ __global__ __launch_bounds__(256) void k_trial_stage1(Dev d, Par par, Stage1 g) 
 //     to [S | I] give L^-1 beside the factor -- so the next launch finds W_{k+1} and y_{k+1} ready.
 // The backward substitution x_k = W_k^T (y_k - sum_j U_kj x_j) is nb small launches of matrix-vector products.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int CHOL_ROWBUF = 2 * 8 * NB;
+constexpr int CHOL_THREADS = 320;           // four waves of 4x4 tiles + the panel wave of factor_tile64
+constexpr int CHOL_ROWBUF = 4 * 8 * NB;     // factor_tile64: published rows (rb) and rows handed to the panel wave (nx), double-buffered
 constexpr int CHOL_LDS_DOUBLES = 3 * NB * NB + CHOL_ROWBUF + NB;
+static_assert(NB * (NB + 1) <= 2 * NB * NB, "Wr (NB x 65) lies over X and the head of Yi");
 
 // acc[a][b] += sum_m X[m][r0+a] * Y[m][c0+b]   (X, Y: 64x64 row-major in LDS)
 __device__ inline void gemm_tn64(const double* X, const double* Y, int r0, int c0, double (&acc)[4][4]) {
@@ -1378,34 +1380,67 @@ __device__ inline double rsqrt_nr(double d) {
     return r;
 }
 
-// In-register factorisation of a 64x64 SPD block spread as 4x4 tiles over 256 threads (thread owns rows r0.., cols c0..),
-// four rows per barrier: the 16 threads owning rows 4jb..4jb+3 (16 adjacent lanes of one wave) fetch the diagonal tile by
-// wave shuffle, factor it redundantly, finish their columns of the 4 x 64 panel of U and of W = L^-1 (the same row
-// operations applied to the identity) and publish both; after one barrier everybody below applies a rank-4 update.
-// S is consumed; rowbuf: 2 x 8 x NB doubles of LDS.
-__device__ inline bool factor_tile64(double (&S)[4][4], double (&W)[4][4], double* rowbuf, int r0, int c0) {
+// Factorisation of a 64x64 SPD block by 320 threads: four UPDATER waves hold S (and W = L^-1, grown from the identity by the same
+// row operations) as 4x4 register tiles (thread owns rows r0.., cols c0..); a fifth PANEL wave (lane = column) owns the serial
+// chain.  Phase p (one workgroup barrier each):
+//   panel     takes rows 4p..4p+3 of [S | W] as the updaters left them one block earlier (nx), applies block p-1 itself (8 values
+//             per lane), fetches the 4x4 diagonal values by v_readlane, factorises them (Newton rsqrt), finishes its column of
+//             the four rows of U and W and publishes them (rb; the W rows also into Wr, pitch 65, for the tail);
+//   updaters  apply block p-1 (rank 4) to every tile below it; the 16 threads owning rows 4(p+1).. then hand their tiles to the
+//             panel wave (nx) for the next phase.
+// The pivot chain and the rank-4 update overlap instead of alternating: 14.1 against 20.6 us per block on MI355X
+// (tools/micro/chol_factor.hip, variants 0 and 5), every element going through the same operations in the same order (the two
+// forms agree in every bit).  S is consumed.  rowbuf: CHOL_ROWBUF doubles of LDS (rb and nx, double-buffered); Wr: NB x 65.
+__device__ inline bool factor_tile64(double (&S)[4][4], double* Wr, double* rowbuf, int r0, int c0) {
     bool bad = false;
     const int t = threadIdx.x, lane = t & 63;
+    const bool panel = t >= 256;
+    double* const rbuf = rowbuf;
+    double* const nx = rowbuf + 2 * 8 * NB;
+    double W[4][4];
+    if (!panel) {
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+        for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) W[a][b] = (r0 + a == c0 + b) ? 1.0 : 0.0;
+            for (int b = 0; b < 4; ++b) W[a][b] = (r0 + a == c0 + b) ? 1.0 : 0.0;
+        if (r0 == 0) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) { nx[a * NB + c0 + b] = S[a][b]; nx[(4 + a) * NB + c0 + b] = W[a][b]; }
+        }
+    }
+    __syncthreads();
 #pragma nounroll
-    for (int jb = 0; jb < NB / 4; ++jb) {
-        double* rb = rowbuf + (jb & 1) * 8 * NB;
-        if ((t >> 4) == jb) {
-            // the 16 lanes at work sit in wave jb / 4 at lanes 16 (jb & 3) ..; the diagonal tile's owner is lane 16 (jb & 3) + jb of it:
-            // a uniform lane index, so v_readlane (to scalar registers) replaces the ds_bpermute pair of a shuffle
-            const int src = 16 * (jb & 3) | jb;
+    for (int p = 0; p < NB / 4; ++p) {
+        double* rb = rbuf + (p & 1) * 8 * NB;
+        const double* rbp = rbuf + ((p + 1) & 1) * 8 * NB;       // block p-1
+        if (panel) {
+            const double* in = nx + (p & 1) * 8 * NB;
+            double s[4], w[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) { s[a] = in[a * NB + lane]; w[a] = in[(4 + a) * NB + lane]; }
+            if (p > 0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const double uc = rbp[q * NB + lane], wc = rbp[(4 + q) * NB + lane];
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        const double ur = rbp[q * NB + 4 * p + a];
+                        s[a] -= ur * uc;
+                        w[a] -= ur * wc;
+                    }
+                }
+            }
             double D[4][4], rs[4];
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
-                for (int b = a; b < 4; ++b) {
+                for (int b = a; b < 4; ++b) {      // (a uniform lane index: v_readlane to scalar registers, no LDS round trip)
                     union { double d; int i[2]; } u, r;
-                    u.d = S[a][b];
-                    r.i[0] = __builtin_amdgcn_readlane(u.i[0], src);
-                    r.i[1] = __builtin_amdgcn_readlane(u.i[1], src);
+                    u.d = s[a];
+                    r.i[0] = __builtin_amdgcn_readlane(u.i[0], 4 * p + b);
+                    r.i[1] = __builtin_amdgcn_readlane(u.i[1], 4 * p + b);
                     D[a][b] = r.d;
                 }
 #pragma unroll
@@ -1423,137 +1458,155 @@ __device__ inline bool factor_tile64(double (&S)[4][4], double (&W)[4][4], doubl
                     for (int b = a; b < 4; ++b) D[a][b] -= D[q][a] * D[q][b];
             }
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    double sv = S[q][b], wv = W[q][b];
-#pragma unroll
-                    for (int pp = 0; pp < q; ++pp) { sv -= D[pp][q] * S[pp][b]; wv -= D[pp][q] * W[pp][b]; }
-                    S[q][b] = sv * rs[q];
-                    W[q][b] = wv * rs[q];
-                    rb[q * NB + c0 + b] = S[q][b];
-                    rb[(4 + q) * NB + c0 + b] = W[q][b];
-                }
-        }
-        __syncthreads();
-        if (r0 > 4 * jb) {
-#pragma unroll
             for (int q = 0; q < 4; ++q) {
-                double ur[4], uc[4], wc[4];
+                double sv = s[q], wv = w[q];
 #pragma unroll
-                for (int a = 0; a < 4; ++a) { ur[a] = rb[q * NB + r0 + a]; uc[a] = rb[q * NB + c0 + a]; wc[a] = rb[(4 + q) * NB + c0 + a]; }
+                for (int pp = 0; pp < q; ++pp) { sv -= D[pp][q] * s[pp]; wv -= D[pp][q] * w[pp]; }
+                s[q] = sv * rs[q];
+                w[q] = wv * rs[q];
+                rb[q * NB + lane] = s[q];
+                rb[(4 + q) * NB + lane] = w[q];
+                Wr[(4 * p + q) * (NB + 1) + lane] = w[q];
+            }
+        } else {
+            if (p > 0 && r0 > 4 * (p - 1)) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    double ur[4], uc[4], wc[4];
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) { ur[a] = rbp[q * NB + r0 + a]; uc[a] = rbp[q * NB + c0 + a]; wc[a] = rbp[(4 + q) * NB + c0 + a]; }
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) { S[a][b] -= ur[a] * uc[b]; W[a][b] -= ur[a] * wc[b]; }
+                }
+            }
+            if (r0 == 4 * (p + 1)) {
+                double* out = nx + ((p + 1) & 1) * 8 * NB;
 #pragma unroll
                 for (int a = 0; a < 4; ++a)
 #pragma unroll
-                    for (int b = 0; b < 4; ++b) { S[a][b] -= ur[a] * uc[b]; W[a][b] -= ur[a] * wc[b]; }
+                    for (int b = 0; b < 4; ++b) { out[a * NB + c0 + b] = S[a][b]; out[(4 + a) * NB + c0 + b] = W[a][b]; }
             }
         }
+        __syncthreads();
     }
     return bad;
 }
 
-// tail shared by the first launch and workgroup (k+1,k+1): factorise block kb, publish W_kb^T and y_kb = W_kb b_kb.
-// bvec (LDS, NB doubles) holds the fully updated right-hand-side block.
-__device__ inline void factor_and_forward(double (&S)[4][4], int kb, double* Winv, double* y, double* lds_mat, double* rowbuf,
+// tail shared by the first launch and workgroup (k+1,k+1), 320 threads: factorise block kb, publish W_kb^T and y_kb = W_kb b_kb.
+// bvec (LDS, NB doubles) holds the fully updated right-hand-side block; Wr (LDS, NB x 65) receives the rows of W.
+__device__ inline void factor_and_forward(double (&S)[4][4], int kb, double* Winv, double* y, double* Wr, double* rowbuf,
                                           const double* bvec, double* scal, int r0, int c0) {
-    double W[4][4];
-    const bool bad = factor_tile64(S, W, rowbuf, r0, c0);
-    if (bad) scal[3] = 1.0;
-    __syncthreads();
-    // W^T into LDS and global: WT[m][q] = W[q][m]
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) lds_mat[(c0 + b) * NB + r0 + a] = W[a][b];
-    __syncthreads();
+    const bool bad = factor_tile64(S, Wr, rowbuf, r0, c0);
+    if (bad) scal[3] = 1.0;                                        // (the panel wave's lanes: one value, 64 writers)
+    // (the loop's last barrier has made Wr complete.)  W^T to global: WT[m][q] = W[q][m]
     double* Wg = Winv + (size_t)kb * NB * NB;
-    for (int e = threadIdx.x; e < NB * NB; e += 256) Wg[e] = lds_mat[e];
+    for (int e = threadIdx.x; e < NB * NB; e += CHOL_THREADS) Wg[e] = Wr[(e % NB) * (NB + 1) + e / NB];
     if (threadIdx.x < NB) {
         double v = 0;
-        for (int m = 0; m < NB; ++m) v += lds_mat[m * NB + threadIdx.x] * bvec[m];
+        for (int m = 0; m < NB; ++m) v += Wr[threadIdx.x * (NB + 1) + m] * bvec[m];
         y[kb * NB + threadIdx.x] = v;
     }
 }
 
-__global__ __launch_bounds__(256) void k_chol_first(const double* A, double* Winv, const double* b, double* y, int ld,
-                                                    double* scal) {
+__global__ __launch_bounds__(CHOL_THREADS) void k_chol_first(const double* A, double* Winv, const double* b, double* y, int ld,
+                                                             double* scal) {
     extern __shared__ __attribute__((aligned(16))) double chol_lds[];
     double* X = chol_lds;
     double* rowbuf = chol_lds + 3 * NB * NB;
     double* bvec = rowbuf + CHOL_ROWBUF;
     const int t = threadIdx.x, r0 = (t >> 4) * 4, c0 = (t & 15) * 4;
     double S[4][4];
+    if (t < 256) {
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+        for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) S[a][q] = A[(size_t)(r0 + a) * ld + c0 + q];
+            for (int q = 0; q < 4; ++q) S[a][q] = A[(size_t)(r0 + a) * ld + c0 + q];
+    }
     if (t < NB) bvec[t] = b[t];
     __syncthreads();
     factor_and_forward(S, 0, Winv, y, X, rowbuf, bvec, scal, r0, c0);
 }
 
-// grid (n, n), n = nb - k - 1: x = j - k - 1, y = i - k - 1; workgroups below the diagonal leave at once
-__global__ __launch_bounds__(256) void k_chol_step(double* A, double* Uf, double* Winv, double* b, double* y, int ld, int k,
-                                                   double* scal) {
+// grid (n, n), n = nb - k - 1: x = j - k - 1, y = i - k - 1; workgroups below the diagonal leave at once.  320 threads: the
+// fifth wave is factor_tile64's panel wave and has work in workgroup (k+1,k+1) only (there it also carries the right-hand side
+// while the others are in the second product).
+__global__ __launch_bounds__(CHOL_THREADS) void k_chol_step(double* A, double* Uf, double* Winv, double* b, double* y, int ld, int k,
+                                                            double* scal) {
     const int j = k + 1 + blockIdx.x, i = k + 1 + blockIdx.y;
     if (i > j) return;
+    const int t = threadIdx.x, r0 = (t >> 4) * 4, c0 = (t & 15) * 4;
+    const bool first_row = (i == k + 1);
+    const bool chain = first_row && i == j;               // this workgroup goes on to factorise block k+1
+    const bool upd = t < 256;                             // (elsewhere the fifth wave only walks through the barriers)
     extern __shared__ __attribute__((aligned(16))) double chol_lds[];
     double* X = chol_lds;
     double* Yi = chol_lds + NB * NB;
     double* Yj = (i == j) ? Yi : chol_lds + 2 * NB * NB;
     double* rowbuf = chol_lds + 3 * NB * NB;
     double* bvec = rowbuf + CHOL_ROWBUF;
-    const int t = threadIdx.x, r0 = (t >> 4) * 4, c0 = (t & 15) * 4;
     const double* Wg = Winv + (size_t)k * NB * NB;
     double S[4][4];                                       // the tile this thread updates: in flight behind the panel loads
+    if (upd) {
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+        for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) S[a][q] = A[(size_t)(i * NB + r0 + a) * ld + j * NB + c0 + q];
-    for (int e = t; e < NB * NB; e += 256) {
-        X[e] = Wg[e];
-        Yi[e] = A[(size_t)(k * NB + e / NB) * ld + i * NB + e % NB];
-        if (i != j) Yj[e] = A[(size_t)(k * NB + e / NB) * ld + j * NB + e % NB];
+            for (int q = 0; q < 4; ++q) S[a][q] = A[(size_t)(i * NB + r0 + a) * ld + j * NB + c0 + q];
+        for (int e = t; e < NB * NB; e += 256) {
+            X[e] = Wg[e];
+            Yi[e] = A[(size_t)(k * NB + e / NB) * ld + i * NB + e % NB];
+            if (i != j) Yj[e] = A[(size_t)(k * NB + e / NB) * ld + j * NB + e % NB];
+        }
     }
     __syncthreads();
     double pi[4][4] = {}, pj[4][4] = {};
-    gemm_tn64(X, Yi, r0, c0, pi);
-    if (i != j) gemm_tn64(X, Yj, r0, c0, pj);
+    if (upd) {
+        gemm_tn64(X, Yi, r0, c0, pi);
+        if (i != j) gemm_tn64(X, Yj, r0, c0, pj);
+    }
     __syncthreads();
+    if (upd) {
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+        for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            Yi[(r0 + a) * NB + c0 + q] = pi[a][q];
-            if (i != j) Yj[(r0 + a) * NB + c0 + q] = pj[a][q];
-        }
+            for (int q = 0; q < 4; ++q) {
+                Yi[(r0 + a) * NB + c0 + q] = pi[a][q];
+                if (i != j) Yj[(r0 + a) * NB + c0 + q] = pj[a][q];
+            }
+    }
     __syncthreads();
-    double acc[4][4] = {};
-    gemm_tn64(Yi, Yj, r0, c0, acc);
+    if (upd) {
+        double acc[4][4] = {};
+        gemm_tn64(Yi, Yj, r0, c0, acc);
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+        for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) S[a][q] -= acc[a][q];
-    const bool first_row = (i == k + 1);
+            for (int q = 0; q < 4; ++q) S[a][q] -= acc[a][q];
+    }
     if (first_row) {
-        // factor block U_kj = P_j (64 x 64) is stored TRANSPOSED, element (m, c) at Uf[(j NB + c) ld + k NB + m]: the backward
-        // substitution walks it by rows m with a lane per row.  Straight from the registers (4 consecutive m per store group).
+        if (upd) {
+            // factor block U_kj = P_j (64 x 64) is stored TRANSPOSED, element (m, c) at Uf[(j NB + c) ld + k NB + m]: the backward
+            // substitution walks it by rows m with a lane per row.  Straight from the registers (4 consecutive m per store group).
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+            for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
-                Uf[(size_t)(j * NB + c0 + q) * ld + k * NB + r0 + a] = (i == j) ? pi[a][q] : pj[a][q];
-        if (t < NB) {
-            double v = b[j * NB + t];
-            for (int q = 0; q < NB; ++q) v -= Yj[q * NB + t] * y[k * NB + q];
-            b[j * NB + t] = v;
-            bvec[t] = v;
+                for (int a = 0; a < 4; ++a)
+                    Uf[(size_t)(j * NB + c0 + q) * ld + k * NB + r0 + a] = (i == j) ? pi[a][q] : pj[a][q];
+        }
+        // b_j -= P_j^T y_k: by the panel wave where there is one (beside the second product), by the first wave elsewhere
+        const int tb = chain ? t - 256 : t;
+        if (tb >= 0 && tb < NB) {
+            double v = b[j * NB + tb];
+            for (int q = 0; q < NB; ++q) v -= Yj[q * NB + tb] * y[k * NB + q];
+            b[j * NB + tb] = v;
+            bvec[tb] = v;
         }
     }
-    if (first_row && i == j) {
+    if (chain) {
         __syncthreads();
         factor_and_forward(S, k + 1, Winv, y, X, rowbuf, bvec, scal, r0, c0);
-    } else {
+    } else if (upd) {
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -2825,9 +2878,9 @@ extern "C" int qsp_ba_optimize(qsp_ba_problem* p, int32_t n_iter, double delta_m
                 if (rc) return rc;
                 const int nb = p->dimp / NB;
                 const size_t lds = sizeof(double) * CHOL_LDS_DOUBLES;
-                hipLaunchKernelGGL(k_chol_first, dim3(1), dim3(256), lds, s, d.Hs, d.Winv, d.bs, d.ych, p->dimp, d.scal);
+                hipLaunchKernelGGL(k_chol_first, dim3(1), dim3(CHOL_THREADS), lds, s, d.Hs, d.Winv, d.bs, d.ych, p->dimp, d.scal);
                 for (int k = 0; k + 1 < nb; ++k)
-                    hipLaunchKernelGGL(k_chol_step, dim3(nb - k - 1, nb - k - 1), dim3(256), lds, s, d.Hs, d.Uf, d.Winv, d.bs,
+                    hipLaunchKernelGGL(k_chol_step, dim3(nb - k - 1, nb - k - 1), dim3(CHOL_THREADS), lds, s, d.Hs, d.Uf, d.Winv, d.bs,
                                        d.ych, p->dimp, k, d.scal);
                 hipLaunchKernelGGL(k_chol_back, dim3(1 + 8 * CHOL_BACK_HELPERS), dim3(1024), sizeof(double) * (size_t)(2 * p->dimp + NB), s, d, par, d.Uf, d.Winv,
                                    d.ych, d.xp, p->dimp);

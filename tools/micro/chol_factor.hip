@@ -8,6 +8,10 @@
 //   variant 3: one tile per thread and round: U is upper and W = L^-1 lower triangular, so a thread right of / on the diagonal
 //              only ever needs its S tile and a thread left of it only its W tile (the diagonal W tiles stay the identity until
 //              their own pivot round and are final after it)
+//   variant 5: a fifth PANEL wave (lane = column) owns the pivot chain: in phase p it takes rows 4p..4p+3 as the updaters left them
+//              one block earlier, applies block p-1 itself (8 values per lane), factorises and publishes block p -- while the four
+//              updater waves are still applying block p-1 to everything below.  One barrier per phase; the chain and the rank-4
+//              update overlap instead of alternating.  Same operations in the same order on every element as variant 0.
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>
@@ -289,6 +293,242 @@ __global__ __launch_bounds__(256) void k_factor(const double* A, double* Wout, d
         }
 }
 
+__device__ unsigned long long g_ts5[16][4];
+__device__ unsigned long long g_ts5f[16][8];
+#ifdef QSP_FINE_STAMPS      // the scheduler may not move anything across a stamp; the wait makes the LDS traffic before it complete
+#define QSP_STAMP(i_) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0); if (lane == 0) g_ts5f[p][i_] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
+#else
+#define QSP_STAMP(i_)
+#endif
+__global__ __launch_bounds__(320) void k_factor5(const double* A, double* Wout, double* Uout) {
+    __shared__ double rowbuf[16 * 8 * NB];      // per phase: 4 rows of U, 4 rows of W
+    __shared__ double nx[2 * 8 * NB];           // rows of the next block as the updaters left them (S: 4 x 64, W: 4 x 64)
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const bool panel = wave == 4;
+    const int r0 = (t >> 4) * 4, c0 = (t & 15) * 4;
+    double S[4][4], W[4][4];
+    if (!panel) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                S[a][b] = A[(r0 + a) * NB + c0 + b];
+                W[a][b] = (r0 + a == c0 + b) ? 1.0 : 0.0;
+            }
+        if ((t >> 4) == 0) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) { nx[a * NB + c0 + b] = S[a][b]; nx[(4 + a) * NB + c0 + b] = W[a][b]; }
+        }
+    }
+    __syncthreads();
+#pragma nounroll
+    for (int p = 0; p < 16; ++p) {
+        double* rb = rowbuf + p * 8 * NB;
+        const double* rbp = rowbuf + (p - 1) * 8 * NB;
+        if (panel) {
+            if (lane == 0) g_ts5[p][0] = __builtin_readcyclecounter();
+            const double* in = nx + (p & 1) * 8 * NB;
+            double s[4], w[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) { s[a] = in[a * NB + lane]; w[a] = in[(4 + a) * NB + lane]; }
+            QSP_STAMP(0)
+            if (p > 0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const double uc = rbp[q * NB + lane], wc = rbp[(4 + q) * NB + lane];
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        const double ur = rbp[q * NB + 4 * p + a];
+                        s[a] -= ur * uc;
+                        w[a] -= ur * wc;
+                    }
+                }
+            }
+            QSP_STAMP(1)
+            double D[4][4], rs[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = a; b < 4; ++b) {
+                    union { double d; int i[2]; } u, r;
+                    u.d = s[a];
+                    r.i[0] = __builtin_amdgcn_readlane(u.i[0], 4 * p + b);
+                    r.i[1] = __builtin_amdgcn_readlane(u.i[1], 4 * p + b);
+                    D[a][b] = r.d;
+                }
+            QSP_STAMP(2)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                rs[q] = rsqrt_nr(D[q][q]);
+#pragma unroll
+                for (int b = q + 1; b < 4; ++b) D[q][b] *= rs[q];
+#pragma unroll
+                for (int a = q + 1; a < 4; ++a)
+#pragma unroll
+                    for (int b = a; b < 4; ++b) D[a][b] -= D[q][a] * D[q][b];
+            }
+            QSP_STAMP(3)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                double sv = s[q], wv = w[q];
+#pragma unroll
+                for (int pp = 0; pp < q; ++pp) { sv -= D[pp][q] * s[pp]; wv -= D[pp][q] * w[pp]; }
+                s[q] = sv * rs[q];
+                w[q] = wv * rs[q];
+                rb[q * NB + lane] = s[q];
+                rb[(4 + q) * NB + lane] = w[q];
+            }
+            QSP_STAMP(4)
+            if (lane == 0) g_ts5[p][1] = __builtin_readcyclecounter();
+        } else {
+            if (t == 255) g_ts5[p][2] = __builtin_readcyclecounter();
+            if (p > 0 && r0 > 4 * (p - 1)) rank4<true>(S, W, rbp, r0, c0);
+            if ((t >> 4) == p + 1) {
+                double* out = nx + ((p + 1) & 1) * 8 * NB;
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) { out[a * NB + c0 + b] = S[a][b]; out[(4 + a) * NB + c0 + b] = W[a][b]; }
+            }
+            if (t == 255) g_ts5[p][3] = __builtin_readcyclecounter();
+        }
+        __syncthreads();
+    }
+    for (int e = t; e < NB * NB; e += 320) {
+        const int q = e / NB, m = e % NB;
+        Uout[e] = rowbuf[(q / 4) * 8 * NB + (q % 4) * NB + m];
+        Wout[e] = rowbuf[(q / 4) * 8 * NB + (4 + q % 4) * NB + m];
+    }
+}
+
+// variants 6 (R = 4) and 7 (R = 8): variant 5 with R rows per phase and the panel wave keeping the block it has just published in
+// registers (its column of the R rows of U and W; the R x R diagonal values by v_readlane) instead of reading it back from LDS
+template <int R>
+__device__ inline void rankR(double (&S)[4][4], double (&W)[4][4], const double* rb, int r0, int c0) {
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+        double ur[4], uc[4], wc[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            ur[a] = rb[q * NB + r0 + a];
+            uc[a] = rb[q * NB + c0 + a];
+            wc[a] = rb[(R + q) * NB + c0 + a];
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                S[a][b] -= ur[a] * uc[b];
+                W[a][b] -= ur[a] * wc[b];
+            }
+    }
+}
+__device__ inline double rdlane(double v, int l) {
+    union { double d; int i[2]; } u, r;
+    u.d = v;
+    r.i[0] = __builtin_amdgcn_readlane(u.i[0], l);
+    r.i[1] = __builtin_amdgcn_readlane(u.i[1], l);
+    return r.d;
+}
+template <int R>
+__global__ __launch_bounds__(320) void k_factorR(const double* A, double* Wout, double* Uout) {
+    constexpr int NP = NB / R;
+    __shared__ double rowbuf[NP * 2 * R * NB];
+    __shared__ double nx[2 * 2 * R * NB];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const bool panel = wave == 4;
+    const int r0 = (t >> 4) * 4, c0 = (t & 15) * 4;
+    double S[4][4], W[4][4];
+    double sp[R], wp[R];          // panel: the block published in the phase before
+    if (!panel) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                S[a][b] = A[(r0 + a) * NB + c0 + b];
+                W[a][b] = (r0 + a == c0 + b) ? 1.0 : 0.0;
+            }
+        if (r0 < R) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) { nx[(r0 + a) * NB + c0 + b] = S[a][b]; nx[(R + r0 + a) * NB + c0 + b] = W[a][b]; }
+        }
+    }
+    __syncthreads();
+#pragma nounroll
+    for (int p = 0; p < NP; ++p) {
+        double* rb = rowbuf + p * 2 * R * NB;
+        const double* rbp = rowbuf + (p - 1) * 2 * R * NB;
+        if (panel) {
+            if (lane == 0) g_ts5[p][0] = __builtin_readcyclecounter();
+            const double* in = nx + (p & 1) * 2 * R * NB;
+            double s[R], w[R];
+#pragma unroll
+            for (int a = 0; a < R; ++a) { s[a] = in[a * NB + lane]; w[a] = in[(R + a) * NB + lane]; }
+            if (p > 0) {
+#pragma unroll
+                for (int q = 0; q < R; ++q) {
+#pragma unroll
+                    for (int a = 0; a < R; ++a) {
+                        const double ur = rdlane(sp[q], R * p + a);
+                        s[a] -= ur * sp[q];
+                        w[a] -= ur * wp[q];
+                    }
+                }
+            }
+            double D[R][R], rs[R];
+#pragma unroll
+            for (int a = 0; a < R; ++a)
+#pragma unroll
+                for (int b = a; b < R; ++b) D[a][b] = rdlane(s[a], R * p + b);
+#pragma unroll
+            for (int q = 0; q < R; ++q) {
+                rs[q] = rsqrt_nr(D[q][q]);
+#pragma unroll
+                for (int b = q + 1; b < R; ++b) D[q][b] *= rs[q];
+#pragma unroll
+                for (int a = q + 1; a < R; ++a)
+#pragma unroll
+                    for (int b = a; b < R; ++b) D[a][b] -= D[q][a] * D[q][b];
+            }
+#pragma unroll
+            for (int q = 0; q < R; ++q) {
+                double sv = s[q], wv = w[q];
+#pragma unroll
+                for (int pp = 0; pp < q; ++pp) { sv -= D[pp][q] * s[pp]; wv -= D[pp][q] * w[pp]; }
+                s[q] = sv * rs[q];
+                w[q] = wv * rs[q];
+                rb[q * NB + lane] = s[q];
+                rb[(R + q) * NB + lane] = w[q];
+                sp[q] = s[q];
+                wp[q] = w[q];
+            }
+            if (lane == 0) g_ts5[p][1] = __builtin_readcyclecounter();
+        } else {
+            if (t == 255) g_ts5[p][2] = __builtin_readcyclecounter();
+            if (p > 0 && r0 >= R * p) rankR<R>(S, W, rbp, r0, c0);
+            if (r0 >= R * (p + 1) && r0 < R * (p + 2)) {
+                double* out = nx + ((p + 1) & 1) * 2 * R * NB;
+                const int rr = r0 - R * (p + 1);
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) { out[(rr + a) * NB + c0 + b] = S[a][b]; out[(R + rr + a) * NB + c0 + b] = W[a][b]; }
+            }
+            if (t == 255) g_ts5[p][3] = __builtin_readcyclecounter();
+        }
+        __syncthreads();
+    }
+    for (int e = t; e < NB * NB; e += 320) {
+        const int q = e / NB, m = e % NB;
+        Uout[e] = rowbuf[(q / R) * 2 * R * NB + (q % R) * NB + m];
+        Wout[e] = rowbuf[(q / R) * 2 * R * NB + (R + q % R) * NB + m];
+    }
+}
+
 int main(int argc, char** argv) {
     const int var = argc > 1 ? atoi(argv[1]) : 0;
     std::vector<double> A(NB * NB), M(NB * NB);
@@ -316,7 +556,10 @@ int main(int argc, char** argv) {
             else if (var == 1) hipLaunchKernelGGL(k_factor<1>, dim3(1), dim3(256), 0, 0, dA, dW, dU);
             else if (var == 2) hipLaunchKernelGGL(k_factor<2>, dim3(1), dim3(256), 0, 0, dA, dW, dU);
             else if (var == 3) hipLaunchKernelGGL(k_factor<3>, dim3(1), dim3(256), 0, 0, dA, dW, dU);
-            else hipLaunchKernelGGL(k_factor<4>, dim3(1), dim3(256), 0, 0, dA, dW, dU);
+            else if (var == 4) hipLaunchKernelGGL(k_factor<4>, dim3(1), dim3(256), 0, 0, dA, dW, dU);
+            else if (var == 5) hipLaunchKernelGGL(k_factor5, dim3(1), dim3(320), 0, 0, dA, dW, dU);
+            else if (var == 6) hipLaunchKernelGGL(k_factorR<4>, dim3(1), dim3(320), 0, 0, dA, dW, dU);
+            else hipLaunchKernelGGL(k_factorR<8>, dim3(1), dim3(320), 0, 0, dA, dW, dU);
         }
         hipEventRecord(e1);
         hipEventSynchronize(e1);
@@ -343,6 +586,40 @@ int main(int argc, char** argv) {
     unsigned long long ts[16][4];
     hipMemcpyFromSymbol(ts, HIP_SYMBOL(g_ts), sizeof(ts));
     printf("variant %d: %.2f us per launch (100 back-to-back); |U^T U - A| %.1e, |W L - I| %.1e\n", var, 10.0 * ms, eU, eW);
+    if (var >= 5) {
+        hipMemcpyFromSymbol(ts, HIP_SYMBOL(g_ts5), sizeof(ts));
+        unsigned long long pn = 0, up = 0;
+        const int np = var == 7 ? 8 : 16;
+        for (int p = 0; p < np; ++p) { pn += ts[p][1] - ts[p][0]; up += ts[p][3] - ts[p][2]; }
+        printf("  cycles summed over phases: panel wave's section %llu, updater wave 3's section %llu; whole loop (panel lane 0) %llu\n", pn, up,
+               ts[np - 1][1] - ts[0][0]);
+        printf("  per phase, panel / updater wave 3:");
+        for (int p = 0; p < np; ++p) printf(" %llu/%llu", ts[p][1] - ts[p][0], ts[p][3] - ts[p][2]);
+        printf("\n");
+#ifdef QSP_FINE_STAMPS
+        if (var == 5) {
+            unsigned long long f[16][8];
+            hipMemcpyFromSymbol(f, HIP_SYMBOL(g_ts5f), sizeof(f));
+            printf("  panel phases (cycles): load | update | readlanes | pivots | rows+store\n");
+            for (int p = 0; p < 16; ++p)
+                printf("   %2d: %llu | %llu | %llu | %llu | %llu\n", p, f[p][0] - ts[p][0], f[p][1] - f[p][0], f[p][2] - f[p][1], f[p][3] - f[p][2],
+                       f[p][4] - f[p][3]);
+        }
+#endif
+        // bit comparison with variant 0
+        hipLaunchKernelGGL(k_factor<0>, dim3(1), dim3(256), 0, 0, dA, dW, dU);
+        std::vector<double> W0(NB * NB), U0(NB * NB);
+        hipMemcpy(W0.data(), dW, sizeof(double) * NB * NB, hipMemcpyDeviceToHost);
+        hipMemcpy(U0.data(), dU, sizeof(double) * NB * NB, hipMemcpyDeviceToHost);
+        int dw = 0, du = 0;
+        for (int i = 0; i < NB; ++i)
+            for (int j = 0; j < NB; ++j) {
+                if (W0[i * NB + j] != Wh[i * NB + j]) ++dw;
+                if (j >= i && U0[i * NB + j] != Uh[i * NB + j]) ++du;
+            }
+        printf("  elements that differ from variant 0 in any bit: W %d, U (upper) %d\n", dw, du);
+        return 0;
+    }
     const int step = var == 2 ? 4 : 1;
     unsigned long long tot_p = 0, tot_b = 0, tot_u = 0;
     for (int jb = 0; jb < 16; jb += step) {
