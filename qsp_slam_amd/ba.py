@@ -91,6 +91,19 @@ class BaProblem(object):
         """objects eliminated in closed form in front of the dense solve (default) or kept inside it (qsp_ba_set_option)"""
         _lib.check(_lib.lib().qsp_ba_set_option(self.handle, 1, 1 if on else 0))
 
+    def set_cholesky_chain(self, on=True):
+        """the dense factorisation as one resident chain workgroup with the trailing updates on a second stream (default where the
+        problem's two streams run concurrently) or as one launch per block step; same bits either way (QSP_BA_OPT_CHOLESKY_CHAIN)"""
+        _lib.check(_lib.lib().qsp_ba_set_option(self.handle, 2, 1 if on else 0))
+
+    @property
+    def cholesky_chain(self):
+        prof = _lib.BaProfile()
+        L = _lib.lib()
+        # (qsp_ba_profile reports and sets the profiling switch: read it, then put the switch back)
+        _lib.check(L.qsp_ba_profile(self.handle, 1 if getattr(self, "_profiling", False) else 0, C.byref(prof)))
+        return bool(prof.cholesky_chain)
+
     def set_deterministic(self, on=True):
         """no atomics in the Schur complement: repeated runs give the same bits (qsp_ba_set_deterministic)"""
         _lib.check(_lib.lib().qsp_ba_set_deterministic(self.handle, 1 if on else 0))
@@ -146,6 +159,7 @@ class BaProblem(object):
                     mono_pos=pm[: self.nm].astype(bool), st_pos=ps[: self.ns].astype(bool))
 
     def profile(self, enable=True):
+        self._profiling = bool(enable)
         p = _lib.BaProfile()
         _lib.check(_lib.lib().qsp_ba_profile(self.handle, 1 if enable else 0, C.byref(p)))
         return p

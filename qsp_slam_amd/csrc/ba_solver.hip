@@ -406,7 +406,7 @@ __global__ __launch_bounds__(64) void k_finish_sum_publish(Dev d, int n, double*
         host[0] = s;
         host[1] = tot;
         host[2] = d.scal[2];
-        host[3] = d.scal[3];
+        host[3] = d.scal[5] != 0.0 ? 2.0 : d.scal[3];      // (scal[5]: a flag wait of the chain factorisation expired -- sticky)
         d.scal[3] = 0.0;
         __threadfence_system();
         *reinterpret_cast<volatile double*>(host + 4) = seq;
@@ -418,6 +418,7 @@ __global__ __launch_bounds__(64) void k_finish_sum_publish(Dev d, int n, double*
 __global__ void k_publish_scal(Dev d, double* __restrict__ host, double seq) {
     if (threadIdx.x == 0) {
         for (int i = 0; i < 4; ++i) host[i] = d.scal[i];
+        if (d.scal[5] != 0.0) host[3] = 2.0;
         d.scal[3] = 0.0;
         __threadfence_system();
         *reinterpret_cast<volatile double*>(host + 4) = seq;      // the host polls this word (wait_scal)
@@ -1357,18 +1358,39 @@ constexpr int CHOL_ROWBUF = 4 * 8 * NB;     // factor_tile64: published rows (rb
 constexpr int CHOL_LDS_DOUBLES = 3 * NB * NB + CHOL_ROWBUF + NB;
 static_assert(NB * (NB + 1) <= 2 * NB * NB, "Wr (NB x 65) lies over X and the head of Yi");
 
-// acc[a][b] += sum_m X[m][r0+a] * Y[m][c0+b]   (X, Y: 64x64 row-major in LDS)
-__device__ inline void gemm_tn64(const double* X, const double* Y, int r0, int c0, double (&acc)[4][4]) {
+// The 64x64x64 products of the factorisation on the FP64 matrix pipe: wave w of four forms rows 16w..16w+15 of the result as
+// four 16x16 tiles, acc[tc] (+)= sum_m A(m, 16w + i) B[m][16 tc + j] with A(m, r) = X[m sk + r si] (so the left operand may be
+// stored either way round, with any pitch) and B row-major with pitch NB.  v_mfma_f64_16x16x4_f64: lane l carries A[i = l & 15]
+// [k = l >> 4] and B[k = l >> 4][j = l & 15]; its four results are rows (l >> 4) + 4 reg, column l & 15 of the tile.  The matrix
+// pipe's FP64 rate equals the vector pipe's on this part; what it saves is LDS traffic -- one operand double per lane and 1024
+// multiply-adds against eight doubles per 16 with 4x4 register tiles, which kept the four waves of a compute unit waiting on the
+// LDS for ~60 % of a product (10.5 k cycles per product measured, 4.1 k of arithmetic).
+typedef double d4_t __attribute__((ext_vector_type(4)));
+__device__ inline void mfma_gemm64(const double* X, int sk, int si, const double* B, int wave, int lane, d4_t (&acc)[4]) {
+    const double* xa = X + (lane >> 4) * sk + (16 * wave + (lane & 15)) * si;
+    const double* yb = B + (lane >> 4) * NB + (lane & 15);
 #pragma unroll 4
-    for (int m = 0; m < NB; ++m) {
-        double x[4], y[4];
+    for (int ks = 0; ks < NB / 4; ++ks) {
+        const double a = xa[4 * ks * sk];
 #pragma unroll
-        for (int a = 0; a < 4; ++a) { x[a] = X[m * NB + r0 + a]; y[a] = Y[m * NB + c0 + a]; }
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) acc[a][b] += x[a] * y[b];
+        for (int tc = 0; tc < 4; ++tc) acc[tc] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, yb[4 * ks * NB + 16 * tc], acc[tc], 0, 0, 0);
     }
+}
+// the wave's four result tiles into a row-major 64x64 LDS image
+__device__ inline void mfma_store64(double* Z, const d4_t (&acc)[4], int wave, int lane) {
+#pragma unroll
+    for (int tc = 0; tc < 4; ++tc)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Z[(16 * wave + (lane >> 4) + 4 * r) * NB + 16 * tc + (lane & 15)] = acc[tc][r];
+}
+// the factor's block U_kj = P (64 x 64) goes to memory TRANSPOSED, element (m, c) at Uf[(j NB + c) ld + k NB + m]: the backward
+// substitution walks it by rows m with a lane per row.  Straight from the result registers (4 consecutive m per 16 lanes).
+__device__ inline void mfma_store_factor(double* Uf, int ld, int j, int k, const d4_t (&acc)[4], int wave, int lane) {
+#pragma unroll
+    for (int tc = 0; tc < 4; ++tc)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            Uf[(size_t)(j * NB + 16 * tc + (lane & 15)) * ld + k * NB + 16 * wave + (lane >> 4) + 4 * r] = acc[tc][r];
 }
 
 // 1/sqrt(d): hardware estimate + two Newton steps (full double precision to an ulp or two; keeps the f64 divide and
@@ -1391,12 +1413,110 @@ __device__ inline double rsqrt_nr(double d) {
 // The pivot chain and the rank-4 update overlap instead of alternating: 14.1 against 20.6 us per block on MI355X
 // (tools/micro/chol_factor.hip, variants 0 and 5), every element going through the same operations in the same order (the two
 // forms agree in every bit).  S is consumed.  rowbuf: CHOL_ROWBUF doubles of LDS (rb and nx, double-buffered); Wr: NB x 65.
-__device__ inline bool factor_tile64(double (&S)[4][4], double* Wr, double* rowbuf, int r0, int c0) {
+// From phase FETCH_PHASE on the first two updater waves have no rows left (rows 0..31 are final): k_chol_chain gives them another
+// job there -- fetching the next step's tiles (Fetch::phase(p), once per phase) -- in a loop of their own, so that what they keep
+// in registers does not weigh on the loops of the waves still at work.
+// (the phases exchange data through LDS only: their barrier waits for this wave's LDS traffic, not for global loads the fetching
+//  waves have in flight across them)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+constexpr int FETCH_PHASE = NB / 8;
+struct NoFetch {
+    static constexpr bool active = false;
+    struct Regs {};
+    __device__ __forceinline__ void phase(int, Regs&) const {}
+    __device__ __forceinline__ void finish(Regs&) const {}
+};
+
+struct FactorLds { double *rbuf, *nx, *Wr; };
+// the panel wave's phase p; returns whether a pivot was not positive
+__device__ __forceinline__ bool factor_panel_phase(int p, const FactorLds& L, int lane) {
+    bool bad = false;
+    double* rb = L.rbuf + (p & 1) * 8 * NB;
+    const double* rbp = L.rbuf + ((p + 1) & 1) * 8 * NB;       // block p-1
+    const double* in = L.nx + (p & 1) * 8 * NB;
+    double s[4], w[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) { s[a] = in[a * NB + lane]; w[a] = in[(4 + a) * NB + lane]; }
+    if (p > 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const double uc = rbp[q * NB + lane], wc = rbp[(4 + q) * NB + lane];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const double ur = rbp[q * NB + 4 * p + a];
+                s[a] -= ur * uc;
+                w[a] -= ur * wc;
+            }
+        }
+    }
+    double D[4][4], rs[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = a; b < 4; ++b) {      // (a uniform lane index: v_readlane to scalar registers, no LDS round trip)
+            union { double d; int i[2]; } u, r;
+            u.d = s[a];
+            r.i[0] = __builtin_amdgcn_readlane(u.i[0], 4 * p + b);
+            r.i[1] = __builtin_amdgcn_readlane(u.i[1], 4 * p + b);
+            D[a][b] = r.d;
+        }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        double dd = D[q][q];
+        const bool isbad = !(dd > 0) || !isfinite(dd);
+        bad |= isbad;
+        if (isbad) dd = 1.0;
+        rs[q] = rsqrt_nr(dd);
+#pragma unroll
+        for (int b = q + 1; b < 4; ++b) D[q][b] *= rs[q];
+#pragma unroll
+        for (int a = q + 1; a < 4; ++a)
+#pragma unroll
+            for (int b = a; b < 4; ++b) D[a][b] -= D[q][a] * D[q][b];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        double sv = s[q], wv = w[q];
+#pragma unroll
+        for (int pp = 0; pp < q; ++pp) { sv -= D[pp][q] * s[pp]; wv -= D[pp][q] * w[pp]; }
+        s[q] = sv * rs[q];
+        w[q] = wv * rs[q];
+        rb[q * NB + lane] = s[q];
+        rb[(4 + q) * NB + lane] = w[q];
+        L.Wr[(4 * p + q) * (NB + 1) + lane] = w[q];
+    }
+    return bad;
+}
+// an updater thread's phase p
+__device__ __forceinline__ void factor_updater_phase(int p, const FactorLds& L, double (&S)[4][4], double (&W)[4][4], int r0, int c0) {
+    const double* rbp = L.rbuf + ((p + 1) & 1) * 8 * NB;       // block p-1
+    if (p > 0 && r0 > 4 * (p - 1)) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            double ur[4], uc[4], wc[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) { ur[a] = rbp[q * NB + r0 + a]; uc[a] = rbp[q * NB + c0 + a]; wc[a] = rbp[(4 + q) * NB + c0 + a]; }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) { S[a][b] -= ur[a] * uc[b]; W[a][b] -= ur[a] * wc[b]; }
+        }
+    }
+    if (r0 == 4 * (p + 1)) {
+        double* out = L.nx + ((p + 1) & 1) * 8 * NB;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) { out[a * NB + c0 + b] = S[a][b]; out[(4 + a) * NB + c0 + b] = W[a][b]; }
+    }
+}
+
+template <class Fetch>
+__device__ __forceinline__ bool factor_tile64(double (&S)[4][4], double* Wr, double* rowbuf, int r0, int c0, Fetch& fetch) {
     bool bad = false;
     const int t = threadIdx.x, lane = t & 63;
     const bool panel = t >= 256;
-    double* const rbuf = rowbuf;
-    double* const nx = rowbuf + 2 * 8 * NB;
+    const FactorLds L{rowbuf, rowbuf + 2 * 8 * NB, Wr};
     double W[4][4];
     if (!panel) {
 #pragma unroll
@@ -1407,89 +1527,37 @@ __device__ inline bool factor_tile64(double (&S)[4][4], double* Wr, double* rowb
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
-                for (int b = 0; b < 4; ++b) { nx[a * NB + c0 + b] = S[a][b]; nx[(4 + a) * NB + c0 + b] = W[a][b]; }
+                for (int b = 0; b < 4; ++b) { L.nx[a * NB + c0 + b] = S[a][b]; L.nx[(4 + a) * NB + c0 + b] = W[a][b]; }
         }
     }
-    __syncthreads();
+    lds_barrier();
+    if (panel) {
 #pragma nounroll
-    for (int p = 0; p < NB / 4; ++p) {
-        double* rb = rbuf + (p & 1) * 8 * NB;
-        const double* rbp = rbuf + ((p + 1) & 1) * 8 * NB;       // block p-1
-        if (panel) {
-            const double* in = nx + (p & 1) * 8 * NB;
-            double s[4], w[4];
-#pragma unroll
-            for (int a = 0; a < 4; ++a) { s[a] = in[a * NB + lane]; w[a] = in[(4 + a) * NB + lane]; }
-            if (p > 0) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const double uc = rbp[q * NB + lane], wc = rbp[(4 + q) * NB + lane];
-#pragma unroll
-                    for (int a = 0; a < 4; ++a) {
-                        const double ur = rbp[q * NB + 4 * p + a];
-                        s[a] -= ur * uc;
-                        w[a] -= ur * wc;
-                    }
-                }
+        for (int p = 0; p < NB / 4; ++p) {
+            bad |= factor_panel_phase(p, L, lane);
+            lds_barrier();
+        }
+    } else {
+#pragma nounroll
+        for (int p = 0; p < FETCH_PHASE; ++p) {
+            factor_updater_phase(p, L, S, W, r0, c0);
+            lds_barrier();
+        }
+        if (Fetch::active && t < 128) {
+            typename Fetch::Regs regs;               // (what is in flight lives in this loop only)
+#pragma nounroll
+            for (int p = FETCH_PHASE; p < NB / 4; ++p) {
+                fetch.phase(p, regs);
+                lds_barrier();
             }
-            double D[4][4], rs[4];
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int b = a; b < 4; ++b) {      // (a uniform lane index: v_readlane to scalar registers, no LDS round trip)
-                    union { double d; int i[2]; } u, r;
-                    u.d = s[a];
-                    r.i[0] = __builtin_amdgcn_readlane(u.i[0], 4 * p + b);
-                    r.i[1] = __builtin_amdgcn_readlane(u.i[1], 4 * p + b);
-                    D[a][b] = r.d;
-                }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                double dd = D[q][q];
-                const bool isbad = !(dd > 0) || !isfinite(dd);
-                bad |= isbad;
-                if (isbad) dd = 1.0;
-                rs[q] = rsqrt_nr(dd);
-#pragma unroll
-                for (int b = q + 1; b < 4; ++b) D[q][b] *= rs[q];
-#pragma unroll
-                for (int a = q + 1; a < 4; ++a)
-#pragma unroll
-                    for (int b = a; b < 4; ++b) D[a][b] -= D[q][a] * D[q][b];
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                double sv = s[q], wv = w[q];
-#pragma unroll
-                for (int pp = 0; pp < q; ++pp) { sv -= D[pp][q] * s[pp]; wv -= D[pp][q] * w[pp]; }
-                s[q] = sv * rs[q];
-                w[q] = wv * rs[q];
-                rb[q * NB + lane] = s[q];
-                rb[(4 + q) * NB + lane] = w[q];
-                Wr[(4 * p + q) * (NB + 1) + lane] = w[q];
-            }
+            fetch.finish(regs);
         } else {
-            if (p > 0 && r0 > 4 * (p - 1)) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    double ur[4], uc[4], wc[4];
-#pragma unroll
-                    for (int a = 0; a < 4; ++a) { ur[a] = rbp[q * NB + r0 + a]; uc[a] = rbp[q * NB + c0 + a]; wc[a] = rbp[(4 + q) * NB + c0 + a]; }
-#pragma unroll
-                    for (int a = 0; a < 4; ++a)
-#pragma unroll
-                        for (int b = 0; b < 4; ++b) { S[a][b] -= ur[a] * uc[b]; W[a][b] -= ur[a] * wc[b]; }
-                }
-            }
-            if (r0 == 4 * (p + 1)) {
-                double* out = nx + ((p + 1) & 1) * 8 * NB;
-#pragma unroll
-                for (int a = 0; a < 4; ++a)
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) { out[a * NB + c0 + b] = S[a][b]; out[(4 + a) * NB + c0 + b] = W[a][b]; }
+#pragma nounroll
+            for (int p = FETCH_PHASE; p < NB / 4; ++p) {
+                factor_updater_phase(p, L, S, W, r0, c0);
+                lds_barrier();
             }
         }
-        __syncthreads();
     }
     return bad;
 }
@@ -1498,7 +1566,8 @@ __device__ inline bool factor_tile64(double (&S)[4][4], double* Wr, double* rowb
 // bvec (LDS, NB doubles) holds the fully updated right-hand-side block; Wr (LDS, NB x 65) receives the rows of W.
 __device__ inline void factor_and_forward(double (&S)[4][4], int kb, double* Winv, double* y, double* Wr, double* rowbuf,
                                           const double* bvec, double* scal, int r0, int c0) {
-    const bool bad = factor_tile64(S, Wr, rowbuf, r0, c0);
+    NoFetch nofetch;
+    const bool bad = factor_tile64(S, Wr, rowbuf, r0, c0, nofetch);
     if (bad) scal[3] = 1.0;                                        // (the panel wave's lanes: one value, 64 writers)
     // (the loop's last barrier has made Wr complete.)  W^T to global: WT[m][q] = W[q][m]
     double* Wg = Winv + (size_t)kb * NB * NB;
@@ -1560,39 +1629,34 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_step(double* A, double* U
         }
     }
     __syncthreads();
-    double pi[4][4] = {}, pj[4][4] = {};
+    const int wave = t >> 6, lane = t & 63;
+    d4_t pi[4] = {}, pj[4] = {};
     if (upd) {
-        gemm_tn64(X, Yi, r0, c0, pi);
-        if (i != j) gemm_tn64(X, Yj, r0, c0, pj);
+        mfma_gemm64(X, NB, 1, Yi, wave, lane, pi);
+        if (i != j) mfma_gemm64(X, NB, 1, Yj, wave, lane, pj);
+    }
+    __syncthreads();
+    if (upd) {
+        mfma_store64(Yi, pi, wave, lane);
+        if (i != j) mfma_store64(Yj, pj, wave, lane);
+    }
+    __syncthreads();
+    if (upd) {
+        d4_t acc[4] = {};
+        mfma_gemm64(Yi, NB, 1, Yj, wave, lane, acc);
+        mfma_store64(X, acc, wave, lane);          // (X is free since the first products: the way back to the 4x4 register tiles)
     }
     __syncthreads();
     if (upd) {
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                Yi[(r0 + a) * NB + c0 + q] = pi[a][q];
-                if (i != j) Yj[(r0 + a) * NB + c0 + q] = pj[a][q];
-            }
-    }
-    __syncthreads();
-    if (upd) {
-        double acc[4][4] = {};
-        gemm_tn64(Yi, Yj, r0, c0, acc);
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) S[a][q] -= acc[a][q];
+            for (int q = 0; q < 4; ++q) S[a][q] -= X[(r0 + a) * NB + c0 + q];
     }
     if (first_row) {
         if (upd) {
-            // factor block U_kj = P_j (64 x 64) is stored TRANSPOSED, element (m, c) at Uf[(j NB + c) ld + k NB + m]: the backward
-            // substitution walks it by rows m with a lane per row.  Straight from the registers (4 consecutive m per store group).
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int a = 0; a < 4; ++a)
-                    Uf[(size_t)(j * NB + c0 + q) * ld + k * NB + r0 + a] = (i == j) ? pi[a][q] : pj[a][q];
+            if (i == j) mfma_store_factor(Uf, ld, j, k, pi, wave, lane);
+            else mfma_store_factor(Uf, ld, j, k, pj, wave, lane);
         }
         // b_j -= P_j^T y_k: by the panel wave where there is one (beside the second product), by the first wave elsewhere
         const int tb = chain ? t - 256 : t;
@@ -1614,6 +1678,359 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_step(double* A, double* U
     }
 }
 
+// ---- the same factorisation as ONE resident chain workgroup plus ONE launch of tile workgroups on a second stream ----
+// k_chol_step pays a kernel boundary on the serial chain of every step: kernel start, the reload of W_k and of two tiles another
+// compute unit has just written, the drain of its own stores (~13 of a step's 31 us at C5).  Here the chain -- update of the next
+// diagonal tile, its factorisation, y_k -- stays in one workgroup that never leaves its compute unit (k_chol_chain; W_k is used
+// where factor_tile64 left it in LDS), and every other tile has a workgroup of its own that keeps it in registers through all its
+// steps (k_chol_trail).  They meet through epoch-valued flags in global memory (no reset between solves):
+//   flag_w[k]         set by the chain once W_k^T and y_k are in global memory   -> awaited by every tile workgroup at its step k
+//   tile_done[i nb+j] set by tile (i,j)'s workgroup once the tile is final in memory (for i = k+1 also: U_kj stored, b_j carried
+//                     through step k)   -> awaited by the tiles of later rows that multiply with it and, for (s-1,s) and (s,s),
+//                     by the chain before its step s
+// Release: stores, workgroup barrier, then one thread's agent-scope fence and flag store; acquire: one thread polls (relaxed,
+// agent scope), fences, workgroup barrier.  Every wait is bounded (CHOL_SPIN_MAX polls): on expiry scal[5] is raised, which fails
+// the call (QSP_ERR_DEVICE), later waits give up at once and the kernels run to their end on whatever they find: the grid always
+// drains.  Every flag a workgroup waits for is set by the chain or by a workgroup of an EARLIER row (smaller blockIdx), and the
+// chain waits for nothing a step ahead of it, so the scheme cannot wait on itself.  The chain's last steps have (transitively)
+// awaited every tile_done of the solve: when k_chol_chain ends, every write of the tile workgroups is complete and visible, and
+// the problem's stream needs no event from the second one.
+// Same operations in the same order on every element as the k_chol_step path (the two agree in every bit).
+#ifdef QSP_CB_STAMPS      // timing experiments only: shader-clock stamps of the chain workgroup's thread 0 at the phase boundaries of every step
+__device__ unsigned long long qsp_chain_ts[64 * 8];
+#define QSP_CHTS(s_, i_) { if (threadIdx.x == 0 && (s_) < 64) qsp_chain_ts[(s_) * 8 + (i_)] = __builtin_readcyclecounter(); }
+#else
+#define QSP_CHTS(s_, i_)
+#endif
+constexpr int CHOL_SPIN_MAX = 1 << 20;      // x (poll + s_sleep) ~ 1-2 us: a second or two
+__device__ inline void chol_signal(unsigned* flag, unsigned epoch) {      // call after a workgroup barrier, one thread
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __hip_atomic_store(flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// one thread: wait until *flag == epoch.  A wait that expires raises scal[5]; every later wait of the solve gives up at once
+// (scal[5] is polled too), so a broken run costs one time-out, not one per step.
+__device__ inline void chol_wait3(const unsigned* fa, const unsigned* fb, const unsigned* fc, unsigned epoch, double* scal) {
+    const unsigned long long* dead = reinterpret_cast<const unsigned long long*>(scal + 5);
+    for (int spin = 0; spin < CHOL_SPIN_MAX; ++spin) {
+        // (the looks go out together: one round trip, not one per flag)
+        const unsigned a = __hip_atomic_load(fa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned b = fb ? __hip_atomic_load(fb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : epoch;
+        const unsigned c = fc ? __hip_atomic_load(fc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : epoch;
+        if (a == epoch && b == epoch && c == epoch) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            return;
+        }
+        if ((spin & 255) == 0 && __hip_atomic_load(dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) return;
+        __builtin_amdgcn_s_sleep(4);
+    }
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(scal + 5), 0x3ff0000000000000ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // 1.0
+}
+__device__ inline void chol_wait(const unsigned* flag, unsigned epoch, double* scal) { chol_wait3(flag, nullptr, nullptr, epoch, scal); }
+
+// do two streams of this process run kernels side by side?  (they may share a hardware queue, whose packets run in order)
+constexpr int HANDSHAKE_POLLS = 4000;           // ~ 4 ms at most, once per problem
+__global__ void k_handshake_wait(unsigned* flag, unsigned token, int* ok) {
+    int seen = 0;
+    for (int spin = 0; spin < HANDSHAKE_POLLS && !seen; ++spin) {
+        seen = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == token;
+        if (!seen) __builtin_amdgcn_s_sleep(16);
+    }
+    *ok = seen;
+}
+__global__ void k_handshake_set(unsigned* flag, unsigned token) {
+    __hip_atomic_store(flag, token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// a wave-load of 64 consecutive doubles from a UNIFORM address: scalar base + this lane's 32-bit byte offset (one VGPR of address
+// for all loads of the kernel instead of a 64-bit pointer per load in flight)
+typedef const __attribute__((address_space(1))) char* gbytes_t;
+__device__ __forceinline__ double ld_row(const double* uniform_ptr, uint32_t voff) {
+    return *reinterpret_cast<const __attribute__((address_space(1))) double*>((gbytes_t)uniform_ptr + voff);
+}
+
+constexpr int CHAIN_LDS_DOUBLES = NB * (NB + 1) + 2 * NB * NB + CHOL_ROWBUF + 3 * NB + 2;
+constexpr int TRAIL_LDS_DOUBLES = 3 * NB * NB + NB;
+constexpr int CHAIN_PROBE_GAP = 2;        // phases between a look at the flags and reading what it returned
+constexpr int CHAIN_PARK_AFTER = 3;       // phases between issuing the next step's loads and parking them in LDS
+// Fetching ahead (the first two updater waves in the second half of factor_tile64, 128 threads): thread 0 looks at the two flags
+// the next step needs -- two relaxed loads, read CHAIN_PROBE_GAP phases later: they take 1-2 us to come back, a phase 0.8 us, and
+// the thread must not sit in front of a phase barrier waiting for them -- and looks again until both are up; then it fences
+// (acquire) and raises go[0]; every fetching thread that sees go[0] issues its share of the two tiles (2 x 32 doubles) and, the
+// first wave, of b; CHAIN_PARK_AFTER phases later, or behind the last phase, the values are parked in LDS (Sn, Yp, bnext: all free
+// during a factorisation).  go[1] = thread 0 has issued its loads (the others have by the
+// phase after): read by the whole workgroup at the top of the next step.
+struct ChainFetch {
+    static constexpr bool active = true;
+    const double* A;
+    const double* b;
+    const unsigned *fa, *fb;       // tile_done of (sn-1, sn) and (sn, sn)
+    double *Sn, *Yp, *bnext;
+    volatile int* go;
+    unsigned epoch, f0, f1;
+    int ld, sn, nb, t;
+    int st;                        // thread 0: bit 0 a look is in flight, bit 1 flags up;  all: bit 2 loads issued, bit 3 parked
+    int p_mark;
+    struct Regs { double T[64], b2; };
+    __device__ __forceinline__ void issue(int p, Regs& r) {
+        // element e = t + 128 i of a tile: row (t >> 6) + 2 i, column t & 63 -- a uniform row base per i and ONE 32-bit offset per
+        // thread (64 full addresses in flight would cost the fetching waves 128 registers)
+        uint32_t voff = 8u * (uint32_t)((t >> 6) * ld + (t & 63));
+        const double* baseS = A + (size_t)(sn * NB) * ld + sn * NB;
+        const double* baseY = A + (size_t)((sn - 1) * NB) * ld + sn * NB;
+        // (opaque to the optimiser: left alone it forms the 64 addresses in vector registers in front of the phase loop and keeps
+        //  them there, 128 registers the loads' results then have to share with)
+        asm volatile("" : "+s"(baseS), "+s"(baseY), "+v"(voff));
+        const size_t step = (size_t)2 * ld;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            r.T[i] = ld_row(baseS, voff);
+            r.T[32 + i] = ld_row(baseY, voff);
+            baseS += step;
+            baseY += step;
+            asm volatile("" : "+s"(baseS), "+s"(baseY));
+        }
+        if (t < NB) r.b2 = b[sn * NB + t];
+        st |= 4;
+        p_mark = p;
+    }
+    __device__ __forceinline__ void park(Regs& r) {
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            Sn[t + 128 * i] = r.T[i];
+            Yp[t + 128 * i] = r.T[32 + i];
+        }
+        if (t < NB) bnext[t] = r.b2;
+        st |= 8;
+    }
+    // (loads issued in the last phases are parked behind the loop: the fetching waves then wait while the others publish W_s)
+    __device__ __forceinline__ void finish(Regs& r) {
+        if ((st & 4) && !(st & 8)) park(r);
+    }
+    __device__ __forceinline__ void phase(int p, Regs& r) {
+        if (sn >= nb) return;
+        if (st & 4) {
+            if (!(st & 8) && p >= p_mark + CHAIN_PARK_AFTER) park(r);
+            return;
+        }
+        if (sn >= 2) {
+            if (t == 0 && !(st & 2) && p < NB / 4 - 1) {
+                if (!(st & 1)) {
+                    f0 = __hip_atomic_load(fa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    f1 = __hip_atomic_load(fb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    st |= 1;
+                    p_mark = p;
+                } else if (p >= p_mark + CHAIN_PROBE_GAP) {
+                    if (f0 == epoch && f1 == epoch) {
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                        go[0] = 1;
+                        st |= 2;
+                    } else {                        // look again
+                        f0 = __hip_atomic_load(fa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        f1 = __hip_atomic_load(fb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        p_mark = p;
+                    }
+                }
+            }
+            if (go[0] == 0) return;
+        }                                           // (step 1 reads the input itself: fetched at once)
+        issue(p, r);
+        if (t == 0) go[1] = 1;
+    }
+};
+
+// One step s of the chain: [tiles (s-1,s), (s,s) and b_s -- normally fetched behind the previous factorisation] ->
+// P = W_{s-1} A_{s-1,s} (the panel wave releases W_{s-1} to the tile workgroups meanwhile) -> S -= P^T P, U_{s-1,s} stored,
+// b_s -= P^T y_{s-1} (panel wave) -> factor_tile64 -> W_s^T and y_s to memory.
+__global__ __launch_bounds__(CHOL_THREADS) void k_chol_chain(const double* A, double* Uf, double* Winv, const double* b, double* y, int ld,
+                                                             int nb, double* scal, unsigned* flag_w, const unsigned* tile_done, unsigned epoch) {
+    extern __shared__ __attribute__((aligned(16))) double chol_lds[];
+    double* Wr = chol_lds;                          // rows of W_s (pitch 65): factor_tile64 writes them, the next step multiplies with them
+    double* Yp = Wr + NB * (NB + 1);                // A_{s-1,s}, then P = W_{s-1} A_{s-1,s}
+    double* Sn = Yp + NB * NB;                      // A_{s,s} as the fetching waves park it
+    double* rowbuf = Sn + NB * NB;
+    double* bvec = rowbuf + CHOL_ROWBUF;
+    double* yprev = bvec + NB;
+    double* bnext = yprev + NB;                     // b_s as the tile workgroups left it
+    int* go_lds = reinterpret_cast<int*>(bnext + NB);
+    const int t = threadIdx.x, r0 = (t >> 4) * 4, c0 = (t & 15) * 4;
+    const int wave = t >> 6, lane = t & 63;
+    const bool upd = t < 256;
+    double S[4][4];
+    if (upd) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) S[a][q] = A[(size_t)(r0 + a) * ld + c0 + q];
+    }
+    if (t < NB) bvec[t] = b[t];
+    if (t == 0) go_lds[0] = go_lds[1] = 0;
+    ChainFetch f;
+    f.A = A; f.b = b; f.Sn = Sn; f.Yp = Yp; f.bnext = bnext; f.go = go_lds; f.epoch = epoch; f.ld = ld; f.nb = nb; f.t = t;
+    f.st = 0; f.p_mark = 0; f.f0 = f.f1 = 0; f.sn = nb; f.fa = f.fb = tile_done;
+    __syncthreads();
+    for (int s = 0; s < nb; ++s) {
+        QSP_CHTS(s, 0)
+        if (s > 0) {
+            // go[1] says for the whole workgroup whether the tiles are on their way: thread 0 issues in the phase in which it raises
+            // go[0], every other fetching thread by the phase after, and go[0] is not raised in the last phase
+            const bool have = go_lds[1] != 0;
+            if (!have) {
+                if (s >= 2) {                       // tiles (s-1,s) and (s,s) and b_s as their workgroups leave them
+                    if (t == 0) {
+                        chol_wait3(tile_done + (s - 1) * nb + s, tile_done + s * nb + s, nullptr, epoch, scal);
+                    }
+                    __syncthreads();
+                }
+                if (t < 128) {
+                    ChainFetch::Regs r;
+                    f.issue(0, r);
+                    f.park(r);
+                }
+            }
+            __syncthreads();                        // (everybody has read go[1]; Sn, Yp, bnext complete)
+            QSP_CHTS(s, 1)
+            if (upd) {
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) S[a][q] = Sn[(r0 + a) * NB + c0 + q];
+            }
+            if (t == 0) go_lds[0] = go_lds[1] = 0;
+            QSP_CHTS(s, 2)
+            // W_{s-1}^T and y_{s-1} have been in memory since the barrier that ended step s-1: released here, by the panel wave,
+            // which has nothing else to do during the first product (the fence costs 1-2 k cycles)
+            if (t == 256) chol_signal(flag_w + s - 1, epoch);
+            d4_t pi[4] = {};
+            if (upd) mfma_gemm64(Wr, 1, NB + 1, Yp, wave, lane, pi);      // P = W_{s-1} A_{s-1,s}: W's rows as factor_tile64 left them
+            __syncthreads();
+            QSP_CHTS(s, 3)
+            if (upd) mfma_store64(Yp, pi, wave, lane);
+            __syncthreads();
+            if (upd) {
+                d4_t acc[4] = {};
+                mfma_gemm64(Yp, NB, 1, Yp, wave, lane, acc);
+                mfma_store64(Wr, acc, wave, lane);      // (W_{s-1} has done its work; a plain 64x64 image: the way back to the 4x4 tiles)
+                // the factor's block U_{s-1,s} = P, transposed (the tile workgroups of row s store the others)
+                mfma_store_factor(Uf, ld, s, s - 1, pi, wave, lane);
+            } else {                                // the panel wave, beside the second product: b_s -= P^T y_{s-1}
+                double v = bnext[lane];
+#pragma unroll 8
+                for (int q = 0; q < NB; ++q) v -= Yp[q * NB + lane] * yprev[q];
+                bvec[lane] = v;
+            }
+            __syncthreads();
+            if (upd) {
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) S[a][q] -= Wr[(r0 + a) * NB + c0 + q];
+            }                                       // (factor_tile64 writes W_s over the image behind its first barrier)
+        }
+        QSP_CHTS(s, 4)
+        f.sn = s + 1;                               // the step to fetch for
+        f.st = 0;
+        f.fa = tile_done + (size_t)s * nb + s + 1;
+        f.fb = tile_done + (size_t)(s + 1) * nb + s + 1;
+        const bool bad = factor_tile64(S, Wr, rowbuf, r0, c0, f);
+        if (bad) scal[3] = 1.0;
+        QSP_CHTS(s, 5)
+        double* Wg = Winv + (size_t)s * NB * NB;
+        for (int e = t; e < NB * NB; e += CHOL_THREADS) Wg[e] = Wr[(e % NB) * (NB + 1) + e / NB];
+        if (t >= 256) {                             // y_s = W_s b_s: the panel wave, a row each
+            double v = 0;
+            for (int m = 0; m < NB; ++m) v += Wr[lane * (NB + 1) + m] * bvec[m];
+            y[s * NB + lane] = v;
+            yprev[lane] = v;
+        }
+        __syncthreads();
+        QSP_CHTS(s, 6)
+    }
+}
+
+// everything off the chain, ONE launch per solve: workgroup per tile (i,j), 1 <= i <= j < nb, row-major in blockIdx.x -- a
+// workgroup only ever waits for the chain and for tiles of earlier rows, i.e. for workgroups dispatched before it, so the grid
+// makes progress however many of its workgroups are resident.  The tile stays in registers across its steps k = 0 .. i-1 (a
+// diagonal tile leaves its last step, k = i-1, to the chain); it goes back to memory once, final, with tile_done(i,j).
+__global__ __launch_bounds__(256) void k_chol_trail(double* A, double* Uf, const double* Winv, double* b, const double* y, int ld, int nb,
+                                                    double* scal, const unsigned* flag_w, unsigned* tile_done, unsigned epoch) {
+    int i = 1, rem = blockIdx.x;
+    while (rem >= nb - i) { rem -= nb - i; ++i; }
+    const int j = i + rem;
+    const int nsteps = (i == j) ? i - 1 : i;
+    if (nsteps == 0) return;                          // (tile (1,1): the chain does its only step)
+    extern __shared__ __attribute__((aligned(16))) double chol_lds[];
+    double* X = chol_lds;
+    double* Yi = chol_lds + NB * NB;
+    double* Yj = (i == j) ? Yi : chol_lds + 2 * NB * NB;
+    double* yk = chol_lds + 3 * NB * NB;
+    const int t = threadIdx.x, r0 = (t >> 4) * 4, c0 = (t & 15) * 4;
+    double S[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) S[a][q] = A[(size_t)(i * NB + r0 + a) * ld + j * NB + c0 + q];
+    for (int k = 0; k < nsteps; ++k) {
+        // row k is final once its workgroups have finished (row 0 is the input itself), W_k once the chain has got there: in the
+        // steady state all three are up when this workgroup asks (the chain is a step ahead), so one look and ONE batch of loads
+        if (t == 0)
+            chol_wait3(flag_w + k, k > 0 ? tile_done + k * nb + i : nullptr, (k > 0 && i != j) ? tile_done + k * nb + j : nullptr, epoch, scal);
+        __syncthreads();
+        const double* Wg = Winv + (size_t)k * NB * NB;
+        {
+            double vx[16], vi[16], vj[16];            // (all 48 loads of a thread in flight before the first LDS store)
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int e = t + 256 * u;
+                vx[u] = Wg[e];
+                vi[u] = A[(size_t)(k * NB + e / NB) * ld + i * NB + e % NB];
+                vj[u] = (i != j) ? A[(size_t)(k * NB + e / NB) * ld + j * NB + e % NB] : 0.0;
+            }
+            if (t < NB) yk[t] = y[k * NB + t];        // (per-lane loads behind the acquire, not a uniform-address scalar load)
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int e = t + 256 * u;
+                X[e] = vx[u];
+                Yi[e] = vi[u];
+                if (i != j) Yj[e] = vj[u];
+            }
+        }
+        __syncthreads();
+        const int wave = t >> 6, lane = t & 63;
+        d4_t pi[4] = {}, pj[4] = {};
+        mfma_gemm64(X, NB, 1, Yi, wave, lane, pi);
+        if (i != j) mfma_gemm64(X, NB, 1, Yj, wave, lane, pj);
+        __syncthreads();
+        mfma_store64(Yi, pi, wave, lane);
+        if (i != j) mfma_store64(Yj, pj, wave, lane);
+        __syncthreads();
+        {
+            d4_t acc[4] = {};
+            mfma_gemm64(Yi, NB, 1, Yj, wave, lane, acc);
+            mfma_store64(X, acc, wave, lane);        // (X is free since the first products: the way back to the 4x4 register tiles)
+        }
+        __syncthreads();
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) S[a][q] -= X[(r0 + a) * NB + c0 + q];
+        if (i == k + 1) {                             // (j > i here) the factor's block U_kj and the right-hand side: b_j -= P_j^T y_k
+            mfma_store_factor(Uf, ld, j, k, pj, wave, lane);
+            if (t < NB) {
+                double v = b[j * NB + t];
+                for (int q = 0; q < NB; ++q) v -= Yj[q * NB + t] * yk[q];
+                b[j * NB + t] = v;
+            }
+        }
+        __syncthreads();                              // (the next step refills X, Yi, Yj, yk)
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) A[(size_t)(i * NB + r0 + a) * ld + j * NB + c0 + q] = S[a][q];
+    __syncthreads();
+    if (t == 0) chol_signal(tile_done + i * nb + j, epoch);
+}
+
 #ifdef QSP_CB_STAMPS      // timing experiments only: shader-clock stamps of thread 0 at the phase boundaries of every step
 __device__ unsigned long long qsp_cb_ts[64 * 5];
 #define QSP_CBTS(j_, i_) { if (t == 0 && (j_) < 64) qsp_cb_ts[(j_) * 5 + (i_)] = __builtin_readcyclecounter(); }
@@ -1621,12 +2038,6 @@ __device__ unsigned long long qsp_cb_ts[64 * 5];
 #define QSP_CBTS(j_, i_)
 #endif
 constexpr int CHOL_BACK_HELPERS = 4;     // workgroups on the solver's XCD that warm its L2 (k_chol_back)
-// a wave-load of 64 consecutive doubles from a UNIFORM address: scalar base + this lane's 32-bit byte offset (one VGPR of address
-// for all loads of the kernel instead of a 64-bit pointer per load in flight)
-typedef const __attribute__((address_space(1))) char* gbytes_t;
-__device__ __forceinline__ double ld_row(const double* uniform_ptr, uint32_t voff) {
-    return *reinterpret_cast<const __attribute__((address_space(1))) double*>((gbytes_t)uniform_ptr + voff);
-}
 // backward substitution x_k = W_k^T (y_k - sum_{j>k} U_kj x_j), k = nb-1 .. 0, in ONE launch of ONE workgroup of 1024
 // threads (16 waves): y lives in LDS; at step j the waves form x_j = W_j^T y_j (4 rows each), then wave w takes the blocks
 // k = w, w+16, ... < j and subtracts U_kj x_j from y_k with a lane per row (the factor is stored transposed, so a wave-load
@@ -2169,6 +2580,13 @@ struct qsp_ba_problem {
     // LM state that persists inside one optimize call only
     qsp_ba_stats prof{};
     bool profiling = false;
+    // the factorisation as a resident chain workgroup + trailing updates on a second stream (k_chol_chain / k_chol_trail)
+    hipStream_t stream2 = nullptr;         // high priority: its own hardware-queue pool
+    hipEvent_t ev_sys = nullptr;
+    unsigned* chol_flags = nullptr;        // [nb_max] flag_w, [nb_max^2] tile_done, [1] handshake, then an int: handshake result
+    unsigned chol_epoch = 0;
+    bool chol_chain_ok = false;            // the two streams were seen running side by side (qsp_ba_create) and QSP_BA_CHOL != steps
+    bool chol_chain = false;               // QSP_BA_OPT_CHOLESKY_CHAIN
     double* scal_host = nullptr; // pinned, device-visible copy of scal[0..3] (k_publish_scal): read back without a copy engine hop
     double* scal_host_dev = nullptr;
     double scal_seq = 0.0;       // sequence number of the last read-back enqueued
@@ -2318,6 +2736,37 @@ static int build_pair_lists(qsp_ba_problem* p) {
     return QSP_OK;
 }
 
+// Second stream, events and flags of the chain factorisation.  The scheme needs k_chol_chain (problem stream) and k_chol_trail
+// (stream2) to RUN SIDE BY SIDE; two HIP streams may share a hardware queue, whose kernels run one after the other.  stream2 is
+// created at high priority (the runtime keeps a separate queue pool per priority), and the pair is tried once: a waiting kernel
+// on stream2, then a setting kernel on the problem stream.  If the waiter does not see the flag (a few ms at most) the problem
+// keeps the one-launch-per-step path.  QSP_BA_CHOL=steps selects that path outright.
+static int chol_chain_setup(qsp_ba_problem* p) {
+    const char* env = getenv("QSP_BA_CHOL");
+    if (env && !strcmp(env, "steps")) return QSP_OK;
+    if (p->dimp_max < 2 * NB) return QSP_OK;          // one block: nothing to overlap
+    const int nbm = p->dimp_max / NB;
+    const size_t nflag = (size_t)nbm + (size_t)nbm * nbm;
+    int rc = dalloc(p, &p->chol_flags, nflag + 8);
+    if (rc) return rc;
+    QSP_HIP(hipMemset(p->chol_flags, 0, sizeof(unsigned) * (nflag + 8)));
+    int least = 0, greatest = 0;
+    QSP_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    QSP_HIP(hipStreamCreateWithPriority(&p->stream2, hipStreamNonBlocking, greatest));
+    QSP_HIP(hipEventCreateWithFlags(&p->ev_sys, hipEventDisableTiming));
+    unsigned* hs_flag = p->chol_flags + nflag;
+    int* hs_ok = reinterpret_cast<int*>(p->chol_flags + nflag + 1);
+    hipLaunchKernelGGL(k_handshake_wait, dim3(1), dim3(1), 0, p->stream2, hs_flag, 0x51u, hs_ok);
+    hipLaunchKernelGGL(k_handshake_set, dim3(1), dim3(1), 0, p->stream, hs_flag, 0x51u);
+    QSP_HIP(hipGetLastError());
+    QSP_HIP(hipStreamSynchronize(p->stream2));
+    QSP_HIP(hipStreamSynchronize(p->stream));
+    int ok = 0;
+    QSP_HIP(hipMemcpy(&ok, hs_ok, sizeof(int), hipMemcpyDeviceToHost));
+    p->chol_chain_ok = p->chol_chain = ok != 0;
+    return QSP_OK;
+}
+
 extern "C" int qsp_ba_create(const qsp_ba_scene* s, int device, qsp_ba_problem** out) {
     if (!s || !out) return qsp_fail(QSP_ERR_INVALID, "qsp_ba_create: null argument");
     if (s->n_kf <= 0 || s->n_pt < 0 || s->n_obj < 0 || s->n_mono < 0 || s->n_stereo < 0 || s->n_objedge < 0)
@@ -2456,6 +2905,7 @@ extern "C" int qsp_ba_create(const qsp_ba_scene* s, int device, qsp_ba_problem**
 #undef AL
     if (!rc) {
         hipError_t e = hipMemset(d.edge_level, 0, std::max(d.n_edge, 1));
+        if (e == hipSuccess) e = hipMemset(d.scal, 0, sizeof(double) * 8);
         if (e == hipSuccess) e = hipMemset(d.oe_level, 0, std::max(d.n_oe, 1));
         if (e == hipSuccess) e = hipMemset(d.edge_chi2, 0, sizeof(double) * std::max(d.n_edge, 1));
         if (e == hipSuccess) e = hipMemset(d.oe_chi2, 0, sizeof(double) * std::max(d.n_oe, 1));
@@ -2466,6 +2916,8 @@ extern "C" int qsp_ba_create(const qsp_ba_scene* s, int device, qsp_ba_problem**
         if (e == hipSuccess) e = hipHostMalloc((void**)&p->lvl_host, (size_t)std::max(d.n_edge + d.n_oe, 1), hipHostMallocDefault);
         if (e == hipSuccess) e = hipHostMalloc((void**)&p->idx_host, sizeof(int32_t) * (size_t)std::max(d.n_kf + d.n_obj + d.n_pt, 1), hipHostMallocDefault);
         const int chol_lds = (int)(sizeof(double) * CHOL_LDS_DOUBLES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_chol_chain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * CHAIN_LDS_DOUBLES));
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_chol_trail, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * TRAIL_LDS_DOUBLES));
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_chol_first, hipFuncAttributeMaxDynamicSharedMemorySize, chol_lds);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_chol_step, hipFuncAttributeMaxDynamicSharedMemorySize, chol_lds);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_schur_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCHUR_ROW_LDS_MAX);
@@ -2473,6 +2925,7 @@ extern "C" int qsp_ba_create(const qsp_ba_scene* s, int device, qsp_ba_problem**
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_obj_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCHUR_ROW_LDS_MAX);
         if (e != hipSuccess) rc = qsp_fail(QSP_ERR_DEVICE, hipGetErrorString(e));
     }
+    if (!rc) rc = chol_chain_setup(p);
     if (rc) {
         qsp_ba_destroy(p);
         return rc;
@@ -2498,6 +2951,8 @@ extern "C" void qsp_ba_destroy(qsp_ba_problem* p) {
     if (p->scal_host) (void)hipHostFree(p->scal_host);
     if (p->lvl_host) (void)hipHostFree(p->lvl_host);
     if (p->idx_host) (void)hipHostFree(p->idx_host);
+    if (p->ev_sys) (void)hipEventDestroy(p->ev_sys);
+    if (p->stream2) (void)hipStreamDestroy(p->stream2);
     if (p->stream) (void)hipStreamDestroy(p->stream);
     delete p;
 }
@@ -2878,10 +3333,27 @@ extern "C" int qsp_ba_optimize(qsp_ba_problem* p, int32_t n_iter, double delta_m
                 if (rc) return rc;
                 const int nb = p->dimp / NB;
                 const size_t lds = sizeof(double) * CHOL_LDS_DOUBLES;
-                hipLaunchKernelGGL(k_chol_first, dim3(1), dim3(CHOL_THREADS), lds, s, d.Hs, d.Winv, d.bs, d.ych, p->dimp, d.scal);
-                for (int k = 0; k + 1 < nb; ++k)
-                    hipLaunchKernelGGL(k_chol_step, dim3(nb - k - 1, nb - k - 1), dim3(CHOL_THREADS), lds, s, d.Hs, d.Uf, d.Winv, d.bs,
-                                       d.ych, p->dimp, k, d.scal);
+                if (p->chol_chain && nb >= 2) {
+                    // one resident chain workgroup on the problem's stream, the other tiles' workgroups beside it on the second one
+                    if (++p->chol_epoch == 0) ++p->chol_epoch;
+                    unsigned* flag_w = p->chol_flags;
+                    unsigned* tile_done = p->chol_flags + p->dimp_max / NB;
+                    if (nb >= 3) {
+                        QSP_HIP(hipEventRecord(p->ev_sys, s));                       // the reduced system is complete
+                        QSP_HIP(hipStreamWaitEvent(p->stream2, p->ev_sys, 0));
+                    }
+                    hipLaunchKernelGGL(k_chol_chain, dim3(1), dim3(CHOL_THREADS), sizeof(double) * CHAIN_LDS_DOUBLES, s, d.Hs, d.Uf, d.Winv, d.bs,
+                                       d.ych, p->dimp, nb, d.scal, flag_w, tile_done, p->chol_epoch);
+                    if (nb >= 3)
+                        hipLaunchKernelGGL(k_chol_trail, dim3(nb * (nb - 1) / 2), dim3(256), sizeof(double) * TRAIL_LDS_DOUBLES, p->stream2,
+                                           d.Hs, d.Uf, d.Winv, d.bs, d.ych, p->dimp, nb, d.scal, flag_w, tile_done, p->chol_epoch);
+                    // (no event back: when the chain has ended every tile workgroup's writes are complete -- see k_chol_chain)
+                } else {
+                    hipLaunchKernelGGL(k_chol_first, dim3(1), dim3(CHOL_THREADS), lds, s, d.Hs, d.Winv, d.bs, d.ych, p->dimp, d.scal);
+                    for (int k = 0; k + 1 < nb; ++k)
+                        hipLaunchKernelGGL(k_chol_step, dim3(nb - k - 1, nb - k - 1), dim3(CHOL_THREADS), lds, s, d.Hs, d.Uf, d.Winv, d.bs,
+                                           d.ych, p->dimp, k, d.scal);
+                }
                 hipLaunchKernelGGL(k_chol_back, dim3(1 + 8 * CHOL_BACK_HELPERS), dim3(1024), sizeof(double) * (size_t)(2 * p->dimp + NB), s, d, par, d.Uf, d.Winv,
                                    d.ych, d.xp, p->dimp);
             } else if (d.n_pt) {
@@ -2925,6 +3397,7 @@ extern "C" int qsp_ba_optimize(qsp_ba_problem* p, int32_t n_iter, double delta_m
             }
             rc = wait_scal(p, sc);
             if (rc) return rc;
+            if (sc[3] == 2.0) return qsp_fail(QSP_ERR_DEVICE, "BA: a flag wait between the factorisation's two streams expired");
             const bool ok2 = sc[3] == 0.0;
             double tempChi = ok2 ? sc[0] : DBL_MAX;
             rho = currentChi - tempChi;
@@ -3041,6 +3514,7 @@ extern "C" int qsp_ba_get_edges(qsp_ba_problem* p, double* mono_chi2, double* st
 extern "C" int qsp_ba_profile(qsp_ba_problem* p, int enable, qsp_ba_stats* out) {
     if (!p) return qsp_fail(QSP_ERR_INVALID, "qsp_ba_profile: null problem");
     p->profiling = enable != 0;
+    p->prof.cholesky_chain = p->chol_chain ? 1 : 0;
     if (out) *out = p->prof;
     return QSP_OK;
 }
@@ -3184,6 +3658,10 @@ extern "C" int qsp_ba_set_option(qsp_ba_problem* p, int32_t option, int32_t valu
     if (!p) return qsp_fail(QSP_ERR_INVALID, "qsp_ba_set_option: null problem");
     switch (option) {
         case QSP_BA_OPT_OBJECT_ELIMINATION: p->elim_allowed = value != 0; return QSP_OK;
+        case QSP_BA_OPT_CHOLESKY_CHAIN:
+            if (value && !p->chol_chain_ok) return qsp_fail(QSP_ERR_UNSUPPORTED, "cholesky chain: the problem's two streams do not run concurrently here");
+            p->chol_chain = value != 0;
+            return QSP_OK;
         default: return qsp_fail(QSP_ERR_INVALID, "qsp_ba_set_option: unknown option");
     }
 }
@@ -3202,6 +3680,9 @@ extern "C" int qsp_ba_set_deterministic(qsp_ba_problem* p, int on) {
 #include "ellipsoid_fit.hpp"
 
 #ifdef QSP_CB_STAMPS
+extern "C" int qsp_debug_chain_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(qsp::ba::qsp_chain_ts), sizeof(unsigned long long) * 64 * 8);
+}
 extern "C" int qsp_debug_cb_stamps(unsigned long long* out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(qsp::ba::qsp_cb_ts), sizeof(unsigned long long) * 64 * 5);
 }

@@ -337,6 +337,35 @@ def test_deterministic_mode_full_size_c4_and_sharded_consistency():
     assert np.allclose(outs[0][1], ka, rtol=1e-7, atol=1e-10) and np.allclose(outs[0][2], pa, rtol=1e-7, atol=1e-10)
 
 
+@pytest.mark.parametrize("size", ["c2", "c4", "c5"])
+def test_cholesky_chain_and_step_forms_give_the_same_bits(size):
+    """QSP_BA_OPT_CHOLESKY_CHAIN: the factorisation as a resident chain workgroup + trailing updates on a second stream against
+    one launch per block step (2, 5 and 19 block rows): the same operations in the same order, so the whole two-stage BA --
+    chi2 and lambda per iteration, trials, final poses and points -- is identical to the bit.  The chain form must be the one
+    in use on a GPU whose streams run concurrently (a silent fall-back to the step form would make this test vacuous)."""
+    import bench
+    from qsp_slam_amd.ba import BaProblem
+    w = bench.WORKLOADS[size]
+    sc = synth.make_ba_scene(2100, w["n_kf"], w["n_map"], w["n_obj"], stereo_frac=0.2)
+    outs = []
+    for chain in (True, False):
+        b = BaProblem(sc)
+        b.set_deterministic(True)
+        if chain:
+            if not b.cholesky_chain:
+                b.close()
+                pytest.skip("this problem's two streams do not run concurrently here: the step form is all there is")
+        else:
+            b.set_cholesky_chain(False)
+        assert b.cholesky_chain == chain
+        b1, b2 = b.local_joint_ba()
+        outs.append((np.array(b1["chi2"]), np.array(b1["lam"]), np.array(b2["chi2"]), np.array(b2["lam"]), list(b1["trials"]) + list(b2["trials"]),
+                     *b.state()))
+        b.close()
+    for x, y in zip(outs[0], outs[1]):
+        assert np.array_equal(np.asarray(x), np.asarray(y))
+
+
 @pytest.mark.parametrize("name", ["mono", "c2", "two_fixed"])
 def test_atomic_schur_kernels_match_oracle(name):
     """set_deterministic(False): the per-landmark kernel with FP64 atomics (what graphs beyond the pair-list cap use
