@@ -1532,11 +1532,13 @@ __device__ __forceinline__ bool factor_tile64(double (&S)[4][4], double* Wr, dou
     }
     lds_barrier();
     if (panel) {
+        __builtin_amdgcn_s_setprio(3);              // (it shares a SIMD with an updater wave and everybody waits for it)
 #pragma nounroll
         for (int p = 0; p < NB / 4; ++p) {
             bad |= factor_panel_phase(p, L, lane);
             lds_barrier();
         }
+        __builtin_amdgcn_s_setprio(0);
     } else {
 #pragma nounroll
         for (int p = 0; p < FETCH_PHASE; ++p) {
@@ -1902,10 +1904,10 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_chain(const double* A, do
             if (t == 256) chol_signal(flag_w + s - 1, epoch);
             d4_t pi[4] = {};
             if (upd) mfma_gemm64(Wr, 1, NB + 1, Yp, wave, lane, pi);      // P = W_{s-1} A_{s-1,s}: W's rows as factor_tile64 left them
-            __syncthreads();
+            lds_barrier();                          // (LDS-only barriers inside a step: nobody waits for the stores of U here)
             QSP_CHTS(s, 3)
             if (upd) mfma_store64(Yp, pi, wave, lane);
-            __syncthreads();
+            lds_barrier();
             if (upd) {
                 d4_t acc[4] = {};
                 mfma_gemm64(Yp, NB, 1, Yp, wave, lane, acc);
@@ -1918,7 +1920,7 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_chain(const double* A, do
                 for (int q = 0; q < NB; ++q) v -= Yp[q * NB + lane] * yprev[q];
                 bvec[lane] = v;
             }
-            __syncthreads();
+            lds_barrier();
             if (upd) {
 #pragma unroll
                 for (int a = 0; a < 4; ++a)
@@ -2738,7 +2740,7 @@ static int build_pair_lists(qsp_ba_problem* p) {
 
 // Second stream, events and flags of the chain factorisation.  The scheme needs k_chol_chain (problem stream) and k_chol_trail
 // (stream2) to RUN SIDE BY SIDE; two HIP streams may share a hardware queue, whose kernels run one after the other.  stream2 is
-// created at high priority (the runtime keeps a separate queue pool per priority), and the pair is tried once: a waiting kernel
+// created at high priority (the runtime keeps a separate queue pool per priority), and the pair is tried: a waiting kernel
 // on stream2, then a setting kernel on the problem stream.  If the waiter does not see the flag (a few ms at most) the problem
 // keeps the one-launch-per-step path.  QSP_BA_CHOL=steps selects that path outright.
 static int chol_chain_setup(qsp_ba_problem* p) {
@@ -2754,16 +2756,23 @@ static int chol_chain_setup(qsp_ba_problem* p) {
     QSP_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
     QSP_HIP(hipStreamCreateWithPriority(&p->stream2, hipStreamNonBlocking, greatest));
     QSP_HIP(hipEventCreateWithFlags(&p->ev_sys, hipEventDisableTiming));
-    unsigned* hs_flag = p->chol_flags + nflag;
-    int* hs_ok = reinterpret_cast<int*>(p->chol_flags + nflag + 1);
-    hipLaunchKernelGGL(k_handshake_wait, dim3(1), dim3(1), 0, p->stream2, hs_flag, 0x51u, hs_ok);
-    hipLaunchKernelGGL(k_handshake_set, dim3(1), dim3(1), 0, p->stream, hs_flag, 0x51u);
-    QSP_HIP(hipGetLastError());
-    QSP_HIP(hipStreamSynchronize(p->stream2));
-    QSP_HIP(hipStreamSynchronize(p->stream));
-    int ok = 0;
-    QSP_HIP(hipMemcpy(&ok, hs_ok, sizeof(int), hipMemcpyDeviceToHost));
-    p->chol_chain_ok = p->chol_chain = ok != 0;
+    // (the outcome is a property of the device and the runtime -- a normal- and a high-priority stream never share a queue pool --
+    //  so one successful trial per device and process stands for the later problems; a failed one is tried again)
+    static std::atomic<int> seen_ok[64];
+    const int dev = p->device >= 0 && p->device < 64 ? p->device : 0;
+    if (!seen_ok[dev].load()) {
+        unsigned* hs_flag = p->chol_flags + nflag;
+        int* hs_ok = reinterpret_cast<int*>(p->chol_flags + nflag + 1);
+        hipLaunchKernelGGL(k_handshake_wait, dim3(1), dim3(1), 0, p->stream2, hs_flag, 0x51u, hs_ok);
+        hipLaunchKernelGGL(k_handshake_set, dim3(1), dim3(1), 0, p->stream, hs_flag, 0x51u);
+        QSP_HIP(hipGetLastError());
+        QSP_HIP(hipStreamSynchronize(p->stream2));
+        QSP_HIP(hipStreamSynchronize(p->stream));
+        int ok = 0;
+        QSP_HIP(hipMemcpy(&ok, hs_ok, sizeof(int), hipMemcpyDeviceToHost));
+        if (ok) seen_ok[dev].store(1);
+    }
+    p->chol_chain_ok = p->chol_chain = seen_ok[dev].load() != 0;
     return QSP_OK;
 }
 

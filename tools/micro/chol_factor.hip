@@ -529,6 +529,167 @@ __global__ __launch_bounds__(320) void k_factorR(const double* A, double* Wout, 
     }
 }
 
+// variant 8: variant 5 with the inverse one phase behind: a sixth wave carries the W rows (it needs the pivots' 4x4 factors of a
+// block, which the S panel wave leaves in LDS, but nothing of it is on the S chain), and the updaters apply block p-1 to their S
+// tiles and block p-2 to their W tiles.  17 phases; the S panel wave's phase is about half as long.
+__global__ __launch_bounds__(384) void k_factor8(const double* A, double* Wout, double* Uout) {
+    __shared__ double rbU[16 * 4 * NB];         // U rows, per block
+    __shared__ double rbW[16 * 4 * NB];         // W rows, per block
+    __shared__ double nxS[2 * 4 * NB], nxW[2 * 4 * NB];
+    __shared__ double dbuf[2 * 16];             // per block: D[0][1], D[0][2], D[0][3], D[1][2], D[1][3], D[2][3], rs[0..3]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int r0 = (t >> 4) * 4, c0 = (t & 15) * 4;
+    double S[4][4], W[4][4];
+    if (wave < 4) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                S[a][b] = A[(r0 + a) * NB + c0 + b];
+                W[a][b] = (r0 + a == c0 + b) ? 1.0 : 0.0;
+            }
+        if (r0 == 0) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) { nxS[a * NB + c0 + b] = S[a][b]; nxW[a * NB + c0 + b] = W[a][b]; }
+        }
+    }
+    __syncthreads();
+#pragma nounroll
+    for (int p = 0; p <= 16; ++p) {
+        if (wave == 4) {                        // S panel: block p
+            if (p < 16) {
+                if (lane == 0) g_ts5[p][0] = __builtin_readcyclecounter();
+                const double* in = nxS + (p & 1) * 4 * NB;
+                const double* up = rbU + (p - 1) * 4 * NB;
+                double s[4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) s[a] = in[a * NB + lane];
+                if (p > 0) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const double uc = up[q * NB + lane];
+#pragma unroll
+                        for (int a = 0; a < 4; ++a) s[a] -= up[q * NB + 4 * p + a] * uc;
+                    }
+                }
+                double D[4][4], rs[4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = a; b < 4; ++b) D[a][b] = rdlane(s[a], 4 * p + b);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    rs[q] = rsqrt_nr(D[q][q]);
+#pragma unroll
+                    for (int b = q + 1; b < 4; ++b) D[q][b] *= rs[q];
+#pragma unroll
+                    for (int a = q + 1; a < 4; ++a)
+#pragma unroll
+                        for (int b = a; b < 4; ++b) D[a][b] -= D[q][a] * D[q][b];
+                }
+                double* ub = rbU + p * 4 * NB;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    double sv = s[q];
+#pragma unroll
+                    for (int pp = 0; pp < q; ++pp) sv -= D[pp][q] * s[pp];
+                    s[q] = sv * rs[q];
+                    ub[q * NB + lane] = s[q];
+                }
+                if (lane == 0) {
+                    double* db = dbuf + (p & 1) * 16;
+                    db[0] = D[0][1]; db[1] = D[0][2]; db[2] = D[0][3]; db[3] = D[1][2]; db[4] = D[1][3]; db[5] = D[2][3];
+                    db[6] = rs[0]; db[7] = rs[1]; db[8] = rs[2]; db[9] = rs[3];
+                }
+                if (lane == 0) g_ts5[p][1] = __builtin_readcyclecounter();
+            }
+        } else if (wave == 5) {                 // W panel: block p-1
+            if (p >= 1) {
+                const int pb = p - 1;
+                const double* in = nxW + (pb & 1) * 4 * NB;
+                double w[4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) w[a] = in[a * NB + lane];
+                if (pb > 0) {
+                    const double* up = rbU + (pb - 1) * 4 * NB;
+                    const double* wp = rbW + (pb - 1) * 4 * NB;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const double wc = wp[q * NB + lane];
+#pragma unroll
+                        for (int a = 0; a < 4; ++a) w[a] -= up[q * NB + 4 * pb + a] * wc;
+                    }
+                }
+                const double* db = dbuf + (pb & 1) * 16;
+                double D[4][4], rs[4];
+                D[0][1] = db[0]; D[0][2] = db[1]; D[0][3] = db[2]; D[1][2] = db[3]; D[1][3] = db[4]; D[2][3] = db[5];
+                rs[0] = db[6]; rs[1] = db[7]; rs[2] = db[8]; rs[3] = db[9];
+                double* wb = rbW + pb * 4 * NB;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    double wv = w[q];
+#pragma unroll
+                    for (int pp = 0; pp < q; ++pp) wv -= D[pp][q] * w[pp];
+                    w[q] = wv * rs[q];
+                    wb[q * NB + lane] = w[q];
+                }
+            }
+        } else {
+            if (t == 255 && p < 16) g_ts5[p][2] = __builtin_readcyclecounter();
+            if (p >= 1 && p <= 16 && r0 > 4 * (p - 1)) {        // S tiles: block p-1
+                const double* up = rbU + (p - 1) * 4 * NB;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    double ur[4], uc[4];
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) { ur[a] = up[q * NB + r0 + a]; uc[a] = up[q * NB + c0 + a]; }
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) S[a][b] -= ur[a] * uc[b];
+                }
+            }
+            if (p >= 2 && r0 > 4 * (p - 2)) {                   // W tiles: block p-2
+                const double* up = rbU + (p - 2) * 4 * NB;
+                const double* wp = rbW + (p - 2) * 4 * NB;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    double ur[4], wc[4];
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) { ur[a] = up[q * NB + r0 + a]; wc[a] = wp[q * NB + c0 + a]; }
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) W[a][b] -= ur[a] * wc[b];
+                }
+            }
+            if (r0 == 4 * (p + 1)) {            // rows of block p+1, S through block p-1
+                double* out = nxS + ((p + 1) & 1) * 4 * NB;
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) out[a * NB + c0 + b] = S[a][b];
+            }
+            if (p >= 1 && r0 == 4 * p) {        // rows of block p, W through block p-2
+                double* out = nxW + (p & 1) * 4 * NB;
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) out[a * NB + c0 + b] = W[a][b];
+            }
+            if (t == 255 && p < 16) g_ts5[p][3] = __builtin_readcyclecounter();
+        }
+        __syncthreads();
+    }
+    for (int e = t; e < NB * NB; e += 384) {
+        const int q = e / NB, m = e % NB;
+        Uout[e] = rbU[q * NB + m];
+        Wout[e] = rbW[q * NB + m];
+    }
+}
+
 int main(int argc, char** argv) {
     const int var = argc > 1 ? atoi(argv[1]) : 0;
     std::vector<double> A(NB * NB), M(NB * NB);
@@ -559,7 +720,8 @@ int main(int argc, char** argv) {
             else if (var == 4) hipLaunchKernelGGL(k_factor<4>, dim3(1), dim3(256), 0, 0, dA, dW, dU);
             else if (var == 5) hipLaunchKernelGGL(k_factor5, dim3(1), dim3(320), 0, 0, dA, dW, dU);
             else if (var == 6) hipLaunchKernelGGL(k_factorR<4>, dim3(1), dim3(320), 0, 0, dA, dW, dU);
-            else hipLaunchKernelGGL(k_factorR<8>, dim3(1), dim3(320), 0, 0, dA, dW, dU);
+            else if (var == 7) hipLaunchKernelGGL(k_factorR<8>, dim3(1), dim3(320), 0, 0, dA, dW, dU);
+            else hipLaunchKernelGGL(k_factor8, dim3(1), dim3(384), 0, 0, dA, dW, dU);
         }
         hipEventRecord(e1);
         hipEventSynchronize(e1);
