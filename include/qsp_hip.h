@@ -419,7 +419,9 @@ int qsp_ba_set_deterministic(qsp_ba_problem* p, int on);
  * high-priority stream; the two meet through flags in device memory (bounded waits: an expired wait fails the call with
  * QSP_ERR_DEVICE).  Needs the problem's two streams to execute concurrently, which qsp_ba_create tries once; where they do not
  * (or with QSP_BA_CHOL=steps in the environment) the solver keeps one launch per block step and value 1 is refused with
- * QSP_ERR_UNSUPPORTED.  Both forms perform the same operations in the same order (identical bits). */
+ * QSP_ERR_UNSUPPORTED.  Both forms perform the same operations in the same order (identical bits).  Value 2 is for tests: the
+ * chain is launched WITHOUT its tile workgroups, so its first wait must expire (about a second) and the call must fail with
+ * QSP_ERR_DEVICE instead of hanging; the problem is unusable afterwards. */
 enum { QSP_BA_OPT_OBJECT_ELIMINATION = 1, QSP_BA_OPT_CHOLESKY_CHAIN = 2 };
 int qsp_ba_set_option(qsp_ba_problem* p, int32_t option, int32_t value);
 

@@ -2589,6 +2589,7 @@ struct qsp_ba_problem {
     unsigned chol_epoch = 0;
     bool chol_chain_ok = false;            // the two streams were seen running side by side (qsp_ba_create) and QSP_BA_CHOL != steps
     bool chol_chain = false;               // QSP_BA_OPT_CHOLESKY_CHAIN
+    bool chol_fault = false;               // (value 2 of the option: the tile workgroups are not launched)
     double* scal_host = nullptr; // pinned, device-visible copy of scal[0..3] (k_publish_scal): read back without a copy engine hop
     double* scal_host_dev = nullptr;
     double scal_seq = 0.0;       // sequence number of the last read-back enqueued
@@ -2751,11 +2752,16 @@ static int chol_chain_setup(qsp_ba_problem* p) {
     const size_t nflag = (size_t)nbm + (size_t)nbm * nbm;
     int rc = dalloc(p, &p->chol_flags, nflag + 8);
     if (rc) return rc;
-    QSP_HIP(hipMemset(p->chol_flags, 0, sizeof(unsigned) * (nflag + 8)));
+    // From here on a failure is not an error of qsp_ba_create: the problem keeps the one-launch-per-step form.
+    auto ok = [](hipError_t e) {
+        if (e != hipSuccess) (void)hipGetLastError();
+        return e == hipSuccess;
+    };
     int least = 0, greatest = 0;
-    QSP_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-    QSP_HIP(hipStreamCreateWithPriority(&p->stream2, hipStreamNonBlocking, greatest));
-    QSP_HIP(hipEventCreateWithFlags(&p->ev_sys, hipEventDisableTiming));
+    if (!ok(hipMemset(p->chol_flags, 0, sizeof(unsigned) * (nflag + 8))) || !ok(hipDeviceGetStreamPriorityRange(&least, &greatest)) ||
+        !ok(hipStreamCreateWithPriority(&p->stream2, hipStreamNonBlocking, greatest)) ||
+        !ok(hipEventCreateWithFlags(&p->ev_sys, hipEventDisableTiming)))
+        return QSP_OK;
     // (the outcome is a property of the device and the runtime -- a normal- and a high-priority stream never share a queue pool --
     //  so one successful trial per device and process stands for the later problems; a failed one is tried again)
     static std::atomic<int> seen_ok[64];
@@ -2765,12 +2771,10 @@ static int chol_chain_setup(qsp_ba_problem* p) {
         int* hs_ok = reinterpret_cast<int*>(p->chol_flags + nflag + 1);
         hipLaunchKernelGGL(k_handshake_wait, dim3(1), dim3(1), 0, p->stream2, hs_flag, 0x51u, hs_ok);
         hipLaunchKernelGGL(k_handshake_set, dim3(1), dim3(1), 0, p->stream, hs_flag, 0x51u);
-        QSP_HIP(hipGetLastError());
-        QSP_HIP(hipStreamSynchronize(p->stream2));
-        QSP_HIP(hipStreamSynchronize(p->stream));
-        int ok = 0;
-        QSP_HIP(hipMemcpy(&ok, hs_ok, sizeof(int), hipMemcpyDeviceToHost));
-        if (ok) seen_ok[dev].store(1);
+        int seen = 0;
+        if (ok(hipGetLastError()) && ok(hipStreamSynchronize(p->stream2)) && ok(hipStreamSynchronize(p->stream)) &&
+            ok(hipMemcpy(&seen, hs_ok, sizeof(int), hipMemcpyDeviceToHost)) && seen)
+            seen_ok[dev].store(1);
     }
     p->chol_chain_ok = p->chol_chain = seen_ok[dev].load() != 0;
     return QSP_OK;
@@ -3353,7 +3357,7 @@ extern "C" int qsp_ba_optimize(qsp_ba_problem* p, int32_t n_iter, double delta_m
                     }
                     hipLaunchKernelGGL(k_chol_chain, dim3(1), dim3(CHOL_THREADS), sizeof(double) * CHAIN_LDS_DOUBLES, s, d.Hs, d.Uf, d.Winv, d.bs,
                                        d.ych, p->dimp, nb, d.scal, flag_w, tile_done, p->chol_epoch);
-                    if (nb >= 3)
+                    if (nb >= 3 && !p->chol_fault)
                         hipLaunchKernelGGL(k_chol_trail, dim3(nb * (nb - 1) / 2), dim3(256), sizeof(double) * TRAIL_LDS_DOUBLES, p->stream2,
                                            d.Hs, d.Uf, d.Winv, d.bs, d.ych, p->dimp, nb, d.scal, flag_w, tile_done, p->chol_epoch);
                     // (no event back: when the chain has ended every tile workgroup's writes are complete -- see k_chol_chain)
@@ -3670,6 +3674,7 @@ extern "C" int qsp_ba_set_option(qsp_ba_problem* p, int32_t option, int32_t valu
         case QSP_BA_OPT_CHOLESKY_CHAIN:
             if (value && !p->chol_chain_ok) return qsp_fail(QSP_ERR_UNSUPPORTED, "cholesky chain: the problem's two streams do not run concurrently here");
             p->chol_chain = value != 0;
+            p->chol_fault = value == 2;     // tests: the chain without its tile workgroups -- every wait must expire, not hang
             return QSP_OK;
         default: return qsp_fail(QSP_ERR_INVALID, "qsp_ba_set_option: unknown option");
     }

@@ -366,6 +366,29 @@ def test_cholesky_chain_and_step_forms_give_the_same_bits(size):
         assert np.array_equal(np.asarray(x), np.asarray(y))
 
 
+@pytest.mark.timeout(120)
+def test_cholesky_chain_waits_are_bounded():
+    """the chain workgroup launched without its tile workgroups (option value 2): the flag it waits for never comes, the wait
+    expires after ~1e6 polls, later waits give up at once, the kernels drain and the call fails with QSP_ERR_DEVICE -- no hang"""
+    import time
+    import bench
+    from qsp_slam_amd import _lib
+    from qsp_slam_amd.ba import BaProblem
+    w = bench.WORKLOADS["c4"]
+    sc = synth.make_ba_scene(2100, w["n_kf"], w["n_map"], w["n_obj"], stereo_frac=0.2)
+    b = BaProblem(sc)
+    if not b.cholesky_chain:
+        b.close()
+        pytest.skip("this problem's two streams do not run concurrently here: the step form is all there is")
+    _lib.check(_lib.lib().qsp_ba_set_option(b.handle, 2, 2))
+    t0 = time.perf_counter()
+    with pytest.raises(_lib.QspError) as e:
+        b.local_joint_ba()
+    assert e.value.code == _lib.QSP_ERR_DEVICE
+    assert time.perf_counter() - t0 < 60
+    b.close()
+
+
 @pytest.mark.parametrize("name", ["mono", "c2", "two_fixed"])
 def test_atomic_schur_kernels_match_oracle(name):
     """set_deterministic(False): the per-landmark kernel with FP64 atomics (what graphs beyond the pair-list cap use
