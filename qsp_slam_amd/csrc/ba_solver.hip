@@ -2223,19 +2223,50 @@ __global__ __launch_bounds__(256) void k_update_all(Dev d, Par par, int gp, int 
         for (int pt = blockIdx.x * 256 + threadIdx.x; pt < d.n_pt; pt += gp * 256) {
             if (d.pt_h[pt] < 0) continue;
             double c[3] = {d.bl[3 * (size_t)pt], d.bl[3 * (size_t)pt + 1], d.bl[3 * (size_t)pt + 2]};
-            for (int a = d.pt_off[pt]; a < d.pt_off[pt + 1]; ++a) {
-                if (d.edge_level[a]) continue;
-                const int ha = d.kf_h[d.edge[a].kf];
-                if (ha < 0) continue;
-                double B[18];
-                if (par.have_hpl) {
-                    const double* Bg = d.Hpl + 18 * (size_t)a;
-                    for (int i = 0; i < 18; ++i) B[i] = Bg[i];
-                } else {
-                    edge_hpl(d, d.edge[a], par, B);
+            const int a_end = d.pt_off[pt + 1];
+            if (par.have_hpl) {
+                // Four observations at a time, their three dependent fetches (level / key-frame -> its index -> x_p and the 6x3
+                // block) each issued for all four before anything waits: one edge after the other this loop was a chain of 3 x
+                // (observations) memory round trips per landmark, 20 of the launch's 23 us at C4.  The subtractions keep their
+                // order (edge by edge, i inside), so every bit of the update is what it was.
+                for (int a0 = d.pt_off[pt]; a0 < a_end; a0 += 4) {
+                    int kf[4], ha[4];
+                    uint8_t lv[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const bool in = a0 + u < a_end;
+                        lv[u] = in ? d.edge_level[a0 + u] : (uint8_t)1;
+                        kf[u] = in ? d.edge[a0 + u].kf : 0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) ha[u] = lv[u] ? -1 : d.kf_h[kf[u]];
+                    double B[4][18], x[4][6];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int au = ha[u] >= 0 ? a0 + u : a0, hu = ha[u] >= 0 ? ha[u] : 0;
+                        const double* Bg = d.Hpl + 18 * (size_t)au;
+#pragma unroll
+                        for (int i = 0; i < 18; ++i) B[u][i] = Bg[i];
+#pragma unroll
+                        for (int i = 0; i < 6; ++i) x[u][i] = d.xp[6 * hu + i];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (ha[u] < 0) continue;
+                        for (int j = 0; j < 3; ++j)
+                            for (int i = 0; i < 6; ++i) c[j] -= B[u][3 * i + j] * x[u][i];
+                    }
                 }
-                for (int j = 0; j < 3; ++j)
-                    for (int i = 0; i < 6; ++i) c[j] -= B[3 * i + j] * d.xp[6 * ha + i];
+            } else {
+                for (int a = d.pt_off[pt]; a < a_end; ++a) {
+                    if (d.edge_level[a]) continue;
+                    const int ha = d.kf_h[d.edge[a].kf];
+                    if (ha < 0) continue;
+                    double B[18];
+                    edge_hpl(d, d.edge[a], par, B);
+                    for (int j = 0; j < 3; ++j)
+                        for (int i = 0; i < 6; ++i) c[j] -= B[3 * i + j] * d.xp[6 * ha + i];
+                }
             }
             const double* Di = d.Dinv + 9 * (size_t)pt;
             for (int i = 0; i < 3; ++i) {

@@ -13,12 +13,17 @@ for r in rows:
     cur.append(r)
 groups.append(cur)
 g = [x for x in groups if len(x) > 50][-1]
-span = g[-1][1] - g[0][0]
-busy = sum(e - s for s, e, _ in g)
+span = max(e for _, e, _ in g) - g[0][0]
+# kernels of two streams overlap (the chain factorisation and its tile workgroups): busy = the union of the intervals, a gap
+# = from the latest end so far to the next start
 gaps = collections.Counter(); gapn = collections.Counter()
-for a, b in zip(g, g[1:]):
-    gap = max(0, b[0] - a[1])
-    gaps[b[2]] += gap; gapn[b[2]] += 1
+busy, end = 0, g[0][0]
+for s_, e_, k_ in g:
+    gap = max(0, s_ - end)
+    if s_ > g[0][0]:
+        gaps[k_] += gap; gapn[k_] += 1
+    busy += max(0, e_ - max(end, s_))
+    end = max(end, e_)
 print("kernels %d   span %.3f ms   busy %.3f ms   idle %.3f ms" % (len(g), span / 1e6, busy / 1e6, (span - busy) / 1e6))
 print("idle time in front of each kernel (total us, count, mean us):")
 for k, v in gaps.most_common(12):
