@@ -1955,12 +1955,15 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_chain(const double* A, do
 // diagonal tile leaves its last step, k = i-1, to the chain); it goes back to memory once, final, with tile_done(i,j).
 __global__ __launch_bounds__(256) void k_chol_trail(double* A, double* Uf, const double* Winv, double* b, const double* y, int ld, int nb,
                                                     double* scal, const unsigned* flag_w, unsigned* tile_done, unsigned epoch) {
-    int i = 1, rem = blockIdx.x;
+    extern __shared__ __attribute__((aligned(16))) double chol_lds[];
+    // (the grid is capped below the number of compute units so that the chain workgroup always finds one: a workgroup then takes
+    //  tiles blockIdx.x, blockIdx.x + gridDim.x, .. in turn -- still only ever waiting for tiles of smaller index)
+    for (int tile = blockIdx.x; tile < nb * (nb - 1) / 2; tile += gridDim.x) {
+    int i = 1, rem = tile;
     while (rem >= nb - i) { rem -= nb - i; ++i; }
     const int j = i + rem;
     const int nsteps = (i == j) ? i - 1 : i;
-    if (nsteps == 0) return;                          // (tile (1,1): the chain does its only step)
-    extern __shared__ __attribute__((aligned(16))) double chol_lds[];
+    if (nsteps == 0) continue;                        // (tile (1,1): the chain does its only step)
     double* X = chol_lds;
     double* Yi = chol_lds + NB * NB;
     double* Yj = (i == j) ? Yi : chol_lds + 2 * NB * NB;
@@ -2031,6 +2034,7 @@ __global__ __launch_bounds__(256) void k_chol_trail(double* A, double* Uf, const
         for (int q = 0; q < 4; ++q) A[(size_t)(i * NB + r0 + a) * ld + j * NB + c0 + q] = S[a][q];
     __syncthreads();
     if (t == 0) chol_signal(tile_done + i * nb + j, epoch);
+    }
 }
 
 #ifdef QSP_CB_STAMPS      // timing experiments only: shader-clock stamps of thread 0 at the phase boundaries of every step
@@ -2621,6 +2625,7 @@ struct qsp_ba_problem {
     bool chol_chain_ok = false;            // the two streams were seen running side by side (qsp_ba_create) and QSP_BA_CHOL != steps
     bool chol_chain = false;               // QSP_BA_OPT_CHOLESKY_CHAIN
     bool chol_fault = false;               // (value 2 of the option: the tile workgroups are not launched)
+    int chol_grid_max = 1;                 // tile workgroups resident at a time: compute units - 16 (one stays free for the chain)
     double* scal_host = nullptr; // pinned, device-visible copy of scal[0..3] (k_publish_scal): read back without a copy engine hop
     double* scal_host_dev = nullptr;
     double scal_seq = 0.0;       // sequence number of the last read-back enqueued
@@ -2788,6 +2793,9 @@ static int chol_chain_setup(qsp_ba_problem* p) {
         if (e != hipSuccess) (void)hipGetLastError();
         return e == hipSuccess;
     };
+    int n_cu = 0;
+    if (!ok(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, p->device)) || n_cu < 32) return QSP_OK;
+    p->chol_grid_max = n_cu - 16;
     int least = 0, greatest = 0;
     if (!ok(hipMemset(p->chol_flags, 0, sizeof(unsigned) * (nflag + 8))) || !ok(hipDeviceGetStreamPriorityRange(&least, &greatest)) ||
         !ok(hipStreamCreateWithPriority(&p->stream2, hipStreamNonBlocking, greatest)) ||
@@ -3389,7 +3397,7 @@ extern "C" int qsp_ba_optimize(qsp_ba_problem* p, int32_t n_iter, double delta_m
                     hipLaunchKernelGGL(k_chol_chain, dim3(1), dim3(CHOL_THREADS), sizeof(double) * CHAIN_LDS_DOUBLES, s, d.Hs, d.Uf, d.Winv, d.bs,
                                        d.ych, p->dimp, nb, d.scal, flag_w, tile_done, p->chol_epoch);
                     if (nb >= 3 && !p->chol_fault)
-                        hipLaunchKernelGGL(k_chol_trail, dim3(nb * (nb - 1) / 2), dim3(256), sizeof(double) * TRAIL_LDS_DOUBLES, p->stream2,
+                        hipLaunchKernelGGL(k_chol_trail, dim3(std::min(nb * (nb - 1) / 2, p->chol_grid_max)), dim3(256), sizeof(double) * TRAIL_LDS_DOUBLES, p->stream2,
                                            d.Hs, d.Uf, d.Winv, d.bs, d.ych, p->dimp, nb, d.scal, flag_w, tile_done, p->chol_epoch);
                     // (no event back: when the chain has ended every tile workgroup's writes are complete -- see k_chol_chain)
                 } else {
