@@ -1428,11 +1428,14 @@ struct NoFetch {
 };
 
 struct FactorLds { double *rbuf, *nx, *Wr; };
+// what the panel wave carries from phase p-1 into phase p: its own column of the block it has just published (U and W rows) and
+// that block's entries in columns 4p..4p+3 -- the latter read back from LDS right behind the stores, in FRONT of the barrier, so
+// that behind it only the rows handed over by the updaters remain to be fetched
+struct PanelCarry { double s[4], w[4], ur[4][4]; };
 // the panel wave's phase p; returns whether a pivot was not positive
-__device__ __forceinline__ bool factor_panel_phase(int p, const FactorLds& L, int lane) {
+__device__ __forceinline__ bool factor_panel_phase(int p, const FactorLds& L, int lane, PanelCarry& pc) {
     bool bad = false;
     double* rb = L.rbuf + (p & 1) * 8 * NB;
-    const double* rbp = L.rbuf + ((p + 1) & 1) * 8 * NB;       // block p-1
     const double* in = L.nx + (p & 1) * 8 * NB;
     double s[4], w[4];
 #pragma unroll
@@ -1440,12 +1443,10 @@ __device__ __forceinline__ bool factor_panel_phase(int p, const FactorLds& L, in
     if (p > 0) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const double uc = rbp[q * NB + lane], wc = rbp[(4 + q) * NB + lane];
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
-                const double ur = rbp[q * NB + 4 * p + a];
-                s[a] -= ur * uc;
-                w[a] -= ur * wc;
+                s[a] -= pc.ur[q][a] * pc.s[q];
+                w[a] -= pc.ur[q][a] * pc.w[q];
             }
         }
     }
@@ -1484,6 +1485,14 @@ __device__ __forceinline__ bool factor_panel_phase(int p, const FactorLds& L, in
         rb[q * NB + lane] = s[q];
         rb[(4 + q) * NB + lane] = w[q];
         L.Wr[(4 * p + q) * (NB + 1) + lane] = w[q];
+        pc.s[q] = s[q];
+        pc.w[q] = w[q];
+    }
+    if (p + 1 < NB / 4) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int a = 0; a < 4; ++a) pc.ur[q][a] = rb[q * NB + 4 * (p + 1) + a];     // (this wave's own stores: LDS keeps their order)
     }
     return bad;
 }
@@ -1533,9 +1542,10 @@ __device__ __forceinline__ bool factor_tile64(double (&S)[4][4], double* Wr, dou
     lds_barrier();
     if (panel) {
         __builtin_amdgcn_s_setprio(3);              // (it shares a SIMD with an updater wave and everybody waits for it)
+        PanelCarry pc;
 #pragma nounroll
         for (int p = 0; p < NB / 4; ++p) {
-            bad |= factor_panel_phase(p, L, lane);
+            bad |= factor_panel_phase(p, L, lane, pc);
             lds_barrier();
         }
         __builtin_amdgcn_s_setprio(0);
