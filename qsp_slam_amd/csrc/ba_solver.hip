@@ -277,6 +277,7 @@ struct Dev {
     double *kf_bk, *pt_bk, *obj_bk;
     Edge* edge;
     uint8_t* edge_level;
+    int32_t* edge_ha;               // per edge: hessian index of its key-frame, -1 if the edge is at level 1 or the key-frame fixed (k_edge_index, per optimize() call)
     double* edge_chi2;
     int32_t *pt_off;             // CSR landmark -> [first,last) in edge[]
     int32_t *kf_off, *kf_edge;   // CSR key-frame -> edge indices
@@ -2172,6 +2173,14 @@ __global__ __launch_bounds__(1024) void k_chol_back(Dev d, Par par, const double
 // back-substitution + oplus + the rho denominator   (block_solver.hpp:461-481, sparse_optimizer.cpp:423-435,
 //                                                    optimization_algorithm_levenberg.cpp:182-189)
 // ---------------------------------------------------------------------------------------------------------------
+// edge -> hessian index of its key-frame (-1: edge at level 1 or key-frame fixed).  Levels and indices are fixed for the length of an
+// optimize() call; the back-substitution of the landmarks reads this instead of level -> key-frame -> index (one dependent memory
+// round trip instead of three per batch of observations).
+__global__ __launch_bounds__(256) void k_edge_index(Dev d) {
+    const int a = blockIdx.x * 256 + threadIdx.x;
+    if (a < d.n_edge) d.edge_ha[a] = d.edge_level[a] ? -1 : d.kf_h[d.edge[a].kf];
+}
+
 __global__ __launch_bounds__(256) void k_update_points(Dev d, Par par) {
     __shared__ double sh[4];
     double sc = 0;
@@ -2239,36 +2248,34 @@ __global__ __launch_bounds__(256) void k_update_all(Dev d, Par par, int gp, int 
             double c[3] = {d.bl[3 * (size_t)pt], d.bl[3 * (size_t)pt + 1], d.bl[3 * (size_t)pt + 2]};
             const int a_end = d.pt_off[pt + 1];
             if (par.have_hpl) {
-                // Four observations at a time, their three dependent fetches (level / key-frame -> its index -> x_p and the 6x3
-                // block) each issued for all four before anything waits: one edge after the other this loop was a chain of 3 x
-                // (observations) memory round trips per landmark, 20 of the launch's 23 us at C4.  The subtractions keep their
+                // Eight observations' key-frame indices in one fetch (k_edge_index), then their 6x3 blocks and x_p four at a time,
+                // each fetch issued for the whole batch before anything waits: one edge after the other this loop was a chain of
+                // 3 x (observations) memory round trips per landmark, 20 of the launch's 23 us at C4.  The subtractions keep their
                 // order (edge by edge, i inside), so every bit of the update is what it was.
-                for (int a0 = d.pt_off[pt]; a0 < a_end; a0 += 4) {
-                    int kf[4], ha[4];
-                    uint8_t lv[4];
+                for (int a0 = d.pt_off[pt]; a0 < a_end; a0 += 8) {
+                    int ha[8];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const bool in = a0 + u < a_end;
-                        lv[u] = in ? d.edge_level[a0 + u] : (uint8_t)1;
-                        kf[u] = in ? d.edge[a0 + u].kf : 0;
-                    }
+                    for (int u = 0; u < 8; ++u) ha[u] = (a0 + u < a_end) ? d.edge_ha[a0 + u] : -1;
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) ha[u] = lv[u] ? -1 : d.kf_h[kf[u]];
-                    double B[4][18], x[4][6];
+                    for (int g = 0; g < 2; ++g) {
+                        if (a0 + 4 * g >= a_end) break;
+                        double B[4][18], x[4][6];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int au = ha[u] >= 0 ? a0 + u : a0, hu = ha[u] >= 0 ? ha[u] : 0;
-                        const double* Bg = d.Hpl + 18 * (size_t)au;
+                        for (int u = 0; u < 4; ++u) {
+                            const int hv = ha[4 * g + u];
+                            const int au = hv >= 0 ? a0 + 4 * g + u : a0, hu = hv >= 0 ? hv : 0;
+                            const double* Bg = d.Hpl + 18 * (size_t)au;
 #pragma unroll
-                        for (int i = 0; i < 18; ++i) B[u][i] = Bg[i];
+                            for (int i = 0; i < 18; ++i) B[u][i] = Bg[i];
 #pragma unroll
-                        for (int i = 0; i < 6; ++i) x[u][i] = d.xp[6 * hu + i];
-                    }
+                            for (int i = 0; i < 6; ++i) x[u][i] = d.xp[6 * hu + i];
+                        }
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        if (ha[u] < 0) continue;
-                        for (int j = 0; j < 3; ++j)
-                            for (int i = 0; i < 6; ++i) c[j] -= B[u][3 * i + j] * x[u][i];
+                        for (int u = 0; u < 4; ++u) {
+                            if (ha[4 * g + u] < 0) continue;
+                            for (int j = 0; j < 3; ++j)
+                                for (int i = 0; i < 6; ++i) c[j] -= B[u][3 * i + j] * x[u][i];
+                        }
                     }
                 }
             } else {
@@ -2932,7 +2939,7 @@ extern "C" int qsp_ba_create(const qsp_ba_scene* s, int device, qsp_ba_problem**
     UP(kf_K, s->kf_K, 5 * d.n_kf);
     AL(kf_bk, 7 * d.n_kf); AL(pt_bk, 3 * d.n_pt); AL(obj_bk, 7 * d.n_obj);
     UP(edge, p->edge_h.data(), d.n_edge);
-    AL(edge_level, d.n_edge); AL(edge_chi2, d.n_edge);
+    AL(edge_level, d.n_edge); AL(edge_ha, std::max(d.n_edge, 1)); AL(edge_chi2, d.n_edge);
     UP(pt_off, p->pt_off_h.data(), d.n_pt + 1);
     UP(kf_off, kf_off.data(), d.n_kf + 1);
     UP(kf_edge, kf_edge.data(), d.n_edge);
@@ -3277,6 +3284,7 @@ extern "C" int qsp_ba_optimize(qsp_ba_problem* p, int32_t n_iter, double delta_m
     }
     if (sizeof(double) * (size_t)(2 * p->dimp + NB) > SCHUR_ROW_LDS_MAX)     // k_chol_back keeps y and x in LDS (dimp <= 10 208):
         return qsp_fail(QSP_ERR_UNSUPPORTED, "qsp_ba_optimize: reduced camera system too large for the dense solver");   // refused before anything is enqueued
+    if (d.n_edge) hipLaunchKernelGGL(k_edge_index, dim3((d.n_edge + 255) / 256), dim3(256), 0, s, d);
     Par par{delta_mono, delta_stereo, delta_obj, 0.0, p->dim, p->dimp, p->n_pose, p->rank == 0 ? 1 : 0,
             (p->deterministic && p->dimp > 0) ? 1 : 0, p->n_dense, p->elim ? 1 : 0};
     if (tr) { tr->n = 0; tr->result = 0; tr->n_pose_blocks = p->n_pose; tr->n_landmarks = p->n_land; }
