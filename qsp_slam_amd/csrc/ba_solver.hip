@@ -2150,19 +2150,38 @@ __global__ __launch_bounds__(1024) void k_chol_back(Dev d, Par par, const double
     // barrier in between.  Nobody reads the padding rows of x.
     for (int i = t; i < par.dim; i += 1024) x[i] = xs[i];
     if (par.elim) {                                       // x_o = G_o b_o - sum_e F_e^T x_k  (the dense x is complete in LDS)
+        // A thread per (object, component); its object's edges eight at a time, each of the four dependent fetches (edge id ->
+        // level, key-frame -> its index -> the column of F_e) issued for the whole batch before anything waits: edge after edge
+        // this tail was a chain of 3 x (edges of an object) memory round trips -- ~20 us of the launch at C4 and C5 alike.  The
+        // subtractions keep their order (edge by edge, m inside): the same bits.
         for (int i = t; i < 6 * d.n_obj; i += 1024) {
             const int ob = i / 6, c = i % 6;
             const int ho = d.obj_h[ob];
-            if (ho < 0) continue;
+            const int q_end = d.obo_off[ob + 1];
             double v = d.obj_G[42 * (size_t)ob + 36 + c];
-            for (int q = d.obo_off[ob]; q < d.obo_off[ob + 1]; ++q) {
-                const int e = d.obo_edge[q];
-                if (d.oe_level[e]) continue;
-                const int hk = d.kf_h[d.oe_kf[e]];
-                if (hk < 0) continue;
-                const double* F = d.oe_F + 36 * (size_t)e;
+            if (ho < 0) continue;
+            for (int q0 = d.obo_off[ob]; q0 < q_end; q0 += 8) {
+                int e[8], kf[8], hk[8];
+                uint8_t lv[8];
 #pragma unroll
-                for (int m = 0; m < 6; ++m) v -= F[6 * m + c] * xs[6 * hk + m];
+                for (int u = 0; u < 8; ++u) e[u] = d.obo_edge[q0 + u < q_end ? q0 + u : q0];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { lv[u] = d.oe_level[e[u]]; kf[u] = d.oe_kf[e[u]]; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) hk[u] = (q0 + u < q_end && !lv[u]) ? d.kf_h[kf[u]] : -1;
+                double F[8][6];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const double* Fe = d.oe_F + 36 * (size_t)e[u];
+#pragma unroll
+                    for (int m = 0; m < 6; ++m) F[u][m] = Fe[6 * m + c];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (hk[u] < 0) continue;
+#pragma unroll
+                    for (int m = 0; m < 6; ++m) v -= F[u][m] * xs[6 * hk[u] + m];
+                }
             }
             x[6 * ho + c] = v;
         }
