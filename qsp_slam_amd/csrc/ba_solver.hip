@@ -2063,11 +2063,18 @@ constexpr int CHOL_BACK_HELPERS = 4;     // workgroups on the solver's XCD that 
 // all 64 loads of a block in flight 201 us; one workgroup per block row chained by device-scope flags (all partial sums
 // but the last off the critical path) 176-195 us -- a dependent round trip to another XCD's data costs ~3 us whichever way
 // it is made, and every row needs three of them.  The simplest form was kept.
+// two consecutive doubles from a UNIFORM address + this lane's byte offset (global_load_dwordx4: a compute unit pulls 148 GB/s out
+// of its L2 with these against 76 GB/s with dwordx2 -- tools/micro/cu_stream.hip)
+typedef double d2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ d2_t ld_row2(const double* uniform_ptr, uint32_t voff) {
+    return *reinterpret_cast<const __attribute__((address_space(1))) d2_t*>((gbytes_t)uniform_ptr + voff);
+}
 __global__ __launch_bounds__(1024) void k_chol_back(Dev d, Par par, const double* __restrict__ Uf, const double* __restrict__ Winv,
-                                                   const double* __restrict__ y, double* x, int n) {
-    extern __shared__ __attribute__((aligned(16))) double ysh[];       // [n] y, [NB] x_j, [n] x
+                                                   const double* __restrict__ y, double* x, int n, int split) {
+    extern __shared__ __attribute__((aligned(16))) double ysh[];       // [n] y, [NB] x_j, [n] x, split: [8 n] partial sums
     double* xj = ysh + n;
     double* xs = xj + NB;      // the solution stays in LDS until the end: a global store per step would sit in front of its barrier
+    double* part = xs + n;     // split: part[((4 k + q) 2 + h) NB + m]
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);      // uniform: block addresses stay in scalar registers
     const uint32_t voff = 8u * lane;
@@ -2075,8 +2082,7 @@ __global__ __launch_bounds__(1024) void k_chol_back(Dev d, Par par, const double
     if (blockIdx.x != 0) {
         // Helpers (speed only, no result): blocks b and b + 8 are observed to share an XCD, so blocks 8, 16, .. touch one double per
         // 128-byte line of the factor rows and diagonal inverses the solver is about to walk -- last block row first, which is the
-        // order of use -- and leave.  The solver's loads then hit its XCD's L2 instead of travelling to the memory side: one
-        // compute unit pulling 5.6 MB (C5) at ~34 GB/s is what bounds the single-workgroup form.
+        // order of use -- and leave.  The solver's loads then hit its XCD's L2 instead of travelling to the memory side.
         if (blockIdx.x & 7) return;
         const int h = (int)blockIdx.x / 8 - 1, H = ((int)gridDim.x - 1) / 8;
         double sink = 0;
@@ -2090,17 +2096,36 @@ __global__ __launch_bounds__(1024) void k_chol_back(Dev d, Par par, const double
     }
     for (int i = t; i < n; i += 1024) ysh[i] = y[i];
     __syncthreads();
+    // The product of block k with x_j: four chains of 16 columns (chain q: columns q, q + 4, ..).
+    //  * split (the partial sums fit LDS beside y and x: up to ~2 000 unknowns): a UNIT is one chain of one block; the 4 j units of
+    //    step j are dealt over the 16 waves one by one, and a unit is fetched with 16-byte loads -- a lane takes two adjacent rows,
+    //    the lower half-wave the chain's even columns, the upper its odd ones: 1 KB per wave-load.  What bounds this kernel is what
+    //    one compute unit can pull through its load path (round 2's form: whole blocks per wave, 8-byte loads, 41 GB/s).  A row's
+    //    sum is ((e0 + o0) + (e1 + o1)) + ((e2 + o2) + (e3 + o3)), e / o the even / odd column sums of chain 0..3, each in ascending
+    //    column order: fixed, so repeated runs agree in every bit.
+    //  * otherwise: a wave takes whole blocks, a lane a row, 8-byte loads, (a0 + a1) + (a2 + a3) (round 2's arithmetic).
     // Nothing a step LOADS from global memory depends on the step before it, only what the loads are multiplied with does: W_{j-1}'s
-    // rows are fetched while step j's blocks are being subtracted, and the first 16 columns of a wave's first block before x_j
-    // exists.  The arithmetic, and so every bit of x, is that of the plain loop (same products, same four chains, same order).
+    // rows are fetched while step j's products are being formed, and a wave's first batch before x_j exists.
+    const int half = lane >> 5, r2 = lane & 31;
+    const uint32_t voff2 = 8u * (uint32_t)(half * 4 * n + 2 * r2);
     double wt[NB / 16];
 #pragma unroll
     for (int i = 0; i < NB / 16; ++i) wt[i] = ld_row(Winv + (size_t)(nb - 1) * NB * NB + (wave + 16 * i) * NB, voff);
     for (int j = nb - 1; j >= 0; --j) {
         const double* Uj = Uf + (size_t)(j * NB) * n;     // element (m, c) of block k at Uj[k * NB + c * n + m]
         QSP_CBTS(j, 0)
+        const int nunit = 4 * j;
         double u[16];
-        if (wave < j) {
+        if (split) {
+            if (wave < nunit) {
+                const int k0 = wave >> 2, q0 = wave & 3;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const d2_t v = ld_row2(Uj + k0 * NB + (size_t)(q0 + 8 * c) * n, voff2);
+                    u[2 * c] = v.x; u[2 * c + 1] = v.y;
+                }
+            }
+        } else if (wave < j) {
 #pragma unroll
             for (int c = 0; c < 16; ++c) u[c] = ld_row(Uj + wave * NB + (size_t)c * n, voff);
         }
@@ -2123,23 +2148,53 @@ __global__ __launch_bounds__(1024) void k_chol_back(Dev d, Par par, const double
         QSP_CBTS(j, 1)
         __syncthreads();
         QSP_CBTS(j, 2)
-        for (int k = wave; k < j; k += 16) {
-            double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-#pragma unroll 1
-            for (int c0 = 0; c0 < NB; c0 += 16) {         // 16 independent wave-loads in flight, four accumulator chains
-                if (c0 > 0 || k > wave) {                 // (the first batch of the first block is already here)
+        if (split) {
+            for (int uu = wave; uu < nunit; uu += 16) {
+                const int k = uu >> 2, q = uu & 3;
+                if (uu != wave) {                         // (the first unit's columns are already here)
 #pragma unroll
-                    for (int c = 0; c < 16; ++c) u[c] = ld_row(Uj + k * NB + (size_t)(c0 + c) * n, voff);
+                    for (int c = 0; c < 8; ++c) {
+                        const d2_t v = ld_row2(Uj + k * NB + (size_t)(q + 8 * c) * n, voff2);
+                        u[2 * c] = v.x; u[2 * c + 1] = v.y;
+                    }
                 }
+                double alo = 0, ahi = 0;                  // rows 2 r2 and 2 r2 + 1, this half's columns q + 8 c + 4 half
 #pragma unroll
-                for (int c = 0; c < 16; c += 4) {
-                    a0 += u[c + 0] * xj[c0 + c + 0];
-                    a1 += u[c + 1] * xj[c0 + c + 1];
-                    a2 += u[c + 2] * xj[c0 + c + 2];
-                    a3 += u[c + 3] * xj[c0 + c + 3];
+                for (int c = 0; c < 8; ++c) {
+                    const double xc = xj[q + 8 * c + 4 * half];
+                    alo += u[2 * c] * xc;
+                    ahi += u[2 * c + 1] * xc;
+                }
+                {
+                    d2_t pv;
+                    pv.x = alo; pv.y = ahi;
+                    *reinterpret_cast<d2_t*>(part + (size_t)(2 * uu + half) * NB + 2 * r2) = pv;
                 }
             }
-            ysh[k * NB + lane] -= (a0 + a1) + (a2 + a3);
+            __syncthreads();
+            for (int k = wave; k < j; k += 16) {
+                const double* pk = part + (size_t)8 * k * NB + lane;
+                ysh[k * NB + lane] -= ((pk[0] + pk[NB]) + (pk[2 * NB] + pk[3 * NB])) + ((pk[4 * NB] + pk[5 * NB]) + (pk[6 * NB] + pk[7 * NB]));
+            }
+        } else {
+            for (int k = wave; k < j; k += 16) {
+                double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+#pragma unroll 1
+                for (int c0 = 0; c0 < NB; c0 += 16) {         // 16 independent wave-loads in flight, four accumulator chains
+                    if (c0 > 0 || k > wave) {                 // (the first batch of the first block is already here)
+#pragma unroll
+                        for (int c = 0; c < 16; ++c) u[c] = ld_row(Uj + k * NB + (size_t)(c0 + c) * n, voff);
+                    }
+#pragma unroll
+                    for (int c = 0; c < 16; c += 4) {
+                        a0 += u[c + 0] * xj[c0 + c + 0];
+                        a1 += u[c + 1] * xj[c0 + c + 1];
+                        a2 += u[c + 2] * xj[c0 + c + 2];
+                        a3 += u[c + 3] * xj[c0 + c + 3];
+                    }
+                }
+                ysh[k * NB + lane] -= (a0 + a1) + (a2 + a3);
+            }
         }
         QSP_CBTS(j, 3)
         __syncthreads();
@@ -3443,8 +3498,12 @@ extern "C" int qsp_ba_optimize(qsp_ba_problem* p, int32_t n_iter, double delta_m
                         hipLaunchKernelGGL(k_chol_step, dim3(nb - k - 1, nb - k - 1), dim3(CHOL_THREADS), lds, s, d.Hs, d.Uf, d.Winv, d.bs,
                                            d.ych, p->dimp, k, d.scal);
                 }
-                hipLaunchKernelGGL(k_chol_back, dim3(1 + 8 * CHOL_BACK_HELPERS), dim3(1024), sizeof(double) * (size_t)(2 * p->dimp + NB), s, d, par, d.Uf, d.Winv,
-                                   d.ych, d.xp, p->dimp);
+                {   // the partial sums of a step's units beside y and x in LDS when they fit (k_chol_back)
+                    const size_t lds_split = sizeof(double) * (size_t)(10 * p->dimp + NB);
+                    const int split = lds_split <= SCHUR_ROW_LDS_MAX ? 1 : 0;
+                    hipLaunchKernelGGL(k_chol_back, dim3(1 + 8 * CHOL_BACK_HELPERS), dim3(1024),
+                                       split ? lds_split : sizeof(double) * (size_t)(2 * p->dimp + NB), s, d, par, d.Uf, d.Winv, d.ych, d.xp, p->dimp, split);
+                }
             } else if (d.n_pt) {
                 if (fused) { /* unreachable: fused needs dimp > 0 */ }
                 hipLaunchKernelGGL(k_schur_dinv, dim3((d.n_pt + 255) / 256), dim3(256), 0, s, d, par);   // only D^-1 is needed
