@@ -2111,13 +2111,14 @@ __global__ __launch_bounds__(1024) void k_chol_back(Dev d, Par par, const double
     double wt[NB / 16];
 #pragma unroll
     for (int i = 0; i < NB / 16; ++i) wt[i] = ld_row(Winv + (size_t)(nb - 1) * NB * NB + (wave + 16 * i) * NB, voff);
-    for (int j = nb - 1; j >= 0; --j) {
-        const double* Uj = Uf + (size_t)(j * NB) * n;     // element (m, c) of block k at Uj[k * NB + c * n + m]
-        QSP_CBTS(j, 0)
-        const int nunit = 4 * j;
-        double u[16];
+    // a wave's first batch of step j: issued at the END of step j + 1 (in front of the loop for the first step), so that it is in
+    // flight behind that step's tail and this step's W^T y; the barriers inside the loop wait for LDS traffic only (no global
+    // store happens in it), so nothing waits for these loads before their first use
+    double u[16];
+    auto first_batch = [&](int j) {
+        const double* Uj = Uf + (size_t)(j * NB) * n;
         if (split) {
-            if (wave < nunit) {
+            if (wave < 4 * j) {
                 const int k0 = wave >> 2, q0 = wave & 3;
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
@@ -2129,6 +2130,12 @@ __global__ __launch_bounds__(1024) void k_chol_back(Dev d, Par par, const double
 #pragma unroll
             for (int c = 0; c < 16; ++c) u[c] = ld_row(Uj + wave * NB + (size_t)c * n, voff);
         }
+    };
+    first_batch(nb - 1);
+    for (int j = nb - 1; j >= 0; --j) {
+        const double* Uj = Uf + (size_t)(j * NB) * n;     // element (m, c) of block k at Uj[k * NB + c * n + m]
+        QSP_CBTS(j, 0)
+        const int nunit = 4 * j;
         {                                                 // x_j[r] = sum_q W_j[q][r] y_j[q];  Winv holds WT[r][q] = W[q][r]
             const double yq = ysh[j * NB + lane];
             double pr[NB / 16];
@@ -2146,7 +2153,7 @@ __global__ __launch_bounds__(1024) void k_chol_back(Dev d, Par par, const double
             }
         }
         QSP_CBTS(j, 1)
-        __syncthreads();
+        lds_barrier();
         QSP_CBTS(j, 2)
         if (split) {
             for (int uu = wave; uu < nunit; uu += 16) {
@@ -2171,7 +2178,8 @@ __global__ __launch_bounds__(1024) void k_chol_back(Dev d, Par par, const double
                     *reinterpret_cast<d2_t*>(part + (size_t)(2 * uu + half) * NB + 2 * r2) = pv;
                 }
             }
-            __syncthreads();
+            if (j > 0) first_batch(j - 1);
+            lds_barrier();
             for (int k = wave; k < j; k += 16) {
                 const double* pk = part + (size_t)8 * k * NB + lane;
                 ysh[k * NB + lane] -= ((pk[0] + pk[NB]) + (pk[2 * NB] + pk[3 * NB])) + ((pk[4 * NB] + pk[5 * NB]) + (pk[6 * NB] + pk[7 * NB]));
@@ -2195,9 +2203,10 @@ __global__ __launch_bounds__(1024) void k_chol_back(Dev d, Par par, const double
                 }
                 ysh[k * NB + lane] -= (a0 + a1) + (a2 + a3);
             }
+            if (j > 0) first_batch(j - 1);
         }
         QSP_CBTS(j, 3)
-        __syncthreads();
+        lds_barrier();
         QSP_CBTS(j, 4)
     }
     // (the last barrier of the loop has made xs complete.)  Only the rows that were solved: with the objects eliminated their
