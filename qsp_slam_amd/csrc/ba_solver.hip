@@ -28,6 +28,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -2875,6 +2876,35 @@ static int build_pair_lists(qsp_ba_problem* p) {
     return QSP_OK;
 }
 
+// Streams are kept for the life of the process: a problem takes a set (its stream, the second, high-priority one of the chain
+// factorisation, their event) from a per-device pool and hands it back when it is destroyed.  Creating a stream costs
+// milliseconds -- the hardware queue behind it comes into being with its first launch: 5.5 ms per create + destroy and 8 ms on
+// the first solve of a fresh problem were measured with one pair per problem (tools/time_ba_create.py) -- and the drop-in
+// Optimizer creates a problem per LocalJointBundleAdjustment call.
+struct StreamSet { hipStream_t s = nullptr, s2 = nullptr; hipEvent_t ev = nullptr; };
+static std::mutex g_stream_pool_mu;
+static std::vector<StreamSet> g_stream_pool[64];
+static bool stream_set_acquire(int dev, StreamSet* out) {
+    {
+        std::lock_guard<std::mutex> lk(g_stream_pool_mu);
+        auto& v = g_stream_pool[dev & 63];
+        if (!v.empty()) {
+            *out = v.back();
+            v.pop_back();
+            return true;
+        }
+    }
+    *out = StreamSet();
+    return hipStreamCreateWithFlags(&out->s, hipStreamNonBlocking) == hipSuccess;
+}
+static void stream_set_release(int dev, const StreamSet& st) {
+    if (!st.s) return;
+    (void)hipStreamSynchronize(st.s);
+    if (st.s2) (void)hipStreamSynchronize(st.s2);
+    std::lock_guard<std::mutex> lk(g_stream_pool_mu);
+    g_stream_pool[dev & 63].push_back(st);
+}
+
 // Second stream, events and flags of the chain factorisation.  The scheme needs k_chol_chain (problem stream) and k_chol_trail
 // (stream2) to RUN SIDE BY SIDE; two HIP streams may share a hardware queue, whose kernels run one after the other.  stream2 is
 // created at high priority (the runtime keeps a separate queue pool per priority), and the pair is tried: a waiting kernel
@@ -2897,10 +2927,13 @@ static int chol_chain_setup(qsp_ba_problem* p) {
     if (!ok(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, p->device)) || n_cu < 32) return QSP_OK;
     p->chol_grid_max = n_cu - 16;
     int least = 0, greatest = 0;
-    if (!ok(hipMemset(p->chol_flags, 0, sizeof(unsigned) * (nflag + 8))) || !ok(hipDeviceGetStreamPriorityRange(&least, &greatest)) ||
-        !ok(hipStreamCreateWithPriority(&p->stream2, hipStreamNonBlocking, greatest)) ||
-        !ok(hipEventCreateWithFlags(&p->ev_sys, hipEventDisableTiming)))
-        return QSP_OK;
+    if (!ok(hipMemset(p->chol_flags, 0, sizeof(unsigned) * (nflag + 8)))) return QSP_OK;
+    if (!p->stream2) {                                 // (a set from the pool brings them along)
+        if (!ok(hipDeviceGetStreamPriorityRange(&least, &greatest)) ||
+            !ok(hipStreamCreateWithPriority(&p->stream2, hipStreamNonBlocking, greatest)))
+            return QSP_OK;
+    }
+    if (!p->ev_sys && !ok(hipEventCreateWithFlags(&p->ev_sys, hipEventDisableTiming))) return QSP_OK;
     // (the outcome is a property of the device and the runtime -- a normal- and a high-priority stream never share a queue pool --
     //  so one successful trial per device and process stands for the later problems; a failed one is tried again)
     static std::atomic<int> seen_ok[64];
@@ -3061,7 +3094,11 @@ extern "C" int qsp_ba_create(const qsp_ba_scene* s, int device, qsp_ba_problem**
         if (e == hipSuccess) e = hipMemset(d.oe_level, 0, std::max(d.n_oe, 1));
         if (e == hipSuccess) e = hipMemset(d.edge_chi2, 0, sizeof(double) * std::max(d.n_edge, 1));
         if (e == hipSuccess) e = hipMemset(d.oe_chi2, 0, sizeof(double) * std::max(d.n_oe, 1));
-        if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);
+        if (e == hipSuccess) {
+            StreamSet st;
+            if (stream_set_acquire(p->device, &st)) { p->stream = st.s; p->stream2 = st.s2; p->ev_sys = st.ev; }
+            else e = hipErrorOutOfMemory;
+        }
         if (e == hipSuccess) e = hipHostMalloc((void**)&p->scal_host, 8 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent);
         if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&p->scal_host_dev, p->scal_host, 0);
         if (e == hipSuccess) p->scal_host[4] = 0.0;
@@ -3103,9 +3140,11 @@ extern "C" void qsp_ba_destroy(qsp_ba_problem* p) {
     if (p->scal_host) (void)hipHostFree(p->scal_host);
     if (p->lvl_host) (void)hipHostFree(p->lvl_host);
     if (p->idx_host) (void)hipHostFree(p->idx_host);
-    if (p->ev_sys) (void)hipEventDestroy(p->ev_sys);
-    if (p->stream2) (void)hipStreamDestroy(p->stream2);
-    if (p->stream) (void)hipStreamDestroy(p->stream);
+    {
+        StreamSet st;
+        st.s = p->stream; st.s2 = p->stream2; st.ev = p->ev_sys;
+        stream_set_release(p->device, st);           // (synchronised and kept for the next problem on this device)
+    }
     delete p;
 }
 
