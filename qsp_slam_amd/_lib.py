@@ -103,7 +103,7 @@ SYMBOLS = [
     "qsp_pose_optimizer_create", "qsp_pose_optimizer_destroy", "qsp_pose_optimize", "qsp_ellipsoid_fit_planes",
     "qsp_ba_create", "qsp_ba_destroy", "qsp_ba_set_levels", "qsp_ba_optimize", "qsp_ba_local_joint",
     "qsp_ba_set_state", "qsp_ba_get_state", "qsp_ba_get_edges", "qsp_ba_get_index", "qsp_ba_profile", "qsp_ba_set_shard", "qsp_ba_set_deterministic",
-    "qsp_ba_set_shard_rccl", "qsp_ba_set_option", "qsp_comm_unique_id", "qsp_comm_create", "qsp_comm_adopt", "qsp_comm_destroy", "qsp_comm_nccl", "qsp_comm_stub_counts",
+    "qsp_ba_set_shard_rccl", "qsp_ba_set_option", "qsp_ba_release_caches", "qsp_comm_unique_id", "qsp_comm_create", "qsp_comm_adopt", "qsp_comm_destroy", "qsp_comm_nccl", "qsp_comm_stub_counts",
     "qsp_comm_rank", "qsp_comm_world", "qsp_comm_allreduce_f64", "qsp_comm_allgather_f32",
 ]
 

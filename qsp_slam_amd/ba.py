@@ -165,6 +165,11 @@ class BaProblem(object):
         return p
 
 
+def release_caches():
+    """give back the streams, device chunks and pinned buffers qsp_ba_destroy keeps for the next problem (qsp_ba_release_caches)"""
+    _lib.lib().qsp_ba_release_caches()
+
+
 class PoseOptimizer(object):
     """Optimizer::PoseOptimization (reference src/Optimizer.cc:244-456) on flattened inputs, one kernel launch per call
     (qsp_pose_optimize, include/qsp_hip.h)."""

@@ -2701,6 +2701,8 @@ struct qsp_ba_problem {
     Dev d{};
     int n_mono = 0, n_stereo = 0;
     std::vector<void*> allocs;
+    std::vector<size_t> alloc_bytes;      // (their sizes: freed chunks go to a per-device cache)
+    size_t host_bytes[3] = {0, 0, 0};     // scal_host, lvl_host, idx_host as allocated
     char* pool_cur = nullptr;     // bump allocator over the chunks in `allocs`
     size_t pool_left = 0;
     // host mirrors needed for index building
@@ -2752,16 +2754,52 @@ struct qsp_ba_problem {
 
 static int upload_levels(qsp_ba_problem* p);
 
+// Freed device chunks and pinned host buffers are kept per device for the next problem (bounded: 16 entries each, 512 MB of device
+// memory): hipMalloc / hipFree and hipHostMalloc / hipHostFree cost 0.1-0.5 ms apiece, and a caller that builds a problem per bundle
+// adjustment (the drop-in Optimizer) asks for the same sizes again and again.  Nothing relies on fresh memory being zero.
+struct CachedBuf { void* p; size_t bytes; unsigned flags; };
+static std::mutex g_buf_cache_mu;
+static std::vector<CachedBuf> g_dev_cache[64], g_host_cache[64];
+static void* buf_cache_take(std::vector<CachedBuf>* cache, int dev, size_t bytes, unsigned flags, size_t* got) {
+    std::lock_guard<std::mutex> lk(g_buf_cache_mu);
+    auto& v = cache[dev & 63];
+    int best = -1;
+    for (int i = 0; i < (int)v.size(); ++i)
+        if (v[i].flags == flags && v[i].bytes >= bytes && v[i].bytes <= 2 * bytes + (1 << 16) && (best < 0 || v[i].bytes < v[best].bytes)) best = i;
+    if (best < 0) return nullptr;
+    void* q = v[best].p;
+    *got = v[best].bytes;
+    v.erase(v.begin() + best);
+    return q;
+}
+// false: the cache is full, the caller frees the buffer
+static bool buf_cache_put(std::vector<CachedBuf>* cache, int dev, void* q, size_t bytes, unsigned flags, size_t max_total) {
+    std::lock_guard<std::mutex> lk(g_buf_cache_mu);
+    auto& v = cache[dev & 63];
+    size_t tot = bytes;
+    for (const CachedBuf& c : v) tot += c.bytes;
+    if (v.size() >= 16 || tot > max_total) return false;
+    v.push_back({q, bytes, flags});
+    return true;
+}
+static hipError_t host_alloc_cached(int dev, void** out, size_t bytes, unsigned flags, size_t* got) {
+    *got = bytes;
+    void* q = buf_cache_take(g_host_cache, dev, bytes, flags, got);
+    if (q) { *out = q; return hipSuccess; }
+    return hipHostMalloc(out, bytes, flags);
+}
+
 // device buffers come out of a few large chunks (a problem has ~50 of them; one hipMalloc each costs more than the
 // uploads at the BASELINE sizes)
 template <typename T>
 static int dalloc(qsp_ba_problem* p, T** ptr, size_t n) {
     const size_t bytes = (std::max<size_t>(n, 1) * sizeof(T) + 255) & ~(size_t)255;
     if (bytes > p->pool_left) {
-        const size_t chunk = std::max<size_t>(bytes, (size_t)8 << 20);
-        void* q = nullptr;
-        QSP_HIP(hipMalloc(&q, chunk));
+        size_t chunk = std::max<size_t>(bytes, (size_t)8 << 20);
+        void* q = buf_cache_take(g_dev_cache, p->device, chunk, 0, &chunk);
+        if (!q) QSP_HIP(hipMalloc(&q, chunk));
         p->allocs.push_back(q);
+        p->alloc_bytes.push_back(chunk);
         if (chunk - bytes > p->pool_left) {          // keep whichever tail is larger for the next requests
             p->pool_cur = (char*)q + bytes;
             p->pool_left = chunk - bytes;
@@ -3099,11 +3137,11 @@ extern "C" int qsp_ba_create(const qsp_ba_scene* s, int device, qsp_ba_problem**
             if (stream_set_acquire(p->device, &st)) { p->stream = st.s; p->stream2 = st.s2; p->ev_sys = st.ev; }
             else e = hipErrorOutOfMemory;
         }
-        if (e == hipSuccess) e = hipHostMalloc((void**)&p->scal_host, 8 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent);
+        if (e == hipSuccess) e = host_alloc_cached(p->device, (void**)&p->scal_host, 8 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent, &p->host_bytes[0]);
         if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&p->scal_host_dev, p->scal_host, 0);
         if (e == hipSuccess) p->scal_host[4] = 0.0;
-        if (e == hipSuccess) e = hipHostMalloc((void**)&p->lvl_host, (size_t)std::max(d.n_edge + d.n_oe, 1), hipHostMallocDefault);
-        if (e == hipSuccess) e = hipHostMalloc((void**)&p->idx_host, sizeof(int32_t) * (size_t)std::max(d.n_kf + d.n_obj + d.n_pt, 1), hipHostMallocDefault);
+        if (e == hipSuccess) e = host_alloc_cached(p->device, (void**)&p->lvl_host, (size_t)std::max(d.n_edge + d.n_oe, 1), hipHostMallocDefault, &p->host_bytes[1]);
+        if (e == hipSuccess) e = host_alloc_cached(p->device, (void**)&p->idx_host, sizeof(int32_t) * (size_t)std::max(d.n_kf + d.n_obj + d.n_pt, 1), hipHostMallocDefault, &p->host_bytes[2]);
         const int chol_lds = (int)(sizeof(double) * CHOL_LDS_DOUBLES);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_chol_chain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * CHAIN_LDS_DOUBLES));
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_chol_trail, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * TRAIL_LDS_DOUBLES));
@@ -3136,16 +3174,48 @@ extern "C" int qsp_ba_create(const qsp_ba_scene* s, int device, qsp_ba_problem**
 extern "C" void qsp_ba_destroy(qsp_ba_problem* p) {
     if (!p) return;
     (void)hipSetDevice(p->device);
-    for (void* q : p->allocs) (void)hipFree(q);
-    if (p->scal_host) (void)hipHostFree(p->scal_host);
-    if (p->lvl_host) (void)hipHostFree(p->lvl_host);
-    if (p->idx_host) (void)hipHostFree(p->idx_host);
     {
         StreamSet st;
         st.s = p->stream; st.s2 = p->stream2; st.ev = p->ev_sys;
         stream_set_release(p->device, st);           // (synchronised and kept for the next problem on this device)
     }
+    // (behind the synchronisation: nothing of this problem is in flight any more)
+    for (size_t i = 0; i < p->allocs.size(); ++i)
+        if (i >= p->alloc_bytes.size() || !p->alloc_bytes[i] || !buf_cache_put(g_dev_cache, p->device, p->allocs[i], p->alloc_bytes[i], 0, (size_t)512 << 20))
+            (void)hipFree(p->allocs[i]);
+    void* hb[3] = {p->scal_host, p->lvl_host, p->idx_host};
+    const unsigned hf[3] = {hipHostMallocMapped | hipHostMallocCoherent, hipHostMallocDefault, hipHostMallocDefault};
+    for (int i = 0; i < 3; ++i)
+        if (hb[i] && !buf_cache_put(g_host_cache, p->device, hb[i], p->host_bytes[i], hf[i], (size_t)64 << 20)) (void)hipHostFree(hb[i]);
     delete p;
+}
+
+extern "C" void qsp_ba_release_caches(void) {
+    int cur = 0;
+    const bool have_cur = hipGetDevice(&cur) == hipSuccess;
+    for (int dev = 0; dev < 64; ++dev) {
+        std::vector<CachedBuf> dv, hv;
+        std::vector<StreamSet> sv;
+        {
+            std::lock_guard<std::mutex> lk(g_buf_cache_mu);
+            dv.swap(g_dev_cache[dev]);
+            hv.swap(g_host_cache[dev]);
+        }
+        {
+            std::lock_guard<std::mutex> lk(g_stream_pool_mu);
+            sv.swap(g_stream_pool[dev]);
+        }
+        if (dv.empty() && hv.empty() && sv.empty()) continue;
+        if (hipSetDevice(dev) != hipSuccess) continue;
+        for (const CachedBuf& c : dv) (void)hipFree(c.p);
+        for (const CachedBuf& c : hv) (void)hipHostFree(c.p);
+        for (const StreamSet& st : sv) {
+            if (st.ev) (void)hipEventDestroy(st.ev);
+            if (st.s2) (void)hipStreamDestroy(st.s2);
+            if (st.s) (void)hipStreamDestroy(st.s);
+        }
+    }
+    if (have_cur) (void)hipSetDevice(cur);
 }
 
 extern "C" int qsp_ba_set_levels(qsp_ba_problem* p, const uint8_t* mono, const uint8_t* stereo, const uint8_t* obj) {
@@ -3329,6 +3399,7 @@ static int set_shard_common(qsp_ba_problem* p, int32_t rank, int32_t world) {
             void* q = nullptr;
             QSP_HIP(hipMalloc(&q, need * sizeof(double)));
             p->allocs.push_back(q);
+            p->alloc_bytes.push_back(0);             // (not a pool chunk: freed, not cached)
             p->comm = (double*)q;
             p->comm_cap = need;
         }

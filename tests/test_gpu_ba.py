@@ -366,6 +366,36 @@ def test_cholesky_chain_and_step_forms_give_the_same_bits(size):
         assert np.array_equal(np.asarray(x), np.asarray(y))
 
 
+def test_destroyed_problems_leave_their_buffers_for_the_next_and_release_gives_them_back():
+    """qsp_ba_destroy caches streams / device chunks / pinned buffers per device (the drop-in Optimizer builds a problem per
+    call); results do not depend on what a recycled buffer held, and qsp_ba_release_caches returns the memory"""
+    import ctypes as C
+    from qsp_slam_amd import ba as gba
+    from qsp_slam_amd.ba import BaProblem
+    hip = C.CDLL("libamdhip64.so")
+
+    def free_mb():
+        f, t = C.c_size_t(), C.c_size_t()
+        assert hip.hipMemGetInfo(C.byref(f), C.byref(t)) == 0
+        return f.value / 2 ** 20
+
+    big = synth.make_ba_scene(**SCENES["c2"])
+    small = synth.make_ba_scene(**SCENES["mono"])
+    gba.release_caches()
+    outs = []
+    for sc in (big, small, big, small, big):       # (recycled chunks hold the other scene's data)
+        b = BaProblem(sc)
+        b.set_deterministic(True)
+        t1, t2 = b.local_joint_ba()
+        outs.append((np.array(t2["chi2"]), b.state()[0]))
+        b.close()
+    assert np.array_equal(outs[0][0], outs[2][0]) and np.array_equal(outs[0][0], outs[4][0]) and np.array_equal(outs[1][0], outs[3][0])
+    assert np.array_equal(outs[0][1], outs[4][1]) and np.array_equal(outs[1][1], outs[3][1])
+    held = free_mb()
+    gba.release_caches()
+    assert free_mb() >= held + 7.5                 # (at least the 8 MB chunk of the last problem came back)
+
+
 @pytest.mark.timeout(120)
 def test_cholesky_chain_waits_are_bounded():
     """the chain workgroup launched without its tile workgroups (option value 2): the flag it waits for never comes, the wait
