@@ -446,6 +446,25 @@ def latency_block(dec):
         one32, four32 = timed()
         dec.set_tile_points(64)
         out["tile_points_32"] = {"ms_reconstruct_object": one32, "ms_four_flips_one_call": four32}
+    # path B the way the drop-in Optimizer calls it (src/Optimizer_util.cc:309-771 builds its graph per call): a qsp_ba_problem
+    # made from host arrays, one two-stage local joint BA, the state read back, the problem destroyed -- per call, C4's graph
+    from qsp_slam_amd.ba import BaProblem
+    w = WORKLOADS["c4"]
+    scene = synth.make_ba_scene(2000, w["n_kf"], w["n_map"], w["n_obj"], stereo_frac=0.2)
+
+    def ba_call():
+        b = BaProblem(scene, device=dec.device)
+        b.local_joint_ba()
+        b.state()
+        b.close()
+
+    for _ in range(2):
+        ba_call()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        ba_call()
+    out["ms_local_joint_ba_problem_per_call"] = 1e3 * (time.perf_counter() - t0) / 10
+    out["ba_workload"] = "C4's graph (%s), created from host arrays and destroyed in every call" % w["desc"].split(":")[0]
     return out
 
 
