@@ -396,6 +396,64 @@ def test_destroyed_problems_leave_their_buffers_for_the_next_and_release_gives_t
     assert free_mb() >= held + 7.5                 # (at least the 8 MB chunk of the last problem came back)
 
 
+@pytest.mark.timeout(300)
+def test_chain_factorisation_beside_a_decoder_that_fills_the_chip(golden_dir):
+    """LocalMapping's bundle adjustment and object refinement run on different threads in the reference's system.  The decoder's
+    kernels are persistent-style grids that hold every compute unit for tens of milliseconds; the BA's chain workgroup and its
+    tile workgroups have to find their compute units in between and must neither starve into a wait time-out nor change a bit."""
+    import threading
+    import bench
+    from qsp_slam_amd import DeepSdfDecoder
+    from qsp_slam_amd.ba import BaProblem
+    from qsp_slam_amd.reconstruct.optimizer import Optimizer, RefineBatch, _joint_cfg
+    from tests.test_gpu_sdf import make_cfg
+    from oracle import sdf_oracle as so
+    w = bench.WORKLOADS["c4"]
+    sc = synth.make_ba_scene(2100, w["n_kf"], w["n_map"], w["n_obj"], stereo_frac=0.2)
+    ref = BaProblem(sc)
+    ref.set_deterministic(True)
+    if not ref.cholesky_chain:
+        ref.close()
+        pytest.skip("this problem's two streams do not run concurrently here: the step form is all there is")
+    r1, r2 = ref.local_joint_ba()
+    want = (np.array(r2["chi2"]), *ref.state())
+    ref.close()
+    dec = DeepSdfDecoder.from_npz(os.path.join(golden_dir, "decoder_8x512.npz"))
+    dec.set_precision("fp16x2")
+    opt = Optimizer(dec, make_cfg(so.JointConfig(n_iter=2)))
+    objs = synth.make_object_views(77, 16, 4000, n_fg=256, n_bg=200)
+    T0, hyp = bench.flip_states(objs, 4)
+    batch = RefineBatch(dec, _joint_cfg(opt), [o["pts"] for o in objs], [o["rays"] for o in objs], [o["depth"] for o in objs], hyp)
+    stop = threading.Event()
+    errors = []
+
+    def load():
+        try:
+            while not stop.is_set():
+                batch.set_state(T0, None)
+                batch.run(2)
+        except Exception as e:      # noqa: BLE001 (reported below)
+            errors.append(e)
+
+    th = threading.Thread(target=load)
+    th.start()
+    try:
+        for _ in range(12):
+            b = BaProblem(sc)
+            b.set_deterministic(True)
+            g1, g2 = b.local_joint_ba()
+            got = (np.array(g2["chi2"]), *b.state())
+            b.close()
+            for x, y in zip(got, want):
+                assert np.array_equal(x, y)
+    finally:
+        stop.set()
+        th.join()
+        batch.close()
+        dec.close()
+    assert not errors, errors
+
+
 @pytest.mark.timeout(120)
 def test_cholesky_chain_waits_are_bounded():
     """the chain workgroup launched without its tile workgroups (option value 2): the flag it waits for never comes, the wait
