@@ -89,7 +89,7 @@ inline void pose7_to_mat(const double* p, float* T /*row-major 4x4*/) {
 }
 
 // the reference's graph walk stamps key-frames / points / objects with the current key-frame id (src/Optimizer_util.cc:314-380);
-// when the GPU path fails those stamps are rolled back so that the g2o fallback walks the same sets
+// when the GPU path fails those stamps are rolled back: the map is left as found (and an opted-in g2o fallback walks the same sets)
 struct Marks {
     std::vector<std::pair<long unsigned int*, long unsigned int>> saved;
     void set(long unsigned int& field, long unsigned int v) { saved.emplace_back(&field, field); field = v; }
@@ -99,23 +99,46 @@ struct Marks {
     }
 };
 
-// Process-wide count of library calls that failed, i.e. of entry points that then ran (or will run) on the reference's g2o code
-// instead.  A deployment that must not silently run on the CPU asserts `qsp_shim::fallback_count() == 0` (or sets
-// QSP_SHIM_NO_FALLBACK=1, which turns the first failure into std::abort() after the message below).
+// What a failed library call does.  DEFAULT: fail loudly -- the error is logged, the BA marks are rolled
+// back, the map is left exactly as found and the entry point returns (the reference's contract, include/Optimizer.h:78-107, is
+// `void`, no throw: the embedding application sees `failure_count()` move and decides; PoseOptimization returns 0 inliers, which
+// Tracking treats as a lost frame).  Nothing runs on the CPU unless the deployment asked for it:
+//   QSP_SHIM_ALLOW_G2O_FALLBACK=1   hand the failed call to the reference's own g2o code compiled into the drop-in (counted in
+//                                   `fallback_count()`, one stderr line per call);
+//   QSP_SHIM_NO_FALLBACK=1          strictest: std::abort() after the message.
+// OptimizeSim3 / OptimizeEssentialGraph are CPU pass-throughs by design and are not affected.
+inline std::atomic<long>& failure_counter() {
+    static std::atomic<long> n{0};
+    return n;
+}
 inline std::atomic<long>& fallback_counter() {
     static std::atomic<long> n{0};
     return n;
 }
-inline long fallback_count() { return fallback_counter().load(); }
-inline void reset_fallback_count() { fallback_counter().store(0); }
+inline long failure_count() { return failure_counter().load(); }     // library calls that returned an error
+inline long fallback_count() { return fallback_counter().load(); }   // of those, entry points handed to g2o (opt-in only)
+inline void reset_fallback_count() { fallback_counter().store(0); failure_counter().store(0); }
+
+inline bool allow_g2o_fallback() {
+    const char* e = std::getenv("QSP_SHIM_ALLOW_G2O_FALLBACK");
+    return e && *e == '1';
+}
 
 inline int report(const char* where, int rc) {
     if (rc != QSP_OK) {
-        fallback_counter().fetch_add(1);
-        std::fprintf(stderr, "[qsp_hip] %s failed (%d): %s -- this call falls back to the reference's g2o path (fallback #%ld)\n",
-                     where, rc, qsp_last_error(), fallback_count());
+        failure_counter().fetch_add(1);
         const char* strict = std::getenv("QSP_SHIM_NO_FALLBACK");
-        if (strict && *strict == '1') std::abort();
+        const bool fatal = strict && *strict == '1';
+        if (!fatal && allow_g2o_fallback()) {
+            fallback_counter().fetch_add(1);
+            std::fprintf(stderr, "[qsp_hip] %s failed (%d): %s -- QSP_SHIM_ALLOW_G2O_FALLBACK=1: this call falls back to the "
+                                 "reference's g2o path (fallback #%ld)\n", where, rc, qsp_last_error(), fallback_count());
+        } else {
+            std::fprintf(stderr, "[qsp_hip] %s failed (%d): %s -- the map is left untouched and the call returns (failure #%ld; "
+                                 "QSP_SHIM_ALLOW_G2O_FALLBACK=1 would run the reference's g2o code instead)\n",
+                         where, rc, qsp_last_error(), failure_count());
+        }
+        if (fatal) std::abort();
     }
     return rc;
 }

@@ -1,0 +1,206 @@
+"""TEST INFRASTRUCTURE ONLY -- measures the REFERENCE's OWN rounding noise on the joint refinement, per iteration.
+
+Build-container only (needs /root/reference).  VERDICT r3 item 1: the teacher-forced bars of `dx`, the KITTI `b` and the next
+state sit above north_star's 1e-4, and the reason given (cond(H) amplifies the 1e-5 of `H, b`) was the builder's word.  This
+script makes the reference say it itself.  For every joint golden case and every Gauss-Newton iteration it restarts the
+reference's `Optimizer.reconstruct_object` (`reconstruct/optimizer.py:96-281`, `num_iterations = 1`) from the state the committed
+fixture recorded for that iteration (`it_T_oc[i]`, `it_code[i]` of tests/golden/sdf_joint_*.npz) and runs it
+
+  ref64   with the decoder, the inputs and the state cast to float64 (`torch.set_default_dtype(torch.float64)`): the value all
+          float32 evaluations scatter around;
+  ref32   in float32, six more times, each a legitimate second evaluation of the same arithmetic:
+          [0]      unpermuted with `torch.set_num_threads(1)` (the committed fixtures ran with 8 threads);
+          [1..4]   with the observation rows PERMUTED (surface points; foreground rays with their depths; background rays -- the
+                   two ray groups stay in place because `depth_obs[n_fg:]` addresses them by position): another summation order
+                   of `sum(0)` and another row order of `torch.where`;
+          [5]      unpermuted, with every 4x4 `torch.inverse` evaluated in float64 and rounded to float32 (a correctly rounded
+                   inverse instead of LAPACK's float32 getrf/getri: the one rounding the row order cannot reach -- it feeds the
+                   scale, the depth range and, with the KITTI weights, `k4 = 1e7` times the float32 cancellation
+                   `1 - cos(tilt)` of loss.py:155-178).
+          [6..7]   unpermuted rows, on a UNIT-PERMUTED copy of the decoder: the reference's own `Decoder` class with plain
+                   `nn.Linear` layers holding exactly the folded weights `g v / |v|` the weight-normed decoder multiplies with, the
+                   hidden units of every layer re-ordered (rows of `W_l`, `b_l`, columns of `W_{l+1}`) -- the same function, every
+                   dot product inside the network summed in another order.  The row permutations cannot reach that order (a
+                   row's arithmetic does not depend on its position), and it is the one that decides on which side of zero a
+                   ReLU pre-activation within rounding of it falls: the knife-edge rows of DESIGN.md section 1.
+          Together with the committed fixture's own values that is NINE float32 samples of the reference per iteration.
+
+The teacher state enters through a harness-side tap on the first `torch.inverse` of a 4x4 (optimizer.py:127, the entry's own
+`t_obj_cam = inverse(t_cam_obj)`), which returns the recorded `T_oc` exactly; `H`, `b`, `dx` and the next `T_oc` are tapped the
+way oracle/gen_golden_sdf.py taps them.  No reference file is modified; the output is arrays only.
+
+    python oracle/gen_noise_sdf.py            -> tests/golden/sdf_noise_<case>.npz
+"""
+import ast
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+from oracle.gen_golden_sdf import GOLD, ref_configs, ref_decoder  # noqa: E402
+from oracle.ref_import import import_reference  # noqa: E402
+
+CASES = ["sdf_joint_redwood_m600", "sdf_joint_redwood_m2000", "sdf_joint_kitti_m250", "sdf_joint_code_m500"]
+
+
+def one_iteration(mods, dec, cfg, T_oc, code, pts, rays, depth, dtype, exact_inv4=False):
+    """the reference's entry point for ONE iteration from the teacher state; returns K, H, b, dx, next T_oc, next code"""
+    opt_mod = mods[0]
+    code_len = code.shape[0]
+    n = 7 + code_len
+    npdt = np.float64 if dtype == torch.float64 else np.float32
+    tap = dict(first=True, inv4=[], H=None, b=None, dx=None, K=None, rot=None)
+    orig_inv, orig_mv, orig_render = torch.inverse, torch.mv, opt_mod.compute_render_loss
+    orig_rot = opt_mod.compute_rotation_loss_sim3
+
+    def tap_rot(t_):
+        j_, r_ = orig_rot(t_)
+        tap["rot"] = (j_.numpy().copy(), float(r_))
+        return j_, r_
+
+    def tap_inv(x):
+        if tuple(x.shape) == (4, 4):
+            if tap["first"]:                          # optimizer.py:127 -- hand the recorded T_oc over, bit for bit
+                tap["first"] = False
+                return torch.from_numpy(T_oc.astype(npdt))
+            tap["inv4"].append(x.numpy().copy())
+            if exact_inv4:
+                return orig_inv(x.double()).to(x.dtype)
+        elif x.shape[0] == n:
+            tap["H"] = x.numpy().copy()
+        return orig_inv(x)
+
+    def tap_mv(a, v):
+        r_ = orig_mv(a, v)
+        if a.shape[0] == n:
+            tap["b"] = v.numpy().copy()
+            tap["dx"] = r_.numpy().copy()
+        return r_
+
+    def tap_render(*a, **k):
+        r_ = orig_render(*a, **k)
+        tap["K"] = -1 if r_ is None else int(r_[2].shape[0])
+        return r_
+
+    old_dtype = torch.get_default_dtype()
+    torch.set_default_dtype(dtype)
+    torch.inverse, torch.mv, opt_mod.compute_render_loss = tap_inv, tap_mv, tap_render
+    opt_mod.compute_rotation_loss_sim3 = tap_rot
+    try:
+        opt = opt_mod.Optimizer(dec, cfg)
+        r = opt.reconstruct_object(np.eye(4, dtype=npdt), pts.astype(npdt), rays.astype(npdt), depth.astype(npdt),
+                                   code=code.astype(npdt).copy())
+    finally:
+        torch.inverse, torch.mv, opt_mod.compute_render_loss = orig_inv, orig_mv, orig_render
+        opt_mod.compute_rotation_loss_sim3 = orig_rot
+        torch.set_default_dtype(old_dtype)
+    assert r.is_good and tap["H"] is not None
+    # 4x4 inverses seen after the entry's: [0] = T_oc at the iteration's head (optimizer.py:144), [1] = the same inside the
+    # rotation prior (loss.py:161), [2] = the NEXT T_oc (optimizer.py:274)
+    assert len(tap["inv4"]) == 3 and all(np.array_equal(tap["inv4"][j], T_oc.astype(npdt)) for j in (0, 1))
+    return dict(K=tap["K"], H=tap["H"], b=tap["b"], dx=tap["dx"], T_next=tap["inv4"][2],
+                code_next=np.asarray(r.code).copy(), Jrot=tap["rot"][0], res_rot=np.array(tap["rot"][1], npdt))
+
+
+N_PERM = 4
+N_UNIT = 2
+
+
+def unit_permuted_decoder(dec_mod, dec, seed):
+    """the same network as `dec` (weight-normed, eval mode) as a plain-Linear `Decoder` with permuted hidden units; seed < 0: no
+    permutation (must then reproduce `dec` bit for bit -- checked by the caller)"""
+    n_lin = dec.num_layers - 1
+    lins = [getattr(dec, "lin%d" % l) for l in range(n_lin)]
+    W = [(torch._weight_norm(m.weight_v, m.weight_g, 0) if hasattr(m, "weight_v") else m.weight).detach() for m in lins]
+    B = [getattr(dec, "lin%d" % l).bias.detach() for l in range(n_lin)]
+    latent = W[0].shape[1] - 3
+    dims = [W[l].shape[0] + (W[0].shape[1] if l + 1 in dec.latent_in else 0) for l in range(n_lin - 1)]
+    cp = dec_mod.Decoder(latent, dims, dropout=list(range(n_lin - 1)), dropout_prob=0.2, norm_layers=[],
+                         latent_in=list(dec.latent_in), weight_norm=False, xyz_in_all=False, use_tanh=dec.use_tanh,
+                         latent_dropout=False)
+    rng = np.random.default_rng(max(seed, 0))
+    prev = None                                                  # permutation of the previous layer's outputs
+    for l in range(n_lin):
+        w, b = W[l].clone(), B[l].clone()
+        if prev is not None:
+            cols = np.arange(w.shape[1])
+            cols[:prev.shape[0]] = prev                           # layer `latent_in`: [h | input] -- the input part stays
+            w = w[:, torch.from_numpy(cols)]
+        if l < n_lin - 1 and seed >= 0:
+            perm = rng.permutation(w.shape[0])
+            w, b = w[torch.from_numpy(perm)], b[torch.from_numpy(perm)]
+            prev = perm
+        else:
+            prev = None
+        lin = getattr(cp, "lin%d" % l)
+        assert tuple(lin.weight.shape) == tuple(w.shape), (l, lin.weight.shape, w.shape)
+        lin.weight.data.copy_(w)
+        lin.bias.data.copy_(b)
+    cp.eval()
+    return cp
+
+
+def main():
+    mods = import_reference()
+    opt_mod, loss_mod, lu, dec_mod, utils_mod = mods
+    dec32 = ref_decoder(dec_mod, os.path.join(GOLD, "decoder_8x512.npz"))
+    dec64 = ref_decoder(dec_mod, os.path.join(GOLD, "decoder_8x512.npz")).double()
+    rel = lambda a, b: float(np.abs(a - b).max() / np.abs(b).max())            # noqa: E731
+    probe = torch.from_numpy(np.random.default_rng(5).uniform(-0.8, 0.8, size=(4096, 67)).astype(np.float32))
+    with torch.no_grad():
+        same = unit_permuted_decoder(dec_mod, dec32, -1)(probe)
+        assert torch.equal(same, dec32(probe)), "the plain-Linear copy must be the weight-normed decoder, bit for bit"
+        dec_u = [unit_permuted_decoder(dec_mod, dec32, 100 + k) for k in range(N_UNIT)]
+        print("unit-permuted copies differ from the decoder by", [float((d(probe) - dec32(probe)).abs().max()) for d in dec_u])
+    for name in CASES:
+        z = np.load(os.path.join(GOLD, name + ".npz"))
+        joint = ast.literal_eval(str(z["joint"]))
+        data_type = joint.pop("data_type")
+        joint["num_iterations"] = 1
+        cfg = ref_configs(utils_mod, joint, data_type)
+        pts, rays, depth = z["pts"], z["rays"], z["depth"]
+        n_fg = depth.shape[0]
+        rng = np.random.default_rng(sum(map(ord, name)))
+        perms = []
+        for _ in range(N_PERM):
+            p_fg = rng.permutation(n_fg)
+            perms.append((rng.permutation(pts.shape[0]), np.concatenate([p_fg, n_fg + rng.permutation(rays.shape[0] - n_fg)]),
+                          p_fg))
+        n_it = z["it_H"].shape[0]
+        keys = ("K", "H", "b", "dx", "T_next", "code_next", "Jrot", "res_rot")
+        out64 = {k: [] for k in keys}
+        out32 = {k: [] for k in keys}
+        for i in range(n_it):
+            T_oc, code = z["it_T_oc"][i], z["it_code"][i]
+            torch.set_num_threads(8)
+            r64 = one_iteration(mods, dec64, cfg, T_oc, code, pts, rays, depth, torch.float64)
+            torch.set_num_threads(1)
+            samples = [one_iteration(mods, dec32, cfg, T_oc, code, pts, rays, depth, torch.float32)]
+            torch.set_num_threads(8)
+            for pp, pr, pf in perms:
+                samples.append(one_iteration(mods, dec32, cfg, T_oc, code, pts[pp], rays[pr], depth[pf], torch.float32))
+            samples.append(one_iteration(mods, dec32, cfg, T_oc, code, pts, rays, depth, torch.float32, exact_inv4=True))
+            for d in dec_u:
+                samples.append(one_iteration(mods, d, cfg, T_oc, code, pts, rays, depth, torch.float32))
+            for k in keys:
+                out64[k].append(r64[k])
+                out32[k].append(np.stack([np.asarray(s_[k]) for s_ in samples]))
+            same_t = all(np.array_equal(samples[0][k], z["it_" + k][i]) for k in ("H", "b"))
+            print("%s it %d  K %d / %d / %s  threads-only run bit-identical to the fixture: %s   |ref32 - ref64| over the 9 "
+                  "samples: dx %.2e .. %.2e   b %.2e .. %.2e   H %.2e .. %.2e"
+                  % ((name, i, int(z["it_K"][i]), r64["K"], [s_["K"] for s_ in samples], same_t)
+                     + tuple(f([rel(s_[k], r64[k]) for s_ in samples] + [rel(z["it_" + k][i], r64[k])])
+                             for k in ("dx", "b", "H") for f in (min, max))), flush=True)
+        sav = {k + "64": np.stack([np.asarray(v) for v in out64[k]]) for k in keys}
+        sav.update({k + "32": np.stack(out32[k]) for k in keys})                        # [iteration][sample]...
+        sav["H32"] = sav["H32"].astype(np.float32)
+        sav.update(perm_pts=np.stack([p[0] for p in perms]), perm_rays=np.stack([p[1] for p in perms]))
+        np.savez_compressed(os.path.join(GOLD, name.replace("sdf_joint_", "sdf_noise_") + ".npz"), **sav)
+
+
+if __name__ == "__main__":
+    main()

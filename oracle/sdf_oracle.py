@@ -357,7 +357,7 @@ def gn_iteration(dec, cfg, T_oc, z, pts, rays, depth_obs, n_fg):
     return dict(fail=None, T_oc=T_oc.copy(), code=z.copy(), res_sdf=res_s, Jp_sdf=Jp_s, Jc_sdf=Jc_s,
                 res_render=rt["res"], Jp_render=rt["J_pose"], Jc_render=rt["J_code"], n_valid=rt["n_valid"],
                 K=int(rt["res"].shape[0]), H=H, b=b, dx=dx, loss=loss, loss_sdf=float(loss_s),
-                loss_render=float(loss_r), T_oc_new=T_new, code_new=z_new)
+                loss_render=float(loss_r), T_oc_new=T_new, code_new=z_new, J_rot=J_rot, res_rot=res_rot)
 
 
 def reconstruct_object(dec, cfg, t_cam_obj, pts, rays, depth, code=None, trace=None):

@@ -82,40 +82,43 @@ void Optimizer::SetGroundPlane(Vector4d& normal) {
     mGroundPlaneNormal = normal;
 }
 
-// ---- the hot path: MI355X, with the reference's g2o code as the fallback of a failed call ---------------------------------
+// ---- the hot path: MI355X.  A failed call is logged by the shim and leaves the map untouched; the reference's g2o code runs in
+// ---- its place only where the deployment opted in (QSP_SHIM_ALLOW_G2O_FALLBACK=1, include/qsp_optimizer_shim.h) ------------
+static inline bool g2o_instead(int rc) { return rc != QSP_OK && qsp_shim::allow_g2o_fallback(); }
+
 void Optimizer::BundleAdjustment(const std::vector<KeyFrame*>& vpKF, const std::vector<MapPoint*>& vpMP, int nIterations,
                                  bool* pbStopFlag, const unsigned long nLoopKF, const bool bRobust) {
-    if (OptimizerHip::BundleAdjustment(vpKF, vpMP, nIterations, pbStopFlag, nLoopKF, bRobust) != QSP_OK)
+    if (g2o_instead(OptimizerHip::BundleAdjustment(vpKF, vpMP, nIterations, pbStopFlag, nLoopKF, bRobust)))
         OptimizerG2O::BundleAdjustment(vpKF, vpMP, nIterations, pbStopFlag, nLoopKF, bRobust);
 }
 
 void Optimizer::JointBundleAdjustment(const std::vector<KeyFrame*>& vpKF, const std::vector<MapPoint*>& vpMP,
                                       const std::vector<MapObject*>& vpMO, int nIterations, bool* pbStopFlag,
                                       const unsigned long nLoopKF, const bool bRobust) {
-    if (OptimizerHip::JointBundleAdjustment(vpKF, vpMP, vpMO, nIterations, pbStopFlag, nLoopKF, bRobust) != QSP_OK)
+    if (g2o_instead(OptimizerHip::JointBundleAdjustment(vpKF, vpMP, vpMO, nIterations, pbStopFlag, nLoopKF, bRobust)))
         OptimizerG2O::JointBundleAdjustment(vpKF, vpMP, vpMO, nIterations, pbStopFlag, nLoopKF, bRobust);
 }
 
 void Optimizer::GlobalBundleAdjustemnt(Map* pMap, int nIterations, bool* pbStopFlag, const unsigned long nLoopKF,
                                        const bool bRobust) {
-    if (OptimizerHip::GlobalBundleAdjustemnt(pMap, nIterations, pbStopFlag, nLoopKF, bRobust) != QSP_OK)
+    if (g2o_instead(OptimizerHip::GlobalBundleAdjustemnt(pMap, nIterations, pbStopFlag, nLoopKF, bRobust)))
         OptimizerG2O::GlobalBundleAdjustemnt(pMap, nIterations, pbStopFlag, nLoopKF, bRobust);
 }
 
 void Optimizer::GlobalJointBundleAdjustemnt(Map* pMap, int nIterations, bool* pbStopFlag, const unsigned long nLoopKF,
                                             const bool bRobust) {
-    if (OptimizerHip::GlobalJointBundleAdjustemnt(pMap, nIterations, pbStopFlag, nLoopKF, bRobust) != QSP_OK)
+    if (g2o_instead(OptimizerHip::GlobalJointBundleAdjustemnt(pMap, nIterations, pbStopFlag, nLoopKF, bRobust)))
         OptimizerG2O::GlobalJointBundleAdjustemnt(pMap, nIterations, pbStopFlag, nLoopKF, bRobust);
 }
 
 void Optimizer::LocalBundleAdjustment(KeyFrame* pKF, bool* pbStopFlag, Map* pMap) {
-    if (OptimizerHip::LocalBundleAdjustment(pKF, pbStopFlag, pMap) != QSP_OK)
+    if (g2o_instead(OptimizerHip::LocalBundleAdjustment(pKF, pbStopFlag, pMap)))
         OptimizerG2O::LocalBundleAdjustment(pKF, pbStopFlag, pMap);
 }
 
 void Optimizer::LocalJointBundleAdjustment(KeyFrame* pKF, bool* pbStopFlag, Map* pMap) {
     const int done = OptimizerHip::nBAdone();
-    if (OptimizerHip::LocalJointBundleAdjustment(pKF, pbStopFlag, pMap) != QSP_OK)
+    if (g2o_instead(OptimizerHip::LocalJointBundleAdjustment(pKF, pbStopFlag, pMap)))
         OptimizerG2O::LocalJointBundleAdjustment(pKF, pbStopFlag, pMap);       // counts in OptimizerG2O::nBAdone itself
     nBAdone += (OptimizerHip::nBAdone() - done);
     nBAdone += OptimizerG2O::nBAdone;                                          // src/Optimizer_util.cc:769
@@ -125,7 +128,8 @@ void Optimizer::LocalJointBundleAdjustment(KeyFrame* pKF, bool* pbStopFlag, Map*
 int Optimizer::PoseOptimization(Frame* pFrame) {
     int status = QSP_OK;
     const int nInliers = OptimizerHip::PoseOptimization(pFrame, &status);
-    return status == QSP_OK ? nInliers : OptimizerG2O::PoseOptimization(pFrame);
+    if (status == QSP_OK) return nInliers;
+    return qsp_shim::allow_g2o_fallback() ? OptimizerG2O::PoseOptimization(pFrame) : 0;   // 0 inliers: Tracking sees a lost frame
 }
 
 // ---- loop closing: CPU pass-through to the reference's g2o code -----------------------------
@@ -142,7 +146,9 @@ int Optimizer::OptimizeSim3(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint
 
 }  // namespace ORB_SLAM2
 
-// For embedders that only see the reference-shaped Optimizer.h: how many library calls have failed in this process, i.e. how many
-// entry points ran on the reference's g2o path instead of the GPU (0 in a healthy deployment; QSP_SHIM_NO_FALLBACK=1 makes the
-// first one fatal).  include/qsp_optimizer_shim.h:fallback_count.
+// For embedders that only see the reference-shaped Optimizer.h.  `qsp_optimizer_failure_count`: library calls that returned an
+// error in this process -- each left the map untouched and was logged (0 in a healthy deployment).  `qsp_optimizer_fallback_count`:
+// how many of them were handed to the reference's g2o path, which happens only with QSP_SHIM_ALLOW_G2O_FALLBACK=1
+// (QSP_SHIM_NO_FALLBACK=1 makes the first failure fatal).  include/qsp_optimizer_shim.h:report.
+extern "C" long qsp_optimizer_failure_count(void) { return ORB_SLAM2::qsp_shim::failure_count(); }
 extern "C" long qsp_optimizer_fallback_count(void) { return ORB_SLAM2::qsp_shim::fallback_count(); }

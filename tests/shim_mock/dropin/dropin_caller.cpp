@@ -17,6 +17,7 @@ struct OptimizerPeek {
 };
 }  // namespace ORB_SLAM2
 
+extern "C" long qsp_optimizer_failure_count(void);
 extern "C" long qsp_optimizer_fallback_count(void);      // exported by Optimizer_hip.cc next to class Optimizer
 
 int main(int argc, char** argv) {
@@ -75,6 +76,7 @@ int main(int argc, char** argv) {
     fprintf(out, "ground1 %d %.1f %.1f\n", OptimizerPeek::ground_set(*mpOptimizer) ? 1 : 0, OptimizerPeek::ground(*mpOptimizer, 1),
             OptimizerPeek::ground(*mpOptimizer, 3));
     delete mpOptimizer;
+    fprintf(out, "failures %ld\n", qsp_optimizer_failure_count());         // library calls that failed (map left untouched)
     fprintf(out, "fallbacks %ld\n", qsp_optimizer_fallback_count());      // what a deployment asserts to be zero
     fclose(out);
     return 0;

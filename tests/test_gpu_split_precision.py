@@ -67,6 +67,14 @@ def test_every_iteration_teacher_forced_vs_reference(bf3_decoder, golden_dir, na
     batch.close()
 
 
+@pytest.mark.parametrize("name", JOINT_CASES)
+def test_every_iteration_vs_the_references_float64_and_its_own_float32_scatter(bf3_decoder, golden_dir, name):
+    """the same yardstick as the f32 tile's (tests/test_gpu_sdf.py, tests/noise.py): within 1e-4 of the reference's float64
+    evaluation, or within twice the reference's own float32 scatter around it"""
+    from tests import noise
+    noise.check_gpu_iterations(bf3_decoder.precision, bf3_decoder, golden_dir, name, make_cfg, cfg_from, within)
+
+
 def test_discrete_decisions_match_the_oracle_on_a_random_sweep(bf3_decoder, oracle_decoder):
     """n_valid (samples in the unit ball) and K (kept render rows: |sdf| < cut-off, de/do > 1e-2) are counts of threshold
     decisions on decoder outputs: exact in 40 random cases, and H, b within 1e-4 except where single ReLU knife-edge rows

@@ -112,6 +112,33 @@ def test_every_iteration_teacher_forced(oracle_decoder, golden_dir, name):
 
 
 @pytest.mark.parametrize("name", JOINT_CASES)
+def test_teacher_forced_error_against_the_references_own_rounding_noise(oracle_decoder, golden_dir, name):
+    """VERDICT r3 item 1.  The quantities the test above holds ABOVE 1e-4 (`dx`, the KITTI `b`, the next state) are compared with
+    the reference's float64 evaluation of the same iteration, next to how far the reference's own seven float32 evaluations
+    land from it (tests/noise.py, tests/golden/sdf_noise_*.npz <- oracle/gen_noise_sdf.py): within 1e-4, or within twice the
+    reference's own scatter, for every quantity and iteration."""
+    from tests import noise
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    nz = noise.load(golden_dir, name)
+    cfg = cfg_from(z)
+    n_fg = z["depth"].shape[0]
+    dobs = np.concatenate([z["depth"], np.zeros(z["rays"].shape[0] - n_fg, np.float32)])
+    worst = {}
+    for i in range(z["it_H"].shape[0]):
+        it = so.gn_iteration(oracle_decoder, cfg, z["it_T_oc"][i], z["it_code"][i], z["pts"], z["rays"], dobs, n_fg)
+        assert it["K"] == int(nz["K64"][i]) == int(z["it_K"][i]) and all(int(k) == it["K"] for k in nz["K32"][i])
+        mine = dict(H=it["H"], b=it["b"], dx=it["dx"], T_next=it["T_oc_new"], code_next=it["code_new"])
+        for q in noise.QUANTITIES:
+            r, err, nse = noise.ratio(z, nz, q, i, mine[q], cfg.k4, (it["J_rot"], it["res_rot"]))
+            worst[q] = max(worst.get(q, 0.0), r)
+            assert r <= 2.0, (name, i, q, err, nse)
+        if cfg.k4 != 0.0:
+            e, bar = noise.res_rot_error(nz, i, it["res_rot"])
+            assert e <= bar, (name, i, e, bar)
+    print(name, {k: round(v, 2) for k, v in worst.items()})
+
+
+@pytest.mark.parametrize("name", JOINT_CASES)
 def test_reconstruct_object_free_running(oracle_decoder, golden_dir, name):
     """Free-running end-to-end result.  The iteration map of reconstruct_object amplifies a perturbation of its state by
     about 5-8x per iteration (measured between the reference under torch-CPU and this restatement: 1e-7 -> 6e-6 -> 5e-5

@@ -395,14 +395,18 @@ def _build_dropin(tmp):
     return out
 
 
-def _run_dropin(fail=None):
+def _run_dropin(fail=None, allow_g2o=False):
     m = make_map(seed=21, n_kf=7, n_pt=80, n_obj=2)
     with tempfile.TemporaryDirectory() as tmp:
         exe = build_dropin(tmp)
         write_scene(m, os.path.join(tmp, "scene.bin"))
         env = dict(os.environ, QSP_G2O_LOG=os.path.join(tmp, "g2o.log"))
+        env.pop("QSP_SHIM_ALLOW_G2O_FALLBACK", None)
+        env.pop("QSP_SHIM_NO_FALLBACK", None)
         if fail:
             env["QSP_STUB_FAIL"] = fail
+        if allow_g2o:
+            env["QSP_SHIM_ALLOW_G2O_FALLBACK"] = "1"
         r = subprocess.run([exe, os.path.join(tmp, "scene.bin"), os.path.join(tmp, "out.txt")], env=env, capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-3000:]
         out = dict(l.split(" ", 1) for l in open(os.path.join(tmp, "out.txt")).read().splitlines())
@@ -428,14 +432,35 @@ def test_dropin_optimizer_class_routes_hot_path_to_the_library_and_loop_closing_
     assert [l.split()[0] for l in log] == ["g2o:OptimizeSim3", "g2o:OptimizeEssentialGraph"]
     assert log[0].split()[1:] == ["5", "10"] and log[1].split()[1] == "2"
     assert "[qsp_hip]" not in err
-    assert out["fallbacks"] == "0"                                  # the counter a deployment asserts on
+    assert out["fallbacks"] == "0" and out["failures"] == "0"       # the counters a deployment asserts on
 
 
 @pytest.mark.parametrize("fail", ["create", "local", "optimize", "pose"])
-def test_dropin_falls_back_to_g2o_when_the_gpu_path_reports_an_error(fail):
-    """a failing qsp_ba_* call must not be silent.  The error is logged, the map is left as found (the BA marks
-    are rolled back so that g2o's own walk finds the same local sets) and the call is handed to the reference's g2o code."""
+def test_dropin_fails_loudly_and_leaves_the_map_untouched_by_default(fail):
+    """a failing qsp_ba_* / qsp_pose_* call is logged and counted, the BA marks are rolled back, NOTHING is
+    written to the map and NOTHING runs on the reference's g2o code -- the entry points return (include/Optimizer.h:78-107 is
+    void / no throw; the embedding application reads qsp_optimizer_failure_count()).  Only the loop-closing pass-throughs
+    (OptimizeSim3 / OptimizeEssentialGraph, CPU by design) reach g2o."""
     m, out, log, err = _run_dropin(fail)
+    names = [l.split()[0] for l in log]
+    assert sorted(set(names)) == ["g2o:OptimizeEssentialGraph", "g2o:OptimizeSim3"]          # no BA, no pose optimisation
+    assert int(out["failures"]) >= 1 and out["fallbacks"] == "0"
+    assert "the map is left untouched" in err and "falls back" not in err
+    if fail in ("create", "local"):
+        assert "[qsp_hip] qsp_ba_%s" % ("create" if fail == "create" else "local_joint") in err
+        assert abs(float(out["kf1_tx"]) - float(m["kfT"][1][0, 3])) < 1e-6   # nobody wrote a pose
+        assert out["nBAdone1"] == "0"                                        # a failed joint BA is not counted as done
+    if fail in ("create", "optimize"):
+        assert out["gba_marks"] == "0"                                       # the global BAs parked nothing in *GBA
+    if fail == "pose":
+        assert out["pose_inliers"].split()[0] == "0"                         # 0 inliers: Tracking treats the frame as lost
+
+
+@pytest.mark.parametrize("fail", ["create", "local", "optimize", "pose"])
+def test_dropin_falls_back_to_g2o_only_when_the_deployment_opted_in(fail):
+    """QSP_SHIM_ALLOW_G2O_FALLBACK=1 restores the hand-over: the error is logged, the map is left as found (the BA marks are
+    rolled back so that g2o's own walk finds the same local sets) and the call runs on the reference's g2o code."""
+    m, out, log, err = _run_dropin(fail, allow_g2o=True)
     names = [l.split()[0] for l in log]
     if fail in ("create", "local"):
         assert "[qsp_hip] qsp_ba_%s" % ("create" if fail == "create" else "local_joint") in err
@@ -452,6 +477,7 @@ def test_dropin_falls_back_to_g2o_when_the_gpu_path_reports_an_error(fail):
         assert "g2o:PoseOptimization" not in names
     assert "g2o:OptimizeSim3" in names
     assert int(out["fallbacks"]) >= 1 and "falls back to the reference's g2o path" in err     # counted and said, not silent
+    assert int(out["failures"]) >= int(out["fallbacks"])
 
 
 def test_dropin_fallback_can_be_made_fatal():
