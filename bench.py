@@ -247,7 +247,7 @@ class Ctx(object):
         return float(t.item())
 
 
-def run_workload(ctx, name, steps, warmup, detailed, precision=None, screening=None):
+def run_workload(ctx, name, steps, warmup, detailed, precision=None, screening=None, audit=None):
     """`steps` timed passes of workload `name` (after `warmup` untimed ones); every rank returns the same dict of whole-job
     numbers (rank 0's kernel timings)."""
     from qsp_slam_amd import DeepSdfDecoder, parallel, synth
@@ -261,6 +261,7 @@ def run_workload(ctx, name, steps, warmup, detailed, precision=None, screening=N
     dec.set_precision(precision or args.precision)
     margin = args.screening_margin if screening is None else screening
     if dec.precision == "fp16x2" and margin > 0:
+        dec.set_screen_audit(args.screen_audit if audit is None else audit)
         dec.set_render_screening(margin)     # two-pass ray-sample forward, bit-identical to the unscreened pipe (tests/test_gpu_screening.py)
     opt = Optimizer(dec, joint_cfg(w["n_iter"]))
     seed_off = 0 if strong else rank
@@ -326,7 +327,7 @@ def run_workload(ctx, name, steps, warmup, detailed, precision=None, screening=N
     ctx.sync_all()
     t0 = time.perf_counter()
     prof = dict(ms_total=0.0, ms_mlp_jtj=0.0, ms_mlp_fwd=0.0, ms_other=0.0, n_jtj=0, n_fwd=0, pts_jtj=0, pts_fwd=0,
-                tiles_jtj=0, tiles_fwd=0, pts_band=0, fallbacks=0)
+                tiles_jtj=0, tiles_fwd=0, pts_band=0, pts_audit=0, audit_failures=0, fallbacks=0)
     for _ in range(steps):
         step(record=True, lin_stats=lin_in_timed)
         if batch is not None:
@@ -342,6 +343,8 @@ def run_workload(ctx, name, steps, warmup, detailed, precision=None, screening=N
             prof["tiles_jtj"] += p.tiles_jtj
             prof["tiles_fwd"] += p.tiles_fwd
             prof["pts_band"] += p.pts_band
+            prof["pts_audit"] += p.pts_audit
+            prof["audit_failures"] += p.screen_audit_failures
             prof["fallbacks"] += p.range_fallbacks
             prof["screen_fallbacks"] = prof.get("screen_fallbacks", 0) + p.screen_fallbacks
             prof["screen_max_diff"] = max(prof.get("screen_max_diff", 0.0), p.screen_max_diff)
@@ -381,6 +384,11 @@ def run_workload(ctx, name, steps, warmup, detailed, precision=None, screening=N
                             "(QSP_DEC_OPT_RANGE_FALLBACK); any non-zero count invalidates the line's dtype"),
         screening=(dict(margin=margin, max_abs_s1_minus_s3_on_band=float(prof.get("screen_max_diff", 0.0)),
                         band_share=prof["pts_band"] / max(prof["pts_fwd"], 1),
+                        audit=dict(one_in=args.screen_audit, out_of_band_samples_re_evaluated_per_launch=prof["pts_audit"] / max(prof["n_fwd"], 1),
+                                   found_inside_the_cut_off=int(prof["audit_failures"]),
+                                   note="the second pass also re-evaluates one in N of the samples the screening pass put OUTSIDE the "
+                                        "band (they are part of band_share); one found inside the cut-off repeats the run in one pass; "
+                                        "`fp16x2_screened_no_audit` is the same line with the audit off (its cost)"),
                         samples_per_launch=prof["pts_fwd"] / max(prof["n_fwd"], 1),
                         band_samples_per_launch=prof["pts_band"] / max(prof["n_fwd"], 1),
                         note="ray-sample forward in two passes: all samples on the one-product fp16 tile, the band "
@@ -480,6 +488,8 @@ def main():
     ap.add_argument("--flips", type=int, default=4)
     ap.add_argument("--screening-margin", type=float, default=0.01,
                     help="fp16x2 only: band margin of the two-pass ray-sample forward (QSP_DEC_OPT_RENDER_SCREENING); 0 = one pass")
+    ap.add_argument("--screen-audit", type=int, default=100,
+                    help="screened forward: one in N out-of-band samples re-evaluated as well (QSP_DEC_OPT_SCREEN_AUDIT); 0 = off")
     ap.add_argument("--allow-hook-fallback", action="store_true",
                     help="N > 1, strong scaling: if the library's own RCCL communicator cannot be created, measure the "
                          "torch.distributed all-reduce hook instead of exiting with an error")
@@ -511,6 +521,8 @@ def main():
                 other[pr] = run_workload(ctx, args.workload, 3, 1, detailed=False, precision=pr)
         if args.precision == "fp16x2" and args.screening_margin > 0:     # the same pipe with the one-pass forward
             other["fp16x2_unscreened"] = run_workload(ctx, args.workload, 3, 1, detailed=False, precision="fp16x2", screening=0.0)
+            if args.screen_audit > 0:        # ... and screened without the out-of-band audit: what the audit costs
+                other["fp16x2_screened_no_audit"] = run_workload(ctx, args.workload, 3, 1, detailed=False, precision="fp16x2", audit=0)
     subs = {}
     if not args.no_sublines:
         for name in ("c2", "c5"):
@@ -583,7 +595,8 @@ def main():
             base = opr.split("_")[0]
             out[opr + ("_mfma" if opr == base else "")] = {
                 "note": ("the same workload with --precision %s, 3 timed steps" % opr) if opr == base else
-                        "the same workload and pipe with --screening-margin 0 (every ray sample on the split-fp16 tile), 3 timed steps",
+                        ("the same workload and pipe, screened, with --screen-audit 0, 3 timed steps" if opr.endswith("no_audit") else
+                         "the same workload and pipe with --screening-margin 0 (every ray sample on the split-fp16 tile), 3 timed steps"),
                 "value": o["value"], "ms_per_step": o["ms_per_step"],
                 "k_mlp_jtj_TFLOPs": o["jtj"]["achieved"],
                 "k_mlp_jtj_frac_of_its_peak": o["jtj"]["achieved"] / peak_for(base),

@@ -101,6 +101,12 @@ void qsp_decoder_destroy(qsp_decoder* dec);
  * margin is repeated from its starting state in one pass (qsp_decoder_get_counter(QSP_DEC_CNT_SCREEN_FALLBACKS) counts them,
  * qsp_refine_profile.screen_max_diff / .screen_fallbacks report the last run), so a decoder whose screening values are worse
  * than the fixtures' costs time, not bits.
+ * QSP_DEC_OPT_SCREEN_AUDIT (N, default 100; 0 = off, 1 = every sample): the band check alone looks only where the screening pass
+ * put a sample INSIDE the band.  The second pass therefore also re-evaluates a fixed pseudo-random one in N of the samples the
+ * screening pass put OUTSIDE (a hash of hypothesis, sample and iteration), folds their |s1 - s3| into screen_max_diff, and counts
+ * each one whose split-fp16 value lies inside the cut-off or has the other sign -- a clamp the one-pass result would not have
+ * made -- as a hard failure (qsp_refine_profile.screen_audit_failures): the run is repeated in one pass like above.  An audited
+ * sample's overwritten value is only ever read through the clamp, so the audit changes no bit of a passing run.
  * QSP_DEC_OPT_SCREENING_MIN_SAMPLES (-1, the default, or a count): a run is screened only when its batch holds more ray samples
  * (rays x depth samples, summed over the hypotheses) than this; -1 = more than two rounds of 64-point tiles over the chip.  A
  * batch that fits one round -- one object per call -- is one tile deep either way and faster in one pass.  The result is the
@@ -116,7 +122,7 @@ void qsp_decoder_destroy(qsp_decoder* dec);
  * qsp_decoder_get_counter(QSP_DEC_CNT_RANGE_FALLBACKS)); 0 fails the call with QSP_ERR_UNSUPPORTED as round 2 did. */
 enum { QSP_DEC_OPT_FORWARD_PRECISION = 1, QSP_DEC_OPT_JACOBIAN_PRECISION = 2, QSP_DEC_OPT_TILE_POINTS = 3,
        QSP_DEC_OPT_RENDER_SCREENING = 4, QSP_DEC_OPT_USE_TANH = 5, QSP_DEC_OPT_RANGE_FALLBACK = 6,
-       QSP_DEC_OPT_SCREENING_MIN_SAMPLES = 7, QSP_DEC_OPT_NARROW_TILE = 8 };
+       QSP_DEC_OPT_SCREENING_MIN_SAMPLES = 7, QSP_DEC_OPT_NARROW_TILE = 8, QSP_DEC_OPT_SCREEN_AUDIT = 9 };
 enum { QSP_DEC_CNT_RANGE_FALLBACKS = 1, QSP_DEC_CNT_ARENA_REUSED = 2, QSP_DEC_CNT_ARENA_CREATED = 3, QSP_DEC_CNT_NARROW_TILE = 4,
        QSP_DEC_CNT_SCREEN_FALLBACKS = 5 };
 /* lifetime counters of a decoder: calls that were re-run on the f32 pipe because a value left fp16's range; calls of
@@ -209,8 +215,10 @@ typedef struct {
     int64_t pts_band;        /* screened forward pass: samples re-evaluated by the second pass (0 when off) */
     int32_t range_fallbacks; /* 1 if this run was repeated on the f32 pipe (QSP_DEC_OPT_RANGE_FALLBACK)     */
     int32_t screen_fallbacks;/* 1 if this run was repeated in one pass (screening self-check, QSP_DEC_OPT_RENDER_SCREENING) */
-    float screen_max_diff;   /* largest |s1 - s3| the second pass saw on a band sample (0 when not screened)                 */
-    int32_t pad_;
+    float screen_max_diff;   /* largest |s1 - s3| the second pass saw on a band or audited sample (0 when not screened)      */
+    int32_t screen_audit_failures; /* audited OUT-of-band samples whose split-fp16 value was inside the cut-off or of the other
+                                * sign: > 0 = the screened attempt was wrong somewhere and the run was repeated in one pass    */
+    int64_t pts_audit;       /* out-of-band samples the second pass re-evaluated as the audit (QSP_DEC_OPT_SCREEN_AUDIT)      */
 } qsp_refine_profile;
 int qsp_refine_batch_profile(qsp_refine_batch* b, int enable, qsp_refine_profile* out);
 

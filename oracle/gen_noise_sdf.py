@@ -25,6 +25,10 @@ fixture recorded for that iteration (`it_T_oc[i]`, `it_code[i]` of tests/golden/
                    ReLU pre-activation within rounding of it falls: the knife-edge rows of DESIGN.md section 1.
           Together with the committed fixture's own values that is NINE float32 samples of the reference per iteration.
 
+The same variants also run the entry point FREE-RUNNING from the fixture's `t_cam_obj` for the configured number of iterations
+(`free_*64`, `free_*32[sample]`: final `t_cam_obj`, code, loss): how far apart the reference's own evaluations END -- the iteration
+map amplifies a rounding difference 5-8 x per iteration -- is the yardstick of the free-running bars.
+
 The teacher state enters through a harness-side tap on the first `torch.inverse` of a 4x4 (optimizer.py:127, the entry's own
 `t_obj_cam = inverse(t_cam_obj)`), which returns the recorded `T_oc` exactly; `H`, `b`, `dx` and the next `T_oc` are tapped the
 way oracle/gen_golden_sdf.py taps them.  No reference file is modified; the output is arrays only.
@@ -45,6 +49,30 @@ from oracle.gen_golden_sdf import GOLD, ref_configs, ref_decoder  # noqa: E402
 from oracle.ref_import import import_reference  # noqa: E402
 
 CASES = ["sdf_joint_redwood_m600", "sdf_joint_redwood_m2000", "sdf_joint_kitti_m250", "sdf_joint_code_m500"]
+
+
+def free_run(mods, dec, cfg, z, pts, rays, depth, dtype, exact_inv4=False):
+    """the reference's entry point, all iterations, from the fixture's initial pose; returns final t_cam_obj, code, loss"""
+    opt_mod = mods[0]
+    npdt = np.float64 if dtype == torch.float64 else np.float32
+    orig_inv = torch.inverse
+
+    def tap_inv(x):
+        if exact_inv4 and tuple(x.shape) == (4, 4):
+            return orig_inv(x.double()).to(x.dtype)
+        return orig_inv(x)
+
+    old_dtype = torch.get_default_dtype()
+    torch.set_default_dtype(dtype)
+    torch.inverse = tap_inv
+    try:
+        r = opt_mod.Optimizer(dec, cfg).reconstruct_object(z["t_cam_obj"].astype(npdt), pts.astype(npdt), rays.astype(npdt),
+                                                           depth.astype(npdt))
+    finally:
+        torch.inverse = orig_inv
+        torch.set_default_dtype(old_dtype)
+    assert r.is_good
+    return dict(T=np.asarray(r.t_cam_obj).copy(), code=np.asarray(r.code).copy(), loss=np.array(float(r.loss)))
 
 
 def one_iteration(mods, dec, cfg, T_oc, code, pts, rays, depth, dtype, exact_inv4=False):
@@ -195,7 +223,26 @@ def main():
                   % ((name, i, int(z["it_K"][i]), r64["K"], [s_["K"] for s_ in samples], same_t)
                      + tuple(f([rel(s_[k], r64[k]) for s_ in samples] + [rel(z["it_" + k][i], r64[k])])
                              for k in ("dx", "b", "H") for f in (min, max))), flush=True)
+        # free-running: the same variants through all iterations
+        joint["num_iterations"] = n_it
+        cfg_free = ref_configs(utils_mod, joint, data_type)
+        f64 = free_run(mods, dec64, cfg_free, z, pts, rays, depth, torch.float64)
+        torch.set_num_threads(1)
+        fs = [free_run(mods, dec32, cfg_free, z, pts, rays, depth, torch.float32)]
+        torch.set_num_threads(8)
+        fs += [free_run(mods, dec32, cfg_free, z, pts[pp], rays[pr], depth[pf], torch.float32) for pp, pr, pf in perms]
+        fs.append(free_run(mods, dec32, cfg_free, z, pts, rays, depth, torch.float32, exact_inv4=True))
+        fs += [free_run(mods, d, cfg_free, z, pts, rays, depth, torch.float32) for d in dec_u]
+        print("%s free-running: |ref32 - ref64| over the samples + the fixture: t_cam_obj %.2e .. %.2e   code (abs) %.2e .. %.2e   "
+              "loss (rel) %.2e .. %.2e" % ((name,) + tuple(
+                  f(v) for v in ([rel(s_["T"], f64["T"]) for s_ in fs] + [rel(z["out_t_cam_obj"], f64["T"])],
+                                 [float(np.abs(s_["code"] - f64["code"]).max()) for s_ in fs]
+                                 + [float(np.abs(z["out_code"] - f64["code"]).max())],
+                                 [abs(float(s_["loss"]) / float(f64["loss"]) - 1) for s_ in fs]
+                                 + [abs(float(z["loss"]) / float(f64["loss"]) - 1)]) for f in (min, max))), flush=True)
         sav = {k + "64": np.stack([np.asarray(v) for v in out64[k]]) for k in keys}
+        sav.update({"free_" + k + "64": f64[k] for k in f64})
+        sav.update({"free_" + k + "32": np.stack([s_[k] for s_ in fs]) for k in f64})
         sav.update({k + "32": np.stack(out32[k]) for k in keys})                        # [iteration][sample]...
         sav["H32"] = sav["H32"].astype(np.float32)
         sav.update(perm_pts=np.stack([p[0] for p in perms]), perm_rays=np.stack([p[1] for p in perms]))

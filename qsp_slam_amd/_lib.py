@@ -43,7 +43,7 @@ class RefineProfile(C.Structure):
                 ("ms_other", C.c_float), ("n_launch_jtj", C.c_int32), ("n_launch_fwd", C.c_int32),
                 ("pts_jtj", C.c_int64), ("pts_fwd", C.c_int64), ("tiles_jtj", C.c_int64), ("tiles_fwd", C.c_int64),
                 ("pts_band", C.c_int64), ("range_fallbacks", C.c_int32), ("screen_fallbacks", C.c_int32),
-                ("screen_max_diff", C.c_float), ("pad_", C.c_int32)]
+                ("screen_max_diff", C.c_float), ("screen_audit_failures", C.c_int32), ("pts_audit", C.c_int64)]
 
 
 class BaScene(C.Structure):

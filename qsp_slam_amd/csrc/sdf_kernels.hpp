@@ -359,6 +359,22 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void k_mlp_fwd(const HypState* __re
     }
 }
 
+// The out-of-band AUDIT of the screened forward (QSP_DEC_OPT_SCREEN_AUDIT).  The band pass only ever sees the
+// samples the screening pass put INSIDE the band; a sample it put outside (|s1| >= cut_off + margin) whose true value is inside the
+// cut-off would be clamped wrongly and never looked at.  So the screening pass also lists a fixed pseudo-random one-in-N of the
+// OUT-of-band samples (a hash of hypothesis, sample and iteration: the same samples on every run of the same state, other samples
+// in the next iteration), flagged with bit 30; the band pass re-evaluates them with the rest, folds their |s1 - s3| into the same
+// maximum, and counts every one whose split-fp16 value is inside the cut-off or has the other sign (a clamp the one-pass result
+// would not have made) as a HARD failure: the host repeats the run in one pass.  Overwriting an audited sample's value with s3
+// changes no bit downstream: k_scan reads such a value through clamp() and the band test only.
+constexpr int32_t BAND_AUDIT_BIT = 1 << 30;
+__device__ __forceinline__ bool screen_audit_pick(int h, int v, int iter, int one_in) {
+    if (one_in <= 1) return one_in == 1;
+    unsigned x = (unsigned)v * 0x9E3779B1u ^ (unsigned)h * 0x85EBCA77u ^ (unsigned)iter * 0xC2B2AE3Du;
+    x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 12; x *= 0x297A2D39u; x ^= x >> 15;
+    return x % (unsigned)one_in == 0u;
+}
+
 // the same work queue on the split-fp16 tile: four waves per workgroup (mlp_tile_h2)
 // NARROW: mlp_tile_h2's form for small decoders, run with NW = 8 waves so that the column blocks that exist spread over all SIMDs
 template <int NR, bool NARROW = false, int NW = 4>      // NR point blocks of 32 per tile (QSP_DEC_OPT_TPOINTS)
@@ -372,7 +388,9 @@ __global__ __launch_bounds__(64 * NW) void k_mlp_fwd_h2(const HypState* __restri
     // band_idx != nullptr: second pass of the screened forward -- the tiles run over the hypothesis's band list (indices into
     // its valid-sample list written by k_mlp_fwd_h1) and overwrite those samples' screening values.  On the way the largest
     // |s1 - s3| over the band samples is kept (*screen_dmax, the bits of a non-negative float): the quantity the screening margin
-    // has to cover, measured on every run -- the host repeats a run unscreened if it ever comes near the margin.
+    // has to cover, measured on every run -- the host repeats a run unscreened if it ever comes near the margin.  Entries flagged
+    // BAND_AUDIT_BIT are out-of-band samples under audit (above): screen_dmax[1] counts those the screening pass clamped wrongly,
+    // (unsigned long long*)(screen_dmax + 2) how many were audited.
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     MlpSmem& s = *reinterpret_cast<MlpSmem*>(smem_raw);
     __shared__ float Tsh[16];
@@ -409,7 +427,7 @@ __global__ __launch_bounds__(64 * NW) void k_mlp_fwd_h2(const HypState* __restri
             const int v = t * TP + threadIdx.x;
             float x = 0, y = 0, z = 0;
             if (v < n) {
-                const int e = rk[sel ? sel[v] : v];
+                const int e = rk[sel ? (sel[v] & ~BAND_AUDIT_BIT) : v];
                 const int r = e >> 6, k = e & 63;
                 const float d = depth_at(d_min, d_max, k, cfg.n_depth);
                 xform(Tsh, R[3 * r] * d, R[3 * r + 1] * d, R[3 * r + 2] * d, x, y, z);
@@ -424,11 +442,23 @@ __global__ __launch_bounds__(64 * NW) void k_mlp_fwd_h2(const HypState* __restri
         staged = true;
         if (threadIdx.x < TP) {
             const int v = t * TP + threadIdx.x;
+            bool audited = false, wrong = false;
             if (v < n) {
-                const int idx = sel ? sel[v] : v;
+                const int ent = sel ? sel[v] : v;
+                const int idx = ent & ~BAND_AUDIT_BIT;
                 const float y = s.y[threadIdx.x];
-                if (sel) dmax = fmaxf(dmax, fabsf(out[idx] - y));      // (out[idx] still holds the screening value s1)
+                if (sel) {
+                    const float s1 = out[idx];                         // (out[idx] still holds the screening value s1)
+                    dmax = fmaxf(dmax, fabsf(s1 - y));
+                    audited = (ent & BAND_AUDIT_BIT) != 0;
+                    wrong = audited && (!(fabsf(y) >= cfg.cut_off) || (s1 < 0.f) != (y < 0.f));
+                }
                 out[idx] = y;
+            }
+            if (sel && screen_dmax && threadIdx.x < 64) {              // (counted per tile: nothing stays live across the tile loop)
+                const unsigned long long ma = __ballot(audited), mw = __ballot(wrong);
+                if (threadIdx.x == 0 && ma) atomicAdd(reinterpret_cast<unsigned long long*>(screen_dmax + 2), (unsigned long long)__popcll(ma));
+                if (threadIdx.x == 0 && mw) atomicAdd(screen_dmax + 1, (unsigned int)__popcll(mw));
             }
         }
     }
@@ -450,7 +480,7 @@ __global__ __launch_bounds__(64 * NW) void k_mlp_fwd_h1(HypState* __restrict__ s
                                                             const int32_t* __restrict__ valid_rk, int64_t rk_stride,
                                                             float* __restrict__ sdf_valid, const int2* __restrict__ work,
                                                             int* __restrict__ qctl, const float* __restrict__ c0_all,
-                                                            int32_t* __restrict__ band_idx, float band_th) {
+                                                            int32_t* __restrict__ band_idx, float band_th, int audit_one_in) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     MlpSmemH1& s = *reinterpret_cast<MlpSmemH1*>(smem_raw);
     __shared__ float Tsh[16];
@@ -505,18 +535,19 @@ __global__ __launch_bounds__(64 * NW) void k_mlp_fwd_h1(HypState* __restrict__ s
         mlp_tile_h1<2, NW>(s, P, amax);
         if (threadIdx.x < H1_ROWS) {           // (waves 0 and 1, all lanes)
             const int v = t * H1_ROWS + threadIdx.x;
-            bool in = false;
+            bool in = false, audit = false;
             if (v < n) {
                 const float y = s.y[threadIdx.x];
                 out[v] = y;
                 in = !(fabsf(y) >= band_th);   // (a NaN goes to the second pass as well)
+                audit = !in && screen_audit_pick(h, v, cfg.iter, audit_one_in);      // a sample of the OUT-of-band ones (above)
             }
-            const unsigned long long m = __ballot(in);
+            const unsigned long long m = __ballot(in || audit);
             const int lane = threadIdx.x & 63;
             int base = 0;
             if (lane == 0 && m) base = atomicAdd(&S.n_band, __popcll(m));
             base = __builtin_amdgcn_readfirstlane(base);
-            if (in) band_idx[h * rk_stride + base + __popcll(m & ((1ull << lane) - 1ull))] = v;
+            if (in || audit) band_idx[h * rk_stride + base + __popcll(m & ((1ull << lane) - 1ull))] = audit ? (v | BAND_AUDIT_BIT) : v;
         }
     }
     if (!(amax <= H2_MAX)) *P->range_flag = 1;

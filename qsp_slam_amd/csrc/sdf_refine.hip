@@ -64,6 +64,7 @@ struct qsp_decoder {
     int* range_flag_h = nullptr;   // host-mapped word the split-fp16 kernels set when a value left fp16's range (check_range)
     bool narrow_capable = false;   // the decoder is small enough for the NARROW tile (narrow_tables); QSP_DEC_OPT_NARROW_TILE toggles its use
     float screen_margin = 0.f;     // QSP_DEC_OPT_RENDER_SCREENING: > 0 = two-pass ray-sample forward with this band margin
+    int32_t screen_audit = 100;    // QSP_DEC_OPT_SCREEN_AUDIT: one in this many OUT-of-band samples is re-evaluated too (0 = off, 1 = all)
     int64_t screen_min_samples = -1;   // QSP_DEC_OPT_SCREENING_MIN_SAMPLES: -1 = more than two rounds of 64-point tiles over the chip
     int range_fallback = 1;        // QSP_DEC_OPT_RANGE_FALLBACK: a call that left fp16's range is repeated on the f32 pipe
     int64_t n_range_fallbacks = 0; // QSP_DEC_CNT_RANGE_FALLBACKS
@@ -656,6 +657,10 @@ extern "C" int qsp_decoder_set_option(qsp_decoder* d, int32_t option, int32_t va
                                                      "QSP_DEC_OPT_FORWARD_PRECISION to 2 first");
             d->screen_margin = 1e-6f * (float)value;
             return QSP_OK;
+        case QSP_DEC_OPT_SCREEN_AUDIT:
+            if (value < 0 || value > 1000000) return qsp_fail(QSP_ERR_INVALID, "screening audit: one in N out-of-band samples, N = 0 (off) .. 1e6");
+            d->screen_audit = (int32_t)value;
+            return QSP_OK;
         case QSP_DEC_OPT_SCREENING_MIN_SAMPLES:
             if (value < -1) return qsp_fail(QSP_ERR_INVALID, "screening threshold: -1 (automatic) or a sample count >= 0");
             d->screen_min_samples = value;
@@ -858,6 +863,9 @@ struct qsp_refine_batch {
     unsigned long long* counters = nullptr;   // [4] points/tiles processed (fwd+bwd, fwd-only)
     int2 *work_fwd = nullptr, *work_jtj = nullptr;   // work-queue items (k_plan)
     int* qctl = nullptr;            // [4] item counts / next-item counters
+    float last_screen_dmax = 0.f;   // the last screened pass: largest |s1 - s3| seen, audited out-of-band samples, how many of them wrong
+    int32_t last_audit_wrong = 0;
+    int64_t last_audited = 0;
     int32_t* band_idx = nullptr;    // screened forward pass: per hypothesis, indices into its valid-sample list (k_mlp_fwd_h1)
     HypState* st_snap = nullptr;    // the hypotheses as a run found them (restored when the run is repeated on the f32 pipe)
     uint8_t* act_snap = nullptr;    // pose-only mode: pt_active likewise
@@ -1136,11 +1144,11 @@ static int run_once(qsp_refine_batch* b, int32_t n_iter, bool* hit, bool* screen
                 if (screen_waves() == 8)
                     hipLaunchKernelGGL(k_mlp_fwd_h1<8>, dim3(b->n_cu), dim3(512), sizeof(MlpSmemH1), s, b->st, b->objs, b->rays,
                                        cfg, b->dec->Pd, b->valid_rk, b->rk_stride, b->sdf_valid, b->work_fwd, b->qctl, b->c0_all,
-                                       b->band_idx, cfg.cut_off + b->dec->screen_margin);
+                                       b->band_idx, cfg.cut_off + b->dec->screen_margin, b->dec->screen_audit);
                 else
                     hipLaunchKernelGGL(k_mlp_fwd_h1<4>, dim3(b->n_cu), dim3(H2_THREADS), sizeof(MlpSmemH1), s, b->st, b->objs, b->rays,
                                        cfg, b->dec->Pd, b->valid_rk, b->rk_stride, b->sdf_valid, b->work_fwd, b->qctl, b->c0_all,
-                                       b->band_idx, cfg.cut_off + b->dec->screen_margin);
+                                       b->band_idx, cfg.cut_off + b->dec->screen_margin, b->dec->screen_audit);
                 hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, s, 2, b->st, b->objs, nH, b->nw_sdf, nw_total - b->nw_sdf,
                                    b->work_fwd, b->qctl, TILE_P);
                 hipLaunchKernelGGL((k_mlp_fwd_h2<2, false, 4>), dim3(b->n_cu), dim3(H2_THREADS), sizeof(MlpSmem), s, b->st, b->objs, b->rays,
@@ -1217,12 +1225,15 @@ static int run_once(qsp_refine_batch* b, int32_t n_iter, bool* hit, bool* screen
         return QSP_OK;
     }
     float dmax = 0.f;
-    if (screened_any) {      // (8 bytes, behind the synchronisation above; a one-object call is never screened and skips it)
-        unsigned long long w = 0;
-        QSP_HIP(hipMemcpy(&w, b->counters + 5, sizeof(w), hipMemcpyDeviceToHost));
-        const unsigned int bits = (unsigned int)w;
+    if (screened_any) {      // (16 bytes, behind the synchronisation above; a one-object call is never screened and skips it)
+        unsigned long long w[2] = {0, 0};
+        QSP_HIP(hipMemcpy(w, b->counters + 5, sizeof(w), hipMemcpyDeviceToHost));
+        const unsigned int bits = (unsigned int)w[0];
         memcpy(&dmax, &bits, sizeof(dmax));
-        if (!(dmax <= SCREEN_TRUST * b->dec->screen_margin)) {
+        b->last_screen_dmax = dmax;
+        b->last_audit_wrong = (int32_t)(w[0] >> 32);      // audited out-of-band samples the screening pass clamped wrongly
+        b->last_audited = (int64_t)w[1];
+        if (!(dmax <= SCREEN_TRUST * b->dec->screen_margin) || b->last_audit_wrong > 0) {
             *screen_hit = true;
             return QSP_OK;
         }
@@ -1231,6 +1242,7 @@ static int run_once(qsp_refine_batch* b, int32_t n_iter, bool* hit, bool* screen
         qsp_refine_profile& p = b->profile;
         memset(&p, 0, sizeof(p));
         p.screen_max_diff = dmax;
+        p.pts_audit = screened_any ? b->last_audited : 0;
         (void)hipEventElapsedTime(&p.ms_total, e_begin, e_end);
         for (const Span& sp : spans) {
             float ms = 0;
@@ -1271,11 +1283,23 @@ extern "C" int qsp_refine_batch_run(qsp_refine_batch* b, int32_t n_iter) {
         if (b->pt_active) QSP_HIP(hipMemcpyAsync(b->pt_active, b->act_snap, (size_t)b->n_hyp * b->act_stride, hipMemcpyDeviceToDevice, d->stream));
         return QSP_OK;
     };
+    // (what the last run reported must not outlive it -- with profiling off nothing else resets these)
+    b->profile.range_fallbacks = b->profile.screen_fallbacks = b->profile.screen_audit_failures = 0;
+    b->profile.screen_max_diff = 0.f;
+    b->profile.pts_audit = 0;
+    b->last_screen_dmax = 0.f;
+    b->last_audit_wrong = 0;
+    b->last_audited = 0;
     bool hit = false, screen_hit = false;
     int rc = run_once(b, n_iter, &hit, &screen_hit);
     if (rc || (!hit && !screen_hit)) return rc;
-    int screen_fallbacks = 0;
+    int screen_fallbacks = 0, audit_failures = 0;
+    float failed_dmax = 0.f;
+    int64_t failed_audited = 0;
     if (screen_hit) {
+        audit_failures = b->last_audit_wrong;
+        failed_dmax = b->last_screen_dmax;
+        failed_audited = b->last_audited;
         // The band samples' two values differ by more than half the margin: the premise "no sample outside the band could have
         // crossed the cut-off" no longer has its safety factor.  Repeat from the starting state in one pass (the path the
         // screened one is bit-identical to when the premise holds).
@@ -1288,6 +1312,9 @@ extern "C" int qsp_refine_batch_run(qsp_refine_batch* b, int32_t n_iter) {
         rc = run_once(b, n_iter, &hit, &screen_hit);
         d->screen_margin = margin;
         b->profile.screen_fallbacks = 1;
+        b->profile.screen_audit_failures = audit_failures;      // what the screened attempt saw (the repeat is one-pass: it sees nothing)
+        b->profile.screen_max_diff = failed_dmax;
+        b->profile.pts_audit = failed_audited;
         if (rc || !hit) return rc;
     }
     if (!may_fall_back) return range_error();
@@ -1300,6 +1327,7 @@ extern "C" int qsp_refine_batch_run(qsp_refine_batch* b, int32_t n_iter) {
     rc = run_once(b, n_iter, &hit, &screen_hit);
     b->profile.range_fallbacks = 1;
     b->profile.screen_fallbacks = screen_fallbacks;
+    b->profile.screen_audit_failures = audit_failures;
     return rc;
 }
 

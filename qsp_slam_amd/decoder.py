@@ -85,6 +85,12 @@ class DeepSdfDecoder(object):
         tiles over the chip), 0 = always (QSP_DEC_OPT_SCREENING_MIN_SAMPLES)"""
         _lib.check(_lib.lib().qsp_decoder_set_option(self.handle, 7, int(n)))
 
+    def set_screen_audit(self, one_in=100):
+        """the screened forward's out-of-band audit (QSP_DEC_OPT_SCREEN_AUDIT): one in `one_in` of the samples the screening pass
+        put OUTSIDE the band is re-evaluated on the split-fp16 tile as well; one found inside the cut-off repeats the run in one
+        pass.  0 = off, 1 = every sample."""
+        _lib.check(_lib.lib().qsp_decoder_set_option(self.handle, 9, int(one_in)))
+
     def set_render_screening(self, margin=0.01):
         """two-pass ray-sample forward of the refinement on the "fp16x2" pipe (QSP_DEC_OPT_RENDER_SCREENING in qsp_hip.h): every
         sample on a one-product tile, only those with |s1| < cut_off + margin on the split-fp16 tile.  Bit-identical results to the

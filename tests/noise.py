@@ -177,3 +177,28 @@ def check_gpu_iterations(tag, decoder, golden_dir, name, make_cfg, cfg_from, wit
     within("%s/%s/knife_edge_rows_replaced" % (tag, name), replaced, 2)
     within("%s/%s/per_iteration/share_of_checks_over_2x_noise" % (tag, name), 1.0 - strict_ok / max(strict_all, 1), 0.1)
     return replaced
+
+
+def free_running_bars(z, nz):
+    """(ref64 finals, bars): twice the largest distance of the reference's own float32 free-running results (nine variants + the
+    committed fixture) from its float64 result, never below 1e-4 -- t_cam_obj relative to its largest entry, code absolute, loss
+    relative"""
+    T64, c64, l64 = nz["free_T64"], nz["free_code64"], float(nz["free_loss64"])
+    Ts = list(nz["free_T32"]) + [z["out_t_cam_obj"]]
+    cs = list(nz["free_code32"]) + [z["out_code"]]
+    ls = [float(v) for v in nz["free_loss32"]] + [float(z["loss"])]
+    bars = dict(T=max(NORTH_STAR, 2 * max(relerr(t, T64) for t in Ts)),
+                code=max(NORTH_STAR, 2 * max(float(np.abs(np.asarray(c, np.float64) - c64).max()) for c in cs)),
+                loss=max(NORTH_STAR, 2 * max(abs(v / l64 - 1) for v in ls)))
+    return (T64, c64, l64), bars
+
+
+def check_free_running(tag, name, golden_dir, r, within):
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    (T64, c64, l64), bars = free_running_bars(z, load(golden_dir, name))
+    assert within("%s/%s/free_running_vs_ref64_over_max(1e-4,2x_reference_scatter)/t_cam_obj" % (tag, name),
+                  relerr(r.t_cam_obj, T64) / bars["T"], 1.0)
+    assert within("%s/%s/free_running_vs_ref64_over_max(1e-4,2x_reference_scatter)/code_abs" % (tag, name),
+                  float(np.abs(r.code - c64).max()) / bars["code"], 1.0)
+    assert within("%s/%s/free_running_vs_ref64_over_max(1e-4,2x_reference_scatter)/loss_rel" % (tag, name),
+                  abs(r.loss / l64 - 1) / bars["loss"], 1.0)

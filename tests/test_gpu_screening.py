@@ -122,6 +122,7 @@ def test_every_screened_run_measures_its_own_premise(dec, golden_dir):
     before = dec.screen_fallbacks
     b = run_batch(dec, opt, [obj], [0], z["t_cam_obj"][None], None, int(z["it_H"].shape[0]), True)
     assert b["prof"].pts_band > 0 and b["prof"].screen_fallbacks == 0 and dec.screen_fallbacks == before
+    assert b["prof"].pts_audit > 0 and b["prof"].screen_audit_failures == 0      # (one in 100 of the out-of-band samples looked at too)
     assert within("fp16x2/screening/run_max_abs_s1_minus_s3", b["prof"].screen_max_diff, MARGIN / 8)
     assert b["prof"].screen_max_diff > 0
 
@@ -150,6 +151,101 @@ def test_a_margin_the_screening_values_do_not_honour_costs_time_not_bits(dec, go
     assert prof.screen_fallbacks == 1 and dec.screen_fallbacks == before + 1
     assert prof.pts_band == 0          # (the profile is the repeated, one-pass run's)
     assert_same_bits(a, out, "self-check fallback")
+
+
+def test_the_out_of_band_audit_changes_no_bit_and_looks_at_its_share(dec, golden_dir):
+    """QSP_DEC_OPT_SCREEN_AUDIT: with the audit off, at one in 100 and at EVERY out-of-band sample the
+    screened run gives the same bits (an audited sample's overwritten value is only read through the clamp); the number of
+    audited samples follows the rate, and on the fitted decoder none of them was clamped wrongly -- with the rate at 1 that is
+    every single ray sample of every iteration checked against the split-fp16 value."""
+    from qsp_slam_amd import synth
+    from qsp_slam_amd.reconstruct.optimizer import Optimizer
+    import bench
+    objs = synth.make_object_views(4242, 12, 600, n_fg=120, n_bg=60)
+    opt = Optimizer(dec, make_cfg(so.JointConfig(n_iter=3)))
+    T0, hyp = bench.flip_states(objs, 4)
+    ref = run_batch(dec, opt, objs, hyp, T0, None, 3, False)
+    outs = {}
+    try:
+        for one_in in (0, 100, 1):
+            dec.set_screen_audit(one_in)
+            outs[one_in] = run_batch(dec, opt, objs, hyp, T0, None, 3, True)
+            assert_same_bits(ref, outs[one_in], "audit one in %d" % one_in)
+            assert outs[one_in]["prof"].screen_fallbacks == 0 and outs[one_in]["prof"].screen_audit_failures == 0
+    finally:
+        dec.set_screen_audit(100)
+    n_out = outs[1]["prof"].pts_audit                       # rate 1: every out-of-band sample
+    assert outs[0]["prof"].pts_audit == 0 and n_out > 0
+    assert outs[1]["prof"].pts_band == outs[1]["prof"].pts_fwd          # (band + audited = everything)
+    assert 0.5 * n_out / 100 < outs[100]["prof"].pts_audit < 2.0 * n_out / 100
+    assert within("fp16x2/screening/max_abs_s1_minus_s3_over_ALL_samples", outs[1]["prof"].screen_max_diff, MARGIN / 8)
+
+
+def adversarial_decoder(golden_dir, A=512.0, n_pair=32):
+    """The fitted decoder with the `n_pair` most active hidden units of layer 5 DUPLICATED into units that are dead on the unit
+    cube (rows j and k of layer 5 identical) and +A / -A added to the two columns of layer 6 that read them.  In exact arithmetic
+    the two contributions cancel and the function is the fitted one (it moves by 8e-3: the float32 rounding of W + A); on the
+    split-fp16 tile they cancel to 2^-22 A; but the ONE-product screening pass rounds W + A and W' - A to 11 bits each and loses
+    the W's: its values miss the decoder's by 0.03 .. 0.06 -- several margins -- on most samples (numpy emulation of the hi-plane
+    pass: median 0.035), so about half of the samples whose true value is inside the cut-off leave the band."""
+    from qsp_slam_amd import DeepSdfDecoder
+    od = so.load_decoder_npz(os.path.join(golden_dir, "decoder_8x512.npz"))
+    rng = np.random.default_rng(3)
+    x = rng.uniform(-0.8, 0.8, size=(2000, 3)).astype(np.float32)
+    inp = np.concatenate([np.zeros((x.shape[0], od.code_len), np.float32), x], 1)
+    h = inp
+    for l in range(6):                                     # activations of layer 5 on the cube (code 0)
+        if l in od.latent_in:
+            h = np.concatenate([h, inp], 1)
+        h = np.maximum(h @ od.layers[l][0].T + od.layers[l][1], 0)
+    act = h.mean(0)
+    most, least = np.argsort(-act), np.argsort(act)
+    layers = [(W.copy(), None, b.copy()) for W, b in od.layers]
+    for q in range(n_pair):
+        j, k = int(most[q]), int(least[q])
+        assert act[k] == 0.0 and act[j] > 0.0
+        layers[5][0][k] = layers[5][0][j]
+        layers[5][2][k] = layers[5][2][j]
+        layers[6][0][:, j] += np.float32(A)
+        layers[6][0][:, k] -= np.float32(A)
+    d = DeepSdfDecoder(layers, latent_in=od.latent_in, code_len=od.code_len)
+    d.set_precision("fp16x2")
+    d.set_screening_min_samples(0)
+    return d
+
+
+def test_an_adversarial_decoder_trips_the_out_of_band_audit(golden_dir):
+    """A decoder whose one-product values miss its split-fp16 values by more than the margin (`adversarial_decoder`): samples
+    whose true value is inside the cut-off are put OUTSIDE the band by the screening pass, where the band check of round 3 never
+    looked.  The audit finds them (screen_audit_failures > 0), the run is repeated in one pass and returns the unscreened bits."""
+    from qsp_slam_amd import synth
+    from qsp_slam_amd.reconstruct.optimizer import Optimizer
+    import bench
+    d = adversarial_decoder(golden_dir)
+    try:
+        rng = np.random.default_rng(3)
+        x = rng.uniform(-0.8, 0.8, size=(20000, 3)).astype(np.float32)
+        code = np.zeros(64, np.float32)
+        s3, s1 = d.decode_sdf(code, x), d.decode_sdf_screen(code, x)
+        diff = np.abs(s1 - s3)
+        dangerous = (np.abs(s3) < 0.01) & (np.abs(s1) >= 0.01 + MARGIN)
+        assert within("fp16x2/screening/adversarial_max_abs_s1_minus_s3_over_margin", MARGIN / max(diff.max(), 1e-30), 1.0)
+        assert dangerous.sum() > 0                       # the failure mode exists for this decoder at all
+        objs = synth.make_object_views(777, 12, 600, n_fg=120, n_bg=60)
+        opt = Optimizer(d, make_cfg(so.JointConfig(n_iter=2)))
+        T0, hyp = bench.flip_states(objs, 4)
+        ref = run_batch(d, opt, objs, hyp, T0, None, 2, False)
+        before = d.screen_fallbacks
+        d.set_screen_audit(1)                            # every out-of-band sample: the count below is then exact, not a sample
+        out = run_batch(d, opt, objs, hyp, T0, None, 2, True)
+        assert out["prof"].screen_audit_failures > 0 and out["prof"].screen_fallbacks == 1 and d.screen_fallbacks == before + 1
+        assert_same_bits(ref, out, "adversarial decoder, audit of every sample")
+        d.set_screen_audit(100)                          # the shipped rate: a one-in-100 sample of them is enough here
+        out = run_batch(d, opt, objs, hyp, T0, None, 2, True)
+        assert out["prof"].screen_audit_failures > 0 and out["prof"].screen_fallbacks == 1
+        assert_same_bits(ref, out, "adversarial decoder, audit one in 100")
+    finally:
+        d.close()
 
 
 def test_screening_needs_the_split_fp16_forward_pass(golden_dir):

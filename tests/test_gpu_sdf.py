@@ -138,6 +138,9 @@ def test_reconstruct_object_free_running_vs_reference(gpu_decoder, golden_dir, n
     assert within(name + "/free_running/t_cam_obj", relerr(r.t_cam_obj, z["out_t_cam_obj"]), tol["T"])
     assert within(name + "/free_running/code_abs", np.abs(r.code - z["out_code"]).max(), tol["code"])
     assert within(name + "/free_running/loss_rel", abs(r.loss - float(z["loss"])) / abs(float(z["loss"])), tol["loss"])
+    # ... and against the reference's float64 result, held to twice the reference's own float32 scatter around it (tests/noise.py)
+    from tests import noise
+    noise.check_free_running("f32", name, golden_dir, r, within)
     with pytest.raises(KeyError):
         r["no_such_key"]
 

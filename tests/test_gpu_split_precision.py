@@ -75,6 +75,18 @@ def test_every_iteration_vs_the_references_float64_and_its_own_float32_scatter(b
     noise.check_gpu_iterations(bf3_decoder.precision, bf3_decoder, golden_dir, name, make_cfg, cfg_from, within)
 
 
+@pytest.mark.parametrize("name", JOINT_CASES)
+def test_free_running_result_vs_the_references_float64_and_its_own_float32_scatter(bf3_decoder, golden_dir, name):
+    """the whole refinement (5 / 10 iterations, a map that amplifies rounding 5-8 x per iteration) ends within twice the distance
+    at which the reference's own float32 evaluations end from its float64 one"""
+    from qsp_slam_amd.reconstruct.optimizer import Optimizer
+    from tests import noise
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    r = Optimizer(bf3_decoder, make_cfg(z)).reconstruct_object(z["t_cam_obj"], z["pts"], z["rays"], z["depth"])
+    assert r.is_good
+    noise.check_free_running(bf3_decoder.precision, name, golden_dir, r, within)
+
+
 def test_discrete_decisions_match_the_oracle_on_a_random_sweep(bf3_decoder, oracle_decoder):
     """n_valid (samples in the unit ball) and K (kept render rows: |sdf| < cut-off, de/do > 1e-2) are counts of threshold
     decisions on decoder outputs: exact in 40 random cases, and H, b within 1e-4 except where single ReLU knife-edge rows
