@@ -398,7 +398,7 @@ def run_workload(ctx, name, steps, warmup, detailed, precision=None, screening=N
         ba_desc="local joint BA 5+10 LM iterations: %d KF / %d map points / %d objects, %d mono + %d stereo + %d "
                 "camera-object edges; dense factorisation: %s"
                 % (w["n_kf"], w["n_map"], w["n_obj"], len(scene["mono_pt"]), len(scene["st_pt"]), len(scene["oe_kf"]),
-                   "resident chain workgroup + tile workgroups on a second stream" if ba.cholesky_chain else "one launch per block step"),
+                   "one launch: resident chain workgroup + tile workgroups by ticket" if ba.cholesky_chain else "one launch per block step"),
         jtj=dict(achieved=achieved, avg_ms=avg_ms, launches=prof["n_jtj"],
                  points_per_launch=prof["pts_jtj"] / max(prof["n_jtj"], 1),
                  tile_padding_overhead=64.0 * prof["tiles_jtj"] / max(prof["pts_jtj"], 1)),

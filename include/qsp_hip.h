@@ -320,9 +320,10 @@ typedef struct {
     int32_t n_linearize, n_trials;
     int64_t bytes_linearize; /* ALGORITHMIC bytes of one linearisation: 176 B/mono edge, 184 B/stereo edge,
                                 392 B/free pose or object, 120 B/point, 352 B/object edge */
-    int32_t cholesky_chain;  /* 1: the dense factorisation runs as a resident chain workgroup with the trailing updates on
-                                a second stream (QSP_BA_OPT_CHOLESKY_CHAIN), 0: one launch per block step            */
-    int32_t pad_;
+    int32_t cholesky_chain;  /* 1: the dense factorisation runs as one launch -- a resident chain workgroup and tile workgroups
+                                beside it (QSP_BA_OPT_CHOLESKY_CHAIN), 0: one launch per block step                  */
+    int32_t chain_timeouts;  /* solves of this problem in which a flag wait of that launch expired: the trial was repeated on
+                                the one-launch-per-step form, which the problem keeps from there on (0 in a healthy run)  */
 } qsp_ba_stats;
 
 typedef struct qsp_ba_problem qsp_ba_problem;
@@ -427,15 +428,16 @@ int qsp_ba_set_deterministic(qsp_ba_problem* p, int on);
  * covers the free key-frames only (what the fill-reducing ordering of the reference's sparse LDLT achieves,
  * Thirdparty/g2o/g2o/solvers/linear_solver_eigen.h:147-201).  0 keeps objects inside the dense system (same solution to
  * rounding; A/B tests).  Takes effect at the next optimize() call.
- * QSP_BA_OPT_CHOLESKY_CHAIN (default 1 where possible): the blocked Cholesky of the reduced system
- * (linear_solver_eigen.h:94-124) as ONE resident workgroup that carries the serial chain -- update of the next diagonal block,
- * its factorisation, the forward substitution -- while the trailing updates of each block step run beside it on a second,
- * high-priority stream; the two meet through flags in device memory (bounded waits: an expired wait fails the call with
- * QSP_ERR_DEVICE).  Needs the problem's two streams to execute concurrently, which qsp_ba_create tries once; where they do not
- * (or with QSP_BA_CHOL=steps in the environment) the solver keeps one launch per block step and value 1 is refused with
- * QSP_ERR_UNSUPPORTED.  Both forms perform the same operations in the same order (identical bits).  Value 2 is for tests: the
- * chain is launched WITHOUT its tile workgroups, so its first wait must expire (about a second) and the call must fail with
- * QSP_ERR_DEVICE instead of hanging; the problem is unusable afterwards. */
+ * QSP_BA_OPT_CHOLESKY_CHAIN (default 1 where the reduced system has more than one block row): the blocked Cholesky of the reduced
+ * system (linear_solver_eigen.h:94-124) as ONE launch on the problem's stream: the first workgroup to start carries the serial
+ * chain -- update of the next diagonal block, its factorisation, the forward substitution -- and never leaves its compute unit, the
+ * others take the remaining tiles by ticket and keep each in registers through all its steps; they meet through flags in device
+ * memory.  A tile waits only for the chain and for tiles with smaller tickets, which running workgroups hold, so the launch makes
+ * progress however few of its workgroups are resident.  Waits are bounded all the same: if one expires (compute units withheld
+ * for ~1-2 s) the trial is repeated on the one-launch-per-step form -- same operations, same order, same bits -- and the problem
+ * stays on it (qsp_ba_stats.chain_timeouts counts; a line on stderr).  QSP_BA_CHOL=steps in the environment selects that form
+ * outright.  Value 2 is for tests: the chain is launched WITHOUT its tile workgroups, so its first wait must expire (about a
+ * second); the call must neither hang nor fail, and must give the step form's bits. */
 enum { QSP_BA_OPT_OBJECT_ELIMINATION = 1, QSP_BA_OPT_CHOLESKY_CHAIN = 2 };
 int qsp_ba_set_option(qsp_ba_problem* p, int32_t option, int32_t value);
 

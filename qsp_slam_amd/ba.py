@@ -92,8 +92,8 @@ class BaProblem(object):
         _lib.check(_lib.lib().qsp_ba_set_option(self.handle, 1, 1 if on else 0))
 
     def set_cholesky_chain(self, on=True):
-        """the dense factorisation as one resident chain workgroup with the trailing updates on a second stream (default where the
-        problem's two streams run concurrently) or as one launch per block step; same bits either way (QSP_BA_OPT_CHOLESKY_CHAIN)"""
+        """the dense factorisation as one launch (a resident chain workgroup + tile workgroups taking tickets; the default) or as
+        one launch per block step; same bits either way (QSP_BA_OPT_CHOLESKY_CHAIN)"""
         _lib.check(_lib.lib().qsp_ba_set_option(self.handle, 2, 1 if on else 0))
 
     @property

@@ -298,6 +298,8 @@ struct Dev {
     double oe_info;
     // hessian indices
     int32_t *kf_h, *obj_h, *pt_h;
+    uint8_t* kf_fixed;              // per key-frame: fixed vertex (never in the index)
+    int32_t* pt_order;              // landmarks sorted by vertex id: the order in which g2o numbers them (k_tail_reindex)
     // system
     double *Hll, *bl, *Dinv, *xl;   // per landmark (indexed by landmark, not by hessian index)
     double *Hdiag;                  // per pose block (hessian index) 6x6
@@ -776,6 +778,9 @@ __global__ __launch_bounds__(256) void k_lin_edges(Dev d, Par par, int nb_poses,
     else lin_objedges_block(d, par, b - nb_poses - nb_points);
 }
 __global__ __launch_bounds__(64) void k_lin_vertices(Dev d, Par par) {
+    // (scal[2] collects k_maxdiag's atomicMax in the first iteration of a call: zeroed here, one launch earlier in the same stream,
+    //  instead of by a memset node -- 13 us of idle device each, profiles/r03_ba_c4_timeline.txt)
+    if (blockIdx.x == 0 && threadIdx.x == 0) d.scal[2] = 0.0;
     if ((int)blockIdx.x < d.n_kf) lin_poses_finish_block(d, par, blockIdx.x);
     else lin_objects_block(d, par, blockIdx.x - d.n_kf);
 }
@@ -1692,23 +1697,24 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_step(double* A, double* U
     }
 }
 
-// ---- the same factorisation as ONE resident chain workgroup plus ONE launch of tile workgroups on a second stream ----
+// ---- the same factorisation as ONE launch: a resident chain workgroup and tile workgroups beside it (k_chol_solve) ----
 // k_chol_step pays a kernel boundary on the serial chain of every step: kernel start, the reload of W_k and of two tiles another
 // compute unit has just written, the drain of its own stores (~13 of a step's 31 us at C5).  Here the chain -- update of the next
-// diagonal tile, its factorisation, y_k -- stays in one workgroup that never leaves its compute unit (k_chol_chain; W_k is used
-// where factor_tile64 left it in LDS), and every other tile has a workgroup of its own that keeps it in registers through all its
-// steps (k_chol_trail).  They meet through epoch-valued flags in global memory (no reset between solves):
+// diagonal tile, its factorisation, y_k -- stays in one workgroup that never leaves its compute unit (chol_chain_body; W_k is used
+// where factor_tile64 left it in LDS), and every other tile is taken by a workgroup that keeps it in registers through all its
+// steps (chol_trail_tile).  They meet through epoch-valued flags in global memory (no reset between solves):
 //   flag_w[k]         set by the chain once W_k^T and y_k are in global memory   -> awaited by every tile workgroup at its step k
 //   tile_done[i nb+j] set by tile (i,j)'s workgroup once the tile is final in memory (for i = k+1 also: U_kj stored, b_j carried
 //                     through step k)   -> awaited by the tiles of later rows that multiply with it and, for (s-1,s) and (s,s),
 //                     by the chain before its step s
 // Release: stores, workgroup barrier, then one thread's agent-scope fence and flag store; acquire: one thread polls (relaxed,
-// agent scope), fences, workgroup barrier.  Every wait is bounded (CHOL_SPIN_MAX polls): on expiry scal[5] is raised, which fails
-// the call (QSP_ERR_DEVICE), later waits give up at once and the kernels run to their end on whatever they find: the grid always
-// drains.  Every flag a workgroup waits for is set by the chain or by a workgroup of an EARLIER row (smaller blockIdx), and the
-// chain waits for nothing a step ahead of it, so the scheme cannot wait on itself.  The chain's last steps have (transitively)
-// awaited every tile_done of the solve: when k_chol_chain ends, every write of the tile workgroups is complete and visible, and
-// the problem's stream needs no event from the second one.
+// agent scope), fences, workgroup barrier.  Every wait is bounded (CHOL_SPIN_MAX polls): on expiry scal[5] is raised, later waits
+// give up at once and the kernel runs to its end on whatever it finds: the grid always drains; the host then repeats THAT trial
+// on the one-launch-per-step form, which the problem keeps from there on (qsp_ba_optimize).  Every flag a workgroup
+// waits for is set by the chain or by a tile of an EARLIER row -- a smaller TICKET, i.e. a workgroup that is running or done
+// (k_chol_solve) -- and the chain waits for nothing a step ahead of it, so the scheme cannot wait on itself whichever workgroups
+// the dispatcher starts first.  The chain's last steps have (transitively) awaited every tile_done of the solve: when the chain
+// workgroup ends, every write of the tile workgroups is complete and visible to the kernels behind it in the stream.
 // Same operations in the same order on every element as the k_chol_step path (the two agree in every bit).
 #ifdef QSP_CB_STAMPS      // timing experiments only: shader-clock stamps of the chain workgroup's thread 0 at the phase boundaries of every step
 __device__ unsigned long long qsp_chain_ts[64 * 8];
@@ -1741,20 +1747,6 @@ __device__ inline void chol_wait3(const unsigned* fa, const unsigned* fb, const 
 }
 __device__ inline void chol_wait(const unsigned* flag, unsigned epoch, double* scal) { chol_wait3(flag, nullptr, nullptr, epoch, scal); }
 
-// do two streams of this process run kernels side by side?  (they may share a hardware queue, whose packets run in order)
-constexpr int HANDSHAKE_POLLS = 4000;           // ~ 4 ms at most, once per problem
-__global__ void k_handshake_wait(unsigned* flag, unsigned token, int* ok) {
-    int seen = 0;
-    for (int spin = 0; spin < HANDSHAKE_POLLS && !seen; ++spin) {
-        seen = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == token;
-        if (!seen) __builtin_amdgcn_s_sleep(16);
-    }
-    *ok = seen;
-}
-__global__ void k_handshake_set(unsigned* flag, unsigned token) {
-    __hip_atomic_store(flag, token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 // a wave-load of 64 consecutive doubles from a UNIFORM address: scalar base + this lane's 32-bit byte offset (one VGPR of address
 // for all loads of the kernel instead of a 64-bit pointer per load in flight)
 typedef const __attribute__((address_space(1))) char* gbytes_t;
@@ -1764,6 +1756,7 @@ __device__ __forceinline__ double ld_row(const double* uniform_ptr, uint32_t vof
 
 constexpr int CHAIN_LDS_DOUBLES = NB * (NB + 1) + 2 * NB * NB + CHOL_ROWBUF + 3 * NB + 2;
 constexpr int TRAIL_LDS_DOUBLES = 3 * NB * NB + NB;
+constexpr int CHOL_SOLVE_LDS_DOUBLES = CHAIN_LDS_DOUBLES > TRAIL_LDS_DOUBLES ? CHAIN_LDS_DOUBLES : TRAIL_LDS_DOUBLES;
 constexpr int CHAIN_PROBE_GAP = 2;        // phases between a look at the flags and reading what it returned
 constexpr int CHAIN_PARK_AFTER = 3;       // phases between issuing the next step's loads and parking them in LDS
 // Fetching ahead (the first two updater waves in the second half of factor_tile64, 128 threads): thread 0 looks at the two flags
@@ -1855,9 +1848,8 @@ struct ChainFetch {
 // One step s of the chain: [tiles (s-1,s), (s,s) and b_s -- normally fetched behind the previous factorisation] ->
 // P = W_{s-1} A_{s-1,s} (the panel wave releases W_{s-1} to the tile workgroups meanwhile) -> S -= P^T P, U_{s-1,s} stored,
 // b_s -= P^T y_{s-1} (panel wave) -> factor_tile64 -> W_s^T and y_s to memory.
-__global__ __launch_bounds__(CHOL_THREADS) void k_chol_chain(const double* A, double* Uf, double* Winv, const double* b, double* y, int ld,
-                                                             int nb, double* scal, unsigned* flag_w, const unsigned* tile_done, unsigned epoch) {
-    extern __shared__ __attribute__((aligned(16))) double chol_lds[];
+__device__ __forceinline__ void chol_chain_body(double* chol_lds, const double* A, double* Uf, double* Winv, const double* b, double* y, int ld,
+                                                int nb, double* scal, unsigned* flag_w, const unsigned* tile_done, unsigned epoch) {
     double* Wr = chol_lds;                          // rows of W_s (pitch 65): factor_tile64 writes them, the next step multiplies with them
     double* Yp = Wr + NB * (NB + 1);                // A_{s-1,s}, then P = W_{s-1} A_{s-1,s}
     double* Sn = Yp + NB * NB;                      // A_{s,s} as the fetching waves park it
@@ -1961,21 +1953,17 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_chain(const double* A, do
     }
 }
 
-// everything off the chain, ONE launch per solve: workgroup per tile (i,j), 1 <= i <= j < nb, row-major in blockIdx.x -- a
-// workgroup only ever waits for the chain and for tiles of earlier rows, i.e. for workgroups dispatched before it, so the grid
-// makes progress however many of its workgroups are resident.  The tile stays in registers across its steps k = 0 .. i-1 (a
-// diagonal tile leaves its last step, k = i-1, to the chain); it goes back to memory once, final, with tile_done(i,j).
-__global__ __launch_bounds__(256) void k_chol_trail(double* A, double* Uf, const double* Winv, double* b, const double* y, int ld, int nb,
-                                                    double* scal, const unsigned* flag_w, unsigned* tile_done, unsigned epoch) {
-    extern __shared__ __attribute__((aligned(16))) double chol_lds[];
-    // (the grid is capped below the number of compute units so that the chain workgroup always finds one: a workgroup then takes
-    //  tiles blockIdx.x, blockIdx.x + gridDim.x, .. in turn -- still only ever waiting for tiles of smaller index)
-    for (int tile = blockIdx.x; tile < nb * (nb - 1) / 2; tile += gridDim.x) {
+// everything off the chain: tile (i,j), 1 <= i <= j < nb, row-major in `tile` -- a tile only ever waits for the chain and for tiles
+// of earlier rows, i.e. of SMALLER index.  The tile stays in registers across its steps k = 0 .. i-1 (a diagonal tile leaves its
+// last step, k = i-1, to the chain); it goes back to memory once, final, with tile_done(i,j).  256 threads.
+__device__ __forceinline__ void chol_trail_tile(double* chol_lds, int tile, double* A, double* Uf, const double* Winv, double* b, const double* y,
+                                                int ld, int nb, double* scal, const unsigned* flag_w, unsigned* tile_done, unsigned epoch) {
+    {
     int i = 1, rem = tile;
     while (rem >= nb - i) { rem -= nb - i; ++i; }
     const int j = i + rem;
     const int nsteps = (i == j) ? i - 1 : i;
-    if (nsteps == 0) continue;                        // (tile (1,1): the chain does its only step)
+    if (nsteps == 0) return;                          // (tile (1,1): the chain does its only step)
     double* X = chol_lds;
     double* Yi = chol_lds + NB * NB;
     double* Yj = (i == j) ? Yi : chol_lds + 2 * NB * NB;
@@ -2046,6 +2034,38 @@ __global__ __launch_bounds__(256) void k_chol_trail(double* A, double* Uf, const
         for (int q = 0; q < 4; ++q) A[(size_t)(i * NB + r0 + a) * ld + j * NB + c0 + q] = S[a][q];
     __syncthreads();
     if (t == 0) chol_signal(tile_done + i * nb + j, epoch);
+    }
+}
+
+// The factorisation in ONE launch on ONE stream (round 4).  Round 3 ran the chain and the tiles as two kernels on two streams
+// that had to be seen running side by side (a handshake per device, an event + a cross-stream wait per solve: 7 us of idle device
+// in front of every factorisation, and a way for two problems' stream pairs to block each other when streams share hardware
+// queues).  Here every workgroup takes TICKETS from one counter: the first ticket of a solve is the chain, ticket n > 0 is tile
+// n - 1.  A ticket is only ever held by a workgroup that is running, a tile waits for the chain and for tiles of smaller index
+// only -- smaller tickets, i.e. running or finished workgroups -- so the grid makes progress whichever workgroups the dispatcher
+// starts first and however few of them are resident (the blockIdx-strided loop of round 3 lost that guarantee beyond
+// 23 block rows).  The counter is never reset: the host passes the value it had before the launch and knows what it will be
+// afterwards (every workgroup draws exactly one ticket beyond the solve's range when it leaves).  The chain workgroup has 320
+// threads; a workgroup that draws a tile first drops its fifth wave (s_barrier counts the waves that are left).
+__global__ __launch_bounds__(CHOL_THREADS) void k_chol_solve(double* A, double* Uf, double* Winv, double* b, double* y, int ld, int nb, double* scal,
+                                                             unsigned* flag_w, unsigned* tile_done, unsigned epoch, unsigned* ticket,
+                                                             unsigned ticket_base, unsigned n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) double chol_lds[];
+    __shared__ unsigned s_tk;
+    if (threadIdx.x == 0) s_tk = atomicAdd(ticket, 1u) - ticket_base;
+    __syncthreads();
+    unsigned tk = s_tk;
+    if (tk == 0u) {
+        chol_chain_body(chol_lds, A, Uf, Winv, b, y, ld, nb, scal, flag_w, tile_done, epoch);
+        return;                                      // (the tiles are the other workgroups' -- the host launches at least one when there are any)
+    }
+    if (threadIdx.x >= 256) return;
+    while (tk <= n_tiles) {
+        chol_trail_tile(chol_lds, (int)tk - 1, A, Uf, Winv, b, y, ld, nb, scal, flag_w, tile_done, epoch);
+        __syncthreads();                             // (everybody has read s_tk and is done with the tile's LDS)
+        if (threadIdx.x == 0) s_tk = atomicAdd(ticket, 1u) - ticket_base;
+        __syncthreads();
+        tk = s_tk;
     }
 }
 
@@ -2410,6 +2430,84 @@ __global__ void k_classify_levels(Dev d, double th_mono, double th_stereo, doubl
     if (i < d.n_oe) d.oe_level[i] = d.oe_chi2[i] > th_obj ? 1 : 0;
 }
 
+// ---- The stage boundary of a local bundle adjustment WITHOUT the host (round 4; src/Optimizer_util.cc:598-661) -------------------------
+// Between optimize(5) and optimize(10) the reference classifies every edge (chi2 of the last evaluated trial, depth at the current
+// estimates), drops the outliers to level 1 and the robust kernels, and re-initialises: vertices without an active edge leave the
+// index (sparse_optimizer.cpp:199-267).  Round 3 did that with a read-back of the levels, a host loop, an upload and two idle
+// copy-engine hops (0.35 ms per BA, profiles/r03_ba_c4_timeline.txt).  Now the LAST iteration of the first stage enqueues, behind
+// the trial's own publish and before the host has even seen its verdict: the classification into SECOND level arrays, the new
+// landmark numbering, the edge -> key-frame index table, and the second stage's first chi2, linearisation and lambda seed on those
+// -- published through a second pinned slot.  If the trial is accepted (it almost always is) the host swaps the buffers in and
+// starts the second stage at its first trial; if it is rejected, or a key-frame / object vertex changed its activity (the reduced
+// system would change shape), the speculative work is discarded and the host path of round 3 runs.
+// act[]: one int per vertex [key-frames | objects | landmarks] holding the epoch of the last classification that saw an active edge
+// at it (no clearing between runs).
+__global__ __launch_bounds__(256) void k_tail_classify(Dev d, uint8_t* __restrict__ lvl_e, uint8_t* __restrict__ lvl_o, int32_t* __restrict__ edge_ha,
+                                                       int32_t* __restrict__ act, int32_t epoch, double th_mono, double th_stereo, double th_obj) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < d.n_edge) {
+        const Edge E = d.edge[i];
+        double p[3];
+        se3_map(d.kf_pose + 7 * E.kf, d.pt_xyz + 3 * E.pt, p);
+        const bool out = d.edge_chi2[i] > (E.stereo ? th_stereo : th_mono) || !(p[2] > 0.0);      // :621-641
+        lvl_e[i] = out ? 1 : 0;
+        edge_ha[i] = out ? -1 : d.kf_h[E.kf];                 // (k_edge_index of the second stage; valid while kf_h stands)
+        if (!out) { act[E.kf] = epoch; act[d.n_kf + d.n_obj + E.pt] = epoch; }
+    }
+    if (i < d.n_oe) {
+        const bool out = d.oe_chi2[i] > th_obj;                                                        // :650-654
+        lvl_o[i] = out ? 1 : 0;
+        if (!out) { act[d.oe_kf[i]] = epoch; act[d.n_kf + d.oe_obj[i]] = epoch; }
+    }
+}
+// one workgroup: did a key-frame or object vertex change its activity (scal[6]); landmarks numbered in vertex-id order (pt_h2),
+// their count (scal[7])
+__global__ __launch_bounds__(1024) void k_tail_reindex(Dev d, const int32_t* __restrict__ act, int32_t epoch, int32_t* __restrict__ pt_h2) {
+    __shared__ int s_cnt[1024];
+    __shared__ int s_changed;
+    const int t = threadIdx.x;
+    if (t == 0) s_changed = 0;
+    __syncthreads();
+    int changed = 0;
+    for (int i = t; i < d.n_kf; i += 1024) changed |= ((act[i] == epoch) && !d.kf_fixed[i]) != (d.kf_h[i] >= 0);
+    for (int i = t; i < d.n_obj; i += 1024) changed |= (act[d.n_kf + i] == epoch) != (d.obj_h[i] >= 0);
+    if (changed) s_changed = 1;
+    const int per = (d.n_pt + 1023) / 1024, lo = min(t * per, d.n_pt), hi = min(lo + per, d.n_pt);
+    const int32_t* pa = act + d.n_kf + d.n_obj;
+    int c = 0;
+    for (int q = lo; q < hi; ++q) c += pa[d.pt_order[q]] == epoch;
+    s_cnt[t] = c;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {                     // inclusive scan
+        const int v = t >= o ? s_cnt[t - o] : 0;
+        __syncthreads();
+        s_cnt[t] += v;
+        __syncthreads();
+    }
+    int k = s_cnt[t] - c;
+    for (int q = lo; q < hi; ++q) {
+        const int pt = d.pt_order[q];
+        pt_h2[pt] = (pa[pt] == epoch) ? k++ : -1;
+    }
+    if (t == 1023) { d.scal[7] = (double)s_cnt[1023]; d.scal[6] = s_changed ? 1.0 : 0.0; }
+}
+// the second stage's opening numbers to the host: chi2 of the new level set (partials of k_errors), lambda's seed, the two scalars above
+__global__ __launch_bounds__(64) void k_tail_publish(Dev d, int n, double* __restrict__ host, double seq) {
+    double s = 0;
+    for (int i = threadIdx.x; i < n; i += 64) s += d.partial[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (threadIdx.x == 0) {
+        d.scal[0] = s;
+        host[0] = s;
+        host[1] = d.scal[2];
+        host[2] = d.scal[6];
+        host[3] = d.scal[7];
+        __threadfence_system();
+        *reinterpret_cast<volatile double*>(host + 4) = seq;
+    }
+}
+
 __global__ void k_depth_positive(Dev d, uint8_t* pos) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= d.n_edge) return;
@@ -2720,19 +2818,28 @@ struct qsp_ba_problem {
     // LM state that persists inside one optimize call only
     qsp_ba_stats prof{};
     bool profiling = false;
-    // the factorisation as a resident chain workgroup + trailing updates on a second stream (k_chol_chain / k_chol_trail)
-    hipStream_t stream2 = nullptr;         // high priority: its own hardware-queue pool
-    hipEvent_t ev_sys = nullptr;
-    unsigned* chol_flags = nullptr;        // [nb_max] flag_w, [nb_max^2] tile_done, [1] handshake, then an int: handshake result
+    // the factorisation as ONE launch: a resident chain workgroup + tile workgroups that take tickets (k_chol_solve)
+    unsigned* chol_flags = nullptr;        // [nb_max] flag_w, [nb_max^2] tile_done, then the ticket counter
+    unsigned* chol_ticket = nullptr;       // (= chol_flags + nflag)
+    unsigned chol_ticket_base = 0;         // the counter's value when everything enqueued so far has drained
     unsigned chol_epoch = 0;
-    bool chol_chain_ok = false;            // the two streams were seen running side by side (qsp_ba_create) and QSP_BA_CHOL != steps
+    bool chol_chain_ok = false;            // the flags exist and QSP_BA_CHOL != steps
     bool chol_chain = false;               // QSP_BA_OPT_CHOLESKY_CHAIN
     bool chol_fault = false;               // (value 2 of the option: the tile workgroups are not launched)
-    int chol_grid_max = 1;                 // tile workgroups resident at a time: compute units - 16 (one stays free for the chain)
+    int chol_grid_max = 1;                 // tile workgroups launched at most: one per compute unit beside the chain's
+    int chain_timeouts = 0;                // solves in which a flag wait expired: repeated on the one-launch-per-step form
     double* scal_host = nullptr; // pinned, device-visible copy of scal[0..3] (k_publish_scal): read back without a copy engine hop
     double* scal_host_dev = nullptr;
     double scal_seq = 0.0;       // sequence number of the last read-back enqueued
     bool speculate = true;       // enqueue the next iteration's linearisation before waiting for a trial's verdict
+    // the device-side stage boundary of qsp_ba_local_joint (k_tail_*): second copies of what a re-initialisation rewrites
+    uint8_t *edge_level2 = nullptr, *oe_level2 = nullptr;
+    int32_t *edge_ha2 = nullptr, *pt_h2 = nullptr, *act = nullptr;
+    int32_t act_epoch = 0;
+    bool pt_order_uploaded = false;
+    double tail_seq = 0.0;       // sequence number of the last k_tail_publish enqueued (scal_host[8..12])
+    bool tail_ready = false;     // the last optimize() call left a valid speculated stage boundary behind
+    bool host_stale = false;     // edge_level_h / oe_level_h / pt_h / n_land on the host lag behind the device (refresh_host_index)
     uint8_t* lvl_host = nullptr; // pinned: edge / object-edge levels classified on the device (qsp_ba_local_joint)
     int32_t* idx_host = nullptr; // pinned staging of the hessian indices [kf | obj | pt]
     std::vector<int32_t> idx_uploaded;   // what the device holds (an optimize() call re-uploads only what changed)
@@ -2919,7 +3026,7 @@ static int build_pair_lists(qsp_ba_problem* p) {
 // milliseconds -- the hardware queue behind it comes into being with its first launch: 5.5 ms per create + destroy and 8 ms on
 // the first solve of a fresh problem were measured with one pair per problem (tools/time_ba_create.py) -- and the drop-in
 // Optimizer creates a problem per LocalJointBundleAdjustment call.
-struct StreamSet { hipStream_t s = nullptr, s2 = nullptr; hipEvent_t ev = nullptr; };
+struct StreamSet { hipStream_t s = nullptr; };
 static std::mutex g_stream_pool_mu;
 static std::vector<StreamSet> g_stream_pool[64];
 static bool stream_set_acquire(int dev, StreamSet* out) {
@@ -2938,16 +3045,11 @@ static bool stream_set_acquire(int dev, StreamSet* out) {
 static void stream_set_release(int dev, const StreamSet& st) {
     if (!st.s) return;
     (void)hipStreamSynchronize(st.s);
-    if (st.s2) (void)hipStreamSynchronize(st.s2);
     std::lock_guard<std::mutex> lk(g_stream_pool_mu);
     g_stream_pool[dev & 63].push_back(st);
 }
 
-// Second stream, events and flags of the chain factorisation.  The scheme needs k_chol_chain (problem stream) and k_chol_trail
-// (stream2) to RUN SIDE BY SIDE; two HIP streams may share a hardware queue, whose kernels run one after the other.  stream2 is
-// created at high priority (the runtime keeps a separate queue pool per priority), and the pair is tried: a waiting kernel
-// on stream2, then a setting kernel on the problem stream.  If the waiter does not see the flag (a few ms at most) the problem
-// keeps the one-launch-per-step path.  QSP_BA_CHOL=steps selects that path outright.
+// Flags and ticket counter of the chain factorisation (k_chol_solve).  QSP_BA_CHOL=steps selects the one-launch-per-step form.
 static int chol_chain_setup(qsp_ba_problem* p) {
     const char* env = getenv("QSP_BA_CHOL");
     if (env && !strcmp(env, "steps")) return QSP_OK;
@@ -2962,31 +3064,12 @@ static int chol_chain_setup(qsp_ba_problem* p) {
         return e == hipSuccess;
     };
     int n_cu = 0;
-    if (!ok(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, p->device)) || n_cu < 32) return QSP_OK;
-    p->chol_grid_max = n_cu - 16;
-    int least = 0, greatest = 0;
+    if (!ok(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, p->device)) || n_cu < 8) return QSP_OK;
+    p->chol_grid_max = n_cu - 1;
     if (!ok(hipMemset(p->chol_flags, 0, sizeof(unsigned) * (nflag + 8)))) return QSP_OK;
-    if (!p->stream2) {                                 // (a set from the pool brings them along)
-        if (!ok(hipDeviceGetStreamPriorityRange(&least, &greatest)) ||
-            !ok(hipStreamCreateWithPriority(&p->stream2, hipStreamNonBlocking, greatest)))
-            return QSP_OK;
-    }
-    if (!p->ev_sys && !ok(hipEventCreateWithFlags(&p->ev_sys, hipEventDisableTiming))) return QSP_OK;
-    // (the outcome is a property of the device and the runtime -- a normal- and a high-priority stream never share a queue pool --
-    //  so one successful trial per device and process stands for the later problems; a failed one is tried again)
-    static std::atomic<int> seen_ok[64];
-    const int dev = p->device >= 0 && p->device < 64 ? p->device : 0;
-    if (!seen_ok[dev].load()) {
-        unsigned* hs_flag = p->chol_flags + nflag;
-        int* hs_ok = reinterpret_cast<int*>(p->chol_flags + nflag + 1);
-        hipLaunchKernelGGL(k_handshake_wait, dim3(1), dim3(1), 0, p->stream2, hs_flag, 0x51u, hs_ok);
-        hipLaunchKernelGGL(k_handshake_set, dim3(1), dim3(1), 0, p->stream, hs_flag, 0x51u);
-        int seen = 0;
-        if (ok(hipGetLastError()) && ok(hipStreamSynchronize(p->stream2)) && ok(hipStreamSynchronize(p->stream)) &&
-            ok(hipMemcpy(&seen, hs_ok, sizeof(int), hipMemcpyDeviceToHost)) && seen)
-            seen_ok[dev].store(1);
-    }
-    p->chol_chain_ok = p->chol_chain = seen_ok[dev].load() != 0;
+    p->chol_ticket = p->chol_flags + nflag;
+    p->chol_ticket_base = 0;
+    p->chol_chain_ok = p->chol_chain = true;
     return QSP_OK;
 }
 
@@ -3134,7 +3217,7 @@ extern "C" int qsp_ba_create(const qsp_ba_scene* s, int device, qsp_ba_problem**
         if (e == hipSuccess) e = hipMemset(d.oe_chi2, 0, sizeof(double) * std::max(d.n_oe, 1));
         if (e == hipSuccess) {
             StreamSet st;
-            if (stream_set_acquire(p->device, &st)) { p->stream = st.s; p->stream2 = st.s2; p->ev_sys = st.ev; }
+            if (stream_set_acquire(p->device, &st)) p->stream = st.s;
             else e = hipErrorOutOfMemory;
         }
         if (e == hipSuccess) e = host_alloc_cached(p->device, (void**)&p->scal_host, 8 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent, &p->host_bytes[0]);
@@ -3143,8 +3226,7 @@ extern "C" int qsp_ba_create(const qsp_ba_scene* s, int device, qsp_ba_problem**
         if (e == hipSuccess) e = host_alloc_cached(p->device, (void**)&p->lvl_host, (size_t)std::max(d.n_edge + d.n_oe, 1), hipHostMallocDefault, &p->host_bytes[1]);
         if (e == hipSuccess) e = host_alloc_cached(p->device, (void**)&p->idx_host, sizeof(int32_t) * (size_t)std::max(d.n_kf + d.n_obj + d.n_pt, 1), hipHostMallocDefault, &p->host_bytes[2]);
         const int chol_lds = (int)(sizeof(double) * CHOL_LDS_DOUBLES);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_chol_chain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * CHAIN_LDS_DOUBLES));
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_chol_trail, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * TRAIL_LDS_DOUBLES));
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_chol_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * CHOL_SOLVE_LDS_DOUBLES));
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_chol_first, hipFuncAttributeMaxDynamicSharedMemorySize, chol_lds);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_chol_step, hipFuncAttributeMaxDynamicSharedMemorySize, chol_lds);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_schur_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCHUR_ROW_LDS_MAX);
@@ -3176,7 +3258,7 @@ extern "C" void qsp_ba_destroy(qsp_ba_problem* p) {
     (void)hipSetDevice(p->device);
     {
         StreamSet st;
-        st.s = p->stream; st.s2 = p->stream2; st.ev = p->ev_sys;
+        st.s = p->stream;
         stream_set_release(p->device, st);           // (synchronised and kept for the next problem on this device)
     }
     // (behind the synchronisation: nothing of this problem is in flight any more)
@@ -3210,8 +3292,6 @@ extern "C" void qsp_ba_release_caches(void) {
         for (const CachedBuf& c : dv) (void)hipFree(c.p);
         for (const CachedBuf& c : hv) (void)hipHostFree(c.p);
         for (const StreamSet& st : sv) {
-            if (st.ev) (void)hipEventDestroy(st.ev);
-            if (st.s2) (void)hipStreamDestroy(st.s2);
             if (st.s) (void)hipStreamDestroy(st.s);
         }
     }
@@ -3525,8 +3605,7 @@ extern "C" int qsp_ba_optimize(qsp_ba_problem* p, int32_t n_iter, double delta_m
         if (rc) return rc;
         lin_ready = false;
         if (it == 0) {
-            QSP_HIP(hipMemsetAsync(d.scal + 2, 0, sizeof(double), s));
-            const int gm = std::max(1, std::min(256, (d.n_pt * 3 + p->n_pose * 6 + 255) / 256));
+            const int gm = std::max(1, std::min(256, (d.n_pt * 3 + p->n_pose * 6 + 255) / 256));      // (scal[2] was zeroed by k_lin_vertices)
             hipLaunchKernelGGL(k_maxdiag, dim3(gm), dim3(256), 0, s, d, par);
             if (p->world > 1 && p->nccl) {   // max over ranks of the local maxima
                 ncclResult_t r = rccl_api()->all_reduce(d.scal + 2, d.scal + 2, 1, ncclDouble, ncclMax, p->nccl, s);
@@ -3597,20 +3676,17 @@ extern "C" int qsp_ba_optimize(qsp_ba_problem* p, int32_t n_iter, double delta_m
                 const int nb = p->dimp / NB;
                 const size_t lds = sizeof(double) * CHOL_LDS_DOUBLES;
                 if (p->chol_chain && nb >= 2) {
-                    // one resident chain workgroup on the problem's stream, the other tiles' workgroups beside it on the second one
+                    // one launch: the first workgroup to start is the chain, the others take the tiles in ticket order (k_chol_solve)
                     if (++p->chol_epoch == 0) ++p->chol_epoch;
                     unsigned* flag_w = p->chol_flags;
                     unsigned* tile_done = p->chol_flags + p->dimp_max / NB;
-                    if (nb >= 3) {
-                        QSP_HIP(hipEventRecord(p->ev_sys, s));                       // the reduced system is complete
-                        QSP_HIP(hipStreamWaitEvent(p->stream2, p->ev_sys, 0));
-                    }
-                    hipLaunchKernelGGL(k_chol_chain, dim3(1), dim3(CHOL_THREADS), sizeof(double) * CHAIN_LDS_DOUBLES, s, d.Hs, d.Uf, d.Winv, d.bs,
-                                       d.ych, p->dimp, nb, d.scal, flag_w, tile_done, p->chol_epoch);
-                    if (nb >= 3 && !p->chol_fault)
-                        hipLaunchKernelGGL(k_chol_trail, dim3(std::min(nb * (nb - 1) / 2, p->chol_grid_max)), dim3(256), sizeof(double) * TRAIL_LDS_DOUBLES, p->stream2,
-                                           d.Hs, d.Uf, d.Winv, d.bs, d.ych, p->dimp, nb, d.scal, flag_w, tile_done, p->chol_epoch);
-                    // (no event back: when the chain has ended every tile workgroup's writes are complete -- see k_chol_chain)
+                    const unsigned n_tiles = (nb >= 3 && !p->chol_fault) ? (unsigned)(nb * (nb - 1) / 2) : 0u;
+                    const unsigned grid = 1u + std::min(n_tiles, (unsigned)p->chol_grid_max);
+                    hipLaunchKernelGGL(k_chol_solve, dim3(grid), dim3(CHOL_THREADS), sizeof(double) * CHOL_SOLVE_LDS_DOUBLES, s, d.Hs, d.Uf, d.Winv,
+                                       d.bs, d.ych, p->dimp, nb, d.scal, flag_w, tile_done, p->chol_epoch, p->chol_ticket, p->chol_ticket_base,
+                                       n_tiles);
+                    p->chol_ticket_base += 1u + n_tiles + (grid - 1u) * (n_tiles ? 1u : 0u);      // what the counter holds when the launch has drained
+                    // (when the chain has ended every tile workgroup's writes are complete -- see chol_chain_body)
                 } else {
                     hipLaunchKernelGGL(k_chol_first, dim3(1), dim3(CHOL_THREADS), lds, s, d.Hs, d.Winv, d.bs, d.ych, p->dimp, d.scal);
                     for (int k = 0; k + 1 < nb; ++k)
@@ -3664,7 +3740,28 @@ extern "C" int qsp_ba_optimize(qsp_ba_problem* p, int32_t n_iter, double delta_m
             }
             rc = wait_scal(p, sc);
             if (rc) return rc;
-            if (sc[3] == 2.0) return qsp_fail(QSP_ERR_DEVICE, "BA: a flag wait between the factorisation's two streams expired");
+            if (sc[3] == 2.0) {
+                // A flag wait of the chain factorisation expired (its workgroups were kept from running together for ~1-2 s: another
+                // process or thread holding the compute units).  Not an error of the problem: the one-launch-per-step form performs
+                // the same operations in the same order.  Clear the sticky flag, keep that form for this problem from here on,
+                // restore the estimates the trial started from and repeat the trial -- same lambda, not counted.
+                if (!p->chol_chain) return qsp_fail(QSP_ERR_DEVICE, "BA: the factorisation reported an expired flag wait on the one-launch-per-step form");
+                p->chol_chain = false;
+                p->chain_timeouts++;
+                p->prof.chain_timeouts = p->chain_timeouts;
+                fprintf(stderr, "[qsp_hip] BA: a flag wait of the chain factorisation expired (#%d); this problem continues on the "
+                                "one-launch-per-step form\n", p->chain_timeouts);
+                QSP_HIP(hipMemsetAsync(d.scal + 5, 0, sizeof(double), s));
+                QSP_HIP(hipMemcpyAsync(d.kf_pose, d.kf_bk, sizeof(double) * 7 * d.n_kf, hipMemcpyDeviceToDevice, s));
+                if (d.n_obj) QSP_HIP(hipMemcpyAsync(d.obj_pose, d.obj_bk, sizeof(double) * 7 * d.n_obj, hipMemcpyDeviceToDevice, s));
+                if (d.n_pt) QSP_HIP(hipMemcpyAsync(d.pt_xyz, d.pt_bk, sizeof(double) * 3 * d.n_pt, hipMemcpyDeviceToDevice, s));
+                if (spec) {      // the speculated system overwrote this iteration's
+                    rc = enqueue_lin(false);
+                    if (rc) return rc;
+                }
+                rho = -1.0;      // (stay in the trial loop)
+                continue;
+            }
             const bool ok2 = sc[3] == 0.0;
             double tempChi = ok2 ? sc[0] : DBL_MAX;
             rho = currentChi - tempChi;
@@ -3782,6 +3879,7 @@ extern "C" int qsp_ba_profile(qsp_ba_problem* p, int enable, qsp_ba_stats* out) 
     if (!p) return qsp_fail(QSP_ERR_INVALID, "qsp_ba_profile: null problem");
     p->profiling = enable != 0;
     p->prof.cholesky_chain = p->chol_chain ? 1 : 0;
+    p->prof.chain_timeouts = p->chain_timeouts;
     if (out) *out = p->prof;
     return QSP_OK;
 }
@@ -3926,7 +4024,7 @@ extern "C" int qsp_ba_set_option(qsp_ba_problem* p, int32_t option, int32_t valu
     switch (option) {
         case QSP_BA_OPT_OBJECT_ELIMINATION: p->elim_allowed = value != 0; return QSP_OK;
         case QSP_BA_OPT_CHOLESKY_CHAIN:
-            if (value && !p->chol_chain_ok) return qsp_fail(QSP_ERR_UNSUPPORTED, "cholesky chain: the problem's two streams do not run concurrently here");
+            if (value && !p->chol_chain_ok) return qsp_fail(QSP_ERR_UNSUPPORTED, "cholesky chain: not set up for this problem (one block row, or QSP_BA_CHOL=steps)");
             p->chol_chain = value != 0;
             p->chol_fault = value == 2;     // tests: the chain without its tile workgroups -- every wait must expire, not hang
             return QSP_OK;
