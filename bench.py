@@ -115,55 +115,90 @@ def select_flips(T, code, loss, good, n_obj, flips):
     return out
 
 
-def cpu_baseline(w, objs, scene, n_hyp, budget_s=20.0):
-    """The oracle (kind "port": numpy restatement of path A, C restatement of path B) timed on this box's host cores on
-    a bounded sample of the same workload: whole Gauss-Newton iterations of single hypotheses until ~budget_s of CPU time
-    is spent, plus ONE full local joint BA of the scene (single thread, as the reference's g2o runs).  `value` is the
-    step rate extrapolated from that sample to the full step (all hypotheses + the BA)."""
+def cpu_baseline(w, objs, scene, n_hyp, budget_s=12.0):
+    """The oracle (kind "port": numpy restatement of path A, C restatement of path B) timed on this box's host cores on a
+    bounded sample of the same workload.  A: whole Gauss-Newton iterations of single hypotheses, once with the
+    BLAS pool limited to ONE thread (the faithful baseline: the reference's Python path runs one object at a time) and once on all
+    cores, ~budget_s of wall time each.  B: the FULL 5 + 10 schedule of the local joint BA, single thread like g2o, with the reduced
+    camera system solved by a block-sparse minimum-degree Cholesky (the stand-in for g2o's AMD-ordered sparse LDL^T,
+    linear_solver_eigen.h:94-124,147-201; oracle/ba_oracle.c) -- not the dense solve the parity tests use.  `value` is the step
+    rate extrapolated from the all-core sample of A plus B; `single_core` the same with the one-thread sample of A."""
+    from threadpoolctl import threadpool_limits
     from oracle import ba_oracle as bo
     from oracle import sdf_oracle as so
     dec = so.load_decoder_npz(os.path.join(ROOT, "tests", "golden", "decoder_8x512.npz"))
     cfg = so.JointConfig(n_iter=w["n_iter"])
     cores = len(os.sched_getaffinity(0))
-    t0 = time.time()
-    iters = 0
-    hyps = 0
-    for o in objs:
-        T_oc = np.linalg.inv(o["t_cam_obj"].astype(np.float64)).astype(np.float32)
-        z = np.zeros(64, np.float32)
-        dobs = np.concatenate([o["depth"], np.zeros(o["rays"].shape[0] - o["depth"].shape[0], np.float32)])
-        for _ in range(cfg.n_iter):
-            it = so.gn_iteration(dec, cfg, T_oc, z, o["pts"], o["rays"], dobs, o["depth"].shape[0])
-            if it["fail"] is not None:
+
+    def sample_a(budget):
+        t0 = time.time()
+        iters = hyps = 0
+        for o in objs:
+            T_oc = np.linalg.inv(o["t_cam_obj"].astype(np.float64)).astype(np.float32)
+            z = np.zeros(64, np.float32)
+            dobs = np.concatenate([o["depth"], np.zeros(o["rays"].shape[0] - o["depth"].shape[0], np.float32)])
+            for _ in range(cfg.n_iter):
+                it = so.gn_iteration(dec, cfg, T_oc, z, o["pts"], o["rays"], dobs, o["depth"].shape[0])
+                if it["fail"] is not None:
+                    break
+                T_oc, z = it["T_oc_new"], it["code_new"]
+                iters += 1
+                if time.time() - t0 > budget:
+                    break
+            hyps += 1
+            if time.time() - t0 > budget:
                 break
-            T_oc, z = it["T_oc_new"], it["code_new"]
-            iters += 1
-        hyps += 1
-        if time.time() - t0 > budget_s:
-            break
-    dt = time.time() - t0
+        return iters, hyps, time.time() - t0
+
+    with threadpool_limits(limits=1):
+        it1, hy1, dt1 = sample_a(budget_s)
+    itn, hyn, dtn = sample_a(budget_s)
     t1 = time.time()
-    prob = bo.BaProblem(scene)
-    n_pose_blocks = int((~scene["kf_fixed"].astype(bool)).sum()) + len(scene["obj_pose"])
-    if n_pose_blocks <= 150:
+    bo.set_sparse_solver(True)
+    try:
+        prob = bo.BaProblem(scene)
         b1, b2 = prob.local_joint_ba()
-        dt_ba = time.time() - t1
-        ba_iters = int(b1["iterations"] + b2["iterations"])
-        ba_note = "one full local joint BA"
-    else:
-        # the restatement solves the reduced system densely (O(dim^3) per trial): bound the sample to one LM iteration
-        # and scale to the 5+10 schedule's usual 11 iterations
-        tr = prob.optimize(1, DM, DS, DO)
-        ba_iters = 11
-        dt_ba = (time.time() - t1) * ba_iters / max(int(tr["iterations"]), 1)
-        ba_note = "ONE LM iteration of the joint BA scaled to 11"
+    finally:
+        bo.set_sparse_solver(False)
+    dt_ba = time.time() - t1
+    ba_iters = int(b1["iterations"] + b2["iterations"])
     step_iters = n_hyp * cfg.n_iter + ba_iters
-    step_s = (dt / max(iters, 1)) * n_hyp * cfg.n_iter + dt_ba
-    return dict(value=step_iters / step_s, unit="iters/s", cores=cores, kind="port",
-                sample="A: %d hypotheses x %d GN iterations (numpy+BLAS oracle, %d threads) in %.1f s, extrapolated to %d "
-                       "hypotheses; B: %s (C oracle, 1 thread, %d LM iterations) in %.2f s"
-                       % (hyps, cfg.n_iter, cores, dt, n_hyp, ba_note, ba_iters, dt_ba),
-                sdf_iters_per_s=iters / dt, ba_ms=1e3 * dt_ba)
+
+    def rate(iters, dt):
+        return step_iters / ((dt / max(iters, 1)) * n_hyp * cfg.n_iter + dt_ba)
+
+    return dict(value=rate(itn, dtn), unit="iters/s", cores=cores, kind="port",
+                sample="A: %d GN iterations of %d hypotheses (numpy+BLAS oracle, %d threads) in %.1f s, extrapolated to %d hypotheses x %d "
+                       "iterations; B: the full local joint BA, %d LM iterations (C oracle, 1 thread as g2o, block-sparse minimum-degree "
+                       "Cholesky of the reduced system) in %.2f s" % (itn, hyn, cores, dtn, n_hyp, cfg.n_iter, ba_iters, dt_ba),
+                sdf_iters_per_s=itn / dtn, ba_ms=1e3 * dt_ba,
+                single_core=dict(value=rate(it1, dt1), unit="iters/s", cores=1,
+                                 sample="A: %d GN iterations in %.1f s with the BLAS pool limited to 1 thread; B as above"
+                                        % (it1, dt1), sdf_iters_per_s=it1 / dt1))
+
+
+def ba_latency_model(n_kf_free, ms_ba, lm_trials):
+    """The BA's roof at the BASELINE sizes is not HBM (one linearisation of C5 moves 24 MB: 3 us at 8 TB/s) but the chain of
+    DEPENDENT steps of one Levenberg-Marquardt trial.  A stated critical-path model, every term measured on MI355X:
+      launches   9 dependent launches per trial (stage 1, pair Schur, factorisation, back-substitution, update, errors, publish, and
+                 the two linearisation launches of the next system) x 1.5 us, the middle of the 1.1-1.9 us boundary cost of a
+                 kernel that depends on its predecessor (guide; tools/micro/graph_launch.hip);
+      chain      nb block steps of the blocked Cholesky, each at its serial minimum: the 64x64 diagonal factorisation with the
+                 explicit inverse, 14.1 us (the micro-benchmark's best form, profiles/r03_chol_factor_micro.txt: a dependent
+                 v_fma_f64 issues every 8.4 cycles, v_rsq_f64 every 20), plus the two 64^3 products that sit between two
+                 factorisations on the same data, 2 x 5.3 k cycles at 2.4 GHz = 4.4 us (FP64 MFMA form, DESIGN section 3);
+      back       the triangular factor streamed once through ONE compute unit at 148 GB/s (tools/micro/cu_stream.hip, 16-byte
+                 loads) + 2 us of dependent round trip per block row.
+    frac = model / achieved time per trial (1.0 = at the floor of this algorithm's dependent chain)."""
+    dimp = ((6 * n_kf_free + 63) // 64) * 64
+    nb = dimp // 64
+    t_launch = 9 * 1.5
+    t_chain = nb * (14.1 + 4.4)
+    t_back = (dimp * dimp * 4) / 148e3 + 2.0 * nb
+    model = t_launch + t_chain + t_back
+    achieved = 1e3 * ms_ba / max(lm_trials, 1)
+    return dict(us_per_trial_model=model, us_per_trial_achieved=achieved, frac=model / max(achieved, 1e-9), block_rows=nb,
+                dense_unknowns=dimp, terms_us=dict(launch_boundaries=t_launch, factor_chain=t_chain, back_substitution=t_back))
 
 
 def pmc_traffic(workload, kernel):
@@ -533,6 +568,7 @@ def main():
                 subs[name]["ba_linearize_us"] = r["kernels"]["ba_linearize_us"]
                 subs[name]["ba_linearize_algorithmic_GBps"] = r["kernels"]["ba_linearize_GBps"]
                 subs[name]["ba_linearize_moved_GBps"] = r["kernels"]["ba_linearize_moved_GBps"]
+                subs[name]["ba_latency_model"] = ba_latency_model(WORKLOADS[name]["n_kf"] - 1, r["ms_ba"], r["ba_lm_trials"])
 
     if rank == 0:
         w = WORKLOADS[args.workload]
@@ -611,6 +647,13 @@ def main():
                                                             "ba_linearize_moved_GBps": m["kernels"]["ba_linearize_moved_GBps"],
                                                             "ba_linearize_algorithmic_GBps": m["kernels"]["ba_linearize_GBps"],
                                                             "ms_ba": m["ms_ba"]}
+        lat = {name: sub["ba_latency_model"] for name, sub in subs.items() if "ba_latency_model" in sub}
+        lat[args.workload] = ba_latency_model(w["n_kf"] - 1, m["ms_ba"], m["ba_lm_trials"])
+        out["ba_latency_roofline"] = {
+            "bound": "latency (dependent chain of one LM trial)", "unit": "us per LM trial", "per_workload": lat,
+            "frac": lat[args.workload]["frac"],
+            "note": "model = 9 dependent launches x 1.5 us + block rows x (14.1 us diagonal factorisation + 4.4 us of products) + the "
+                    "factor through one compute unit at 148 GB/s; frac = model / achieved; see bench.py:ba_latency_model"}
         if c5:
             out["ba_roofline"] = {"bound": "hbm", "kernel": "k_lin_edges + k_lin_vertices (BA linearisation, J^T J build)",
                                   "workload": "C5: 200 KF / 20000 map points / 256 objects", "unit": "GB/s",

@@ -55,7 +55,15 @@ def lib():
         _LIB.ba_obj_edge.argtypes = [dp, dp, dp, dp, dp, dp]
         _LIB.ba_oracle_pose_optimization.argtypes = [C.c_int, dp, dp, dp, dp, dp, up, dp, up, dp, ip]
         _LIB.ba_oracle_pose_optimization.restype = C.c_int
+        _LIB.ba_oracle_set_sparse_solver.argtypes = [C.c_int]
     return _LIB
+
+
+def set_sparse_solver(on):
+    """the reduced camera system by a block-sparse Cholesky in minimum-degree order (what g2o's LinearSolverEigen does with AMD +
+    sparse LDL^T, linear_solver_eigen.h:94-124,147-201) instead of the dense solve; the TIMED baseline of bench.py uses it, the
+    parity tests keep the dense one.  Process-wide switch of the oracle library."""
+    lib().ba_oracle_set_sparse_solver(1 if on else 0)
 
 
 def _p(a, t):

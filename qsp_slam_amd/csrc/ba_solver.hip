@@ -2803,6 +2803,10 @@ struct qsp_ba_problem {
     size_t host_bytes[3] = {0, 0, 0};     // scal_host, lvl_host, idx_host as allocated
     char* pool_cur = nullptr;     // bump allocator over the chunks in `allocs`
     size_t pool_left = 0;
+    // qsp_ba_create only: pinned staging of its ~30 uploads, so that they are asynchronous copies on the problem's stream with ONE
+    // synchronisation at the end instead of a synchronous staged copy each (0.4 ms of a 1.3 ms create + destroy at C4)
+    char* stage = nullptr;
+    size_t stage_cap = 0, stage_used = 0, stage_alloc = 0;
     // host mirrors needed for index building
     std::vector<Edge> edge_h;
     std::vector<int32_t> pt_off_h, oe_kf_h, oe_obj_h;
@@ -2860,6 +2864,7 @@ struct qsp_ba_problem {
 };
 
 static int upload_levels(qsp_ba_problem* p);
+static void build_orders(qsp_ba_problem* p);
 
 // Freed device chunks and pinned host buffers are kept per device for the next problem (bounded: 16 entries each, 512 MB of device
 // memory): hipMalloc / hipFree and hipHostMalloc / hipHostFree cost 0.1-0.5 ms apiece, and a caller that builds a problem per bundle
@@ -2923,7 +2928,15 @@ template <typename T>
 static int dupload(qsp_ba_problem* p, T** ptr, const T* src, size_t n) {
     int rc = dalloc(p, ptr, n);
     if (rc) return rc;
-    if (n) QSP_HIP(hipMemcpy(*ptr, src, n * sizeof(T), hipMemcpyHostToDevice));
+    const size_t bytes = n * sizeof(T);
+    if (!n) return QSP_OK;
+    if (p->stage && p->stream && bytes <= p->stage_cap - p->stage_used) {
+        memcpy(p->stage + p->stage_used, src, bytes);
+        QSP_HIP(hipMemcpyAsync(*ptr, p->stage + p->stage_used, bytes, hipMemcpyHostToDevice, p->stream));
+        p->stage_used += (bytes + 255) & ~(size_t)255;
+    } else {
+        QSP_HIP(hipMemcpy(*ptr, src, bytes, hipMemcpyHostToDevice));
+    }
     return QSP_OK;
 }
 
@@ -3066,7 +3079,7 @@ static int chol_chain_setup(qsp_ba_problem* p) {
     int n_cu = 0;
     if (!ok(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, p->device)) || n_cu < 8) return QSP_OK;
     p->chol_grid_max = n_cu - 1;
-    if (!ok(hipMemset(p->chol_flags, 0, sizeof(unsigned) * (nflag + 8)))) return QSP_OK;
+    if (!ok(hipMemsetAsync(p->chol_flags, 0, sizeof(unsigned) * (nflag + 8), p->stream))) return QSP_OK;
     p->chol_ticket = p->chol_flags + nflag;
     p->chol_ticket_base = 0;
     p->chol_chain_ok = p->chol_chain = true;
@@ -3092,6 +3105,14 @@ extern "C" int qsp_ba_create(const qsp_ba_scene* s, int device, qsp_ba_problem**
     QSP_HIP(hipSetDevice(device));
     qsp_ba_problem* p = new qsp_ba_problem();
     p->device = device;
+    {
+        StreamSet st;
+        if (!stream_set_acquire(p->device, &st)) { delete p; return qsp_fail(QSP_ERR_DEVICE, "qsp_ba_create: no stream"); }
+        p->stream = st.s;
+        const size_t want = (size_t)24 << 20;
+        if (host_alloc_cached(p->device, (void**)&p->stage, want, hipHostMallocDefault, &p->stage_alloc) == hipSuccess) p->stage_cap = p->stage_alloc;
+        else { (void)hipGetLastError(); p->stage = nullptr; }
+    }
     Dev& d = p->d;
     d.n_kf = s->n_kf; d.n_pt = s->n_pt; d.n_obj = s->n_obj; d.n_oe = s->n_objedge;
     d.n_edge = s->n_mono + s->n_stereo;
@@ -3195,6 +3216,18 @@ extern "C" int qsp_ba_create(const qsp_ba_scene* s, int device, qsp_ba_problem**
     UP(obo_off, obo_off.data(), d.n_obj + 1);
     UP(obo_edge, obo_edge.data(), d.n_oe);
     AL(kf_h, d.n_kf); AL(obj_h, d.n_obj); AL(pt_h, d.n_pt);
+    UP(kf_fixed, p->kf_fixed_h.data(), d.n_kf);
+    build_orders(p);
+    {
+        std::vector<int32_t> po(p->pt_order.begin(), p->pt_order.end());
+        UP(pt_order, po.data(), d.n_pt);                   // (g2o's numbering order of the landmarks, for k_tail_reindex)
+        p->pt_order_uploaded = true;
+    }
+    if (!rc) rc = dalloc(p, &p->edge_level2, (size_t)std::max(d.n_edge, 1));
+    if (!rc) rc = dalloc(p, &p->oe_level2, (size_t)std::max(d.n_oe, 1));
+    if (!rc) rc = dalloc(p, &p->edge_ha2, (size_t)std::max(d.n_edge, 1));
+    if (!rc) rc = dalloc(p, &p->pt_h2, (size_t)std::max(d.n_pt, 1));
+    if (!rc) rc = dalloc(p, &p->act, (size_t)(d.n_kf + d.n_obj + d.n_pt));
     AL(Hll, 9 * (size_t)d.n_pt); AL(bl, 3 * (size_t)d.n_pt); AL(Dinv, 9 * (size_t)d.n_pt); AL(xl, 3 * (size_t)d.n_pt);
     AL(Hdiag, 36 * (size_t)(d.n_kf + d.n_obj));
     AL(Hoff, 36 * (size_t)d.n_oe);
@@ -3210,19 +3243,15 @@ extern "C" int qsp_ba_create(const qsp_ba_scene* s, int device, qsp_ba_problem**
 #undef UP
 #undef AL
     if (!rc) {
-        hipError_t e = hipMemset(d.edge_level, 0, std::max(d.n_edge, 1));
-        if (e == hipSuccess) e = hipMemset(d.scal, 0, sizeof(double) * 8);
-        if (e == hipSuccess) e = hipMemset(d.oe_level, 0, std::max(d.n_oe, 1));
-        if (e == hipSuccess) e = hipMemset(d.edge_chi2, 0, sizeof(double) * std::max(d.n_edge, 1));
-        if (e == hipSuccess) e = hipMemset(d.oe_chi2, 0, sizeof(double) * std::max(d.n_oe, 1));
-        if (e == hipSuccess) {
-            StreamSet st;
-            if (stream_set_acquire(p->device, &st)) p->stream = st.s;
-            else e = hipErrorOutOfMemory;
-        }
-        if (e == hipSuccess) e = host_alloc_cached(p->device, (void**)&p->scal_host, 8 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent, &p->host_bytes[0]);
+        hipError_t e = hipMemsetAsync(d.edge_level, 0, std::max(d.n_edge, 1), p->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(d.scal, 0, sizeof(double) * 8, p->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(d.oe_level, 0, std::max(d.n_oe, 1), p->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(d.edge_chi2, 0, sizeof(double) * std::max(d.n_edge, 1), p->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(d.oe_chi2, 0, sizeof(double) * std::max(d.n_oe, 1), p->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(p->act, 0, sizeof(int32_t) * (size_t)(d.n_kf + d.n_obj + d.n_pt), p->stream);
+        if (e == hipSuccess) e = host_alloc_cached(p->device, (void**)&p->scal_host, 16 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent, &p->host_bytes[0]);
         if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&p->scal_host_dev, p->scal_host, 0);
-        if (e == hipSuccess) p->scal_host[4] = 0.0;
+        if (e == hipSuccess) p->scal_host[4] = p->scal_host[12] = 0.0;      // ([0..4] a trial's scalars + sequence word, [8..12] k_tail_publish's)
         if (e == hipSuccess) e = host_alloc_cached(p->device, (void**)&p->lvl_host, (size_t)std::max(d.n_edge + d.n_oe, 1), hipHostMallocDefault, &p->host_bytes[1]);
         if (e == hipSuccess) e = host_alloc_cached(p->device, (void**)&p->idx_host, sizeof(int32_t) * (size_t)std::max(d.n_kf + d.n_obj + d.n_pt, 1), hipHostMallocDefault, &p->host_bytes[2]);
         const int chol_lds = (int)(sizeof(double) * CHOL_LDS_DOUBLES);
@@ -3249,11 +3278,27 @@ extern "C" int qsp_ba_create(const qsp_ba_scene* s, int device, qsp_ba_problem**
         }
         p->deterministic = true;
     }
+    {   // every upload and memset above was asynchronous on the problem's stream: one wait, then the staging buffer goes back
+        const hipError_t e = hipStreamSynchronize(p->stream);
+        if (p->stage && !buf_cache_put(g_host_cache, p->device, p->stage, p->stage_alloc, hipHostMallocDefault, (size_t)64 << 20)) (void)hipHostFree(p->stage);
+        p->stage = nullptr;
+        p->stage_cap = p->stage_used = 0;
+        if (e != hipSuccess) {
+            qsp_ba_destroy(p);
+            return qsp_fail(QSP_ERR_DEVICE, hipGetErrorString(e));
+        }
+    }
     *out = p;
     return QSP_OK;
 }
 
 extern "C" void qsp_ba_destroy(qsp_ba_problem* p) {
+    if (p && p->stage) {      // (a create that failed half-way)
+        (void)hipSetDevice(p->device);
+        if (p->stream) (void)hipStreamSynchronize(p->stream);
+        (void)hipHostFree(p->stage);
+        p->stage = nullptr;
+    }
     if (!p) return;
     (void)hipSetDevice(p->device);
     {
@@ -3301,6 +3346,8 @@ extern "C" void qsp_ba_release_caches(void) {
 extern "C" int qsp_ba_set_levels(qsp_ba_problem* p, const uint8_t* mono, const uint8_t* stereo, const uint8_t* obj) {
     if (!p) return qsp_fail(QSP_ERR_INVALID, "qsp_ba_set_levels: null problem");
     QSP_HIP(hipSetDevice(p->device));
+    p->host_stale = false;                 // (every level is rewritten below, on both sides)
+    p->tail_ready = false;
     std::fill(p->edge_level_h.begin(), p->edge_level_h.end(), 0);
     if (mono) for (int e = 0; e < p->n_mono; ++e) p->edge_level_h[p->mono_pos[e]] = mono[e] ? 1 : 0;
     if (stereo) for (int e = 0; e < p->n_stereo; ++e) p->edge_level_h[p->st_pos[e]] = stereo[e] ? 1 : 0;
@@ -3332,6 +3379,23 @@ extern "C" int qsp_ba_get_state(qsp_ba_problem* p, double* kf_pose, double* pt_x
 }
 
 // SparseOptimizer::initializeOptimization(level) + buildIndexMapping (sparse_optimizer.cpp:199-267,166-190)
+// vertices in id order (g2o's hessian order): the argsort is a property of the problem, computed once (qsp_ba_create)
+static void build_orders(qsp_ba_problem* p) {
+    const Dev& d = p->d;
+    if (p->pose_order.size() == (size_t)(d.n_kf + d.n_obj) && p->pt_order.size() == (size_t)d.n_pt) return;
+    std::vector<std::pair<int64_t, int>> v;
+    for (int i = 0; i < d.n_kf; ++i) v.push_back({p->kf_id_h[i], i});
+    for (int i = 0; i < d.n_obj; ++i) v.push_back({p->obj_id_h[i], d.n_kf + i});
+    std::sort(v.begin(), v.end());
+    p->pose_order.clear();
+    for (const auto& q : v) p->pose_order.push_back(q.second);
+    v.clear();
+    for (int i = 0; i < d.n_pt; ++i) v.push_back({p->pt_id_h[i], i});
+    std::sort(v.begin(), v.end());
+    p->pt_order.clear();
+    for (const auto& q : v) p->pt_order.push_back(q.second);
+}
+
 static void build_index(qsp_ba_problem* p) {
     const Dev& d = p->d;
     std::vector<uint8_t> ka(d.n_kf, 0), oa(d.n_obj, 0), pa(d.n_pt, 0);
@@ -3339,20 +3403,7 @@ static void build_index(qsp_ba_problem* p) {
         if (!p->edge_level_h[e]) { ka[p->edge_h[e].kf] = 1; pa[p->edge_h[e].pt] = 1; }
     for (int e = 0; e < d.n_oe; ++e)
         if (!p->oe_level_h[e]) { ka[p->oe_kf_h[e]] = 1; oa[p->oe_obj_h[e]] = 1; }
-    // vertices in id order (g2o's hessian order): the argsort is a property of the problem, computed once
-    if (p->pose_order.size() != (size_t)(d.n_kf + d.n_obj)) {
-        std::vector<std::pair<int64_t, int>> v;
-        for (int i = 0; i < d.n_kf; ++i) v.push_back({p->kf_id_h[i], i});
-        for (int i = 0; i < d.n_obj; ++i) v.push_back({p->obj_id_h[i], d.n_kf + i});
-        std::sort(v.begin(), v.end());
-        p->pose_order.clear();
-        for (const auto& q : v) p->pose_order.push_back(q.second);
-        v.clear();
-        for (int i = 0; i < d.n_pt; ++i) v.push_back({p->pt_id_h[i], i});
-        std::sort(v.begin(), v.end());
-        p->pt_order.clear();
-        for (const auto& q : v) p->pt_order.push_back(q.second);
-    }
+    build_orders(p);
     p->kf_h.assign(d.n_kf, -1); p->obj_h.assign(d.n_obj, -1); p->pt_h.assign(d.n_pt, -1);
     int k = 0;
     for (int i : p->pose_order) {
@@ -3394,29 +3445,45 @@ static int publish_scal(qsp_ba_problem* p) {
 // that word in coherent pinned memory and sees the scalars a few microseconds after the kernel, with no event object or
 // signal packet in the stream.  (The ~10 us in front of the kernel that follows the publish are the system-scope release of a
 // kernel that wrote host memory: they were there with an event record as well.)
-static int wait_scal(qsp_ba_problem* p, double* out4) {
-    volatile double* seq = p->scal_host + 4;
+static int wait_words(qsp_ba_problem* p, int base, double want, double* out4) {
+    volatile double* seq = p->scal_host + base + 4;
     const auto t0 = std::chrono::steady_clock::now();
-    for (uint64_t spin = 0; *seq != p->scal_seq; ++spin) {
+    for (uint64_t spin = 0; *seq != want; ++spin) {
         // the word normally arrives within tens of microseconds; past ~0.5 ms of spinning (a slow peer rank in a sharded run, a
         // preempted process) the core is handed back between polls instead of being burnt for up to the timeout
         if (spin > 0xFFFF) std::this_thread::yield();
         if ((spin & 0xFFFF) == 0xFFFF) {     // a faulted or wedged kernel must not hang the caller: ask the runtime now and then
             const hipError_t e = hipStreamQuery(p->stream);
             if (e != hipSuccess && e != hipErrorNotReady) return qsp_fail(QSP_ERR_DEVICE, hipGetErrorString(e));
-            if (e == hipSuccess && *seq != p->scal_seq)     // the stream has drained: the word is visible at the latest now
+            if (e == hipSuccess && *seq != want)     // the stream has drained: the word is visible at the latest now
                 return qsp_fail(QSP_ERR_DEVICE, "BA scalar read-back: sequence word never arrived");
             if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30))
                 return qsp_fail(QSP_ERR_DEVICE, "BA scalar read-back timed out");
         }
     }
     std::atomic_thread_fence(std::memory_order_acquire);
-    for (int i = 0; i < 4; ++i) out4[i] = p->scal_host[i];
+    for (int i = 0; i < 4; ++i) out4[i] = p->scal_host[base + i];
     return QSP_OK;
 }
+static int wait_scal(qsp_ba_problem* p, double* out4) { return wait_words(p, 0, p->scal_seq, out4); }
 static int read_scal(qsp_ba_problem* p, double* out4) {
     int rc = publish_scal(p);
     return rc ? rc : wait_scal(p, out4);
+}
+
+// After a device-side stage boundary (k_tail_*) the host's copies of the levels and of the landmark numbering lag behind the
+// device; whoever needs them (the next index build, qsp_ba_get_index) fetches the levels and rebuilds the tables -- host work
+// that is off the path of the bundle adjustment that produced them.
+static void build_index(qsp_ba_problem* p);
+static int refresh_host_index(qsp_ba_problem* p) {
+    if (!p->host_stale) return QSP_OK;
+    const Dev& d = p->d;
+    QSP_HIP(hipStreamSynchronize(p->stream));
+    if (d.n_edge) QSP_HIP(hipMemcpy(p->edge_level_h.data(), d.edge_level, d.n_edge, hipMemcpyDeviceToHost));
+    if (d.n_oe) QSP_HIP(hipMemcpy(p->oe_level_h.data(), d.oe_level, d.n_oe, hipMemcpyDeviceToHost));
+    p->host_stale = false;
+    build_index(p);
+    return QSP_OK;
 }
 
 static int upload_levels(qsp_ba_problem* p) {
@@ -3534,14 +3601,22 @@ static int launch_errors(qsp_ba_problem* p, const Par& par) {
 // chi2 (scal[0]) and the rho denominator (scal[1]) summed over ranks
 static int reduce_scalars(qsp_ba_problem* p) { return allreduce_gather(p, p->d.scal, 2, nullptr, 0, nullptr, 0); }
 
-extern "C" int qsp_ba_optimize(qsp_ba_problem* p, int32_t n_iter, double delta_mono, double delta_stereo,
-                               double delta_obj, const volatile uint8_t* stop_flag, qsp_ba_trace* tr) {
-    if (!p) return qsp_fail(QSP_ERR_INVALID, "qsp_ba_optimize: null problem");
+// want_tail: the call is the first stage of a local bundle adjustment -- its last iteration also enqueues the stage boundary
+// (k_tail_*) and leaves p->tail_ready.  head: the call is the second stage behind a boundary that was committed -- levels, index
+// tables, first chi2, first system and lambda's seed are on the device already.
+struct StageHead { double chi2, maxdiag; };
+static int ba_optimize(qsp_ba_problem* p, int32_t n_iter, double delta_mono, double delta_stereo, double delta_obj,
+                       const volatile uint8_t* stop_flag, qsp_ba_trace* tr, bool want_tail, const StageHead* head) {
     QSP_HIP(hipSetDevice(p->device));
     Dev& d = p->d;
     hipStream_t s = p->stream;
-    build_index(p);
-    {   // hessian indices: through pinned staging (a pageable source makes the "async" copy a synchronous staged one), and only
+    p->tail_ready = false;
+    if (!head) {
+        const int rc0 = refresh_host_index(p);
+        if (rc0) return rc0;
+        build_index(p);
+    }
+    if (!head) {   // hessian indices: through pinned staging (a pageable source makes the "async" copy a synchronous staged one), and only
         // the arrays that differ from what the device already holds (the second round of a local BA rarely changes them)
         const size_t nk = d.n_kf, no = d.n_obj, np_ = d.n_pt;
         if (p->idx_uploaded.size() != nk + no + np_) p->idx_uploaded.assign(nk + no + np_, INT32_MIN);
@@ -3557,7 +3632,7 @@ extern "C" int qsp_ba_optimize(qsp_ba_problem* p, int32_t n_iter, double delta_m
     }
     if (sizeof(double) * (size_t)(2 * p->dimp + NB) > SCHUR_ROW_LDS_MAX)     // k_chol_back keeps y and x in LDS (dimp <= 10 208):
         return qsp_fail(QSP_ERR_UNSUPPORTED, "qsp_ba_optimize: reduced camera system too large for the dense solver");   // refused before anything is enqueued
-    if (d.n_edge) hipLaunchKernelGGL(k_edge_index, dim3((d.n_edge + 255) / 256), dim3(256), 0, s, d);
+    if (d.n_edge && !head) hipLaunchKernelGGL(k_edge_index, dim3((d.n_edge + 255) / 256), dim3(256), 0, s, d);
     Par par{delta_mono, delta_stereo, delta_obj, 0.0, p->dim, p->dimp, p->n_pose, p->rank == 0 ? 1 : 0,
             (p->deterministic && p->dimp > 0) ? 1 : 0, p->n_dense, p->elim ? 1 : 0};
     if (tr) { tr->n = 0; tr->result = 0; tr->n_pose_blocks = p->n_pose; tr->n_landmarks = p->n_land; }
@@ -3593,18 +3668,49 @@ extern "C" int qsp_ba_optimize(qsp_ba_problem* p, int32_t n_iter, double delta_m
         }
         return allreduce_gather(p, d.Hdiag, (size_t)36 * p->n_pose, d.bp, (size_t)p->dim_all, d.scal, with_chi2 ? 1 : 0);   // pose blocks, b_p, chi2
     };
+    // The stage boundary, speculated behind the last iteration's trial (k_tail_*): classification into the second level arrays, new
+    // landmark numbering, then the second stage's first chi2 / system / lambda seed on those buffers.
+    const bool tail_possible = want_tail && p->world == 1 && p->pt_order_uploaded && (d.n_edge + d.n_oe) > 0;
+    auto enqueue_tail = [&]() -> int {
+        ++p->act_epoch;
+        const int n = std::max(std::max(d.n_edge, d.n_oe), 1);
+        hipLaunchKernelGGL(k_tail_classify, dim3((n + 255) / 256), dim3(256), 0, s, d, p->edge_level2, p->oe_level2, p->edge_ha2, p->act,
+                           p->act_epoch, 5.991, 7.815, 1e3);
+        hipLaunchKernelGGL(k_tail_reindex, dim3(1), dim3(1024), 0, s, d, (const int32_t*)p->act, p->act_epoch, p->pt_h2);
+        Dev d2 = d;
+        d2.edge_level = p->edge_level2; d2.oe_level = p->oe_level2; d2.edge_ha = p->edge_ha2; d2.pt_h = p->pt_h2;
+        Par par2 = par;
+        par2.delta_mono = par2.delta_stereo = par2.delta_obj = 0.0;      // robust kernels dropped, src/Optimizer_util.cc:628,643,655
+        par2.lambda = 0.0;
+        const int n_tot = d.n_edge + d.n_oe;
+        const int grid = std::max(1, std::min(p->n_partial, (n_tot + 255) / 256));
+        hipLaunchKernelGGL(k_errors, dim3(grid), dim3(256), 0, s, d2, par2);
+        const int nb_e = d.n_ksplit + d.n_chunk + (d.n_oe + 3) / 4;
+        if (nb_e) hipLaunchKernelGGL(k_lin_edges, dim3(nb_e), dim3(256), 0, s, d2, par2, d.n_ksplit, d.n_chunk);
+        hipLaunchKernelGGL(k_lin_vertices, dim3(d.n_kf + d.n_obj), dim3(64), 0, s, d2, par2);
+        const int gm = std::max(1, std::min(256, (d.n_pt * 3 + p->n_pose * 6 + 255) / 256));
+        hipLaunchKernelGGL(k_maxdiag, dim3(gm), dim3(256), 0, s, d2, par2);
+        p->tail_seq += 1.0;
+        hipLaunchKernelGGL(k_tail_publish, dim3(1), dim3(64), 0, s, d2, grid, p->scal_host_dev + 8, p->tail_seq);
+        return QSP_OK;
+    };
+    bool tail_ok = false;        // the last trial of the call was accepted with the stage boundary enqueued behind it
     bool lin_ready = false;      // the system of the current estimates is already enqueued (speculated behind an accepted trial)
     for (int it = 0; it < n_iter; ++it) {
         if (stop_flag && *stop_flag) { result = 2; break; }
         // computeActiveErrors + chi2 (sparse_optimizer.cpp:61-114).  After the first iteration the state is the one the last
         // accepted trial was evaluated on -- the same kernel on the same numbers -- so its chi2 is carried over instead of
         // being recomputed and read back (an iteration never starts after a rejected trial: that ends the call).
-        if (it == 0) launch_errors(p, par);
+        if (it == 0 && !head) launch_errors(p, par);
         int rc = QSP_OK;
-        if (!lin_ready) rc = enqueue_lin(it == 0);
+        if (!lin_ready && !(it == 0 && head)) rc = enqueue_lin(it == 0);
         if (rc) return rc;
         lin_ready = false;
-        if (it == 0) {
+        if (it == 0 && head) {      // chi2, system and lambda's seed of these estimates and levels are there (k_tail_*)
+            sc[0] = head->chi2;
+            sc[2] = head->maxdiag;
+            currentChi = sc[0];
+        } else if (it == 0) {
             const int gm = std::max(1, std::min(256, (d.n_pt * 3 + p->n_pose * 6 + 255) / 256));      // (scal[2] was zeroed by k_lin_vertices)
             hipLaunchKernelGGL(k_maxdiag, dim3(gm), dim3(256), 0, s, d, par);
             if (p->world > 1 && p->nccl) {   // max over ranks of the local maxima
@@ -3734,10 +3840,16 @@ extern "C" int qsp_ba_optimize(qsp_ba_problem* p, int32_t n_iter, double delta_m
             // the host's turn-around hide behind ~50 us of device work.  If the trial is rejected the speculated system (of the
             // estimates about to be rolled back) is rebuilt after the restore.
             const bool spec = p->speculate && it + 1 < n_iter;
+            const bool tail = tail_possible && it + 1 == n_iter;      // (spec is false then: both overwrite the system's buffers)
             if (spec) {
                 rc = enqueue_lin(false);
                 if (rc) return rc;
             }
+            if (tail) {
+                rc = enqueue_tail();
+                if (rc) return rc;
+            }
+            tail_ok = false;
             rc = wait_scal(p, sc);
             if (rc) return rc;
             if (sc[3] == 2.0) {
@@ -3755,7 +3867,7 @@ extern "C" int qsp_ba_optimize(qsp_ba_problem* p, int32_t n_iter, double delta_m
                 QSP_HIP(hipMemcpyAsync(d.kf_pose, d.kf_bk, sizeof(double) * 7 * d.n_kf, hipMemcpyDeviceToDevice, s));
                 if (d.n_obj) QSP_HIP(hipMemcpyAsync(d.obj_pose, d.obj_bk, sizeof(double) * 7 * d.n_obj, hipMemcpyDeviceToDevice, s));
                 if (d.n_pt) QSP_HIP(hipMemcpyAsync(d.pt_xyz, d.pt_bk, sizeof(double) * 3 * d.n_pt, hipMemcpyDeviceToDevice, s));
-                if (spec) {      // the speculated system overwrote this iteration's
+                if (spec || tail) {      // the speculated system overwrote this iteration's
                     rc = enqueue_lin(false);
                     if (rc) return rc;
                 }
@@ -3775,6 +3887,7 @@ extern "C" int qsp_ba_optimize(qsp_ba_problem* p, int32_t n_iter, double delta_m
                 currentChi = tempChi;
                 accepted = 1;
                 lin_ready = spec;
+                tail_ok = tail;
             } else {
                 lambda *= ni;
                 ni *= 2;
@@ -3782,7 +3895,7 @@ extern "C" int qsp_ba_optimize(qsp_ba_problem* p, int32_t n_iter, double delta_m
                 if (d.n_obj) QSP_HIP(hipMemcpyAsync(d.obj_pose, d.obj_bk, sizeof(double) * 7 * d.n_obj, hipMemcpyDeviceToDevice, s));
                 if (d.n_pt) QSP_HIP(hipMemcpyAsync(d.pt_xyz, d.pt_bk, sizeof(double) * 3 * d.n_pt, hipMemcpyDeviceToDevice, s));
                 accepted = 0;
-                if (spec) {      // the speculated system overwrote this iteration's: rebuild it for the restored estimates
+                if (spec || tail) {      // the speculated system overwrote this iteration's: rebuild it for the restored estimates
                     rc = enqueue_lin(false);
                     if (rc) return rc;
                 }
@@ -3818,6 +3931,7 @@ extern "C" int qsp_ba_optimize(qsp_ba_problem* p, int32_t n_iter, double delta_m
         }
         for (hipEvent_t e : lin_ev) (void)hipEventDestroy(e);
         // algorithmic bytes of one linearisation
+        (void)refresh_host_index(p);      // (profiling only: the level counts come from the host's copies)
         int64_t nm = 0, ns = 0, no = 0;
         for (int e = 0; e < d.n_edge; ++e)
             if (!p->edge_level_h[e]) (p->edge_h[e].stereo ? ns : nm)++;
@@ -3827,11 +3941,23 @@ extern "C" int qsp_ba_optimize(qsp_ba_problem* p, int32_t n_iter, double delta_m
     if (tr) tr->result = result;
     QSP_HIP(hipGetLastError());
     if (tr) tr->iterations = done;
+    p->tail_ready = tail_ok;
     return QSP_OK;
+}
+
+extern "C" int qsp_ba_optimize(qsp_ba_problem* p, int32_t n_iter, double delta_mono, double delta_stereo,
+                               double delta_obj, const volatile uint8_t* stop_flag, qsp_ba_trace* tr) {
+    if (!p) return qsp_fail(QSP_ERR_INVALID, "qsp_ba_optimize: null problem");
+    return ba_optimize(p, n_iter, delta_mono, delta_stereo, delta_obj, stop_flag, tr, false, nullptr);
 }
 
 extern "C" int qsp_ba_get_index(qsp_ba_problem* p, int32_t* kf_hidx, int32_t* obj_hidx, int32_t* pt_hidx) {
     if (!p) return qsp_fail(QSP_ERR_INVALID, "qsp_ba_get_index: null problem");
+    QSP_HIP(hipSetDevice(p->device));
+    {
+        const int rc = refresh_host_index(p);
+        if (rc) return rc;
+    }
     if (kf_hidx) memcpy(kf_hidx, p->kf_h.data(), sizeof(int32_t) * p->kf_h.size());
     if (obj_hidx) memcpy(obj_hidx, p->obj_h.data(), sizeof(int32_t) * p->obj_h.size());
     if (pt_hidx) memcpy(pt_hidx, p->pt_h.data(), sizeof(int32_t) * p->pt_h.size());
@@ -3894,13 +4020,39 @@ extern "C" int qsp_ba_local_joint(qsp_ba_problem* p, const volatile uint8_t* sto
     const double t0 = now();
     int rc = qsp_ba_set_levels(p, nullptr, nullptr, nullptr);
     const double t1s = now();
-    if (!rc) rc = qsp_ba_optimize(p, 5, (double)(float)sqrt(5.991), (double)(float)sqrt(7.815), (double)thObj, stop_flag, t1);
+    static const bool no_tail = getenv("QSP_BA_HOST_BOUNDARY") != nullptr;      // (A/B: the host-side stage boundary of round 3)
+    if (!rc) rc = ba_optimize(p, 5, (double)(float)sqrt(5.991), (double)(float)sqrt(7.815), (double)thObj, stop_flag, t1, !no_tail, nullptr);
     (void)thMono; (void)thStereo;
     if (rc) return rc;
     const double t2s = now();
     if (stop_flag && *stop_flag) return QSP_OK;                                   // :603-610 (no write-back by the caller)
-    const Dev& d = p->d;
+    Dev& d = p->d;
     double t3s = t2s;
+    if (p->tail_ready) {
+        // The stage boundary ran on the device behind the first stage's last trial (k_tail_*): its four numbers are in (or on their
+        // way to) the second pinned slot.  No pose vertex changed its activity -> the second level arrays, landmark numbering and
+        // edge table become the current ones by a pointer swap, and the second stage starts at its first trial.
+        double th[4];
+        rc = wait_words(p, 8, p->tail_seq, th);
+        if (rc) return rc;
+        if (th[2] == 0.0) {
+            std::swap(d.edge_level, p->edge_level2);
+            std::swap(d.oe_level, p->oe_level2);
+            std::swap(d.edge_ha, p->edge_ha2);
+            std::swap(d.pt_h, p->pt_h2);
+            p->n_land = (int)th[3];
+            p->host_stale = true;                                             // (levels / landmark numbering: fetched when somebody asks)
+            if (!p->idx_uploaded.empty()) std::fill(p->idx_uploaded.begin() + d.n_kf + d.n_obj, p->idx_uploaded.end(), INT32_MIN);
+            const StageHead head{th[0], th[1]};
+            t3s = now();
+            rc = ba_optimize(p, 10, 0.0, 0.0, 0.0, stop_flag, t2, false, &head);   // robust kernels dropped, :628,643,655
+            if (tm)
+                fprintf(stderr, "local_joint us: set_levels %.0f  optimize(5) %.0f  boundary (device) %.0f  optimize(10) %.0f\n",
+                        t1s - t0, t2s - t1s, t3s - t2s, now() - t3s);
+            return rc;
+        }
+        // (a key-frame or an object lost its last active edge: the reduced system changes shape -- the host path below)
+    }
     if (p->world == 1) {
         // one GPU: classify where the chi2 values are; the host needs the levels only (build_index), one byte per edge
         const int n = std::max(std::max(d.n_edge, d.n_oe), 1);
