@@ -22,7 +22,28 @@ constexpr int MAX_DEPTH = 64;
 constexpr int NW_REND = QSP_NW_REND;     // render slots per hypothesis (work items looping over render-row tiles beyond 16 x 64 rows)
 constexpr int NW_SDF_MAX = QSP_NW_SDF_MAX;  // work items per hypothesis looping over surface-point tiles
 constexpr int NH = 71;          // 7 pose + 64 code unknowns
-constexpr int PART_FLOATS = HT_TILES * 1024;
+// One partial sum of J~^T J~ per (hypothesis, slot): the UPPER TRIANGLE of the 72 x 72 matrix, packed row by row (2628 floats,
+// padded to a multiple of 32: 10.4 KB).  Rounds 1-3 stored the six 32 x 32 MFMA tiles of the padded 96 x 96 upper triangle whole
+// (24 KB: 0.8 GB of writes per C4 launch, and k_solve pulled 1.9 MB per hypothesis through one compute unit).  Same values, same
+// order of summation over the slots: same bits.
+constexpr int PART_FLOATS = ((NJ * (NJ + 1) / 2 + 31) / 32) * 32;
+__device__ __forceinline__ int tri72(int r, int c) { return r * NJ - (r * (r - 1)) / 2 + (c - r); }      // r <= c < NJ
+// the accumulator tile (ta, tb) of a wave <-> its entries of the packed triangle (entries below the diagonal or beyond column 71
+// are not stored: nobody reads them; a continued item restarts them from 0)
+__device__ __forceinline__ void part_store(float* __restrict__ slot, int ta, int tb, int lane, const f32x16& hacc) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int r = 32 * ta + acc_row(i, lane), c = 32 * tb + (lane & 31);
+        if (r <= c && c < NJ) slot[tri72(r, c)] = hacc[i];
+    }
+}
+__device__ __forceinline__ void part_load(const float* __restrict__ slot, int ta, int tb, int lane, bool first, f32x16& hacc) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int r = 32 * ta + acc_row(i, lane), c = 32 * tb + (lane & 31);
+        hacc[i] = (!first && r <= c && c < NJ) ? slot[tri72(r, c)] : 0.f;
+    }
+}
 
 // per-hypothesis state, resident in HBM
 struct HypState {
@@ -810,12 +831,8 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void k_mlp_jtj(const HypState* __re
         }
         QSP_TSK(4)
     }
-    // partial slot [h][slot][tile][32][32]
-    if (wave < 6) {
-        float* out = partials + ((int64_t)h * nw_total + slot) * PART_FLOATS + wave * 1024;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) out[acc_row(i, lane) * 32 + (lane & 31)] = hacc[i];
-    }
+    // partial slot [h][slot][packed upper triangle of 72 x 72]
+    if (wave < 6) part_store(partials + ((int64_t)h * nw_total + slot) * PART_FLOATS, ta, tb, lane, hacc);
     QSP_TSK(5)
     tsk_first = false;
   }
@@ -1008,32 +1025,28 @@ __global__ __launch_bounds__(64 * NW) void k_mlp_jtj_h2(JtjArgs /* read through 
                 }
             }
             // upper-triangular 32x32 tiles in the order (0,0) (0,1) (0,2) (1,1) (1,2) (2,2).  Four waves: tile w on every wave, tile
-            // w + 4 on waves 0, 1; eight waves: tile w on waves 0..5.  Partial slot [h][slot][tile][32][32].
-            float* out = A->partials + ((int64_t)h * nw_total + slot) * PART_FLOATS + wave * 1024;
+            // w + 4 on waves 0, 1; eight waves: tile w on waves 0..5.  Partial slot [h][slot][packed upper triangle].
+            float* out = A->partials + ((int64_t)h * nw_total + slot) * PART_FLOATS;
             const bool first = t == j0;
             if (NW == 4 || wave < 6) {
                 const int ta0 = wave < 3 ? 0 : (wave < 5 ? 1 : 2), tb0 = wave < 3 ? wave : (wave < 5 ? wave - 2 : 2);
                 f32x16 hacc;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) hacc[i] = first ? 0.f : out[acc_row(i, lane) * 32 + (lane & 31)];
+                part_load(out, ta0, tb0, lane, first, hacc);
                 const float* Aj = Jt + (lane >> 5) * LDJ + 32 * ta0 + (lane & 31);
                 const float* Bj = Jt + (lane >> 5) * LDJ + 32 * tb0 + (lane & 31);
 #pragma unroll 8
                 for (int ks = 0; ks < TP / 2; ++ks) hacc = mfma32t<false>(Aj[2 * ks * LDJ], Bj[2 * ks * LDJ], hacc);
-#pragma unroll
-                for (int i = 0; i < 16; ++i) out[acc_row(i, lane) * 32 + (lane & 31)] = hacc[i];
+                part_store(out, ta0, tb0, lane, hacc);
             }
             if (NW == 4 && wave < 2) {
                 const int ta1 = wave == 0 ? 1 : 2, tb1 = 2;
                 f32x16 hacc;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) hacc[i] = first ? 0.f : out[4 * 1024 + acc_row(i, lane) * 32 + (lane & 31)];
+                part_load(out, ta1, tb1, lane, first, hacc);
                 const float* Aj = Jt + (lane >> 5) * LDJ + 32 * ta1 + (lane & 31);
                 const float* Bj = Jt + (lane >> 5) * LDJ + 32 * tb1 + (lane & 31);
 #pragma unroll 8
                 for (int ks = 0; ks < TP / 2; ++ks) hacc = mfma32t<false>(Aj[2 * ks * LDJ], Bj[2 * ks * LDJ], hacc);
-#pragma unroll
-                for (int i = 0; i < 16; ++i) out[4 * 1024 + acc_row(i, lane) * 32 + (lane & 31)] = hacc[i];
+                part_store(out, ta1, tb1, lane, hacc);
             }
             // the item's next tile (more than nw_sdf x TP surface points, or more than 16 x TP render rows), or the next item
             t += stride;
@@ -1160,7 +1173,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(HypState* __restrict__ 
     for (int e = tid; e < NJ * NJ; e += SOLVE_THREADS) {
         const int a = e / NJ, b = e % NJ;
         if (a > b) continue;
-        const int off = tri_tile(a >> 5, b >> 5) * 1024 + (a & 31) * 32 + (b & 31);
+        const int off = tri72(a, b);
         float ss = 0.f, sr = 0.f;
         // same left-to-right order as ever; unrolled so that 32 of the (24 KiB-strided) loads are in flight at a time (a single
         // object's 2 k points are 63 slots of 32-point tiles: two batches instead of four in front of every entry)
