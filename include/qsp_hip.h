@@ -59,6 +59,12 @@ typedef struct {
 
 typedef struct qsp_decoder qsp_decoder;
 
+/* Threads.  A decoder owns one HIP stream, one resident refinement batch and a few fields that a call rewrites for its own duration
+ * (the f32 override of a range fallback, the screening margin of a self-check repeat).  Every entry point that launches on a
+ * decoder -- qsp_decode_sdf*, qsp_sdf_value_grad, qsp_refine_batch_set_state / _run / _get, qsp_reconstruct_objects,
+ * qsp_estimate_pose, qsp_refine_detections, qsp_mesh_extract / _from_volume, qsp_decoder_set_option -- takes the decoder's lock:
+ * host threads may share a decoder and get correct results, one call at a time.  Threads that should overlap on the GPU use a
+ * decoder each. */
 int qsp_decoder_create(const qsp_decoder_desc* desc, int device, qsp_decoder** out);
 /* Batches and mesh extractors created from a decoder use it until they are destroyed: destroy them first.  (Destroying one of
  * them after its decoder only frees its own memory and is harmless; any other call on it is undefined.) */

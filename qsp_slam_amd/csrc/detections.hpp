@@ -187,6 +187,8 @@ struct DevPool {            // the call's temporary device arrays
 
 extern "C" int qsp_refine_detections(qsp_decoder* dec, const qsp_joint_cfg* cfg, const qsp_detections* in,
                                      qsp_detection_results* out) {
+    std::unique_lock<std::recursive_mutex> lk_d;
+    if (dec) lk_d = std::unique_lock<std::recursive_mutex>(dec->mu);
     using namespace qsp::det;
     if (!dec || !cfg || !in || !out) return qsp_fail(QSP_ERR_INVALID, "qsp_refine_detections: null argument");
     const int n = in->n_det;

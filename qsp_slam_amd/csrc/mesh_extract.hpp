@@ -412,6 +412,8 @@ static int mesh_decode(qsp_mesh_extractor* m, const float* code, bool* hit) {
 }
 
 extern "C" int qsp_mesh_extract(qsp_mesh_extractor* m, const float* code, int64_t* n_verts, int64_t* n_faces) {
+    std::unique_lock<std::recursive_mutex> lk_d;
+    if (m && m->dec) lk_d = std::unique_lock<std::recursive_mutex>(m->dec->mu);
     if (!m || !code) return qsp_fail(QSP_ERR_INVALID, "qsp_mesh_extract: null argument");
     QSP_HIP(hipSetDevice(m->dec->device));
     bool hit = false;
@@ -428,6 +430,8 @@ extern "C" int qsp_mesh_extract(qsp_mesh_extractor* m, const float* code, int64_
 }
 
 extern "C" int qsp_mesh_from_volume(qsp_mesh_extractor* m, const float* sdf_volume, int64_t* n_verts, int64_t* n_faces) {
+    std::unique_lock<std::recursive_mutex> lk_d;
+    if (m && m->dec) lk_d = std::unique_lock<std::recursive_mutex>(m->dec->mu);
     if (!m || !sdf_volume) return qsp_fail(QSP_ERR_INVALID, "qsp_mesh_from_volume: null argument");
     QSP_HIP(hipSetDevice(m->dec->device));
     QSP_HIP(hipMemcpyAsync(m->sdf, sdf_volume, sizeof(float) * m->n, hipMemcpyHostToDevice, m->dec->stream));

@@ -156,11 +156,11 @@ __device__ __forceinline__ float huber_w(float r, float b) {
 // ---------------------------------------------------------------------------------------------------------------
 // k_sample: per-hypothesis prologue + valid ray samples (loss.py:60-74, optimizer.py:144-153)
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_sample(HypState* __restrict__ st, const ObjView* __restrict__ objs,
-                                                const float* __restrict__ rays, RefineCfg cfg,
-                                                int32_t* __restrict__ valid_rk, int64_t rk_stride,
-                                                int32_t* __restrict__ ray_voff, int64_t ray_stride,
-                                                const MlpParams* __restrict__ Pm, float* __restrict__ c0_all) {
+__device__ __forceinline__ void sample_body(HypState* __restrict__ st, const ObjView* __restrict__ objs,
+                                            const float* __restrict__ rays, const RefineCfg& cfg,
+                                            int32_t* __restrict__ valid_rk, int64_t rk_stride,
+                                            int32_t* __restrict__ ray_voff, int64_t ray_stride,
+                                            const MlpParams* __restrict__ Pm, float* __restrict__ c0_all) {
     const int h = blockIdx.x;
     HypState& S = st[h];
     if (!S.alive) return;
@@ -236,6 +236,35 @@ __global__ __launch_bounds__(256) void k_sample(HypState* __restrict__ st, const
     }
 }
 
+// The work-queue plan of the kernel that FOLLOWS (k_plan's arithmetic) in the tail of its producer: every workgroup of k_sample /
+// k_scan counts itself done behind its last store to the hypothesis state, the one that finishes last builds the item list.  One
+// launch and one kernel boundary less in front of each of the two MLP kernels (~9 us each, 10 per one-object call: round 3's
+// one-object call spent 0.1 of its 2.8 ms there).  done[] is reset by its last reader.
+struct PlanTail {
+    int2* work;            // nullptr: no tail (the plan is a launch of its own)
+    int* qctl;
+    int* done;
+    int n_hyp, nw_sdf, nw_rend, tile_p, mode;
+};
+template <int NT>
+__device__ __forceinline__ void plan_body(int mode, const HypState* __restrict__ st, const ObjView* __restrict__ objs, int n_hyp, int nw_sdf,
+                                          int nw_rend, int2* __restrict__ work, int* __restrict__ qctl, int tile_p);
+template <int NT>
+__device__ __forceinline__ void plan_tail(const PlanTail& pt, const HypState* st, const ObjView* objs) {
+    if (!pt.work) return;
+    __shared__ int s_last;
+    __syncthreads();                                   // (thread 0's stores to the hypothesis state are behind us)
+    if (threadIdx.x == 0) {
+        __threadfence();
+        s_last = atomicAdd(pt.done, 1) == pt.n_hyp - 1;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();                                   // (acquire: the other workgroups' n_valid / n_render / alive)
+    plan_body<NT>(pt.mode, st, objs, pt.n_hyp, pt.nw_sdf, pt.nw_rend, pt.work, pt.qctl, pt.tile_p);
+    if (threadIdx.x == 0) *pt.done = 0;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // staging of one tile's inputs
 // ---------------------------------------------------------------------------------------------------------------
@@ -277,15 +306,15 @@ __global__ __launch_bounds__(MLP_THREADS) void k_c0(const HypState* __restrict__
 
 // mode 0: forward items (h, tile) over the valid ray samples; mode 1: jtj items (h, slot), surface slots then render slots;
 // mode 2: forward items (h, tile) over the hypothesis's band list (screened forward pass)
-__global__ __launch_bounds__(1024) void k_plan(int mode, const HypState* __restrict__ st, const ObjView* __restrict__ objs,
-                                               int n_hyp, int nw_sdf, int nw_rend, int2* __restrict__ work, int* __restrict__ qctl,
-                                               int tile_p) {
-    __shared__ int wsum[16];
+template <int NT>
+__device__ __forceinline__ void plan_body(int mode, const HypState* __restrict__ st, const ObjView* __restrict__ objs, int n_hyp, int nw_sdf,
+                                          int nw_rend, int2* __restrict__ work, int* __restrict__ qctl, int tile_p) {
+    __shared__ int wsum[NT / 64];
     __shared__ int carry_sh;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     if (t == 0) carry_sh = 0;
     __syncthreads();
-    for (int base = 0; base < n_hyp; base += 1024) {
+    for (int base = 0; base < n_hyp; base += NT) {
         const int h = base + t;
         int n_a = 0, n_b = 0;
         if (h < n_hyp && st[h].alive) {
@@ -310,7 +339,7 @@ __global__ __launch_bounds__(1024) void k_plan(int mode, const HypState* __restr
         for (int j = 0; j < n_a; ++j) work[off + j] = make_int2(h, j);
         for (int j = 0; j < n_b; ++j) work[off + n_a + j] = make_int2(h, nw_sdf + j);
         __syncthreads();
-        if (t == 1023) carry_sh = off + cnt;
+        if (t == NT - 1) carry_sh = off + cnt;
         __syncthreads();
     }
     if (t == 0) {
@@ -318,6 +347,20 @@ __global__ __launch_bounds__(1024) void k_plan(int mode, const HypState* __restr
         qctl[2 * q] = carry_sh;
         qctl[2 * q + 1] = 0;
     }
+}
+
+__global__ __launch_bounds__(1024) void k_plan(int mode, const HypState* __restrict__ st, const ObjView* __restrict__ objs,
+                                               int n_hyp, int nw_sdf, int nw_rend, int2* __restrict__ work, int* __restrict__ qctl,
+                                               int tile_p) {
+    plan_body<1024>(mode, st, objs, n_hyp, nw_sdf, nw_rend, work, qctl, tile_p);
+}
+__global__ __launch_bounds__(256) void k_sample(HypState* __restrict__ st, const ObjView* __restrict__ objs,
+                                                const float* __restrict__ rays, RefineCfg cfg,
+                                                int32_t* __restrict__ valid_rk, int64_t rk_stride,
+                                                int32_t* __restrict__ ray_voff, int64_t ray_stride,
+                                                const MlpParams* __restrict__ Pm, float* __restrict__ c0_all, PlanTail pt) {
+    sample_body(st, objs, rays, cfg, valid_rk, rk_stride, ray_voff, ray_stride, Pm, c0_all);
+    plan_tail<256>(pt, st, objs);        // the forward kernel's item list (k_plan mode 0)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -639,16 +682,15 @@ __device__ __forceinline__ int scan_ray(const float* __restrict__ row, int ray, 
     }
     return n;
 }
-__global__ __launch_bounds__(SCAN_RAYS) void k_scan(HypState* __restrict__ st, const ObjView* __restrict__ objs,
-                                                    const float* __restrict__ depth, RefineCfg cfg,
-                                                    const int32_t* __restrict__ valid_rk, int64_t rk_stride,
-                                                    const int32_t* __restrict__ ray_voff, int64_t ray_stride,
-                                                    const float* __restrict__ sdf_valid, int32_t* __restrict__ rend_rk,
-                                                    float* __restrict__ rend_deds, float* __restrict__ rend_res) {
+__device__ __forceinline__ void scan_body(float* __restrict__ rows /*[SCAN_RAYS][SCAN_LD]*/, HypState* __restrict__ st,
+                                          const ObjView* __restrict__ objs, const float* __restrict__ depth, const RefineCfg& cfg,
+                                          const int32_t* __restrict__ valid_rk, int64_t rk_stride,
+                                          const int32_t* __restrict__ ray_voff, int64_t ray_stride,
+                                          const float* __restrict__ sdf_valid, int32_t* __restrict__ rend_rk,
+                                          float* __restrict__ rend_deds, float* __restrict__ rend_res) {
     const int h = blockIdx.x;
     HypState& S = st[h];
     if (!S.alive) return;
-    extern __shared__ __attribute__((aligned(16))) float rows[];     // [SCAN_RAYS][SCAN_LD]
     __shared__ int sc[8];
     const ObjView ov = objs[S.obj];
     const int D = cfg.n_depth;
@@ -689,6 +731,16 @@ __global__ __launch_bounds__(SCAN_RAYS) void k_scan(HypState* __restrict__ st, c
         carry += tot;
     }
     if (threadIdx.x == 0) S.n_render = carry;
+}
+__global__ __launch_bounds__(SCAN_RAYS) void k_scan(HypState* __restrict__ st, const ObjView* __restrict__ objs,
+                                                    const float* __restrict__ depth, RefineCfg cfg,
+                                                    const int32_t* __restrict__ valid_rk, int64_t rk_stride,
+                                                    const int32_t* __restrict__ ray_voff, int64_t ray_stride,
+                                                    const float* __restrict__ sdf_valid, int32_t* __restrict__ rend_rk,
+                                                    float* __restrict__ rend_deds, float* __restrict__ rend_res, PlanTail pt) {
+    extern __shared__ __attribute__((aligned(16))) float rows[];     // [SCAN_RAYS][SCAN_LD]
+    scan_body(rows, st, objs, depth, cfg, valid_rk, rk_stride, ray_voff, ray_stride, sdf_valid, rend_rk, rend_deds, rend_res);
+    plan_tail<SCAN_RAYS>(pt, st, objs);      // the Jacobian kernel's item list (k_plan mode 1)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1280,7 +1332,12 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(HypState* __restrict__ 
     // Gauss-Jordan elimination in f64 on the augmented system (reference: torch.inverse(H) @ b, f32).  H is symmetric
     // positive definite by construction (Gram matrices plus the identity damping of optimizer.py:240-252 / :75), so no
     // pivot search is needed: one barrier per column, every (row, column strip) pair on its own thread.
-    const int STR = SOLVE_THREADS / N;         // 14 strips for the 71 x 71 system
+    // Four waves do the elimination (the other twelve leave: s_barrier counts the waves that are left).  Every element (r, j) is
+    // updated once per column whichever thread owns it, so the strip count changes no bit; what it changes is the cost of the 71
+    // barriers -- 16 waves at a barrier took ~0.4 us a column (30 of the kernel's 59 us on the one-object path), four take ~0.15.
+    constexpr int ELIM_THREADS = 256;
+    if (tid >= ELIM_THREADS) return;
+    const int STR = ELIM_THREADS / N;          // 3 strips for the 71 x 71 system
     for (int c = 0; c < N; ++c) {
         const double inv = 1.0 / Hd[c * (N + 1) + c];
         const int r = tid / STR, q = tid - r * STR;
@@ -1290,10 +1347,10 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(HypState* __restrict__ 
         }
         __syncthreads();
     }
-    for (int a = tid; a < N; a += SOLVE_THREADS) dxs[a] = (float)(Hd[a * (N + 1) + N] / Hd[a * (N + 1) + a]);
+    for (int a = tid; a < N; a += ELIM_THREADS) dxs[a] = (float)(Hd[a * (N + 1) + N] / Hd[a * (N + 1) + a]);
     __syncthreads();
     if (trdx)
-        for (int a = tid; a < N; a += SOLVE_THREADS) trdx[(int64_t)h * NH + a] = dxs[a];
+        for (int a = tid; a < N; a += ELIM_THREADS) trdx[(int64_t)h * NH + a] = dxs[a];
     if (tid == 0) {
         float d[7], Td[16], Tn[16];
         if (cfg.pose_only) {

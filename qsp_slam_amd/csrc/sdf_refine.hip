@@ -28,6 +28,7 @@
 
 #include <algorithm>
 #include <string>
+#include <mutex>
 #include <vector>
 
 #include "../../include/qsp_hip.h"
@@ -72,6 +73,11 @@ struct qsp_decoder {
     // qsp_reconstruct_objects keeps ONE resident batch per decoder, sized by the high-water mark of the calls so far: the
     // reference's call pattern is one object per call (src/LocalMapping_util.cc:705-760), and creating / destroying ~25 device
     // buffers per call cost ~0.5 ms of a 3 ms call
+    // One decoder = one stream, one resident batch (arena) and a few fields that calls rewrite for their own duration (the f32
+    // override of a range fallback, the screening margin of a self-check repeat): entry points that launch on the decoder or
+    // touch those serialise on this lock -- two host threads sharing a decoder get correct results, one call at a
+    // time; threads that want to overlap use a decoder each (the weights are 15 MB).
+    std::recursive_mutex mu;
     struct qsp_refine_batch* arena = nullptr;
     int64_t n_arena_reuse = 0, n_arena_create = 0;
 };
@@ -633,6 +639,8 @@ extern "C" int qsp_decoder_create(const qsp_decoder_desc* desc, int device, qsp_
 }
 
 extern "C" int qsp_decoder_set_option(qsp_decoder* d, int32_t option, int32_t value) {
+    std::unique_lock<std::recursive_mutex> lk_d;
+    if (d) lk_d = std::unique_lock<std::recursive_mutex>(d->mu);
     if (!d) return qsp_fail(QSP_ERR_INVALID, "qsp_decoder_set_option: null decoder");
     switch (option) {
         case QSP_DEC_OPT_FORWARD_PRECISION:
@@ -793,11 +801,15 @@ static int decode_common(qsp_decoder* d, const float* code, const float* xyz, in
 }
 
 extern "C" int qsp_decode_sdf(qsp_decoder* d, const float* code, const float* xyz, int64_t n, float* sdf_out) {
+    std::unique_lock<std::recursive_mutex> lk_d;
+    if (d) lk_d = std::unique_lock<std::recursive_mutex>(d->mu);
     return decode_common(d, code, xyz, n, sdf_out, nullptr);
 }
 
 // The screening tile's values on explicit points (diagnostic: tests and tools/screen_margin.py measure |s1 - s3| with it).
 extern "C" int qsp_decode_sdf_screen(qsp_decoder* d, const float* code, const float* xyz, int64_t n, float* s1_out) {
+    std::unique_lock<std::recursive_mutex> lk_d;
+    if (d) lk_d = std::unique_lock<std::recursive_mutex>(d->mu);
     if (!d || !code || !xyz || n < 0 || !s1_out) return qsp_fail(QSP_ERR_INVALID, "decode_screen: bad argument");
     if (n == 0) return QSP_OK;
     if (!d->fp16_ok) return qsp_fail(QSP_ERR_UNSUPPORTED, "split fp16: a weight of this decoder is outside fp16's range");
@@ -828,6 +840,8 @@ extern "C" int qsp_decode_sdf_screen(qsp_decoder* d, const float* code, const fl
 }
 
 extern "C" int qsp_sdf_value_grad(qsp_decoder* d, const float* code, const float* xyz, int64_t n, float* y, float* grad) {
+    std::unique_lock<std::recursive_mutex> lk_d;
+    if (d) lk_d = std::unique_lock<std::recursive_mutex>(d->mu);
     if (!grad) return qsp_fail(QSP_ERR_INVALID, "qsp_sdf_value_grad: grad is null");
     return decode_common(d, code, xyz, n, y, grad);
 }
@@ -1020,7 +1034,7 @@ static int batch_create(qsp_decoder* dec, const RefineCfg& cfg, int n_iter, int3
     QSP_ALLOC(b->trrot, sizeof(float) * (size_t)cap_hyp * 4);
     QSP_ALLOC(b->counters, sizeof(unsigned long long) * 8);
     QSP_ALLOC(b->st_snap, sizeof(HypState) * cap_hyp);
-    QSP_ALLOC(b->qctl, sizeof(int) * 4);
+    QSP_ALLOC(b->qctl, sizeof(int) * 8);      // [0..3] the two queues, [4], [5] the done counters of the plans in k_sample's / k_scan's tail
     QSP_ALLOC(b->c0_all, sizeof(float) * (size_t)cap_hyp * 2 * HID);
     QSP_ALLOC(b->work_jtj, sizeof(int2) * (size_t)cap_hyp * nw_total);
     if (!cfg.pose_only) QSP_ALLOC(b->work_fwd, sizeof(int2) * (size_t)cap_hyp * ((b->rk_stride + TILE_P - 1) / TILE_P));
@@ -1072,6 +1086,8 @@ extern "C" int qsp_refine_batch_create(qsp_decoder* dec, const qsp_joint_cfg* cf
 extern "C" void qsp_refine_batch_destroy(qsp_refine_batch* b) { batch_free(b); }
 
 extern "C" int qsp_refine_batch_set_state(qsp_refine_batch* b, const float* t_cam_obj, const float* code) {
+    std::unique_lock<std::recursive_mutex> lk_d;
+    if (b && b->dec) lk_d = std::unique_lock<std::recursive_mutex>(b->dec->mu);
     if (!b || !t_cam_obj) return qsp_fail(QSP_ERR_INVALID, "set_state: bad argument");
     QSP_HIP(hipSetDevice(b->dec->device));
     std::vector<HypState> hs(b->n_hyp);
@@ -1114,6 +1130,7 @@ static int run_once(qsp_refine_batch* b, int32_t n_iter, bool* hit, bool* screen
     std::vector<Span> spans;
     hipEvent_t e_begin = nullptr, e_end = nullptr;
     QSP_HIP(hipMemsetAsync(b->counters, 0, sizeof(unsigned long long) * 8, s));
+    QSP_HIP(hipMemsetAsync(b->qctl + 4, 0, sizeof(int) * 2, s));      // (the done counters of the plan tails: a run that was cut short may have left them)
     if (b->prof) e_begin = next_event(b, cur);
     for (int it = 0; it < n_iter; ++it) {
         RefineCfg cfg = b->cfg;
@@ -1124,10 +1141,6 @@ static int run_once(qsp_refine_batch* b, int32_t n_iter, bool* hit, bool* screen
         if (cfg.pose_only) hipLaunchKernelGGL(k_c0, dim3(nH), dim3(MLP_THREADS), 0, s, b->st, b->dec->Pd, b->c0_all);
         if (!cfg.pose_only) {      // (k_sample also forms the bias vectors k_c0 forms in pose-only mode)
             if (b->prof) a = next_event(b, cur);
-            hipLaunchKernelGGL(k_sample, dim3(nH), dim3(256), 0, s, b->st, b->objs, b->rays, cfg, b->valid_rk, b->rk_stride,
-                               b->ray_voff, b->ray_stride, b->dec->Pd, b->c0_all);
-            if (b->prof) spans.push_back({a, next_event(b, cur), 2});
-            if (b->prof) a = next_event(b, cur);
             // Two passes pay when the one-pass kernel would need more than one round of 64-point tiles over the chip; a batch that
             // fits one round (a single object per call) is faster in one pass: one tile deep either way, without the second
             // launch.  Both give the same bits, so the choice is free.  (~half of the ray samples are inside the unit ball.)
@@ -1136,9 +1149,14 @@ static int run_once(qsp_refine_batch* b, int32_t n_iter, bool* hit, bool* screen
             const int64_t min_samples = b->dec->screen_min_samples >= 0 ? b->dec->screen_min_samples : 2 * (int64_t)b->n_cu * TILE_P;
             // (a narrow decoder's one-pass forward on the NARROW tile is cheaper than the full-width screening pass: not screened)
             const bool screen = b->dec->fwd_bf3 == 2 && b->dec->screen_margin > 0.f && ub_samples > min_samples && !b->dec->P.narrow;
-            hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, s, 0, b->st, b->objs, nH, b->nw_sdf, nw_total - b->nw_sdf,
-                               b->work_fwd, b->qctl, screen ? H1_ROWS : TILE_P);     // (the forward pass keeps 64-point tiles: tens of
-            if (screen) {                                                            //  thousands of ray samples fill the chip either way)
+            // the forward kernel's item list is built in k_sample's tail (plan_tail; the forward pass keeps 64-point tiles: tens of
+            // thousands of ray samples fill the chip either way)
+            const PlanTail pt_fwd{b->work_fwd, b->qctl, b->qctl + 4, nH, b->nw_sdf, nw_total - b->nw_sdf, screen ? H1_ROWS : TILE_P, 0};
+            hipLaunchKernelGGL(k_sample, dim3(nH), dim3(256), 0, s, b->st, b->objs, b->rays, cfg, b->valid_rk, b->rk_stride,
+                               b->ray_voff, b->ray_stride, b->dec->Pd, b->c0_all, pt_fwd);
+            if (b->prof) spans.push_back({a, next_event(b, cur), 2});
+            if (b->prof) a = next_event(b, cur);
+            if (screen) {
                 // two passes (QSP_DEC_OPT_RENDER_SCREENING): every sample on the one-product tile, then the band around the
                 // surface on the split-fp16 tile; the queue's control words and item list are reused behind the first pass
                 if (screen_waves() == 8)
@@ -1171,13 +1189,16 @@ static int run_once(qsp_refine_batch* b, int32_t n_iter, bool* hit, bool* screen
                                    cfg, b->dec->Pd, b->valid_rk, b->rk_stride, b->sdf_valid, b->work_fwd, b->qctl, b->c0_all);
             if (b->prof) spans.push_back({a, next_event(b, cur), 1});
             if (b->prof) a = next_event(b, cur);
+            // (the Jacobian kernel's item list is built in k_scan's tail)
+            const PlanTail pt_jtj{b->work_jtj, b->qctl, b->qctl + 5, nH, b->nw_sdf, nw_total - b->nw_sdf, cfg.tile_p, 1};
             hipLaunchKernelGGL(k_scan, dim3(nH), dim3(SCAN_RAYS), sizeof(float) * SCAN_RAYS * SCAN_LD, s, b->st, b->objs, b->depth, cfg, b->valid_rk, b->rk_stride,
-                               b->ray_voff, b->ray_stride, b->sdf_valid, b->rend_rk, b->rend_deds, b->rend_res);
+                               b->ray_voff, b->ray_stride, b->sdf_valid, b->rend_rk, b->rend_deds, b->rend_res, pt_jtj);
             if (b->prof) spans.push_back({a, next_event(b, cur), 2});
         }
         if (b->prof) a = next_event(b, cur);
-        hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, s, 1, b->st, b->objs, nH, b->nw_sdf, nw_total - b->nw_sdf,
-                           b->work_jtj, b->qctl, cfg.tile_p);
+        if (cfg.pose_only)      // (no render pass in front of it: the plan is a launch of its own)
+            hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, s, 1, b->st, b->objs, nH, b->nw_sdf, nw_total - b->nw_sdf,
+                               b->work_jtj, b->qctl, cfg.tile_p);
         if (b->dec->jac_bf3 == 2) {
             const JtjArgs ja{b->st, b->objs, b->pts, b->rays, cfg, b->dec->Pd, b->nw_sdf, nw_total, b->rend_rk, b->rend_deds, b->rend_res,
                              b->rk_stride, b->pt_active, b->act_stride, b->res_buf, b->rows, b->rows_stride, b->partials, b->work_jtj,
@@ -1263,6 +1284,8 @@ static int run_once(qsp_refine_batch* b, int32_t n_iter, bool* hit, bool* screen
 }
 
 extern "C" int qsp_refine_batch_run(qsp_refine_batch* b, int32_t n_iter) {
+    std::unique_lock<std::recursive_mutex> lk_d;
+    if (b && b->dec) lk_d = std::unique_lock<std::recursive_mutex>(b->dec->mu);
     if (!b) return qsp_fail(QSP_ERR_INVALID, "run: null batch");
     QSP_HIP(hipSetDevice(b->dec->device));
     if (n_iter <= 0) n_iter = b->n_iter_cfg;
@@ -1341,6 +1364,8 @@ extern "C" int qsp_refine_batch_profile(qsp_refine_batch* b, int enable, qsp_ref
 
 extern "C" int qsp_refine_batch_get(qsp_refine_batch* b, float* t_cam_obj_out, float* code_out, float* loss_out,
                                     uint8_t* is_good_out) {
+    std::unique_lock<std::recursive_mutex> lk_d;
+    if (b && b->dec) lk_d = std::unique_lock<std::recursive_mutex>(b->dec->mu);
     if (!b) return qsp_fail(QSP_ERR_INVALID, "get: null batch");
     QSP_HIP(hipSetDevice(b->dec->device));
     std::vector<HypState> hs(b->n_hyp);
@@ -1417,6 +1442,8 @@ extern "C" int qsp_reconstruct_objects(qsp_decoder* dec, const qsp_joint_cfg* cf
                                        const float* const* depth, const int32_t* n_fg, int32_t n_hyp,
                                        const int32_t* hyp_obj, const float* t_cam_obj, const float* code,
                                        float* t_cam_obj_out, float* code_out, float* loss_out, uint8_t* is_good_out) {
+    std::unique_lock<std::recursive_mutex> lk_d;
+    if (dec) lk_d = std::unique_lock<std::recursive_mutex>(dec->mu);
     if (!dec || !cfg) return qsp_fail(QSP_ERR_INVALID, "qsp_reconstruct_objects: null argument");
     if (cfg->code_len != dec->code_len) return qsp_fail(QSP_ERR_INVALID, "code_len of the optimizer config differs from the decoder's");
     if (n_obj <= 0 || n_hyp <= 0 || !pts || !n_pts || !rays || !n_rays || !depth || !n_fg || !hyp_obj)
@@ -1476,6 +1503,8 @@ extern "C" int qsp_reconstruct_objects(qsp_decoder* dec, const qsp_joint_cfg* cf
 extern "C" int qsp_estimate_pose(qsp_decoder* dec, int32_t n, const float* t_co_se3, const float* scale,
                                  const float* const* pts, const int32_t* n_pts, const float* code, int32_t n_iter,
                                  float* t_co_out) {
+    std::unique_lock<std::recursive_mutex> lk_d;
+    if (dec) lk_d = std::unique_lock<std::recursive_mutex>(dec->mu);
     if (!dec || n <= 0 || !t_co_se3 || !scale || !pts || !n_pts || !code || !t_co_out)
         return qsp_fail(QSP_ERR_INVALID, "qsp_estimate_pose: bad argument");
     if (n_iter <= 0) n_iter = 5;

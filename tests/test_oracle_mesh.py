@@ -153,3 +153,30 @@ def test_canonical_form_is_order_independent():
     f3 = f.copy()
     f3[0] = f3[0][::-1]
     assert not np.array_equal(canonical_mesh(v, f3)[1], cf)
+
+
+def test_decoder_volumes_have_no_ambiguous_marching_cubes_faces(oracle_decoder):
+    """VERDICT r3 item 8.  The reference triangulates with skimage's marching_cubes_lewiner (reconstruct/utils.py:131); what sets
+    Lewiner's 33-case algorithm apart from a 256-case table are its face and interior tests, which only ever decide cells with an
+    AMBIGUOUS face (two diagonally opposite corners inside, the other two outside).  The volumes this path actually meshes are the
+    decoder's: smooth signed-distance fields sampled at 2/(n-1).  Counted here on the fitted decoder at three code scales: not one
+    ambiguous face among the surface cells of the 32^3 grid (the 64^3 grid likewise, tools run) -- on such volumes every
+    marching-cubes variant produces the same vertex set and the same surface topology; what is left unpinned against skimage is
+    the choice of diagonals inside a cell's polygons and the order of vertices / faces."""
+    from oracle import sdf_oracle as so
+    rng = np.random.default_rng(0)
+    n = 32
+    g = so.create_voxel_grid(n).reshape(-1, 3).astype(np.float32)
+    faces = [(0, 1, 3, 2), (4, 5, 7, 6), (0, 1, 5, 4), (2, 3, 7, 6), (0, 2, 6, 4), (1, 3, 7, 5)]
+    for scale in (0.0, 0.1, 0.3):
+        code = (scale * rng.normal(size=64)).astype(np.float32)
+        ins = so.decode_sdf(oracle_decoder, code, g).reshape(n, n, n) < 0
+        c = np.stack([ins[dx:n - 1 + dx, dy:n - 1 + dy, dz:n - 1 + dz] for dx in (0, 1) for dy in (0, 1) for dz in (0, 1)], 0)
+        cnt = c.sum(0)
+        surface = (cnt > 0) & (cnt < 8)
+        assert surface.sum() > 40
+        amb = np.zeros_like(surface)
+        for f in faces:
+            a, b, cc, d = [c[i] for i in f]
+            amb |= (a == cc) & (b == d) & (a != b)
+        assert int((amb & surface).sum()) == 0
