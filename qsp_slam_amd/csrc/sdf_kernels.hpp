@@ -1332,12 +1332,9 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(HypState* __restrict__ 
     // Gauss-Jordan elimination in f64 on the augmented system (reference: torch.inverse(H) @ b, f32).  H is symmetric
     // positive definite by construction (Gram matrices plus the identity damping of optimizer.py:240-252 / :75), so no
     // pivot search is needed: one barrier per column, every (row, column strip) pair on its own thread.
-    // Four waves do the elimination (the other twelve leave: s_barrier counts the waves that are left).  Every element (r, j) is
-    // updated once per column whichever thread owns it, so the strip count changes no bit; what it changes is the cost of the 71
-    // barriers -- 16 waves at a barrier took ~0.4 us a column (30 of the kernel's 59 us on the one-object path), four take ~0.15.
-    constexpr int ELIM_THREADS = 256;
-    if (tid >= ELIM_THREADS) return;
-    const int STR = ELIM_THREADS / N;          // 3 strips for the 71 x 71 system
+    // (measured, round 4: the same elimination on four waves -- cheaper barriers, 24 elements per thread and column -- took the
+    //  one-object call from 2.76 to 2.94 ms: with 1024 threads a column is 5 elements per thread and the LDS latency hides.)
+    const int STR = SOLVE_THREADS / N;         // 14 strips for the 71 x 71 system
     for (int c = 0; c < N; ++c) {
         const double inv = 1.0 / Hd[c * (N + 1) + c];
         const int r = tid / STR, q = tid - r * STR;
@@ -1347,10 +1344,10 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(HypState* __restrict__ 
         }
         __syncthreads();
     }
-    for (int a = tid; a < N; a += ELIM_THREADS) dxs[a] = (float)(Hd[a * (N + 1) + N] / Hd[a * (N + 1) + a]);
+    for (int a = tid; a < N; a += SOLVE_THREADS) dxs[a] = (float)(Hd[a * (N + 1) + N] / Hd[a * (N + 1) + a]);
     __syncthreads();
     if (trdx)
-        for (int a = tid; a < N; a += ELIM_THREADS) trdx[(int64_t)h * NH + a] = dxs[a];
+        for (int a = tid; a < N; a += SOLVE_THREADS) trdx[(int64_t)h * NH + a] = dxs[a];
     if (tid == 0) {
         float d[7], Td[16], Tn[16];
         if (cfg.pose_only) {
