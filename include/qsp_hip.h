@@ -530,6 +530,22 @@ int qsp_ellipsoid_fit_planes(int device, int32_t n, const double* ellipsoid_in, 
                              const double* planes, int32_t n_iter, int32_t normal_direction, double* ellipsoid_out,
                              double* chi2_out, int32_t* iters_out, double* trace);
 
+/* The OTHER single-ellipsoid problem of the reference: priorInfer::infer, src/core/PriorInfer.cpp:331-427 -- one
+ * VertexEllipsoidXYZABCYaw (7 unknowns: translation in the ellipsoid's frame, half-axes, yaw; include/core/BasicEllipsoidEdges.h:46,
+ * src/core/Ellipsoid.cpp:78-106), a fixed identity camera, and per ellipsoid
+ *   planes_normal [off_normal[i], off_normal[i+1]): EdgeSE3EllipsoidPlaneWithNormal (2-D: nearest tangent distance, smallest angle
+ *       between the plane normal and an ellipsoid axis; information diag(1, 1 / sigma^2) w^2; Huber delta 1),
+ *       src/pca/EllipsoidExtractorEdges.h:52, .cpp:297-375;
+ *   planes [off_plane[i], off_plane[i+1]): EdgeSE3EllipsoidPlane with setNormalDirection(true) (1-D; information w^2; Huber);
+ *   pri (n,2), weight (n): EdgePri, error = (mid / min, max / min of the |half-axes|) - pri, information weight^2, no kernel;
+ *   ground_plane_weight (n) or NULL: w of the FIRST plane of each of the two lists (bUseGroundPlaneWeight), otherwise w = 1;
+ * g2o's numeric Jacobians (delta 1e-9), dense Levenberg-Marquardt, optimize(n_iter) (reference: 10).  One wave per ellipsoid.
+ * Outputs as qsp_ellipsoid_fit_planes (the quaternion changes here).  Host pointers. */
+int qsp_ellipsoid_fit_prior(int device, int32_t n, const double* ellipsoid_in, const int32_t* off_normal, const double* planes_normal,
+                            const int32_t* off_plane, const double* planes, const double* pri, const double* weight,
+                            const double* ground_plane_weight, double angle_sigma_deg, int32_t n_iter, double* ellipsoid_out,
+                            double* chi2_out, int32_t* iters_out, double* trace);
+
 #ifdef __cplusplus
 }
 #endif

@@ -151,3 +151,162 @@ def tangent_planes(ell, normals):
         h = np.sqrt(np.sum((s * (R.T @ n)) ** 2))             # support function
         out.append([n[0], n[1], n[2], -(n @ t + h)])
     return np.array(out)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# priorInfer::infer's single-ellipsoid problem (reference src/core/PriorInfer.cpp:331-427) -- SURVEY section 8f row 4, the other
+# live-code-shaped quadric piece: one VertexEllipsoidXYZABCYaw (7 unknowns: translation in the ellipsoid's own frame, half-axes,
+# yaw; oplus = exp_update_XYZABCYaw, src/core/Ellipsoid.cpp:78-106: pose * SE3(fromXYZPRY(t, 0, 0, yaw)), scale + ds), a FIXED
+# identity VertexSE3Expmap, and
+#   EdgeSE3EllipsoidPlaneWithNormal (2-D: nearest tangent distance, calculateMinAngle of the plane normal against the ellipsoid's
+#       axes; information diag(1, 1 / sigma_angle^2) * w^2; RobustKernelHuber, delta 1)   src/pca/EllipsoidExtractorEdges.cpp:297-375
+#   EdgeSE3EllipsoidPlane with setNormalDirection(true) (1-D; information w^2; Huber)      :197-226
+#   EdgePri (2-D: Pri(ellipsoid) - prior, Pri = (mid / min, max / min) of |half-axes|; information weight^2, no kernel)
+#       src/core/PriorInfer.cpp:60-78,437-450
+# with g2o's numeric Jacobians (delta 1e-9), BlockSolverX + dense solver, Levenberg-Marquardt, optimize(10).
+# Like OptimizeEllipsoidUsingPlanes above the function has no live caller in this revision (`priorInfer` is never instantiated):
+# PARITY UNPINNED, pins = closed-form geometry and recovery of a known ellipsoid (tests/test_oracle_ellipsoid.py).
+# ---------------------------------------------------------------------------------------------------------------------------
+def quat_mul(a, b):
+    ax, ay, az, aw = a
+    bx, by, bz, bw = b
+    return np.array([aw * bx + ax * bw + ay * bz - az * by, aw * by + ay * bw + az * bx - ax * bz,
+                     aw * bz + az * bw + ax * by - ay * bx, aw * bw - ax * bx - ay * by - az * bz])
+
+
+def yaw_update(t, q, s, u):
+    """exp_update_XYZABCYaw: pose * SE3Quat(zyx_euler_to_quat(0, 0, yaw), trans) (se3quat.h:110-116,208-225), scale + ds"""
+    u = np.asarray(u, np.float64)
+    dq = np.array([0.0, 0.0, np.sin(u[6] * 0.5), np.cos(u[6] * 0.5)])
+    R = quat_to_R(q)
+    t2 = np.asarray(t, np.float64) + R @ u[:3]
+    q2 = quat_mul(q, dq)
+    if q2[3] < 0:
+        q2 = -q2
+    q2 = q2 / np.linalg.norm(q2)
+    return t2, q2, np.asarray(s, np.float64) + u[3:6]
+
+
+def min_angle(normal, q):
+    """EdgeSE3EllipsoidPlaneWithNormal::calculateMinAngle, EllipsoidExtractorEdges.cpp:297-358"""
+    R = quat_to_R(q)
+    Nc = np.linalg.inv(R) @ np.asarray(normal, np.float64)
+    cz = Nc[2] / np.linalg.norm(Nc)
+    az = np.arccos(cz)
+    if min(abs(az), abs(az - np.pi)) < np.pi / 180.0 * 30:
+        return 0.0
+    nxy = np.array([Nc[0], Nc[1], 0.0])
+    ang = np.arccos(nxy[0] / np.linalg.norm(nxy))
+    return min(min(ang, abs(ang - np.pi / 2)), abs(ang - np.pi))
+
+
+def pri_of(s):
+    a = np.sort(np.abs(np.asarray(s, np.float64)))
+    return np.array([a[1] / a[0], a[2] / a[0]])
+
+
+def _huber(e2, delta=1.0):
+    if e2 <= delta * delta:
+        return e2, 1.0
+    r = np.sqrt(e2)
+    return 2 * r * delta - delta * delta, delta / r
+
+
+def prior_fit(ell, planes_normal, planes, pri, weight, angle_sigma_deg=10.0, ground_plane_weight=None, n_iter=10):
+    """-> dict(ell (10,), chi2, iters, trace (iters,3)).  ground_plane_weight: weight of the FIRST plane of each list
+    (bUseGroundPlaneWeight), None = 1."""
+    ell = np.asarray(ell, np.float64)
+    PN = np.asarray(planes_normal, np.float64).reshape(-1, 4)
+    PL = np.asarray(planes, np.float64).reshape(-1, 4)
+    pri = np.asarray(pri, np.float64)
+    sig = angle_sigma_deg / 180.0 * np.pi
+    state = (ell[:3].copy(), ell[3:7].copy(), ell[7:10].copy())
+
+    def w_of(i):
+        return ground_plane_weight if (ground_plane_weight is not None and i == 0) else 1.0
+
+    edges = []                                  # (kind, data, omega diagonal, robust)
+    for i, p in enumerate(PN):
+        w = w_of(i)
+        edges.append((0, p, np.array([w * w, (w / sig) ** 2]), True))
+    for i, p in enumerate(PL):
+        w = w_of(i)
+        edges.append((1, p, np.array([w * w]), True))
+    edges.append((2, pri, np.array([weight * weight, weight * weight]), False))
+
+    def err(kind, data, st):
+        t, q, s = st
+        if kind == 0:
+            return np.array([plane_error(t, quat_to_R(q), s, data, False), min_angle(data[:3], q)])
+        if kind == 1:
+            return np.array([plane_error(t, quat_to_R(q), s, data, True)])
+        return pri_of(s) - data
+
+    def chi2_at(st):
+        tot = 0.0
+        for kind, data, om, rob in edges:
+            e = err(kind, data, st)
+            c = float(np.sum(om * e * e))
+            tot += _huber(c)[0] if rob else c
+        return tot
+
+    trace = []
+    lam, ni, nbad, cur = 0.0, 2.0, 0, 0.0
+    delta = 1e-9
+    for it in range(n_iter):
+        H, b, cur = np.zeros((7, 7)), np.zeros(7), 0.0
+        for kind, data, om, rob in edges:
+            e = err(kind, data, state)
+            J = np.zeros((e.shape[0], 7))
+            for d in range(7):
+                u = np.zeros(7)
+                u[d] = delta
+                e1 = err(kind, data, yaw_update(*state, u))
+                u[d] = -delta
+                e2 = err(kind, data, yaw_update(*state, u))
+                J[:, d] = (1.0 / (2 * delta)) * (e1 - e2)
+            c = float(np.sum(om * e * e))
+            r0, r1 = _huber(c) if rob else (c, 1.0)
+            W = np.diag(r1 * om)
+            H += J.T @ W @ J
+            b -= J.T @ (W @ e)
+            cur += r0
+        ini = cur
+        if it == 0:
+            lam, ni, nbad = 1e-5 * np.max(np.abs(np.diag(H))), 2.0, 0
+        qmax, rho = 0, 0.0
+        while True:
+            bk = state
+            x = np.zeros(7)
+            ok = True
+            A = H + lam * np.eye(7)
+            if np.any(A != 0):
+                try:
+                    np.linalg.cholesky(A)
+                    x = np.linalg.solve(A, b)
+                except np.linalg.LinAlgError:
+                    ok = False
+            if ok:
+                state = yaw_update(*state, x)
+            temp = chi2_at(state) if ok else np.finfo(np.float64).max
+            rho = (cur - temp) / (1e-3 + float(np.sum(x * (lam * x + b))))
+            if rho > 0 and np.isfinite(temp):
+                alpha = min(1.0 - (2 * rho - 1) ** 3, 2.0 / 3.0)
+                lam *= max(1.0 / 3.0, alpha)
+                ni = 2.0
+                cur = temp
+            else:
+                lam *= ni
+                ni *= 2
+                state = bk
+            qmax += 1
+            if not (rho < 0 and qmax < 10):
+                break
+        trace.append((cur, lam, qmax))
+        if qmax == 10 or rho == 0:
+            break
+        nbad = nbad + 1 if (ini - cur) * 1e3 < ini else 0
+        if nbad >= 3:
+            break
+    out = np.concatenate([state[0], state[1], state[2]])
+    return dict(ell=out, chi2=cur, iters=len(trace), trace=np.array(trace).reshape(-1, 3))

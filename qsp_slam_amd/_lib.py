@@ -100,7 +100,7 @@ SYMBOLS = [
     "qsp_reconstruct_objects", "qsp_estimate_pose", "qsp_refine_detections",
     "qsp_mesh_extractor_create", "qsp_mesh_extractor_destroy", "qsp_mesh_extract", "qsp_mesh_from_volume", "qsp_mesh_fetch",
     "qsp_mc_tables",
-    "qsp_pose_optimizer_create", "qsp_pose_optimizer_destroy", "qsp_pose_optimize", "qsp_ellipsoid_fit_planes",
+    "qsp_pose_optimizer_create", "qsp_pose_optimizer_destroy", "qsp_pose_optimize", "qsp_ellipsoid_fit_planes", "qsp_ellipsoid_fit_prior",
     "qsp_ba_create", "qsp_ba_destroy", "qsp_ba_set_levels", "qsp_ba_optimize", "qsp_ba_local_joint",
     "qsp_ba_set_state", "qsp_ba_get_state", "qsp_ba_get_edges", "qsp_ba_get_index", "qsp_ba_profile", "qsp_ba_set_shard", "qsp_ba_set_deterministic",
     "qsp_ba_set_shard_rccl", "qsp_ba_set_option", "qsp_ba_release_caches", "qsp_comm_unique_id", "qsp_comm_create", "qsp_comm_adopt", "qsp_comm_destroy", "qsp_comm_nccl", "qsp_comm_stub_counts",
@@ -162,6 +162,8 @@ def lib():
                                     c_double_p, c_uint8_p, c_int32_p, C.POINTER(PoseTrace)]
     L.qsp_ellipsoid_fit_planes.argtypes = [C.c_int, C.c_int32, c_double_p, c_int32_p, c_double_p, C.c_int32, C.c_int32,
                                            c_double_p, c_double_p, c_int32_p, c_double_p]
+    L.qsp_ellipsoid_fit_prior.argtypes = [C.c_int, C.c_int32, c_double_p, c_int32_p, c_double_p, c_int32_p, c_double_p, c_double_p,
+                                          c_double_p, c_double_p, C.c_double, C.c_int32, c_double_p, c_double_p, c_int32_p, c_double_p]
     L.qsp_ba_create.argtypes = [C.POINTER(BaScene), C.c_int, C.POINTER(vp)]
     L.qsp_ba_destroy.argtypes = [vp]
     L.qsp_ba_destroy.restype = None

@@ -96,3 +96,58 @@ def test_fit_argument_errors():
     rc = L.qsp_ellipsoid_fit_planes(0, 1, _lib.dptr(e), _lib.i32ptr(off), _lib.c_double_p(), 10, 0, _lib.dptr(out),
                                     _lib.c_double_p(), _lib.c_int32_p(), _lib.c_double_p())
     assert rc == _lib.QSP_ERR_INVALID
+
+
+# ---- qsp_ellipsoid_fit_prior: priorInfer::infer's problem (src/core/PriorInfer.cpp:331-427), batched
+def test_prior_fit_matches_oracle_and_recovers_ground_truth():
+    from qsp_slam_amd.ellipsoid import infer_ellipsoids_with_prior
+    from tests.test_oracle_ellipsoid import _prior_scene
+    rng = np.random.default_rng(21)
+    scenes = [_prior_scene(rng, yaw_err=rng.uniform(-0.15, 0.15)) for _ in range(24)]
+    gts = np.array([s[0] for s in scenes])
+    ells = np.array([s[1] for s in scenes])
+    pn = [s[2] for s in scenes]
+    pl = [s[3] + np.r_[0, 0, 0, 1] * rng.normal(scale=0.004, size=(10, 1)) for s in scenes]      # noisy plane offsets
+    pri = np.array([EO.pri_of(g[7:]) for g in gts])
+    w = rng.uniform(0.5, 2.0, size=len(scenes))
+    gw = rng.uniform(1.0, 3.0, size=len(scenes))
+    out, chi2, iters, tr = infer_ellipsoids_with_prior(ells, pn, pl, pri, w, angle_sigma_deg=10.0, ground_plane_weight=gw, trace=True)
+    total = 0
+    for i in range(len(scenes)):
+        r = EO.prior_fit(ells[i], pn[i], pl[i], pri[i], w[i], 10.0, gw[i])
+        assert np.abs(out[i] - r["ell"]).max() < 1e-5
+        assert abs(chi2[i] - r["chi2"]) < 1e-6 * max(1.0, r["chi2"]) + 1e-9
+        assert abs(int(iters[i]) - r["iters"]) <= 2
+        assert np.abs(out[i, :3] - gts[i, :3]).max() < 0.05 and np.abs(out[i, 7:] - gts[i, 7:]).max() < 0.05    # (noisy planes)
+        prev = None
+        for it in range(min(int(iters[i]), r["iters"])):
+            c = r["trace"][it, 0]
+            if c < 1e-8:
+                break
+            assert abs(tr[i, it, 0] - c) < 1e-5 * c
+            if prev is not None and prev - c > 1e-4 * prev:
+                assert tr[i, it, 2] == r["trace"][it, 2]
+                assert abs(tr[i, it, 1] - r["trace"][it, 1]) < 1e-3 * r["trace"][it, 1]
+                total += 1
+            prev = c
+    assert total >= 10
+    # one wave per ellipsoid: alone = in the batch, bit for bit
+    o1, c1, i1 = infer_ellipsoids_with_prior(ells[3:4], pn[3:4], pl[3:4], pri[3:4], w[3:4], 10.0, gw[3:4])
+    assert np.array_equal(o1[0], out[3]) and c1[0] == chi2[3] and i1[0] == iters[3]
+
+
+def test_prior_fit_exact_planes_and_argument_errors():
+    from qsp_slam_amd import _lib
+    from qsp_slam_amd.ellipsoid import infer_ellipsoids_with_prior
+    from tests.test_oracle_ellipsoid import _prior_scene
+    rng = np.random.default_rng(22)
+    scenes = [_prior_scene(rng) for _ in range(200)]
+    gts = np.array([s[0] for s in scenes])
+    out, chi2, iters = infer_ellipsoids_with_prior(np.array([s[1] for s in scenes]), [s[2] for s in scenes], [s[3] for s in scenes],
+                                                   np.array([EO.pri_of(g[7:]) for g in gts]), 1.0)
+    assert np.isfinite(out).all() and (chi2 < 1e-10).mean() > 0.7        # (measured 0.81: ten LM iterations from a 0.1 rad yaw error;
+    assert np.median(np.abs(out - gts).max(axis=1)) < 1e-5               #  the rest stop in the angle term's 30-degree dead zone or a side minimum)
+    with pytest.raises(ValueError):
+        infer_ellipsoids_with_prior(gts[:1], [], [], [[2, 3]], 1.0)
+    with pytest.raises(_lib.QspError):
+        infer_ellipsoids_with_prior(gts[:1], [np.zeros((0, 4))], [np.zeros((0, 4))], [[2, 3]], 1.0, angle_sigma_deg=0.0)
