@@ -2280,9 +2280,15 @@ __global__ __launch_bounds__(1024) void k_chol_back(Dev d, Par par, const double
 // edge -> hessian index of its key-frame (-1: edge at level 1 or key-frame fixed).  Levels and indices are fixed for the length of an
 // optimize() call; the back-substitution of the landmarks reads this instead of level -> key-frame -> index (one dependent memory
 // round trip instead of three per batch of observations).
-__global__ __launch_bounds__(256) void k_edge_index(Dev d) {
+// reset != 0: the call follows qsp_ba_set_levels(NULL, NULL, NULL) -- every edge active: the level arrays are written here instead of
+// by two memset nodes (37 us of idle device in front of each, profiles/r04_ba_c4_timeline.txt)
+__global__ __launch_bounds__(256) void k_edge_index(Dev d, int reset) {
     const int a = blockIdx.x * 256 + threadIdx.x;
-    if (a < d.n_edge) d.edge_ha[a] = d.edge_level[a] ? -1 : d.kf_h[d.edge[a].kf];
+    if (a < d.n_edge) {
+        if (reset) d.edge_level[a] = 0;
+        d.edge_ha[a] = (!reset && d.edge_level[a]) ? -1 : d.kf_h[d.edge[a].kf];
+    }
+    if (reset && a < d.n_oe) d.oe_level[a] = 0;
 }
 
 __global__ __launch_bounds__(256) void k_update_points(Dev d, Par par) {
@@ -2842,6 +2848,10 @@ struct qsp_ba_problem {
     int32_t act_epoch = 0;
     bool pt_order_uploaded = false;
     double tail_seq = 0.0;       // sequence number of the last k_tail_publish enqueued (scal_host[8..12])
+    bool levels_reset_pending = false;   // qsp_ba_set_levels(NULL..): the device level arrays are zeroed by the next k_edge_index
+    bool all_active = true;              // the host's level arrays are all zero (set_levels(NULL..) / a fresh problem)
+    // the index of the all-active level set is a property of the problem: built once, restored by later first stages
+    struct IndexCache { bool valid = false; std::vector<int32_t> kf_h, obj_h, pt_h; int n_pose, n_land, dim, dimp, n_dense, dim_all; bool elim, elim_allowed; } idx_cache;
     bool tail_ready = false;     // the last optimize() call left a valid speculated stage boundary behind
     bool host_stale = false;     // edge_level_h / oe_level_h / pt_h / n_land on the host lag behind the device (refresh_host_index)
     uint8_t* lvl_host = nullptr; // pinned: edge / object-edge levels classified on the device (qsp_ba_local_joint)
@@ -3352,11 +3362,12 @@ extern "C" int qsp_ba_set_levels(qsp_ba_problem* p, const uint8_t* mono, const u
     if (mono) for (int e = 0; e < p->n_mono; ++e) p->edge_level_h[p->mono_pos[e]] = mono[e] ? 1 : 0;
     if (stereo) for (int e = 0; e < p->n_stereo; ++e) p->edge_level_h[p->st_pos[e]] = stereo[e] ? 1 : 0;
     for (int e = 0; e < p->d.n_oe; ++e) p->oe_level_h[e] = (obj && obj[e]) ? 1 : 0;
-    if (!mono && !stereo && !obj && p->world == 1) {     // everything active: no host array has to travel
-        if (p->d.n_edge) QSP_HIP(hipMemsetAsync(p->d.edge_level, 0, p->d.n_edge, p->stream));
-        if (p->d.n_oe) QSP_HIP(hipMemsetAsync(p->d.oe_level, 0, p->d.n_oe, p->stream));
+    p->all_active = !mono && !stereo && !obj;
+    if (p->all_active && p->world == 1) {     // everything active: no host array has to travel, and the device arrays are zeroed
+        p->levels_reset_pending = true;       // by the next optimize() call's k_edge_index
         return QSP_OK;
     }
+    p->levels_reset_pending = false;
     return upload_levels(p);
 }
 
@@ -3478,6 +3489,7 @@ static void build_index(qsp_ba_problem* p);
 static int refresh_host_index(qsp_ba_problem* p) {
     if (!p->host_stale) return QSP_OK;
     const Dev& d = p->d;
+    p->all_active = false;
     QSP_HIP(hipStreamSynchronize(p->stream));
     if (d.n_edge) QSP_HIP(hipMemcpy(p->edge_level_h.data(), d.edge_level, d.n_edge, hipMemcpyDeviceToHost));
     if (d.n_oe) QSP_HIP(hipMemcpy(p->oe_level_h.data(), d.oe_level, d.n_oe, hipMemcpyDeviceToHost));
@@ -3614,7 +3626,20 @@ static int ba_optimize(qsp_ba_problem* p, int32_t n_iter, double delta_mono, dou
     if (!head) {
         const int rc0 = refresh_host_index(p);
         if (rc0) return rc0;
-        build_index(p);
+        auto& ic = p->idx_cache;
+        if (p->all_active && p->world == 1 && ic.valid && ic.elim_allowed == p->elim_allowed) {
+            p->kf_h = ic.kf_h; p->obj_h = ic.obj_h; p->pt_h = ic.pt_h;
+            p->n_pose = ic.n_pose; p->n_land = ic.n_land; p->dim = ic.dim; p->dimp = ic.dimp; p->n_dense = ic.n_dense;
+            p->dim_all = ic.dim_all; p->elim = ic.elim;
+        } else {
+            build_index(p);
+            if (p->all_active && p->world == 1) {
+                ic.kf_h = p->kf_h; ic.obj_h = p->obj_h; ic.pt_h = p->pt_h;
+                ic.n_pose = p->n_pose; ic.n_land = p->n_land; ic.dim = p->dim; ic.dimp = p->dimp; ic.n_dense = p->n_dense;
+                ic.dim_all = p->dim_all; ic.elim = p->elim; ic.elim_allowed = p->elim_allowed;
+                ic.valid = true;
+            }
+        }
     }
     if (!head) {   // hessian indices: through pinned staging (a pageable source makes the "async" copy a synchronous staged one), and only
         // the arrays that differ from what the device already holds (the second round of a local BA rarely changes them)
@@ -3632,7 +3657,10 @@ static int ba_optimize(qsp_ba_problem* p, int32_t n_iter, double delta_mono, dou
     }
     if (sizeof(double) * (size_t)(2 * p->dimp + NB) > SCHUR_ROW_LDS_MAX)     // k_chol_back keeps y and x in LDS (dimp <= 10 208):
         return qsp_fail(QSP_ERR_UNSUPPORTED, "qsp_ba_optimize: reduced camera system too large for the dense solver");   // refused before anything is enqueued
-    if (d.n_edge && !head) hipLaunchKernelGGL(k_edge_index, dim3((d.n_edge + 255) / 256), dim3(256), 0, s, d);
+    if (!head && (d.n_edge || d.n_oe)) {
+        hipLaunchKernelGGL(k_edge_index, dim3((std::max(d.n_edge, d.n_oe) + 255) / 256), dim3(256), 0, s, d, p->levels_reset_pending ? 1 : 0);
+        p->levels_reset_pending = false;
+    }
     Par par{delta_mono, delta_stereo, delta_obj, 0.0, p->dim, p->dimp, p->n_pose, p->rank == 0 ? 1 : 0,
             (p->deterministic && p->dimp > 0) ? 1 : 0, p->n_dense, p->elim ? 1 : 0};
     if (tr) { tr->n = 0; tr->result = 0; tr->n_pose_blocks = p->n_pose; tr->n_landmarks = p->n_land; }
@@ -4041,6 +4069,7 @@ extern "C" int qsp_ba_local_joint(qsp_ba_problem* p, const volatile uint8_t* sto
             std::swap(d.edge_ha, p->edge_ha2);
             std::swap(d.pt_h, p->pt_h2);
             p->n_land = (int)th[3];
+            p->all_active = false;
             p->host_stale = true;                                             // (levels / landmark numbering: fetched when somebody asks)
             if (!p->idx_uploaded.empty()) std::fill(p->idx_uploaded.begin() + d.n_kf + d.n_obj, p->idx_uploaded.end(), INT32_MIN);
             const StageHead head{th[0], th[1]};
@@ -4063,6 +4092,7 @@ extern "C" int qsp_ba_local_joint(qsp_ba_problem* p, const volatile uint8_t* sto
         t3s = now();
         if (d.n_edge) memcpy(p->edge_level_h.data(), p->lvl_host, d.n_edge);
         if (d.n_oe) memcpy(p->oe_level_h.data(), p->lvl_host + d.n_edge, d.n_oe);
+        p->all_active = false;
     } else {
     std::vector<double> cm(std::max(p->n_mono, 1)), cs(std::max(p->n_stereo, 1)), co(std::max(d.n_oe, 1));
     std::vector<uint8_t> pm(std::max(p->n_mono, 1)), ps(std::max(p->n_stereo, 1));
