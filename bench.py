@@ -204,7 +204,7 @@ def ba_latency_model(n_kf_free, ms_ba, lm_trials):
 def pmc_traffic(workload, kernel):
     """Memory-side bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of this same command
     (PMC counters cannot be read from inside the process); None when the workload was not profiled."""
-    for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+    for name in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 return json.load(f)[workload][kernel]["bytes_per_launch"], name
