@@ -30,18 +30,34 @@ constexpr int PART_FLOATS = ((NJ * (NJ + 1) / 2 + 31) / 32) * 32;
 __device__ __forceinline__ int tri72(int r, int c) { return r * NJ - (r * (r - 1)) / 2 + (c - r); }      // r <= c < NJ
 // the accumulator tile (ta, tb) of a wave <-> its entries of the packed triangle (entries below the diagonal or beyond column 71
 // are not stored: nobody reads them; a continued item restarts them from 0)
+// (row r0 + o of the tile, o = acc_row(i, 0) a compile-time constant: tri72(r0 + o, c) = tri72(r0, c) + o (71 - r0) - o (o - 1) / 2 --
+//  one multiply-add per element on two per-lane values; the f32 tile's kernel has no registers to spare in its epilogue)
 __device__ __forceinline__ void part_store(float* __restrict__ slot, int ta, int tb, int lane, const f32x16& hacc) {
+    const int r0 = 32 * ta + 4 * (lane >> 5), c = 32 * tb + (lane & 31);
+    const int k = (NJ - 1) - r0, m = c < NJ ? c - r0 : -1;      // entry o is stored iff o <= m
+    // ONE running index, stepped from row to row (idx(o + 1) - idx(o) = k - o) and pinned between the steps: sixteen independent
+    // per-lane offsets cost the exact-f32 kernel 30 more spilled registers in an epilogue that has none to spare
+    int idx = tri72(r0, c);
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        const int r = 32 * ta + acc_row(i, lane), c = 32 * tb + (lane & 31);
-        if (r <= c && c < NJ) slot[tri72(r, c)] = hacc[i];
+        const int o = (i & 3) + 8 * (i >> 2);
+        if (o <= m) slot[idx] = hacc[i];
+        if (i < 15) {
+            const int o2 = ((i + 1) & 3) + 8 * ((i + 1) >> 2);      // next row: idx += sum_{q = o}^{o2 - 1} (k - q)
+            idx += (o2 - o) * k - ((o2 - o) * (o + o2 - 1)) / 2;
+            asm volatile("" : "+v"(idx));
+        }
     }
 }
 __device__ __forceinline__ void part_load(const float* __restrict__ slot, int ta, int tb, int lane, bool first, f32x16& hacc) {
+    const int r0 = 32 * ta + 4 * (lane >> 5), c = 32 * tb + (lane & 31);
+    const int base = tri72(r0, c), k = (NJ - 1) - r0, m = c < NJ ? c - r0 : -1;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        const int r = 32 * ta + acc_row(i, lane), c = 32 * tb + (lane & 31);
-        hacc[i] = (!first && r <= c && c < NJ) ? slot[tri72(r, c)] : 0.f;
+        const int o = (i & 3) + 8 * (i >> 2);
+        float v = 0.f;
+        if (!first && o <= m) v = slot[base + o * k - (o * (o - 1)) / 2];
+        hacc[i] = v;
     }
 }
 

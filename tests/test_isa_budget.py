@@ -3,14 +3,14 @@ ISA.  A tile kernel of this library owns a whole SIMD's register file (one wave 
 on the others); what the allocator cannot place goes to scratch memory -- private_segment_fixed_size bytes per lane, written and
 read back once per tile.  Round 2 shipped k_mlp_jtj_h2<2> with 274 spilled VGPRs / 516 B per lane (5.2 GB of scratch writes per C4
 launch) without anybody noticing; this test fails when a change pushes a kernel over its budget.  Budgets = what the current source
-compiles to (profiles/r03_isa_budget.txt) plus a little slack; lower them when a kernel improves."""
+compiles to (profiles/r04_isa_budget.txt) plus a little slack; lower them when a kernel improves."""
 import re
 import subprocess
 
 # kernel (demangled prefix) -> (max spilled VGPRs, max scratch bytes per lane, max spilled SGPRs)
 BUDGET = {
-    "qsp::k_mlp_jtj_h2<2, 4, false>": (32, 128, 0),
-    "qsp::k_mlp_jtj_h2<1, 4, false>": (0, 0, 0),
+    "qsp::k_mlp_jtj_h2<2, 4, false>": (32, 128, 2),      # (round 4: one SGPR spilled to a VGPR lane by the packed-triangle epilogue)
+    "qsp::k_mlp_jtj_h2<1, 4, false>": (0, 0, 2),
     "qsp::k_mlp_jtj_h2<2, 8, false>": (32, 128, 0),
     "qsp::k_mlp_jtj_h2<1, 8, false>": (0, 0, 0),
     "qsp::k_mlp_jtj_h2<2, 8, true>": (72, 200, 0),       # the NARROW forms: runtime slab counts and skipped slots cost the allocator
@@ -27,8 +27,8 @@ BUDGET = {
     "qsp::k_decode_h2<true, true>": (80, 200, 4),
     "qsp::k_mlp_fwd<false>": (0, 0, 0),
     "qsp::k_mlp_fwd<true>": (48, 192, 0),
-    "qsp::k_mlp_jtj<false>": (72, 224, 152),
-    "qsp::k_mlp_jtj<true>": (76, 300, 136),
+    "qsp::k_mlp_jtj<false>": (72, 232, 184),             # (round 4: the packed-triangle store of the partial sums walks ONE running
+    "qsp::k_mlp_jtj<true>": (76, 308, 172),              #  index -- sixteen independent per-lane offsets cost 25 more spilled VGPRs here)
     "qsp::k_decode<false, false>": (0, 0, 0),
     "qsp::k_decode<true, false>": (0, 0, 0),
     "qsp::k_decode<false, true>": (36, 136, 0),
