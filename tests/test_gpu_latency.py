@@ -78,3 +78,43 @@ def test_an_initial_code_and_a_failure_through_the_resident_batch(golden_dir):
     T, code, loss, good = fresh(dec, opt, o, o["t_cam_obj"][None], code0[None])
     assert np.array_equal(good1.t_cam_obj, T[0]) and np.array_equal(good1.code, code[0])
     dec.close()
+
+
+@pytest.mark.timeout(300)
+def test_two_host_threads_sharing_one_decoder_get_the_serial_results(golden_dir):
+    """qsp_reconstruct_objects refills a batch that is resident with the DECODER and rewrites decoder fields for the
+    duration of a call.  Entry points that launch on a decoder serialise on its lock (include/qsp_hip.h, "Threads"): two threads
+    hammering the same decoder with objects of different sizes -- so that the resident batch is refilled, and regrown, under
+    them -- and with decode calls in between get, call for call, the bits a single thread gets."""
+    import threading
+    from qsp_slam_amd import DeepSdfDecoder, synth
+    from qsp_slam_amd.reconstruct.optimizer import Optimizer
+    dec = DeepSdfDecoder.from_npz(os.path.join(golden_dir, "decoder_8x512.npz"))
+    dec.set_precision("fp16x2")
+    opt = Optimizer(dec, make_cfg(so.JointConfig(n_iter=2)))
+    objs = [synth.make_object_views(900 + i, 1, m, n_fg=nf, n_bg=nb)[0]
+            for i, (m, nf, nb) in enumerate([(300, 64, 32), (1500, 200, 100), (700, 128, 64), (2200, 256, 200)])]
+    x = np.random.default_rng(1).uniform(-0.8, 0.8, size=(500, 3)).astype(np.float32)
+    want = [opt.reconstruct_object(o["t_cam_obj"], o["pts"], o["rays"], o["depth"]) for o in objs]
+    want_sdf = dec.decode_sdf(np.zeros(64, np.float32), x)
+    errors = []
+
+    def work(order):
+        try:
+            for rep in range(6):
+                for i in order:
+                    o = objs[i]
+                    r = opt.reconstruct_object(o["t_cam_obj"], o["pts"], o["rays"], o["depth"])
+                    assert r.is_good == want[i].is_good and np.array_equal(r.t_cam_obj, want[i].t_cam_obj)
+                    assert np.array_equal(r.code, want[i].code) and r.loss == want[i].loss
+                    assert np.array_equal(dec.decode_sdf(np.zeros(64, np.float32), x), want_sdf)
+        except Exception as e:      # noqa: BLE001 (reported below)
+            errors.append(e)
+
+    th = [threading.Thread(target=work, args=(order,)) for order in ([0, 1, 2, 3], [3, 2, 1, 0])]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    dec.close()
+    assert not errors, errors
