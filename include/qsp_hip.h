@@ -330,6 +330,10 @@ typedef struct {
                                 beside it (QSP_BA_OPT_CHOLESKY_CHAIN), 0: one launch per block step                  */
     int32_t chain_timeouts;  /* solves of this problem in which a flag wait of that launch expired: the trial was repeated on
                                 the one-launch-per-step form, which the problem keeps from there on (0 in a healthy run)  */
+    int32_t boundary_device; /* qsp_ba_local_joint calls of this problem whose stage boundary (outlier classification, re-index,
+                                the second stage's first system) ran on the device behind the first stage's last trial ...  */
+    int32_t boundary_host;   /* ... and those that took the host path: the last trial was rejected, a key-frame or object
+                                vertex lost its last active edge (the reduced system changes shape), or several ranks       */
 } qsp_ba_stats;
 
 typedef struct qsp_ba_problem qsp_ba_problem;

@@ -66,7 +66,8 @@ class BaTrace(C.Structure):
 class BaProfile(C.Structure):
     _fields_ = [("ms_total", C.c_float), ("ms_linearize", C.c_float), ("ms_schur", C.c_float),
                 ("ms_solve", C.c_float), ("ms_update", C.c_float), ("n_linearize", C.c_int32),
-                ("n_trials", C.c_int32), ("bytes_linearize", C.c_int64), ("cholesky_chain", C.c_int32), ("chain_timeouts", C.c_int32)]
+                ("n_trials", C.c_int32), ("bytes_linearize", C.c_int64), ("cholesky_chain", C.c_int32), ("chain_timeouts", C.c_int32),
+                ("boundary_device", C.c_int32), ("boundary_host", C.c_int32)]
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)   # qsp_allreduce_fn

@@ -2838,6 +2838,7 @@ struct qsp_ba_problem {
     bool chol_fault = false;               // (value 2 of the option: the tile workgroups are not launched)
     int chol_grid_max = 1;                 // tile workgroups launched at most: one per compute unit beside the chain's
     int chain_timeouts = 0;                // solves in which a flag wait expired: repeated on the one-launch-per-step form
+    int n_boundary_device = 0, n_boundary_host = 0;      // local joint BAs by the path their stage boundary took (qsp_ba_stats)
     double* scal_host = nullptr; // pinned, device-visible copy of scal[0..3] (k_publish_scal): read back without a copy engine hop
     double* scal_host_dev = nullptr;
     double scal_seq = 0.0;       // sequence number of the last read-back enqueued
@@ -4034,6 +4035,8 @@ extern "C" int qsp_ba_profile(qsp_ba_problem* p, int enable, qsp_ba_stats* out) 
     p->profiling = enable != 0;
     p->prof.cholesky_chain = p->chol_chain ? 1 : 0;
     p->prof.chain_timeouts = p->chain_timeouts;
+    p->prof.boundary_device = p->n_boundary_device;
+    p->prof.boundary_host = p->n_boundary_host;
     if (out) *out = p->prof;
     return QSP_OK;
 }
@@ -4073,6 +4076,7 @@ extern "C" int qsp_ba_local_joint(qsp_ba_problem* p, const volatile uint8_t* sto
             p->host_stale = true;                                             // (levels / landmark numbering: fetched when somebody asks)
             if (!p->idx_uploaded.empty()) std::fill(p->idx_uploaded.begin() + d.n_kf + d.n_obj, p->idx_uploaded.end(), INT32_MIN);
             const StageHead head{th[0], th[1]};
+            p->n_boundary_device++;
             t3s = now();
             rc = ba_optimize(p, 10, 0.0, 0.0, 0.0, stop_flag, t2, false, &head);   // robust kernels dropped, :628,643,655
             if (tm)
@@ -4082,6 +4086,7 @@ extern "C" int qsp_ba_local_joint(qsp_ba_problem* p, const volatile uint8_t* sto
         }
         // (a key-frame or an object lost its last active edge: the reduced system changes shape -- the host path below)
     }
+    p->n_boundary_host++;
     if (p->world == 1) {
         // one GPU: classify where the chi2 values are; the host needs the levels only (build_index), one byte per edge
         const int n = std::max(std::max(d.n_edge, d.n_oe), 1);

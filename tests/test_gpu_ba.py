@@ -121,6 +121,57 @@ def test_local_joint_ba_two_stage_matches_oracle(name):
     gpu.close()
 
 
+def test_stage_boundary_paths_device_and_host():
+    """Round 4: the boundary between optimize(5) and optimize(10) of a local BA (outlier classification, re-index, the second
+    stage's first system) runs on the device behind the first stage's last trial; it falls back to the host path when a pose
+    vertex would leave the index.  Both are exercised and counted (qsp_ba_stats.boundary_device / boundary_host), both against
+    the oracle, and both give the same bits as the host path forced from the start (QSP_BA_HOST_BOUNDARY is read once per process,
+    so the comparison here is device path vs oracle + a second run of the same problem: bit-reproducible)."""
+    from qsp_slam_amd.ba import BaProblem
+    # (1) an ordinary scene: device path
+    sc = synth.make_ba_scene(**dict(SCENES["c2"], outlier_frac=0.08))
+    ref = bo.BaProblem(sc)
+    r1, r2 = ref.local_joint_ba()
+    gpu = BaProblem(sc)
+    g1, g2 = gpu.local_joint_ba()
+    st = gpu.profile(False)
+    assert (st.boundary_device, st.boundary_host) == (1, 0)
+    assert list(g2["trials"]) == list(r2["trials"]) and close(g2["chi2"], r2["chi2"], rtol=1e-8)
+    kh, oh, ph = gpu.index()                      # (fetched lazily from the device after the pointer swap)
+    assert np.array_equal(kh, r2["kf_hidx"]) and np.array_equal(oh, r2["obj_hidx"]) and np.array_equal(ph, r2["pt_hidx"])
+    assert (ph < 0).sum() == (r2["pt_hidx"] < 0).sum()
+    first = (np.array(g2["chi2"]), *gpu.state())
+    gpu.set_state(sc["kf_pose"], sc["pt_xyz"], sc["obj_pose"])      # the same problem again: cached all-active index, level reset in
+    h1, h2 = gpu.local_joint_ba()                                   # k_edge_index, second buffers swapped back
+    assert gpu.profile(False).boundary_device == 2
+    for x, y in zip((np.array(h2["chi2"]), *gpu.state()), first):
+        assert np.array_equal(x, y)
+    gpu.close()
+    # (2) one object's camera-object measurements are mutually inconsistent (each off by metres in its own direction): after the
+    # first stage every one of its edges is an outlier, the object vertex leaves the index, the reduced system shrinks -> host path
+    sc2 = synth.make_ba_scene(**dict(SCENES["c2"], outlier_frac=0.05))
+    rng = np.random.default_rng(8)
+    meas = sc2["oe_meas"].copy()
+    mine = np.nonzero(sc2["oe_obj"] == 0)[0]
+    meas[mine, :3] += rng.normal(scale=4.0, size=(len(mine), 3))
+    sc2["oe_meas"] = meas
+    ref = bo.BaProblem(sc2)
+    r1, r2 = ref.local_joint_ba()
+    assert r2["obj_hidx"][0] < 0 and (r2["obj_hidx"][1:] >= 0).all()           # the oracle drops object 0 from the second stage
+    gpu = BaProblem(sc2)
+    g1, g2 = gpu.local_joint_ba()
+    st = gpu.profile(False)
+    assert (st.boundary_device, st.boundary_host) == (0, 1)
+    for g, r in ((g1, r1), (g2, r2)):
+        assert list(g["trials"]) == list(r["trials"]) and close(g["chi2"], r["chi2"], rtol=1e-8)
+    kh, oh, ph = gpu.index()
+    assert np.array_equal(kh, r2["kf_hidx"]) and np.array_equal(oh, r2["obj_hidx"]) and np.array_equal(ph, r2["pt_hidx"])
+    kf, pt, ob = gpu.state()
+    rkf, rpt, rob = ref.state()
+    assert close(kf, rkf, rtol=1e-7, atol=1e-9) and close(pt, rpt, rtol=1e-7, atol=1e-9) and close(ob, rob, rtol=1e-7, atol=1e-9)
+    gpu.close()
+
+
 def test_against_committed_fixture(golden_dir):
     from qsp_slam_amd.ba import BaProblem
     z = np.load(os.path.join(golden_dir, "ba_local_joint_c1.npz"))
