@@ -1191,6 +1191,9 @@ __device__ void exp_se3_dev(const float* x, float* T) {   // loss_utils.py:129-1
     T[15] = 1.f;
 }
 
+#ifndef QSP_SOLVE_EXP
+#define QSP_SOLVE_EXP 0      // timing experiments only (1: no elimination, 2: no slot reads); 0 in every build that ships
+#endif
 constexpr int SOLVE_THREADS = 1024;   // latency, not throughput: more loads in flight for the partial sums, shorter row strips per pivot
 __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(HypState* __restrict__ st, const ObjView* __restrict__ objs,
                                                RefineCfg cfg, const float* __restrict__ partials, int nw_sdf,
@@ -1245,10 +1248,14 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(HypState* __restrict__ 
         float ss = 0.f, sr = 0.f;
         // same left-to-right order as ever; unrolled so that 32 of the (24 KiB-strided) loads are in flight at a time (a single
         // object's 2 k points are 63 slots of 32-point tiles: two batches instead of four in front of every entry)
+#if QSP_SOLVE_EXP != 2
 #pragma unroll 32
         for (int j = 0; j < n_sdf_slots; ++j) ss += base[(int64_t)j * PART_FLOATS + off];
 #pragma unroll 4
         for (int j = 0; j < n_rend_slots; ++j) sr += base[(int64_t)(nw_sdf + j) * PART_FLOATS + off];
+#else
+        ss = 1.f + 0.001f * (float)off; sr = 1.f;      // (timing experiment: no slot reads)
+#endif
         if (b < NH) {                      // normal-matrix entry
             if (a >= N || b >= N) continue;
             float v;
@@ -1351,7 +1358,11 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(HypState* __restrict__ 
     // (measured, round 4: the same elimination on four waves -- cheaper barriers, 24 elements per thread and column -- took the
     //  one-object call from 2.76 to 2.94 ms: with 1024 threads a column is 5 elements per thread and the LDS latency hides.)
     const int STR = SOLVE_THREADS / N;         // 14 strips for the 71 x 71 system
+#if QSP_SOLVE_EXP == 1
+    for (int c = 0; c < 0; ++c) {              // (timing experiment: no elimination)
+#else
     for (int c = 0; c < N; ++c) {
+#endif
         const double inv = 1.0 / Hd[c * (N + 1) + c];
         const int r = tid / STR, q = tid - r * STR;
         if (r < N && r != c) {
