@@ -140,3 +140,7 @@ def test_bench_strong_scaling_rehearsal_two_ranks():
     assert two["kernels"]["ba_lm_iterations"] == one["kernels"]["ba_lm_iterations"]
     assert two["good_hypotheses"] == one["good_hypotheses"]
     assert two["value"] > 0 and "roofline" in two
+    # the blocks round 4 added to the driver line
+    lat = one["ba_latency_roofline"]
+    assert lat["per_workload"]["c2"]["block_rows"] == 2 and 0 < lat["frac"] <= 1.0
+    assert one["roofline"]["bound"] == "mfma" and 0 < one["roofline"]["frac"] < 1
