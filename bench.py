@@ -282,7 +282,7 @@ class Ctx(object):
         return float(t.item())
 
 
-def run_workload(ctx, name, steps, warmup, detailed, precision=None, screening=None, audit=None):
+def run_workload(ctx, name, steps, warmup, detailed, precision=None, screening=None, audit=None, staging=None):
     """`steps` timed passes of workload `name` (after `warmup` untimed ones); every rank returns the same dict of whole-job
     numbers (rank 0's kernel timings)."""
     from qsp_slam_amd import DeepSdfDecoder, parallel, synth
@@ -297,6 +297,7 @@ def run_workload(ctx, name, steps, warmup, detailed, precision=None, screening=N
     margin = args.screening_margin if screening is None else screening
     if dec.precision == "fp16x2" and margin > 0:
         dec.set_screen_audit(args.screen_audit if audit is None else audit)
+        dec.set_depth_staging(not args.no_depth_staging if staging is None else staging)
         dec.set_render_screening(margin)     # two-pass ray-sample forward, bit-identical to the unscreened pipe (tests/test_gpu_screening.py)
     opt = Optimizer(dec, joint_cfg(w["n_iter"]))
     seed_off = 0 if strong else rank
@@ -419,6 +420,10 @@ def run_workload(ctx, name, steps, warmup, detailed, precision=None, screening=N
                             "(QSP_DEC_OPT_RANGE_FALLBACK); any non-zero count invalidates the line's dtype"),
         screening=(dict(margin=margin, max_abs_s1_minus_s3_on_band=float(prof.get("screen_max_diff", 0.0)),
                         band_share=prof["pts_band"] / max(prof["pts_fwd"], 1),
+                        depth_staging=dict(on=bool(dec.precision == "fp16x2" and not (args.no_depth_staging if staging is None else not staging)),
+                                           note="two depth stages: samples behind a ray's first opaque sample (exact zero transmittance, "
+                                                "loss.py:101) are not evaluated; samples_per_launch counts the evaluated ones; "
+                                                "`fp16x2_screened_one_depth_stage` is the same line with every valid sample evaluated"),
                         audit=dict(one_in=args.screen_audit, out_of_band_samples_re_evaluated_per_launch=prof["pts_audit"] / max(prof["n_fwd"], 1),
                                    found_inside_the_cut_off=int(prof["audit_failures"]),
                                    note="the second pass also re-evaluates one in N of the samples the screening pass put OUTSIDE the "
@@ -523,6 +528,8 @@ def main():
     ap.add_argument("--flips", type=int, default=4)
     ap.add_argument("--screening-margin", type=float, default=0.01,
                     help="fp16x2 only: band margin of the two-pass ray-sample forward (QSP_DEC_OPT_RENDER_SCREENING); 0 = one pass")
+    ap.add_argument("--no-depth-staging", action="store_true",
+                    help="screened forward: evaluate every valid ray sample in one depth stage (QSP_DEC_OPT_DEPTH_STAGING = 0; same bits)")
     ap.add_argument("--screen-audit", type=int, default=100,
                     help="screened forward: one in N out-of-band samples re-evaluated as well (QSP_DEC_OPT_SCREEN_AUDIT); 0 = off")
     ap.add_argument("--allow-hook-fallback", action="store_true",
@@ -558,6 +565,8 @@ def main():
             other["fp16x2_unscreened"] = run_workload(ctx, args.workload, 3, 1, detailed=False, precision="fp16x2", screening=0.0)
             if args.screen_audit > 0:        # ... and screened without the out-of-band audit: what the audit costs
                 other["fp16x2_screened_no_audit"] = run_workload(ctx, args.workload, 3, 1, detailed=False, precision="fp16x2", audit=0)
+            if not args.no_depth_staging:    # ... and screened in ONE depth stage: what the samples behind opaque ones cost
+                other["fp16x2_screened_one_depth_stage"] = run_workload(ctx, args.workload, 3, 1, detailed=False, precision="fp16x2", staging=False)
     subs = {}
     if not args.no_sublines:
         for name in ("c2", "c5"):
@@ -632,6 +641,7 @@ def main():
             out[opr + ("_mfma" if opr == base else "")] = {
                 "note": ("the same workload with --precision %s, 3 timed steps" % opr) if opr == base else
                         ("the same workload and pipe, screened, with --screen-audit 0, 3 timed steps" if opr.endswith("no_audit") else
+                         "the same workload and pipe, screened, with --no-depth-staging (every valid sample evaluated), 3 timed steps" if opr.endswith("depth_stage") else
                          "the same workload and pipe with --screening-margin 0 (every ray sample on the split-fp16 tile), 3 timed steps"),
                 "value": o["value"], "ms_per_step": o["ms_per_step"],
                 "k_mlp_jtj_TFLOPs": o["jtj"]["achieved"],

@@ -113,6 +113,12 @@ void qsp_decoder_destroy(qsp_decoder* dec);
  * each one whose split-fp16 value lies inside the cut-off or has the other sign -- a clamp the one-pass result would not have
  * made -- as a hard failure (qsp_refine_profile.screen_audit_failures): the run is repeated in one pass like above.  An audited
  * sample's overwritten value is only ever read through the clamp, so the audit changes no bit of a passing run.
+ * QSP_DEC_OPT_DEPTH_STAGING (1, the default / 0): a screened run evaluates the ray samples in two depth stages -- indices [0, D/2)
+ * of every ray, then [D/2, D) of the rays that have no OPAQUE sample (sdf <= -cut_off: occupancy exactly 1) yet.  Behind an
+ * opaque sample the transmittance of reconstruct/loss.py:101 is exactly 0, so those samples' values reach no output (every term
+ * they enter is multiplied by that zero; d e / d o of an in-band one is 0 and dropped by the 1e-2 rule, :103-128): they are not
+ * evaluated.  ~20 % of the samples on the synthetic scenes; every output bit-identical to 0 (tests/test_gpu_screening.py).  Only
+ * a decoder that returns NaN behind a surface would tell the two apart.
  * QSP_DEC_OPT_SCREENING_MIN_SAMPLES (-1, the default, or a count): a run is screened only when its batch holds more ray samples
  * (rays x depth samples, summed over the hypotheses) than this; -1 = more than two rounds of 64-point tiles over the chip.  A
  * batch that fits one round -- one object per call -- is one tile deep either way and faster in one pass.  The result is the
@@ -128,7 +134,8 @@ void qsp_decoder_destroy(qsp_decoder* dec);
  * qsp_decoder_get_counter(QSP_DEC_CNT_RANGE_FALLBACKS)); 0 fails the call with QSP_ERR_UNSUPPORTED as round 2 did. */
 enum { QSP_DEC_OPT_FORWARD_PRECISION = 1, QSP_DEC_OPT_JACOBIAN_PRECISION = 2, QSP_DEC_OPT_TILE_POINTS = 3,
        QSP_DEC_OPT_RENDER_SCREENING = 4, QSP_DEC_OPT_USE_TANH = 5, QSP_DEC_OPT_RANGE_FALLBACK = 6,
-       QSP_DEC_OPT_SCREENING_MIN_SAMPLES = 7, QSP_DEC_OPT_NARROW_TILE = 8, QSP_DEC_OPT_SCREEN_AUDIT = 9 };
+       QSP_DEC_OPT_SCREENING_MIN_SAMPLES = 7, QSP_DEC_OPT_NARROW_TILE = 8, QSP_DEC_OPT_SCREEN_AUDIT = 9,
+       QSP_DEC_OPT_DEPTH_STAGING = 10 };
 enum { QSP_DEC_CNT_RANGE_FALLBACKS = 1, QSP_DEC_CNT_ARENA_REUSED = 2, QSP_DEC_CNT_ARENA_CREATED = 3, QSP_DEC_CNT_NARROW_TILE = 4,
        QSP_DEC_CNT_SCREEN_FALLBACKS = 5 };
 /* lifetime counters of a decoder: calls that were re-run on the f32 pipe because a value left fp16's range; calls of

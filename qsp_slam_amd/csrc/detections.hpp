@@ -133,7 +133,7 @@ __global__ void __launch_bounds__(64) k_det_init(Inputs in, HypState* st, float*
     S.n_valid = S.n_render = 0;
     S.obj = d;
     S.n_band = 0;
-    S.pad = 0;
+    S.n_stage = S.n_band_total = S.n_eval = 0;
 }
 
 // one thread per detection: the keep rule of :738-752 over its hypotheses, in order

@@ -65,6 +65,7 @@ struct qsp_decoder {
     int* range_flag_h = nullptr;   // host-mapped word the split-fp16 kernels set when a value left fp16's range (check_range)
     bool narrow_capable = false;   // the decoder is small enough for the NARROW tile (narrow_tables); QSP_DEC_OPT_NARROW_TILE toggles its use
     float screen_margin = 0.f;     // QSP_DEC_OPT_RENDER_SCREENING: > 0 = two-pass ray-sample forward with this band margin
+    int32_t depth_staging = 1;     // QSP_DEC_OPT_DEPTH_STAGING: the screened forward in two depth stages (k_stage_list); same bits
     int32_t screen_audit = 100;    // QSP_DEC_OPT_SCREEN_AUDIT: one in this many OUT-of-band samples is re-evaluated too (0 = off, 1 = all)
     int64_t screen_min_samples = -1;   // QSP_DEC_OPT_SCREENING_MIN_SAMPLES: -1 = more than two rounds of 64-point tiles over the chip
     int range_fallback = 1;        // QSP_DEC_OPT_RANGE_FALLBACK: a call that left fp16's range is repeated on the f32 pipe
@@ -665,6 +666,10 @@ extern "C" int qsp_decoder_set_option(qsp_decoder* d, int32_t option, int32_t va
                                                      "QSP_DEC_OPT_FORWARD_PRECISION to 2 first");
             d->screen_margin = 1e-6f * (float)value;
             return QSP_OK;
+        case QSP_DEC_OPT_DEPTH_STAGING:
+            if (value != 0 && value != 1) return qsp_fail(QSP_ERR_INVALID, "depth staging: 0 or 1");
+            d->depth_staging = (int32_t)value;
+            return QSP_OK;
         case QSP_DEC_OPT_SCREEN_AUDIT:
             if (value < 0 || value > 1000000) return qsp_fail(QSP_ERR_INVALID, "screening audit: one in N out-of-band samples, N = 0 (off) .. 1e6");
             d->screen_audit = (int32_t)value;
@@ -881,6 +886,8 @@ struct qsp_refine_batch {
     int32_t last_audit_wrong = 0;
     int64_t last_audited = 0;
     int32_t* band_idx = nullptr;    // screened forward pass: per hypothesis, indices into its valid-sample list (k_mlp_fwd_h1)
+    int32_t* stage_idx = nullptr;   // depth-staged forward: the current stage's samples, as positions in the valid list (k_stage_list)
+    uint8_t* ray_open = nullptr;    //   per (hypothesis, ray): no opaque sample in the stages so far
     HypState* st_snap = nullptr;    // the hypotheses as a run found them (restored when the run is repeated on the f32 pipe)
     uint8_t* act_snap = nullptr;    // pose-only mode: pt_active likewise
     float* c0_all = nullptr;        // [n_hyp][2][512] code part of layers 0 and 4 (bias included) per hypothesis (k_c0)
@@ -898,7 +905,7 @@ static void batch_free(qsp_refine_batch* b) {
     (void)hipSetDevice(b->device);
     void* ptrs[] = {b->st, b->objs, b->pts, b->rays, b->depth, b->valid_rk, b->ray_voff, b->rend_rk, b->sdf_valid,
                     b->rend_deds, b->rend_res, b->partials, b->trH, b->trb, b->trdx, b->trrot, b->pt_active, b->res_buf, b->rows, b->counters,
-                    b->work_fwd, b->work_jtj, b->qctl, b->c0_all, b->band_idx, b->st_snap, b->act_snap};
+                    b->work_fwd, b->work_jtj, b->qctl, b->c0_all, b->band_idx, b->stage_idx, b->ray_open, b->st_snap, b->act_snap};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : b->ev) (void)hipEventDestroy(e);
@@ -1050,6 +1057,8 @@ static int batch_create(qsp_decoder* dec, const RefineCfg& cfg, int n_iter, int3
         QSP_ALLOC(b->rend_deds, sizeof(float) * (size_t)cap_hyp * b->rk_stride);
         QSP_ALLOC(b->rend_res, sizeof(float) * (size_t)cap_hyp * b->rk_stride);
         QSP_ALLOC(b->band_idx, sizeof(int32_t) * (size_t)cap_hyp * b->rk_stride);
+        QSP_ALLOC(b->stage_idx, sizeof(int32_t) * (size_t)cap_hyp * b->rk_stride);
+        QSP_ALLOC(b->ray_open, (size_t)cap_hyp * b->ray_stride);
     } else {
         QSP_ALLOC(b->pt_active, (size_t)cap_hyp * b->act_stride);
         QSP_ALLOC(b->act_snap, (size_t)cap_hyp * b->act_stride);
@@ -1150,28 +1159,44 @@ static int run_once(qsp_refine_batch* b, int32_t n_iter, bool* hit, bool* screen
             // (a narrow decoder's one-pass forward on the NARROW tile is cheaper than the full-width screening pass: not screened)
             const bool screen = b->dec->fwd_bf3 == 2 && b->dec->screen_margin > 0.f && ub_samples > min_samples && !b->dec->P.narrow;
             // the forward kernel's item list is built in k_sample's tail (plan_tail; the forward pass keeps 64-point tiles: tens of
-            // thousands of ray samples fill the chip either way)
-            const PlanTail pt_fwd{b->work_fwd, b->qctl, b->qctl + 4, nH, b->nw_sdf, nw_total - b->nw_sdf, screen ? H1_ROWS : TILE_P, 0};
+            // thousands of ray samples fill the chip either way) -- or, when the screened pass runs in depth stages, in the tail of
+            // each stage's k_stage_list
+            const bool staged = screen && b->dec->depth_staging && cfg.n_depth >= 4;
+            const PlanTail pt_fwd{staged ? nullptr : b->work_fwd, b->qctl, b->qctl + 4, nH, b->nw_sdf, nw_total - b->nw_sdf,
+                                  screen ? H1_ROWS : TILE_P, 0};
             hipLaunchKernelGGL(k_sample, dim3(nH), dim3(256), 0, s, b->st, b->objs, b->rays, cfg, b->valid_rk, b->rk_stride,
                                b->ray_voff, b->ray_stride, b->dec->Pd, b->c0_all, pt_fwd);
             if (b->prof) spans.push_back({a, next_event(b, cur), 2});
             if (b->prof) a = next_event(b, cur);
             if (screen) {
                 // two passes (QSP_DEC_OPT_RENDER_SCREENING): every sample on the one-product tile, then the band around the
-                // surface on the split-fp16 tile; the queue's control words and item list are reused behind the first pass
-                if (screen_waves() == 8)
-                    hipLaunchKernelGGL(k_mlp_fwd_h1<8>, dim3(b->n_cu), dim3(512), sizeof(MlpSmemH1), s, b->st, b->objs, b->rays,
+                // surface on the split-fp16 tile; the queue's control words and item list are reused behind the first pass.
+                // Depth-staged (QSP_DEC_OPT_DEPTH_STAGING): that pair once for the depth indices [0, D/2) of every ray and once
+                // for [D/2, D) of the rays that have no opaque sample yet (k_stage_list).
+                const int n_stage = staged ? 2 : 1, k_mid = cfg.n_depth / 2;
+                for (int sg = 0; sg < n_stage; ++sg) {
+                    const int32_t* stage_list = nullptr;
+                    if (staged) {
+                        const PlanTail pt_st{b->work_fwd, b->qctl, b->qctl + 4, nH, b->nw_sdf, nw_total - b->nw_sdf, H1_ROWS, 3};
+                        hipLaunchKernelGGL(k_stage_list, dim3(nH), dim3(256), 0, s, b->st, b->objs, cfg, b->valid_rk, b->rk_stride, b->ray_voff,
+                                           b->ray_stride, b->sdf_valid, b->ray_open, b->stage_idx, 0, sg == 0 ? 0 : k_mid,
+                                           sg == 0 ? k_mid : cfg.n_depth, pt_st);
+                        stage_list = b->stage_idx;
+                    }
+                    if (screen_waves() == 8)
+                        hipLaunchKernelGGL(k_mlp_fwd_h1<8>, dim3(b->n_cu), dim3(512), sizeof(MlpSmemH1), s, b->st, b->objs, b->rays,
+                                           cfg, b->dec->Pd, b->valid_rk, b->rk_stride, b->sdf_valid, b->work_fwd, b->qctl, b->c0_all,
+                                           b->band_idx, cfg.cut_off + b->dec->screen_margin, b->dec->screen_audit, stage_list);
+                    else
+                        hipLaunchKernelGGL(k_mlp_fwd_h1<4>, dim3(b->n_cu), dim3(H2_THREADS), sizeof(MlpSmemH1), s, b->st, b->objs, b->rays,
+                                           cfg, b->dec->Pd, b->valid_rk, b->rk_stride, b->sdf_valid, b->work_fwd, b->qctl, b->c0_all,
+                                           b->band_idx, cfg.cut_off + b->dec->screen_margin, b->dec->screen_audit, stage_list);
+                    hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, s, 2, b->st, b->objs, nH, b->nw_sdf, nw_total - b->nw_sdf,
+                                       b->work_fwd, b->qctl, TILE_P);
+                    hipLaunchKernelGGL((k_mlp_fwd_h2<2, false, 4>), dim3(b->n_cu), dim3(H2_THREADS), sizeof(MlpSmem), s, b->st, b->objs, b->rays,
                                        cfg, b->dec->Pd, b->valid_rk, b->rk_stride, b->sdf_valid, b->work_fwd, b->qctl, b->c0_all,
-                                       b->band_idx, cfg.cut_off + b->dec->screen_margin, b->dec->screen_audit);
-                else
-                    hipLaunchKernelGGL(k_mlp_fwd_h1<4>, dim3(b->n_cu), dim3(H2_THREADS), sizeof(MlpSmemH1), s, b->st, b->objs, b->rays,
-                                       cfg, b->dec->Pd, b->valid_rk, b->rk_stride, b->sdf_valid, b->work_fwd, b->qctl, b->c0_all,
-                                       b->band_idx, cfg.cut_off + b->dec->screen_margin, b->dec->screen_audit);
-                hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, s, 2, b->st, b->objs, nH, b->nw_sdf, nw_total - b->nw_sdf,
-                                   b->work_fwd, b->qctl, TILE_P);
-                hipLaunchKernelGGL((k_mlp_fwd_h2<2, false, 4>), dim3(b->n_cu), dim3(H2_THREADS), sizeof(MlpSmem), s, b->st, b->objs, b->rays,
-                                   cfg, b->dec->Pd, b->valid_rk, b->rk_stride, b->sdf_valid, b->work_fwd, b->qctl, b->c0_all,
-                                   (const int32_t*)b->band_idx, (unsigned int*)(b->counters + 5));
+                                       (const int32_t*)b->band_idx, (unsigned int*)(b->counters + 5));
+                }
                 screened_any = true;
             } else if (b->dec->fwd_bf3 == 2 && b->dec->P.narrow)
                 hipLaunchKernelGGL((k_mlp_fwd_h2<2, true, 8>), dim3(b->n_cu), dim3(512), sizeof(MlpSmem), s, b->st, b->objs, b->rays,

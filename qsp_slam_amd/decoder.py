@@ -85,6 +85,11 @@ class DeepSdfDecoder(object):
         tiles over the chip), 0 = always (QSP_DEC_OPT_SCREENING_MIN_SAMPLES)"""
         _lib.check(_lib.lib().qsp_decoder_set_option(self.handle, 7, int(n)))
 
+    def set_depth_staging(self, on=True):
+        """the screened forward in two depth stages: samples behind a ray's first opaque sample are multiplied by an exact zero
+        transmittance and are not evaluated (QSP_DEC_OPT_DEPTH_STAGING; on by default, bit-identical results)"""
+        _lib.check(_lib.lib().qsp_decoder_set_option(self.handle, 10, 1 if on else 0))
+
     def set_screen_audit(self, one_in=100):
         """the screened forward's out-of-band audit (QSP_DEC_OPT_SCREEN_AUDIT): one in `one_in` of the samples the screening pass
         put OUTSIDE the band is re-evaluated on the split-fp16 tile as well; one found inside the cut-off repeats the run in one

@@ -181,6 +181,47 @@ def test_the_out_of_band_audit_changes_no_bit_and_looks_at_its_share(dec, golden
     assert within("fp16x2/screening/max_abs_s1_minus_s3_over_ALL_samples", outs[1]["prof"].screen_max_diff, MARGIN / 8)
 
 
+def test_depth_staging_skips_samples_behind_an_opaque_one_and_changes_no_bit(dec, golden_dir):
+    """QSP_DEC_OPT_DEPTH_STAGING (round 4): behind the first sample of a ray with sdf <= -cut_off the transmittance of
+    reconstruct/loss.py:101 is exactly 0, so those samples' decoder values reach no output; the screened pass evaluates depth
+    indices [0, D/2) of every ray, then [D/2, D) of the rays that are still open.  Everything -- n_valid, K, H, b, dx, every
+    iterate, pose, code, loss -- equals the unstaged screened run AND the one-pass run bit for bit; the profile shows the samples
+    that were not evaluated (and, with the audit at 1, that band + audited = everything that was)."""
+    from qsp_slam_amd import synth
+    from qsp_slam_amd.reconstruct.optimizer import Optimizer
+    import bench
+    objs = synth.make_object_views(5151, 16, 700, n_fg=160, n_bg=90)
+    opt = Optimizer(dec, make_cfg(so.JointConfig(n_iter=4)))
+    T0, hyp = bench.flip_states(objs, 4)
+    one_pass = run_batch(dec, opt, objs, hyp, T0, None, 4, False)
+    try:
+        dec.set_depth_staging(False)
+        flat = run_batch(dec, opt, objs, hyp, T0, None, 4, True)
+        dec.set_depth_staging(True)
+        staged = run_batch(dec, opt, objs, hyp, T0, None, 4, True)
+        dec.set_screen_audit(1)
+        staged_all = run_batch(dec, opt, objs, hyp, T0, None, 4, True)
+    finally:
+        dec.set_depth_staging(True)
+        dec.set_screen_audit(100)
+    assert_same_bits(one_pass, flat, "screened, one depth stage")
+    assert_same_bits(one_pass, staged, "screened, two depth stages")
+    assert_same_bits(one_pass, staged_all, "screened, two depth stages, audit of every sample")
+    skipped = 1.0 - staged["prof"].pts_fwd / flat["prof"].pts_fwd
+    assert within("fp16x2/screening/depth_staging_share_of_samples_not_evaluated", 0.05 / max(skipped, 1e-9), 1.0)     # (>= 5 %)
+    assert staged["prof"].pts_band < flat["prof"].pts_band and staged["prof"].screen_fallbacks == 0
+    assert staged_all["prof"].pts_band == staged_all["prof"].pts_fwd == staged["prof"].pts_fwd
+    # the golden cases (reference-run fixtures), staged, against the one-pass bits
+    for name in JOINT_CASES:
+        z = np.load(os.path.join(golden_dir, name + ".npz"))
+        o2 = Optimizer(dec, make_cfg(z))
+        obj = dict(pts=z["pts"], rays=z["rays"], depth=z["depth"])
+        n_it = int(z["it_H"].shape[0])
+        a = run_batch(dec, o2, [obj], [0], z["t_cam_obj"][None], None, n_it, False)
+        b = run_batch(dec, o2, [obj], [0], z["t_cam_obj"][None], None, n_it, True)
+        assert_same_bits(a, b, name + ", staged")
+
+
 def adversarial_decoder(golden_dir, A=512.0, n_pair=32):
     """The fitted decoder with the `n_pair` most active hidden units of layer 5 DUPLICATED into units that are dead on the unit
     cube (rows j and k of layer 5 identical) and +A / -A added to the two columns of layer 6 that read them.  In exact arithmetic
