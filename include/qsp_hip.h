@@ -113,7 +113,8 @@ void qsp_decoder_destroy(qsp_decoder* dec);
  * each one whose split-fp16 value lies inside the cut-off or has the other sign -- a clamp the one-pass result would not have
  * made -- as a hard failure (qsp_refine_profile.screen_audit_failures): the run is repeated in one pass like above.  An audited
  * sample's overwritten value is only ever read through the clamp, so the audit changes no bit of a passing run.
- * QSP_DEC_OPT_DEPTH_STAGING (1, the default / 0): a screened run evaluates the ray samples in two depth stages -- indices [0, D/2)
+ * QSP_DEC_OPT_DEPTH_STAGING (1, the default: batches of more than 64 rounds of 128-sample tiles over the chip / 2: always / 0: never):
+ * a screened run evaluates the ray samples in two depth stages -- indices [0, D/2)
  * of every ray, then [D/2, D) of the rays that have no OPAQUE sample (sdf <= -cut_off: occupancy exactly 1) yet.  Behind an
  * opaque sample the transmittance of reconstruct/loss.py:101 is exactly 0, so those samples' values reach no output (every term
  * they enter is multiplied by that zero; d e / d o of an in-band one is 0 and dropped by the 1e-2 rule, :103-128): they are not

@@ -667,7 +667,7 @@ extern "C" int qsp_decoder_set_option(qsp_decoder* d, int32_t option, int32_t va
             d->screen_margin = 1e-6f * (float)value;
             return QSP_OK;
         case QSP_DEC_OPT_DEPTH_STAGING:
-            if (value != 0 && value != 1) return qsp_fail(QSP_ERR_INVALID, "depth staging: 0 or 1");
+            if (value < 0 || value > 2) return qsp_fail(QSP_ERR_INVALID, "depth staging: 0 (off), 1 (large batches) or 2 (always)");
             d->depth_staging = (int32_t)value;
             return QSP_OK;
         case QSP_DEC_OPT_SCREEN_AUDIT:
@@ -1161,7 +1161,11 @@ static int run_once(qsp_refine_batch* b, int32_t n_iter, bool* hit, bool* screen
             // the forward kernel's item list is built in k_sample's tail (plan_tail; the forward pass keeps 64-point tiles: tens of
             // thousands of ray samples fill the chip either way) -- or, when the screened pass runs in depth stages, in the tail of
             // each stage's k_stage_list
-            const bool staged = screen && b->dec->depth_staging && cfg.n_depth >= 4;
+            // (a stage costs a list kernel, a plan and a band pass that is one tile deep whatever its size: it pays once the screening
+            //  pass is tens of tile rounds over the chip -- C4 and C5; measured break-even around C2, 0.7 M samples: 18.1 against
+            //  19.1 ms per step; four yaw flips of one object: 3.8 against 4.8 ms per call)
+            const bool staged = screen && cfg.n_depth >= 4 &&
+                                (b->dec->depth_staging == 2 || (b->dec->depth_staging == 1 && ub_samples > 64 * (int64_t)b->n_cu * H1_ROWS));
             const PlanTail pt_fwd{staged ? nullptr : b->work_fwd, b->qctl, b->qctl + 4, nH, b->nw_sdf, nw_total - b->nw_sdf,
                                   screen ? H1_ROWS : TILE_P, 0};
             hipLaunchKernelGGL(k_sample, dim3(nH), dim3(256), 0, s, b->st, b->objs, b->rays, cfg, b->valid_rk, b->rk_stride,

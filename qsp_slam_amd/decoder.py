@@ -87,8 +87,9 @@ class DeepSdfDecoder(object):
 
     def set_depth_staging(self, on=True):
         """the screened forward in two depth stages: samples behind a ray's first opaque sample are multiplied by an exact zero
-        transmittance and are not evaluated (QSP_DEC_OPT_DEPTH_STAGING; on by default, bit-identical results)"""
-        _lib.check(_lib.lib().qsp_decoder_set_option(self.handle, 10, 1 if on else 0))
+        transmittance and are not evaluated (QSP_DEC_OPT_DEPTH_STAGING; bit-identical results).  True: large batches only (the
+        default: a stage costs launches that only pay beyond ~2 M samples); "always": whatever the size (tests); False: never."""
+        _lib.check(_lib.lib().qsp_decoder_set_option(self.handle, 10, 2 if on == "always" else (1 if on else 0)))
 
     def set_screen_audit(self, one_in=100):
         """the screened forward's out-of-band audit (QSP_DEC_OPT_SCREEN_AUDIT): one in `one_in` of the samples the screening pass

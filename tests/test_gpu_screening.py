@@ -197,7 +197,7 @@ def test_depth_staging_skips_samples_behind_an_opaque_one_and_changes_no_bit(dec
     try:
         dec.set_depth_staging(False)
         flat = run_batch(dec, opt, objs, hyp, T0, None, 4, True)
-        dec.set_depth_staging(True)
+        dec.set_depth_staging("always")          # (the default stages batches beyond ~2 M samples only: bench-sized)
         staged = run_batch(dec, opt, objs, hyp, T0, None, 4, True)
         dec.set_screen_audit(1)
         staged_all = run_batch(dec, opt, objs, hyp, T0, None, 4, True)
@@ -212,6 +212,7 @@ def test_depth_staging_skips_samples_behind_an_opaque_one_and_changes_no_bit(dec
     assert staged["prof"].pts_band < flat["prof"].pts_band and staged["prof"].screen_fallbacks == 0
     assert staged_all["prof"].pts_band == staged_all["prof"].pts_fwd == staged["prof"].pts_fwd
     # the golden cases (reference-run fixtures), staged, against the one-pass bits
+    dec.set_depth_staging("always")
     for name in JOINT_CASES:
         z = np.load(os.path.join(golden_dir, name + ".npz"))
         o2 = Optimizer(dec, make_cfg(z))
@@ -220,6 +221,8 @@ def test_depth_staging_skips_samples_behind_an_opaque_one_and_changes_no_bit(dec
         a = run_batch(dec, o2, [obj], [0], z["t_cam_obj"][None], None, n_it, False)
         b = run_batch(dec, o2, [obj], [0], z["t_cam_obj"][None], None, n_it, True)
         assert_same_bits(a, b, name + ", staged")
+        assert b["prof"].pts_fwd < a["prof"].pts_fwd
+    dec.set_depth_staging(True)
 
 
 def adversarial_decoder(golden_dir, A=512.0, n_pair=32):
