@@ -46,6 +46,8 @@ class DeepSdfDecoder(object):
                 # ... or on the screened split-fp16 pipe, every batch in two passes whatever its size (QSP_SCREENING = margin)
                 self.set_render_screening(float(os.environ["QSP_SCREENING"]))
                 self.set_screening_min_samples(0)
+                if os.environ.get("QSP_DEPTH_STAGING"):      # ... and in two depth stages whatever its size ("always"), or never ("0")
+                    self.set_depth_staging({"always": "always", "0": False}.get(os.environ["QSP_DEPTH_STAGING"], True))
         self.mac_per_point = int(sum(int(i) * int(o) for i, o in zip(in_dim, out_dim)))
 
     PRECISIONS = {"f32": 0, "bf16x3": 1, "fp16x2": 2}
