@@ -265,6 +265,7 @@ extern "C" int qsp_refine_detections(qsp_decoder* dec, const qsp_joint_cfg* cfg,
 
     hipStream_t s = dec->stream;
     const int gx = std::min(64, (max_items + 255) / 256);
+    if ((rc = batch_upload(b))) return rc;      // (the object table batch_fill left in the mirror)
     hipLaunchKernelGGL(k_det_assemble, dim3(gx, n), dim3(256), 0, s, I, b->objs, b->pts, b->rays, b->depth);
     hipLaunchKernelGGL(k_det_init, dim3(n), dim3(64), 0, s, I, b->st, d_tinit);
     QSP_HIP(hipGetLastError());

@@ -140,9 +140,8 @@ __device__ __forceinline__ float det3(const float* T) {   // of the upper-left 3
     return (float)(a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g));
 }
 
-// exclusive scan of one int per thread over the block (a multiple of 64, at most 512 threads); returns the exclusive prefix,
-// total in *total
-__device__ int block_excl_scan_256(int v, int* smem /* >= 8 ints */, int* total) {
+// exclusive scan of one int per thread over the block (a multiple of 64 threads); returns the exclusive prefix, total in *total
+__device__ int block_excl_scan_256(int v, int* smem /* >= one int per wave */, int* total) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int x = v;
 #pragma unroll
@@ -173,6 +172,28 @@ __device__ __forceinline__ float huber_w(float r, float b) {
 // ---------------------------------------------------------------------------------------------------------------
 // k_sample: per-hypothesis prologue + valid ray samples (loss.py:60-74, optimizer.py:144-153)
 // ---------------------------------------------------------------------------------------------------------------
+#ifndef QSP_PHASE_CLOCK
+#define QSP_PHASE_CLOCK 0    // timing experiment only (tools/phase_clock.py): thread 0 of workgroup 0 of k_sample (0), k_scan (1) and k_solve
+#endif                       // (2) stamps the constant 100 MHz counter at its marks; correct results; 0 in every build that ships
+#if QSP_PHASE_CLOCK
+__device__ unsigned long long qsp_phase_abs[3][16];      // the launch's stamps
+__device__ unsigned long long qsp_phase_ticks[3][16];    // [kernel][i]: ticks between mark i-1 and mark i, summed over launches; [kernel][0]: launches
+#define PHASE_MARK(kern, i)                                                                     \
+    if (blockIdx.x == 0 && threadIdx.x == 0) qsp_phase_abs[kern][i] = __builtin_amdgcn_s_memrealtime();
+#define PHASE_END(kern, n)                                                                      \
+    if (blockIdx.x == 0 && threadIdx.x == 0) {                                                  \
+        qsp_phase_abs[kern][n] = __builtin_amdgcn_s_memrealtime();                              \
+        for (int i_ = 1; i_ <= (n); ++i_) qsp_phase_ticks[kern][i_] += qsp_phase_abs[kern][i_] - qsp_phase_abs[kern][i_ - 1]; \
+        qsp_phase_ticks[kern][0] += 1;                                                          \
+    }
+#else
+#define PHASE_MARK(kern, i)
+#define PHASE_END(kern, n)
+#endif
+#ifndef QSP_PHASE_EXP
+#define QSP_PHASE_EXP 0      // timing experiments only (tools/list_phases.sh: k_sample / k_scan cut short at a phase boundary); 0 in every build that ships
+#endif
+constexpr int SAMPLE_THREADS = 1024;      // k_sample's workgroup: latency, not throughput (a one-object call is ONE workgroup)
 __device__ __forceinline__ void sample_body(HypState* __restrict__ st, const ObjView* __restrict__ objs,
                                             const float* __restrict__ rays, const RefineCfg& cfg,
                                             int32_t* __restrict__ valid_rk, int64_t rk_stride,
@@ -183,24 +204,26 @@ __device__ __forceinline__ void sample_body(HypState* __restrict__ st, const Obj
     if (!S.alive) return;
     __shared__ float T[16];
     __shared__ float dm[2];
-    __shared__ int sc[8];
+    __shared__ int sc[SAMPLE_THREADS / 64];
     __shared__ float code_sh[CODE_LEN];
+    __shared__ uint64_t mask_sh[SAMPLE_THREADS];     // one pass's rays: bit k = depth sample k is inside the unit ball
+    __shared__ int off_sh[SAMPLE_THREADS];           // and where each ray's entries start in the pass's part of the list
     if (threadIdx.x < CODE_LEN) code_sh[threadIdx.x] = S.code[threadIdx.x];
     __syncthreads();
+    PHASE_MARK(0, 1);
     // the per-hypothesis bias vectors of layers 0 and 4 (k_c0's arithmetic, folded in here: one launch less per iteration; the other
     // waves work on it while thread 0 inverts the pose)
-    for (int u = threadIdx.x; u < HID; u += 256) {
-        const float* w = Pm->w0c + (size_t)u * CODE_LEN;
-        const float* w4 = Pm->w4c + (size_t)u * CODE_LEN;
-        float a = Pm->bias[0][u], a4 = Pm->bias[4][u];
+    {   // (code_bias's sums, layer 0's on the first 512 threads and layer 4's on the other 512)
+        static_assert(SAMPLE_THREADS == 2 * HID, "one bias entry per thread");
+        const int u = threadIdx.x & (HID - 1);
+        const bool l4 = threadIdx.x >= HID;
+        const float* w = (l4 ? Pm->w4c : Pm->w0c) + u;
+        float a = Pm->bias[l4 ? 4 : 0][u];
 #pragma unroll 8
-        for (int k = 0; k < CODE_LEN; ++k) {
-            a += w[k] * code_sh[k];
-            a4 += w4[k] * code_sh[k];
-        }
-        c0_all[(size_t)h * 2 * HID + u] = a;
-        c0_all[(size_t)h * 2 * HID + HID + u] = a4;
+        for (int k = 0; k < CODE_LEN; ++k) a += w[(size_t)k * HID] * code_sh[k];
+        c0_all[(size_t)h * 2 * HID + threadIdx.x] = a;
     }
+    PHASE_MARK(0, 2);
     if (threadIdx.x == 0) {
         float Tco[16];
         inv4(S.T_oc, Tco);
@@ -214,36 +237,55 @@ __device__ __forceinline__ void sample_body(HypState* __restrict__ st, const Obj
         for (int i = 0; i < 16; ++i) T[i] = S.T_oc[i];
     }
     __syncthreads();
+    PHASE_MARK(0, 3);
+#if QSP_PHASE_EXP == 11
+    return;
+#endif
     const ObjView ov = objs[S.obj];
     const int D = cfg.n_depth;
     const float* R = rays + 3 * ov.ray_off;
     int32_t* rk = valid_rk + h * rk_stride;
     int32_t* voff = ray_voff + h * ray_stride;
+    // A wave per ray, a lane per depth sample: the ray's mask of samples inside the unit ball is one ballot, its list entries one
+    // store of consecutive words.  (A thread per ray walked its 64 samples one after the other with one wave on each SIMD, and
+    // stored its entries a line per lane: 25 of this kernel's 41 us on a one-object call.)  Same expressions per sample.
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, NW = SAMPLE_THREADS / 64;
+    const float d = depth_at(dm[0], dm[1], lane, D);
     int carry = 0;
-    for (int base = 0; base < ov.n_rays; base += 256) {
-        const int r = base + threadIdx.x;
-        uint64_t mask = 0;
-        float rx = 0, ry = 0, rz = 0;
-        if (r < ov.n_rays) {
-            rx = R[3 * r], ry = R[3 * r + 1], rz = R[3 * r + 2];
-            for (int k = 0; k < D; ++k) {
-                const float d = depth_at(dm[0], dm[1], k, D);
-                float x, y, z;
-                xform(T, rx * d, ry * d, rz * d, x, y, z);
-                if (sqrtf(x * x + y * y + z * z) < 1.0f) mask |= (1ull << k);
-            }
+    for (int base = 0; base < ov.n_rays; base += SAMPLE_THREADS) {
+        const int n_pass = min(SAMPLE_THREADS, ov.n_rays - base);
+        // (lane i fetches the ray of its wave's i-th turn: three loads in flight per lane once, instead of a load's latency per turn)
+        const int mine = wave + NW * lane;
+        float fx = 0.f, fy = 0.f, fz = 0.f;
+        if (mine < n_pass) fx = R[3 * (base + mine)], fy = R[3 * (base + mine) + 1], fz = R[3 * (base + mine) + 2];
+        for (int rl = wave, turn = 0; rl < n_pass; rl += NW, ++turn) {
+            const float rx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(fx), turn));
+            const float ry = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(fy), turn));
+            const float rz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(fz), turn));
+            float x, y, z;
+            xform(T, rx * d, ry * d, rz * d, x, y, z);
+            const uint64_t m = __ballot(lane < D && sqrtf(x * x + y * y + z * z) < 1.0f);
+            if (lane == 0) mask_sh[rl] = m;
         }
-        const int cnt = __popcll(mask);
+        __syncthreads();
+        PHASE_MARK(0, 4);
+        const int cnt = (threadIdx.x < n_pass) ? __popcll(mask_sh[threadIdx.x]) : 0;
         int tot;
         const int ex = block_excl_scan_256(cnt, sc, &tot);
-        if (r < ov.n_rays) {
-            voff[r] = carry + ex;
-            int w = carry + ex;
-            for (int k = 0; k < D; ++k)
-                if (mask >> k & 1ull) rk[w++] = (r << 6) | k;
+        if (threadIdx.x < n_pass) {
+            voff[base + threadIdx.x] = carry + ex;
+            off_sh[threadIdx.x] = ex;
+        }
+        __syncthreads();
+        PHASE_MARK(0, 5);
+        for (int rl = wave; rl < n_pass; rl += NW) {
+            const uint64_t m = mask_sh[rl];
+            if (m >> lane & 1ull) rk[carry + off_sh[rl] + __popcll(m & ((1ull << lane) - 1ull))] = ((base + rl) << 6) | lane;
         }
         carry += tot;
+        __syncthreads();        // (mask_sh and off_sh are the next pass's)
     }
+    PHASE_MARK(0, 6);
     if (threadIdx.x == 0) {
         voff[ov.n_rays] = carry;
         S.n_valid = carry;
@@ -312,14 +354,8 @@ __global__ __launch_bounds__(MLP_THREADS) void k_c0(const HypState* __restrict__
     if (threadIdx.x < CODE_LEN) code[threadIdx.x] = S.code[threadIdx.x];
     __syncthreads();
     const int u = threadIdx.x;
-    const float* w = Pm->w0c + (size_t)u * CODE_LEN;
-    const float* w4 = Pm->w4c + (size_t)u * CODE_LEN;
-    float a = Pm->bias[0][u], a4 = Pm->bias[4][u];
-#pragma unroll 8
-    for (int k = 0; k < CODE_LEN; ++k) {
-        a += w[k] * code[k];
-        a4 += w4[k] * code[k];
-    }
+    float a, a4;
+    code_bias(Pm, u, code, a, a4);
     c0_all[(size_t)blockIdx.x * 2 * HID + u] = a;
     c0_all[(size_t)blockIdx.x * 2 * HID + HID + u] = a4;     // layer 4's bias with the skip connection's code part
 }
@@ -331,6 +367,7 @@ __device__ __forceinline__ void plan_body(int mode, const HypState* __restrict__
                                           int nw_rend, int2* __restrict__ work, int* __restrict__ qctl, int tile_p) {
     __shared__ int wsum[NT / 64];
     __shared__ int carry_sh;
+    __shared__ int off_s[NT], na_s[NT], nb_s[NT];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     if (t == 0) carry_sh = 0;
     __syncthreads();
@@ -357,9 +394,15 @@ __device__ __forceinline__ void plan_body(int mode, const HypState* __restrict__
         __syncthreads();
         int off = carry_sh + inc - cnt;
         for (int w = 0; w < wave; ++w) off += wsum[w];
-        for (int j = 0; j < n_a; ++j) work[off + j] = make_int2(h, j);
-        for (int j = 0; j < n_b; ++j) work[off + n_a + j] = make_int2(h, nw_sdf + j);
+        // the items of a hypothesis are written by a wave, 64 consecutive words per store (its own thread wrote them one by one:
+        // ~400 stores in a row when the launch holds ONE hypothesis, most of the 10 us this tail took in k_sample)
+        off_s[t] = off, na_s[t] = n_a, nb_s[t] = n_b;
         __syncthreads();
+        const int n_here = min(NT, n_hyp - base);
+        for (int i = wave; i < n_here; i += NT / 64) {
+            const int o = off_s[i], a = na_s[i], b = nb_s[i];
+            for (int j = lane; j < a + b; j += 64) work[o + j] = make_int2(base + i, j < a ? j : nw_sdf + (j - a));
+        }
         if (t == NT - 1) carry_sh = off + cnt;
         __syncthreads();
     }
@@ -444,13 +487,19 @@ __global__ __launch_bounds__(1024) void k_plan(int mode, const HypState* __restr
                                                int tile_p) {
     plan_body<1024>(mode, st, objs, n_hyp, nw_sdf, nw_rend, work, qctl, tile_p);
 }
-__global__ __launch_bounds__(256) void k_sample(HypState* __restrict__ st, const ObjView* __restrict__ objs,
+__global__ __launch_bounds__(SAMPLE_THREADS) void k_sample(HypState* __restrict__ st, const ObjView* __restrict__ objs,
                                                 const float* __restrict__ rays, RefineCfg cfg,
                                                 int32_t* __restrict__ valid_rk, int64_t rk_stride,
                                                 int32_t* __restrict__ ray_voff, int64_t ray_stride,
                                                 const MlpParams* __restrict__ Pm, float* __restrict__ c0_all, PlanTail pt) {
+    PHASE_MARK(0, 0);
     sample_body(st, objs, rays, cfg, valid_rk, rk_stride, ray_voff, ray_stride, Pm, c0_all);
-    plan_tail<256>(pt, st, objs);        // the forward kernel's item list (k_plan mode 0)
+#if QSP_PHASE_EXP == 11 || QSP_PHASE_EXP == 12
+    return;
+#endif
+    PHASE_MARK(0, 7);
+    plan_tail<SAMPLE_THREADS>(pt, st, objs);        // the forward kernel's item list (k_plan mode 0)
+    PHASE_END(0, 8);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -719,16 +768,18 @@ struct RayScan {
     int n_emit;
 };
 
-// walks one ray; if `emit` != nullptr writes the kept rows starting at emit index `w`
 // One ray: `row` holds the SDF value of its depth sample k at row[k] (SCAN_NONE where the sample is outside the unit ball), staged
 // in LDS by the workgroup (k_scan).  Every per-sample array is indexed by the unrolled loop counter only, so it lives in
 // registers.  (Indexing them by the sample's k made them scratch memory, and reading the samples through a cursor made every
 // load wait for the one before: 110 us per launch for 456 rays.)  Same operations in the same order as the reference's rows.
+// Returns the number of kept rows n; their d e / d s go to row[0..n) (every sample has been read by then), their depth indices to
+// the bits of `kept`, the ray's clamped residual to `res_out`: the caller writes them out once it knows where (one walk per ray --
+// it used to walk every ray twice, once to count and once to write: 23 of k_scan's 39 us on a one-object call).
 constexpr float SCAN_NONE = 1e30f;
 constexpr int SCAN_RAYS = 512;                 // rays per pass = threads of k_scan
 constexpr int SCAN_LD = MAX_DEPTH + 1;         // row stride in LDS: odd, so that the threads of a wave hit different banks
-__device__ __forceinline__ int scan_ray(const float* __restrict__ row, int ray, int D, float d_min, float d_max, float th,
-                                        float depth_obs, int32_t* e_rk, float* e_deds, float* e_res, int w) {
+__device__ __forceinline__ int scan_ray(float* row, int D, float d_min, float d_max, float th, float depth_obs, uint64_t& kept,
+                                        float& res_out) {
     float occ[MAX_DEPTH];          // occupancy row (zeros outside the unit ball)
     float Tl[MAX_DEPTH];           // transmittance T_l = prod_{j<=l} (1 - occ_j), then its suffix sums (loss.py:99-113)
     uint64_t inband = 0;           // bit k: a valid sample with |sdf| < th
@@ -760,20 +811,20 @@ __device__ __forceinline__ int scan_ray(const float* __restrict__ row, int ray, 
     for (int k = MAX_DEPTH - 1; k >= 0; --k)
         if (k < D) { ssum += Tl[k]; Tl[k] = ssum; }
     int n = 0;
+    uint64_t km = 0;
 #pragma unroll
-    for (int k = 0; k < MAX_DEPTH; ++k) {              // emission in ascending k
+    for (int k = 0; k < MAX_DEPTH; ++k) {              // kept rows in ascending k
         if (k < D && ((inband >> k) & 1ull)) {
             const float de_do = Tl[k] / (1.f - occ[k]);
             if (de_do > 1e-2f) {
-                if (e_rk) {
-                    e_rk[w + n] = (ray << 6) | k;
-                    e_deds[w + n] = de_do * delta_d * do_ds;
-                    e_res[w + n] = res;
-                }
+                row[n] = de_do * delta_d * do_ds;
+                km |= 1ull << k;
                 ++n;
             }
         }
     }
+    kept = km;
+    res_out = res;
     return n;
 }
 __device__ __forceinline__ void scan_body(float* __restrict__ rows /*[SCAN_RAYS][SCAN_LD]*/, HypState* __restrict__ st,
@@ -799,9 +850,12 @@ __device__ __forceinline__ void scan_body(float* __restrict__ rows /*[SCAN_RAYS]
     int carry = 0;
     for (int base = 0; base < ov.n_rays; base += SCAN_RAYS) {        // one ray per thread: 456 rays in one pass
         // the pass's samples into a dense [ray][k] table: coalesced reads of the (ray, k)-sorted lists, one table row per thread
+        if (base > 0) {      // (the first pass's table is cleared by k_scan, in front of the loads this function starts with)
+            __syncthreads();
+            for (int e = threadIdx.x; e < SCAN_RAYS * SCAN_LD; e += SCAN_RAYS) rows[e] = SCAN_NONE;
+        }
         __syncthreads();
-        for (int e = threadIdx.x; e < SCAN_RAYS * SCAN_LD; e += SCAN_RAYS) rows[e] = SCAN_NONE;
-        __syncthreads();
+        PHASE_MARK(1, 1);
         const int r_end = min(base + SCAN_RAYS, ov.n_rays);
         const int v_beg = voff[base], v_end = voff[r_end];
         for (int v = v_beg + threadIdx.x; v < v_end; v += SCAN_RAYS) {
@@ -809,22 +863,32 @@ __device__ __forceinline__ void scan_body(float* __restrict__ rows /*[SCAN_RAYS]
             rows[((e >> 6) - base) * SCAN_LD + (e & 63)] = sdf[v];
         }
         __syncthreads();
+        PHASE_MARK(1, 2);
         const int r = base + threadIdx.x;
         int n = 0;
-        float dobs = 0.f;
-        const float* row = rows + threadIdx.x * SCAN_LD;
-        bool any = false;
+        float dobs = 0.f, res = 0.f;
+        uint64_t kept = 0;
+        float* row = rows + threadIdx.x * SCAN_LD;
         if (r < ov.n_rays) {
-            any = voff[r + 1] > voff[r];
             dobs = (r < ov.n_fg) ? dep[r] : 1.1f * d_max;   // optimizer.py:153
-            if (any) n = scan_ray(row, r, D, d_min, d_max, cfg.cut_off, dobs, nullptr, nullptr, nullptr, 0);
+            if (voff[r + 1] > voff[r] && QSP_PHASE_EXP != 21) n = scan_ray(row, D, d_min, d_max, cfg.cut_off, dobs, kept, res);
         }
         int tot;
+        PHASE_MARK(1, 3);
         const int ex = block_excl_scan_256(n, sc, &tot);
-        if (n > 0) scan_ray(row, r, D, d_min, d_max, cfg.cut_off, dobs, e_rk, e_deds, e_res, carry + ex);
+        PHASE_MARK(1, 4);
+        if (QSP_PHASE_EXP != 22) {
+            int w = carry + ex;
+            for (uint64_t m = kept; m; m &= m - 1, ++w) {
+                e_rk[w] = (r << 6) | (__ffsll((long long)m) - 1);
+                e_deds[w] = row[w - (carry + ex)];
+                e_res[w] = res;
+            }
+        }
         carry += tot;
     }
-    if (threadIdx.x == 0) S.n_render = carry;
+    PHASE_MARK(1, 5);
+    if (threadIdx.x == 0) S.n_render = (QSP_PHASE_EXP == 22) ? 0 : carry;
 }
 __global__ __launch_bounds__(SCAN_RAYS) void k_scan(HypState* __restrict__ st, const ObjView* __restrict__ objs,
                                                     const float* __restrict__ depth, RefineCfg cfg,
@@ -833,8 +897,15 @@ __global__ __launch_bounds__(SCAN_RAYS) void k_scan(HypState* __restrict__ st, c
                                                     const float* __restrict__ sdf_valid, int32_t* __restrict__ rend_rk,
                                                     float* __restrict__ rend_deds, float* __restrict__ rend_res, PlanTail pt) {
     extern __shared__ __attribute__((aligned(16))) float rows[];     // [SCAN_RAYS][SCAN_LD]
+    PHASE_MARK(1, 0);
+    for (int e = threadIdx.x; e < SCAN_RAYS * SCAN_LD; e += SCAN_RAYS) rows[e] = SCAN_NONE;
     scan_body(rows, st, objs, depth, cfg, valid_rk, rk_stride, ray_voff, ray_stride, sdf_valid, rend_rk, rend_deds, rend_res);
+#if QSP_PHASE_EXP == 23
+    return;
+#endif
+    PHASE_MARK(1, 6);
     plan_tail<SCAN_RAYS>(pt, st, objs);      // the Jacobian kernel's item list (k_plan mode 1)
+    PHASE_END(1, 7);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1282,6 +1353,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(HypState* __restrict__ 
     const int h = blockIdx.x;
     HypState& S = st[h];
     if (!S.alive) return;
+    PHASE_MARK(2, 0);
     if (threadIdx.x == 0 && counters) {   // work actually done this iteration (for the roofline figures)
         const ObjView o = objs[S.obj];
         atomicAdd(&counters[0], (unsigned long long)(o.n_pts + S.n_render));
@@ -1314,22 +1386,27 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(HypState* __restrict__ 
         if (tid == 0) n_act_sh = cnt_sh;
         __syncthreads();
     }
+    PHASE_MARK(2, 1);
     const float M = (float)n_act_sh;
     const float Kf = (float)K;
     const int N = cfg.pose_only ? 6 : NH;
     // Fixed-order sum of the tile partials (deterministic), then H, b in f32 exactly as optimizer.py:217-252 orders the
     // operations; entries are promoted to f64 only for the linear solve.
-    for (int e = tid; e < NJ * NJ; e += SOLVE_THREADS) {
-        const int a = e / NJ, b = e % NJ;
-        if (a > b) continue;
-        const int off = tri72(a, b);
+    // (one packed entry per thread and turn: 2628 entries are three turns of consecutive words -- walking the 72 x 72 square and
+    //  skipping its lower half was five turns, 14 us of a one-object call's 58)
+    for (int off = tid; off < NJ * (NJ + 1) / 2; off += SOLVE_THREADS) {
+        int a = (int)(0.5f * ((float)(2 * NJ + 1) - sqrtf((float)((2 * NJ + 1) * (2 * NJ + 1) - 8 * off))));      // row of the packed entry,
+        a = min(max(a, 0), NJ - 1);
+        while (a + 1 < NJ && tri72(a + 1, a + 1) <= off) ++a;                                                     // made exact
+        while (tri72(a, a) > off) --a;
+        const int b = a + (off - tri72(a, a));
         float ss = 0.f, sr = 0.f;
         // same left-to-right order as ever; unrolled so that 32 of the (24 KiB-strided) loads are in flight at a time (a single
         // object's 2 k points are 63 slots of 32-point tiles: two batches instead of four in front of every entry)
 #if QSP_SOLVE_EXP != 2
 #pragma unroll 32
         for (int j = 0; j < n_sdf_slots; ++j) ss += base[(int64_t)j * PART_FLOATS + off];
-#pragma unroll 4
+#pragma unroll 16
         for (int j = 0; j < n_rend_slots; ++j) sr += base[(int64_t)(nw_sdf + j) * PART_FLOATS + off];
 #else
         ss = 1.f + 0.001f * (float)off; sr = 1.f;      // (timing experiment: no slot reads)
@@ -1365,6 +1442,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(HypState* __restrict__ 
         }
     }
     __syncthreads();
+    PHASE_MARK(2, 2);
     const float loss_s = loss_sh[0], loss_r = loss_sh[1];
     const bool bad = isnan(loss_s) || isnan(loss_r);           // optimizer.py:168-169,193-194
     __syncthreads();
@@ -1430,11 +1508,19 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(HypState* __restrict__ 
         for (int a = tid; a < N; a += SOLVE_THREADS) trb[(int64_t)h * NH + a] = (float)Hd[a * (N + 1) + N];
     }
     __syncthreads();
+    PHASE_MARK(2, 3);
+#if QSP_PHASE_CLOCK
+    const unsigned long long cyc0 = __builtin_readcyclecounter();
+#endif
     // Gauss-Jordan elimination in f64 on the augmented system (reference: torch.inverse(H) @ b, f32).  H is symmetric
     // positive definite by construction (Gram matrices plus the identity damping of optimizer.py:240-252 / :75), so no
     // pivot search is needed: one barrier per column, every (row, column strip) pair on its own thread.
-    // (measured, round 4: the same elimination on four waves -- cheaper barriers, 24 elements per thread and column -- took the
-    //  one-object call from 2.76 to 2.94 ms: with 1024 threads a column is 5 elements per thread and the LDS latency hides.)
+    // ~1200 cycles of the 2.4 GHz shader clock per column (tools/phase_clock.py), 36 of this kernel's 58 us on a one-object call.
+    // Measured against it in round 4, none faster: the same loop on four waves (2.76 -> 2.94 ms per call); a column's reads issued
+    // in front of the division (1650 cycles per column: six predicated read pairs every column instead of the 2.5 the strip
+    // needs on average); the matrix in registers with the pivot row, the pivot column and ONE reciprocal published through LDS, on
+    // sixteen waves with a runtime column loop (1640) and on eight waves with the loop unrolled (1280: a column is ~9 LDS reads and
+    // 14 f64 operations per wave whichever way the entries are dealt, behind the pivot's division and a barrier).
     const int STR = SOLVE_THREADS / N;         // 14 strips for the 71 x 71 system
 #if QSP_SOLVE_EXP == 1
     for (int c = 0; c < 0; ++c) {              // (timing experiment: no elimination)
@@ -1449,6 +1535,10 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(HypState* __restrict__ 
         }
         __syncthreads();
     }
+#if QSP_PHASE_CLOCK
+    if (blockIdx.x == 0 && tid == 0) qsp_phase_ticks[2][8] += __builtin_readcyclecounter() - cyc0;
+#endif
+    PHASE_MARK(2, 4);
     for (int a = tid; a < N; a += SOLVE_THREADS) dxs[a] = (float)(Hd[a * (N + 1) + N] / Hd[a * (N + 1) + a]);
     __syncthreads();
     if (trdx)
@@ -1474,6 +1564,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(HypState* __restrict__ 
         S.loss = cfg.k1 * loss_r + cfg.k2 * loss_s;    // optimizer.py:203
     }
     if (!cfg.pose_only && tid < CODE_LEN) S.code[tid] += cfg.lr * dxs[7 + tid];
+    PHASE_END(2, 5);
 }
 
 // pose-only inlier filter after iteration index 4 (optimizer.py:80-82): |res| <= 0.05 on the residuals of THAT iteration
@@ -1537,14 +1628,8 @@ __global__ __launch_bounds__(H2_THREADS) void k_decode_h2(const float* __restric
     if (threadIdx.x < CODE_LEN) s.code[threadIdx.x] = code[threadIdx.x];
     __syncthreads();
     for (int u = threadIdx.x; u < HID; u += H2_THREADS) {      // mlp_prepare for 256 threads
-        const float* w = P->w0c + (size_t)u * CODE_LEN;
-        const float* w4 = P->w4c + (size_t)u * CODE_LEN;
-        float a = P->bias[0][u], a4 = P->bias[4][u];
-#pragma unroll 8
-        for (int k = 0; k < CODE_LEN; ++k) {
-            a += w[k] * s.code[k];
-            a4 += w4[k] * s.code[k];
-        }
+        float a, a4;
+        code_bias(P, u, s.code, a, a4);
         s.c0[u] = a;
         s.c4[u] = a4;
     }
@@ -1590,14 +1675,8 @@ __global__ __launch_bounds__(64 * NW) void k_decode_screen(const float* __restri
     if (threadIdx.x < CODE_LEN) codes[threadIdx.x] = code[threadIdx.x];
     __syncthreads();
     for (int u = threadIdx.x; u < HID; u += 64 * NW) {
-        const float* w = P->w0c + (size_t)u * CODE_LEN;
-        const float* w4 = P->w4c + (size_t)u * CODE_LEN;
-        float a = P->bias[0][u], a4 = P->bias[4][u];
-#pragma unroll 8
-        for (int k = 0; k < CODE_LEN; ++k) {
-            a += w[k] * codes[k];
-            a4 += w4[k] * codes[k];
-        }
+        float a, a4;
+        code_bias(P, u, codes, a, a4);
         s.c0[u] = a;
         s.c4[u] = a4;
         s.w8[u] = P->w8[u];

@@ -77,8 +77,8 @@ struct MlpParams {
     const float* bias[8];   // [512] zero-padded
     const float* w8;        // [512] last layer row
     float b8;
-    const float* w0c;       // [512][64] layer-0 weights of the latent code (row-major)
-    const float* w4c;       // [512][64] layer-4 weights of the latent code (input columns 445..508)
+    const float* w0c;       // [64][512] layer-0 weights of the latent code, [code entry][unit]: a wave's loads are one line (code_bias)
+    const float* w4c;       // [64][512] layer-4 weights of the latent code (input columns 445..508), same layout
     const float4* w0x;      // [128 unit quads][3] layer-0 weights of x, y, z for four consecutive units
     const float4* wf3[8];   // split-bf16 forward weights of layers 1..7: [col block 16][slab K/16][plane hi|mid|lo][lane 64][8 bf16]
     const float4* wb3[8];   // split-bf16 backward weights of layers 0..7 (column blocks over the layer's inputs, slabs over outputs)
@@ -421,19 +421,27 @@ __device__ __forceinline__ void stash_extract(MlpSmem& s) {
     }
 }
 
+// The code part of layers 0 and 4 for unit u: a = b0[u] + sum_k W0[u][k] code[k], a4 likewise with layer 4's skip columns, summed in
+// ascending k.  The weights are stored [k][unit], so the 64 units of a wave read one line per k (stored [unit][k] every lane read
+// its own line: 128 strided loads per thread, ~20 us in front of every decode workgroup and in k_sample's one-workgroup prologue).
+__device__ __forceinline__ void code_bias(const MlpParams* __restrict__ P, int u, const float* code, float& a, float& a4) {
+    const float* w = P->w0c + u;
+    const float* w4 = P->w4c + u;
+    a = P->bias[0][u], a4 = P->bias[4][u];
+#pragma unroll 8
+    for (int k = 0; k < CODE_LEN; ++k) {
+        a += w[(size_t)k * HID] * code[k];
+        a4 += w4[(size_t)k * HID] * code[k];
+    }
+}
+
 // Once per workgroup, after s.code is written (all threads): the code part of layer 0 is the same for every point,
 // c0[u] = b0[u] + sum_k W0[u][k] code[k].  The caller's next barrier (top of its tile loop) publishes c0.
 __device__ __forceinline__ void mlp_prepare(MlpSmem& s, const MlpParams* __restrict__ Pm) {
     __syncthreads();
     const int u = threadIdx.x;
-    const float* w = Pm->w0c + (size_t)u * CODE_LEN;
-    const float* w4 = Pm->w4c + (size_t)u * CODE_LEN;
-    float a = Pm->bias[0][u], a4 = Pm->bias[4][u];
-#pragma unroll 8
-    for (int k = 0; k < CODE_LEN; ++k) {
-        a += w[k] * s.code[k];
-        a4 += w4[k] * s.code[k];
-    }
+    float a, a4;
+    code_bias(Pm, u, s.code, a, a4);
     s.c0[u] = a;
     s.c4[u] = a4;
 }

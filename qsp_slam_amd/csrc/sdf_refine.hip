@@ -320,10 +320,10 @@ static int pack_weights(qsp_decoder* d, const qsp_decoder_desc* desc) {
         const int in = in_dim[l], out = out_dim[l];
         int rc = QSP_OK;
         if (l == 0) {
-            // layer 0 is evaluated directly (mlp_prepare + mlp_tile): code columns row-major, xyz columns per unit quad
+            // layer 0 is evaluated directly (mlp_prepare + mlp_tile): code columns [k][unit], xyz columns per unit quad
             std::vector<float> wc((size_t)HID * CODE_LEN), wx((size_t)(HID / 4) * 3 * 4);
             for (int o = 0; o < HID; ++o)
-                for (int k = 0; k < CODE_LEN; ++k) wc[(size_t)o * CODE_LEN + k] = W[0][(size_t)o * in + k];
+                for (int k = 0; k < CODE_LEN; ++k) wc[(size_t)k * HID + o] = W[0][(size_t)o * in + k];     // [k][unit]: code_bias
             for (int q = 0; q < HID / 4; ++q)
                 for (int a = 0; a < 3; ++a)
                     for (int e = 0; e < 4; ++e) wx[((size_t)q * 3 + a) * 4 + e] = W[0][(size_t)(4 * q + e) * in + CODE_LEN + a];
@@ -425,7 +425,7 @@ static int pack_weights(qsp_decoder* d, const qsp_decoder_desc* desc) {
             if (!rc && l == 4) {
                 std::vector<float> wc((size_t)HID * CODE_LEN);
                 for (int o = 0; o < HID; ++o)
-                    for (int k = 0; k < CODE_LEN; ++k) wc[(size_t)o * CODE_LEN + k] = W[4][(size_t)o * in + SKIP_COL + k];
+                    for (int k = 0; k < CODE_LEN; ++k) wc[(size_t)k * HID + o] = W[4][(size_t)o * in + SKIP_COL + k];
                 rc = upload(wc, (const void**)&d->P.w4c);
             }
         }
@@ -894,18 +894,46 @@ struct qsp_refine_batch {
     int n_cu = 256;
     float* rows = nullptr;          // optional tap of the Jacobian rows (qsp_refine_batch_rows)
     int64_t rows_stride = 0;
+    // What the host provides per call -- hypothesis states, object table, depth, rays, surface points -- lives in ONE device arena
+    // [st | objs | depth | rays | pts] (parts packed to what the fill holds, 256-byte aligned) with a pinned host mirror: fill and
+    // set_state write the mirror, the next consumer (run, get, ...) uploads what changed as ONE asynchronous copy on the
+    // decoder's stream.  (They were five blocking copies from pageable memory: 0.25 ms of idle GPU in front of every one-object
+    // call of 2.7 ms, profiles/r04_call_timeline.txt.)
+    char* in_dev = nullptr;
+    char* in_host = nullptr;        // pinned
+    HypState* out_host = nullptr;   // pinned: the states on their way back (get, trace)
+    size_t in_bytes = 0;
+    size_t st_bytes = 0;            // this fill's states
+    size_t obs_lo = 0, obs_hi = 0;  // the part of the mirror behind the states that waits for its upload
+    bool st_dirty = false;
     // profiling
     bool prof = false;
     qsp_refine_profile profile{};
     std::vector<hipEvent_t> ev;
 };
 
+static size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
+
+// uploads what fill / set_state left in the mirror (one copy; nothing when nothing changed)
+static int batch_upload(qsp_refine_batch* b) {
+    size_t lo = 0, hi = 0;
+    if (b->st_dirty && b->obs_hi > b->obs_lo) lo = 0, hi = b->obs_hi;
+    else if (b->st_dirty) lo = 0, hi = b->st_bytes;
+    else if (b->obs_hi > b->obs_lo) lo = b->obs_lo, hi = b->obs_hi;
+    b->st_dirty = false;
+    b->obs_lo = b->obs_hi = 0;
+    if (hi > lo) QSP_HIP(hipMemcpyAsync(b->in_dev + lo, b->in_host + lo, hi - lo, hipMemcpyHostToDevice, b->dec->stream));
+    return QSP_OK;
+}
+
 static void batch_free(qsp_refine_batch* b) {
     if (!b) return;
     (void)hipSetDevice(b->device);
-    void* ptrs[] = {b->st, b->objs, b->pts, b->rays, b->depth, b->valid_rk, b->ray_voff, b->rend_rk, b->sdf_valid,
+    if (b->in_host) (void)hipHostFree(b->in_host);
+    if (b->out_host) (void)hipHostFree(b->out_host);
+    void* ptrs[] = {b->in_dev, b->valid_rk, b->ray_voff, b->rend_rk, b->sdf_valid,
                     b->rend_deds, b->rend_res, b->partials, b->trH, b->trb, b->trdx, b->trrot, b->pt_active, b->res_buf, b->rows, b->counters,
-                    b->work_fwd, b->work_jtj, b->qctl, b->c0_all, b->band_idx, b->stage_idx, b->ray_open, b->st_snap, b->act_snap};
+                    b->work_fwd, b->work_jtj, b->c0_all, b->band_idx, b->stage_idx, b->ray_open, b->st_snap, b->act_snap};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : b->ev) (void)hipEventDestroy(e);
@@ -958,20 +986,35 @@ static int batch_fill(qsp_refine_batch* b, int32_t n_obj, const float* const* pt
         ro += nr;
     }
     b->hyp_obj.assign(hyp_obj, hyp_obj + n_hyp);
-    std::vector<float> hp((size_t)std::max<int64_t>(po, 1) * 3), hr((size_t)std::max<int64_t>(ro, 1) * 3),
-        hd((size_t)std::max<int64_t>(ro, 1), 0.f);
-    for (int o = 0; o < n_obj && !device_fill; ++o) {
-        const ObjView& v = b->objs_h[o];
-        if (v.n_pts) memcpy(&hp[3 * v.pts_off], pts[o], sizeof(float) * 3 * v.n_pts);
-        if (v.n_rays) memcpy(&hr[3 * v.ray_off], rays[o], sizeof(float) * 3 * v.n_rays);
-        if (v.n_fg) memcpy(&hd[v.ray_off], depth[o], sizeof(float) * v.n_fg);
+    // this fill's layout of the input arena (sizes <= the capacities it was allocated for, part by part)
+    const size_t n_ray_f = (size_t)std::max<int64_t>(ro, 1), n_pt_f = (size_t)std::max<int64_t>(po, 1);
+    b->st_bytes = sizeof(HypState) * (size_t)n_hyp;
+    const size_t o_objs = align256(b->st_bytes), o_depth = o_objs + align256(sizeof(ObjView) * (size_t)n_obj);
+    const size_t o_rays = o_depth + align256(sizeof(float) * n_ray_f), o_pts = o_rays + align256(sizeof(float) * 3 * n_ray_f);
+    const size_t o_end = o_pts + sizeof(float) * 3 * n_pt_f;
+    if (o_end > b->in_bytes) return qsp_fail(QSP_ERR_INVALID, "refine batch: inputs exceed the batch's capacities");
+    b->objs = (ObjView*)(b->in_dev + o_objs);
+    b->depth = (float*)(b->in_dev + o_depth);
+    b->rays = (float*)(b->in_dev + o_rays);
+    b->pts = (float*)(b->in_dev + o_pts);
+    memcpy(b->in_host + o_objs, b->objs_h.data(), sizeof(ObjView) * (size_t)n_obj);
+    b->obs_lo = o_objs;
+    b->obs_hi = o_depth;
+    if (device_fill) {        // (the observation arrays are written by a kernel; depth entries beyond a ray's foreground stay 0)
+        QSP_HIP(hipMemsetAsync(b->depth, 0, sizeof(float) * n_ray_f, b->dec->stream));
+        return QSP_OK;
     }
-    hipError_t e = hipMemcpy(b->objs, b->objs_h.data(), sizeof(ObjView) * n_obj, hipMemcpyHostToDevice);
-    if (e == hipSuccess && !device_fill) e = hipMemcpy(b->pts, hp.data(), hp.size() * sizeof(float), hipMemcpyHostToDevice);
-    if (e == hipSuccess && !device_fill) e = hipMemcpy(b->rays, hr.data(), hr.size() * sizeof(float), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = device_fill ? hipMemset(b->depth, 0, hd.size() * sizeof(float))
-                                         : hipMemcpy(b->depth, hd.data(), hd.size() * sizeof(float), hipMemcpyHostToDevice);
-    if (e != hipSuccess) return qsp_fail(QSP_ERR_DEVICE, hipGetErrorString(e));
+    float* hp = (float*)(b->in_host + o_pts);
+    float* hr = (float*)(b->in_host + o_rays);
+    float* hd = (float*)(b->in_host + o_depth);
+    memset(hd, 0, sizeof(float) * n_ray_f);
+    for (int o = 0; o < n_obj; ++o) {
+        const ObjView& v = b->objs_h[o];
+        if (v.n_pts) memcpy(hp + 3 * v.pts_off, pts[o], sizeof(float) * 3 * v.n_pts);
+        if (v.n_rays) memcpy(hr + 3 * v.ray_off, rays[o], sizeof(float) * 3 * v.n_rays);
+        if (v.n_fg) memcpy(hd + v.ray_off, depth[o], sizeof(float) * v.n_fg);
+    }
+    b->obs_hi = o_end;
     return QSP_OK;
 }
 
@@ -1029,19 +1072,24 @@ static int batch_create(qsp_decoder* dec, const RefineCfg& cfg, int n_iter, int3
         hipError_t e_ = hipMalloc((void**)&(ptr), (size_t)(bytes));                           \
         if (e_ != hipSuccess) rc = qsp_fail(QSP_ERR_DEVICE, hipGetErrorString(e_));           \
     }
-    QSP_ALLOC(b->st, sizeof(HypState) * cap_hyp);
-    QSP_ALLOC(b->objs, sizeof(ObjView) * caps.obj);
-    QSP_ALLOC(b->pts, cp * 3 * sizeof(float));
-    QSP_ALLOC(b->rays, cr * 3 * sizeof(float));
-    QSP_ALLOC(b->depth, cr * sizeof(float));
+    b->in_bytes = align256(sizeof(HypState) * (size_t)cap_hyp) + align256(sizeof(ObjView) * (size_t)caps.obj) +
+                  align256(sizeof(float) * (size_t)cr) + align256(sizeof(float) * 3 * (size_t)cr) + align256(sizeof(float) * 3 * (size_t)cp);
+    QSP_ALLOC(b->in_dev, b->in_bytes);
+    b->st = (HypState*)b->in_dev;
+    if (!rc) {
+        hipError_t e_ = hipHostMalloc((void**)&b->in_host, b->in_bytes, hipHostMallocDefault);
+        if (e_ == hipSuccess) e_ = hipHostMalloc((void**)&b->out_host, sizeof(HypState) * (size_t)cap_hyp, hipHostMallocDefault);
+        if (e_ != hipSuccess) rc = qsp_fail(QSP_ERR_DEVICE, hipGetErrorString(e_));
+    }
     QSP_ALLOC(b->partials, sizeof(float) * (size_t)cap_hyp * nw_total * PART_FLOATS);
     QSP_ALLOC(b->trH, sizeof(float) * (size_t)cap_hyp * NH * NH);
     QSP_ALLOC(b->trb, sizeof(float) * (size_t)cap_hyp * NH);
     QSP_ALLOC(b->trdx, sizeof(float) * (size_t)cap_hyp * NH);
     QSP_ALLOC(b->trrot, sizeof(float) * (size_t)cap_hyp * 4);
-    QSP_ALLOC(b->counters, sizeof(unsigned long long) * 8);
+    QSP_ALLOC(b->counters, sizeof(unsigned long long) * 8 + sizeof(int) * 8);      // [counters | qctl]: one fill clears both
+    if (!rc) b->qctl = (int*)(b->counters + 8);
     QSP_ALLOC(b->st_snap, sizeof(HypState) * cap_hyp);
-    QSP_ALLOC(b->qctl, sizeof(int) * 8);      // [0..3] the two queues, [4], [5] the done counters of the plans in k_sample's / k_scan's tail
+    // qctl: [0..3] the two queues, [4], [5] the done counters of the plans in k_sample's / k_scan's tail
     QSP_ALLOC(b->c0_all, sizeof(float) * (size_t)cap_hyp * 2 * HID);
     QSP_ALLOC(b->work_jtj, sizeof(int2) * (size_t)cap_hyp * nw_total);
     if (!cfg.pose_only) QSP_ALLOC(b->work_fwd, sizeof(int2) * (size_t)cap_hyp * ((b->rk_stride + TILE_P - 1) / TILE_P));
@@ -1099,7 +1147,7 @@ extern "C" int qsp_refine_batch_set_state(qsp_refine_batch* b, const float* t_ca
     if (b && b->dec) lk_d = std::unique_lock<std::recursive_mutex>(b->dec->mu);
     if (!b || !t_cam_obj) return qsp_fail(QSP_ERR_INVALID, "set_state: bad argument");
     QSP_HIP(hipSetDevice(b->dec->device));
-    std::vector<HypState> hs(b->n_hyp);
+    HypState* hs = (HypState*)b->in_host;      // (the mirror; uploaded by the next run / get)
     for (int h = 0; h < b->n_hyp; ++h) {
         HypState& S = hs[h];
         memset(&S, 0, sizeof(S));
@@ -1108,8 +1156,8 @@ extern "C" int qsp_refine_batch_set_state(qsp_refine_batch* b, const float* t_ca
         S.alive = 1;
         S.obj = b->hyp_obj[h];
     }
-    QSP_HIP(hipMemcpy(b->st, hs.data(), sizeof(HypState) * b->n_hyp, hipMemcpyHostToDevice));
-    if (b->pt_active) QSP_HIP(hipMemset(b->pt_active, 1, (size_t)b->n_hyp * b->act_stride));
+    b->st_dirty = true;
+    if (b->pt_active) QSP_HIP(hipMemsetAsync(b->pt_active, 1, (size_t)b->n_hyp * b->act_stride, b->dec->stream));
     return QSP_OK;
 }
 
@@ -1138,8 +1186,8 @@ static int run_once(qsp_refine_batch* b, int32_t n_iter, bool* hit, bool* screen
     struct Span { hipEvent_t a, b; int kind; };
     std::vector<Span> spans;
     hipEvent_t e_begin = nullptr, e_end = nullptr;
-    QSP_HIP(hipMemsetAsync(b->counters, 0, sizeof(unsigned long long) * 8, s));
-    QSP_HIP(hipMemsetAsync(b->qctl + 4, 0, sizeof(int) * 2, s));      // (the done counters of the plan tails: a run that was cut short may have left them)
+    // (the work counters, and with them the queue words: the done counters of the plan tails may be left over from a run cut short)
+    QSP_HIP(hipMemsetAsync(b->counters, 0, sizeof(unsigned long long) * 8 + sizeof(int) * 8, s));
     if (b->prof) e_begin = next_event(b, cur);
     for (int it = 0; it < n_iter; ++it) {
         RefineCfg cfg = b->cfg;
@@ -1168,7 +1216,7 @@ static int run_once(qsp_refine_batch* b, int32_t n_iter, bool* hit, bool* screen
                                 (b->dec->depth_staging == 2 || (b->dec->depth_staging == 1 && ub_samples > 64 * (int64_t)b->n_cu * H1_ROWS));
             const PlanTail pt_fwd{staged ? nullptr : b->work_fwd, b->qctl, b->qctl + 4, nH, b->nw_sdf, nw_total - b->nw_sdf,
                                   screen ? H1_ROWS : TILE_P, 0};
-            hipLaunchKernelGGL(k_sample, dim3(nH), dim3(256), 0, s, b->st, b->objs, b->rays, cfg, b->valid_rk, b->rk_stride,
+            hipLaunchKernelGGL(k_sample, dim3(nH), dim3(SAMPLE_THREADS), 0, s, b->st, b->objs, b->rays, cfg, b->valid_rk, b->rk_stride,
                                b->ray_voff, b->ray_stride, b->dec->Pd, b->c0_all, pt_fwd);
             if (b->prof) spans.push_back({a, next_event(b, cur), 2});
             if (b->prof) a = next_event(b, cur);
@@ -1319,6 +1367,10 @@ extern "C" int qsp_refine_batch_run(qsp_refine_batch* b, int32_t n_iter) {
     QSP_HIP(hipSetDevice(b->dec->device));
     if (n_iter <= 0) n_iter = b->n_iter_cfg;
     qsp_decoder* d = b->dec;
+    {
+        const int rc_up = batch_upload(b);
+        if (rc_up) return rc_up;
+    }
     const bool may_fall_back = range_should_fall_back(d);
     if (may_fall_back) {      // the state this run starts from, in case it has to be repeated on the f32 pipe (n_hyp x 432 bytes)
         QSP_HIP(hipMemcpyAsync(b->st_snap, b->st, sizeof(HypState) * b->n_hyp, hipMemcpyDeviceToDevice, d->stream));
@@ -1391,14 +1443,27 @@ extern "C" int qsp_refine_batch_profile(qsp_refine_batch* b, int enable, qsp_ref
     return QSP_OK;
 }
 
+// the hypothesis states as the device holds them (pending uploads first), through the pinned buffer; valid until the next call
+static int batch_states(qsp_refine_batch* b, const HypState** out) {
+    const int rc = batch_upload(b);
+    if (rc) return rc;
+    QSP_HIP(hipMemcpyAsync(b->out_host, b->st, sizeof(HypState) * b->n_hyp, hipMemcpyDeviceToHost, b->dec->stream));
+    QSP_HIP(hipStreamSynchronize(b->dec->stream));
+    *out = b->out_host;
+    return QSP_OK;
+}
+
 extern "C" int qsp_refine_batch_get(qsp_refine_batch* b, float* t_cam_obj_out, float* code_out, float* loss_out,
                                     uint8_t* is_good_out) {
     std::unique_lock<std::recursive_mutex> lk_d;
     if (b && b->dec) lk_d = std::unique_lock<std::recursive_mutex>(b->dec->mu);
     if (!b) return qsp_fail(QSP_ERR_INVALID, "get: null batch");
     QSP_HIP(hipSetDevice(b->dec->device));
-    std::vector<HypState> hs(b->n_hyp);
-    QSP_HIP(hipMemcpy(hs.data(), b->st, sizeof(HypState) * b->n_hyp, hipMemcpyDeviceToHost));
+    const HypState* hs = nullptr;
+    {
+        const int rc = batch_states(b, &hs);
+        if (rc) return rc;
+    }
     for (int h = 0; h < b->n_hyp; ++h) {
         const HypState& S = hs[h];
         if (t_cam_obj_out) {
@@ -1413,14 +1478,19 @@ extern "C" int qsp_refine_batch_get(qsp_refine_batch* b, float* t_cam_obj_out, f
 
 extern "C" int qsp_refine_batch_trace(qsp_refine_batch* b, float* H, float* rhs, float* dx, int32_t* n_valid,
                                       int32_t* n_render, float* loss_terms) {
+    std::unique_lock<std::recursive_mutex> lk_d;
+    if (b && b->dec) lk_d = std::unique_lock<std::recursive_mutex>(b->dec->mu);
     if (!b) return qsp_fail(QSP_ERR_INVALID, "trace: null batch");
     QSP_HIP(hipSetDevice(b->dec->device));
     if (H) QSP_HIP(hipMemcpy(H, b->trH, sizeof(float) * (size_t)b->n_hyp * NH * NH, hipMemcpyDeviceToHost));
     if (rhs) QSP_HIP(hipMemcpy(rhs, b->trb, sizeof(float) * (size_t)b->n_hyp * NH, hipMemcpyDeviceToHost));
     if (dx) QSP_HIP(hipMemcpy(dx, b->trdx, sizeof(float) * (size_t)b->n_hyp * NH, hipMemcpyDeviceToHost));
     if (n_valid || n_render || loss_terms) {
-        std::vector<HypState> hs(b->n_hyp);
-        QSP_HIP(hipMemcpy(hs.data(), b->st, sizeof(HypState) * b->n_hyp, hipMemcpyDeviceToHost));
+        const HypState* hs = nullptr;
+        {
+            const int rc = batch_states(b, &hs);
+            if (rc) return rc;
+        }
         for (int h = 0; h < b->n_hyp; ++h) {
             if (n_valid) n_valid[h] = hs[h].n_valid;
             if (n_render) n_render[h] = hs[h].n_render;
@@ -1441,6 +1511,8 @@ extern "C" int qsp_refine_batch_trace_rot(qsp_refine_batch* b, float* rot4) {
 }
 
 extern "C" int qsp_refine_batch_rows(qsp_refine_batch* b, int enable, int32_t hyp, float* rows_sdf, float* rows_render) {
+    std::unique_lock<std::recursive_mutex> lk_d;
+    if (b && b->dec) lk_d = std::unique_lock<std::recursive_mutex>(b->dec->mu);
     if (!b) return qsp_fail(QSP_ERR_INVALID, "rows: null batch");
     QSP_HIP(hipSetDevice(b->dec->device));
     if (enable && !b->rows) {
@@ -1453,8 +1525,11 @@ extern "C" int qsp_refine_batch_rows(qsp_refine_batch* b, int enable, int32_t hy
     }
     if (enable && (rows_sdf || rows_render)) {
         if (hyp < 0 || hyp >= b->n_hyp) return qsp_fail(QSP_ERR_INVALID, "rows: hyp out of range");
-        std::vector<HypState> hs(b->n_hyp);
-        QSP_HIP(hipMemcpy(hs.data(), b->st, sizeof(HypState) * b->n_hyp, hipMemcpyDeviceToHost));
+        const HypState* hs = nullptr;
+        {
+            const int rc = batch_states(b, &hs);
+            if (rc) return rc;
+        }
         const ObjView& ov = b->objs_h[b->hyp_obj[hyp]];
         const float* base = b->rows + (size_t)hyp * b->rows_stride * NJ;
         if (rows_sdf && ov.n_pts)
@@ -1573,6 +1648,18 @@ extern "C" int qsp_debug_timestamps(unsigned long long* out /*96*/, int* n, unsi
     (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(qsp::qsp_dbg_ts), sizeof(unsigned long long) * 96);
     if (rt) (void)hipMemcpyFromSymbol(rt, HIP_SYMBOL(qsp::qsp_dbg_rt), sizeof(unsigned long long) * 96);
     (void)hipMemcpyFromSymbol(n, HIP_SYMBOL(qsp::qsp_dbg_n), sizeof(int));
+    return 0;
+}
+#endif
+
+#if QSP_PHASE_CLOCK
+// timing experiment only (tools/phase_clock.py): ticks of the 100 MHz counter between the marks of k_sample / k_scan / k_solve, summed
+// over the launches since the last call (which clears them)
+extern "C" int qsp_debug_phase_ticks(unsigned long long* out /*48*/) {
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(qsp::qsp_phase_ticks), sizeof(unsigned long long) * 48);
+    static const unsigned long long zero[48] = {};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(qsp::qsp_phase_ticks), zero, sizeof(zero));
     return 0;
 }
 #endif

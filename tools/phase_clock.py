@@ -1,21 +1,30 @@
-"""Shader clock and tile cycles of the stamped variant builds (16 = as shipped, 17 = no weight loads, 18 = no LDS operand reads, 19 = neither)."""
-import ctypes as C, os, subprocess, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-if len(sys.argv) > 1:
-    sys.path.insert(0, ROOT)
-    os.environ["QSP_HIP_LIB"] = os.path.join(ROOT, "build", "exp", "libqsp_v%s.so" % sys.argv[1])
-    import numpy as np
-    from qsp_slam_amd import DeepSdfDecoder, _lib
-    n = 2 ** 21
-    dec = DeepSdfDecoder.from_npz(os.path.join(ROOT, "tests/golden/decoder_8x512.npz"))
-    x = np.random.default_rng(0).uniform(-1, 1, size=(n, 3)).astype(np.float32); code = np.zeros(64, np.float32)
-    L = _lib.lib()
-    for name, fn in (("fwd+bwd", lambda: dec.sdf_value_grad(code, x)), ("fwd", lambda: dec.decode_sdf(code, x)), ("fwd+bwd", lambda: dec.sdf_value_grad(code, x))):
-        fn(); fn(); fn()
-        ts = (C.c_ulonglong * 96)(); rt = (C.c_ulonglong * 96)(); cnt = C.c_int()
-        L.qsp_debug_timestamps(ts, C.byref(cnt), rt)
-        t = np.array(ts[:cnt.value], dtype=np.int64); r = np.array(rt[:cnt.value], dtype=np.int64)
-        print("variant %s %-8s tile %8d cycles, %.1f us, clock %.3f GHz" % (sys.argv[1], name, t[-1] - t[0], (r[-1] - r[0]) / 100.0, (t[-1] - t[0]) / max(r[-1] - r[0], 1) * 0.1))
-else:
-    for v in ("16", "17", "18", "19", "16"):
-        subprocess.run([sys.executable, os.path.abspath(__file__), v], check=True)
+"""Where k_sample and k_scan spend a one-object call's launches: ticks of the constant 100 MHz counter between the marks thread 0 of
+workgroup 0 stamps (PHASE_MARK in csrc/sdf_kernels.hpp).  Needs build/exp/libqsp_phase.so:
+   (here)     bash tools/phase_clock.sh        (GPU box)  python tools/phase_clock.py"""
+import ctypes as C, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+os.environ["QSP_HIP_LIB"] = os.path.join(ROOT, "build", "exp", "libqsp_phase.so")
+import bench
+from qsp_slam_amd import DeepSdfDecoder, synth, _lib
+from qsp_slam_amd.reconstruct.optimizer import Optimizer
+dec = DeepSdfDecoder.from_npz(os.path.join(ROOT, "tests", "golden", "decoder_8x512.npz"))
+dec.set_precision("fp16x2"); dec.set_render_screening(0.01)
+opt = Optimizer(dec, bench.joint_cfg(5))
+o = synth.make_object_views(3003, 1, 2000, n_fg=256, n_bg=200)[0]
+L = _lib.lib()
+t = (C.c_ulonglong * 48)()
+for _ in range(3):
+    opt.reconstruct_object(o["t_cam_obj"], o["pts"], o["rays"], o["depth"])
+L.qsp_debug_phase_ticks(t)
+for _ in range(20):
+    opt.reconstruct_object(o["t_cam_obj"], o["pts"], o["rays"], o["depth"])
+L.qsp_debug_phase_ticks(t)
+names = {0: ("k_sample", ["code", "bias vectors", "pose inverse", "ray masks", "offsets", "list", "state", "plan tail"]),
+         2: ("k_solve", ["state, active points", "slot sums, H and b", "rotation prior, taps", "elimination", "update"]),
+         1: ("k_scan", ["table clear", "table fill", "walk", "offsets", "write", "state", "plan tail"])}
+for k, (name, marks) in names.items():
+    n = max(t[16 * k], 1)
+    parts = ["%s %.1f" % (m, t[16 * k + 1 + i] / n / 100.0) for i, m in enumerate(marks)]
+    print("%s: %d launches, us between marks: %s; sum %.1f" % (name, n, ", ".join(parts), sum(t[16 * k + 1 + i] for i in range(len(marks))) / n / 100.0))
+print("k_solve elimination: %.0f shader-clock cycles per launch (%.0f per column), shader clock %.2f GHz" % (
+    t[32 + 8] / max(t[32], 1), t[32 + 8] / max(t[32], 1) / 71, t[32 + 8] / max(t[32 + 4], 1) * 0.1))
