@@ -219,8 +219,8 @@ __device__ __forceinline__ void sample_body(HypState* __restrict__ st, const Obj
         const bool l4 = threadIdx.x >= HID;
         const float* w = (l4 ? Pm->w4c : Pm->w0c) + u;
         float a = Pm->bias[l4 ? 4 : 0][u];
-#pragma unroll 8
-        for (int k = 0; k < CODE_LEN; ++k) a += w[(size_t)k * HID] * code_sh[k];
+#pragma unroll
+        for (int k = 0; k < CODE_LEN; ++k) a += w[(size_t)k * HID] * code_sh[k];      // (all 64 loads in flight: one round trip, not eight)
         c0_all[(size_t)h * 2 * HID + threadIdx.x] = a;
     }
     PHASE_MARK(0, 2);
@@ -898,7 +898,9 @@ __global__ __launch_bounds__(SCAN_RAYS) void k_scan(HypState* __restrict__ st, c
                                                     float* __restrict__ rend_deds, float* __restrict__ rend_res, PlanTail pt) {
     extern __shared__ __attribute__((aligned(16))) float rows[];     // [SCAN_RAYS][SCAN_LD]
     PHASE_MARK(1, 0);
-    for (int e = threadIdx.x; e < SCAN_RAYS * SCAN_LD; e += SCAN_RAYS) rows[e] = SCAN_NONE;
+    static_assert((SCAN_RAYS * SCAN_LD) % 4 == 0, "the table is cleared four words at a time");
+    for (int e = threadIdx.x; e < SCAN_RAYS * SCAN_LD / 4; e += SCAN_RAYS)
+        reinterpret_cast<float4*>(rows)[e] = make_float4(SCAN_NONE, SCAN_NONE, SCAN_NONE, SCAN_NONE);
     scan_body(rows, st, objs, depth, cfg, valid_rk, rk_stride, ray_voff, ray_stride, sdf_valid, rend_rk, rend_deds, rend_res);
 #if QSP_PHASE_EXP == 23
     return;
@@ -1390,6 +1392,51 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(HypState* __restrict__ 
     const float M = (float)n_act_sh;
     const float Kf = (float)K;
     const int N = cfg.pose_only ? 6 : NH;
+    // The rotation prior's Jacobian and residual (loss.py:155-178) need the pose only: the LAST thread forms them while the others
+    // sum the partial slots (its wave has no entry in the third turn of that loop), thread 0 applies them behind the barrier.
+    // (Thread 0 used to do both behind the barrier: 3 us of one lane's divisions with 1023 threads waiting.)
+    __shared__ float prior_sh[8];      // Jr[0..6], rr
+    if (tid == SOLVE_THREADS - 1 && !cfg.pose_only) {
+        float rco[9];
+        const float sc = powf(det3(S.T_co), (float)(1.0 / 3.0));
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) rco[3 * i + j] = S.T_co[4 * i + j] / sc;
+        // r_oc = inverse(r_co); for a rotation this is the transpose up to rounding -- invert generally (3x3, f64)
+        double m[9];
+        for (int i = 0; i < 9; ++i) m[i] = rco[i];
+        const double det = m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) +
+                           m[2] * (m[3] * m[7] - m[4] * m[6]);
+        float roc[9];
+        roc[0] = (float)((m[4] * m[8] - m[5] * m[7]) / det);
+        roc[1] = (float)((m[2] * m[7] - m[1] * m[8]) / det);
+        roc[2] = (float)((m[1] * m[5] - m[2] * m[4]) / det);
+        roc[3] = (float)((m[5] * m[6] - m[3] * m[8]) / det);
+        roc[4] = (float)((m[0] * m[8] - m[2] * m[6]) / det);
+        roc[5] = (float)((m[2] * m[3] - m[0] * m[5]) / det);
+        roc[6] = (float)((m[3] * m[7] - m[4] * m[6]) / det);
+        roc[7] = (float)((m[1] * m[6] - m[0] * m[7]) / det);
+        roc[8] = (float)((m[0] * m[4] - m[1] * m[3]) / det);
+        // ry = r_co e_y ; res = 1 - ry . n_g, n_g = (0,-1,0)
+        const float res_rot = 1.f - (-(rco[4]));
+        float Jr[7] = {0, 0, 0, 0, 0, 0, 0};
+        float rr = 0.f;
+        if (!(res_rot < 1e-7f)) {
+            // (r_oc n_g) x e_y with n_g = (0,-1,0): a = -r_oc[:,1]; a x e_y = (-a_z, 0, a_x)
+            const float ax = -roc[1], az = -roc[7];
+            Jr[3] = -az;
+            Jr[4] = 0.f;
+            Jr[5] = ax;
+            rr = res_rot;
+        }
+        if (trrot) {     // parity-test tap: the rotation prior's own Jacobian and residual (loss.py:155-178)
+            trrot[4 * h + 0] = Jr[3];
+            trrot[4 * h + 1] = Jr[4];
+            trrot[4 * h + 2] = Jr[5];
+            trrot[4 * h + 3] = rr;
+        }
+        for (int a = 0; a < 7; ++a) prior_sh[a] = Jr[a];
+        prior_sh[7] = rr;
+    }
     // Fixed-order sum of the tile partials (deterministic), then H, b in f32 exactly as optimizer.py:217-252 orders the
     // operations; entries are promoted to f64 only for the linear solve.
     // (one packed entry per thread and turn: 2628 entries are three turns of consecutive words -- walking the 72 x 72 square and
@@ -1451,44 +1498,10 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(HypState* __restrict__ 
         return;
     }
     if (tid == 0 && !cfg.pose_only) {
-        // rotation prior (loss.py:155-178) on the pose block, then damping (optimizer.py:240-252)
-        float rco[9];
-        const float sc = powf(det3(S.T_co), (float)(1.0 / 3.0));
-        for (int i = 0; i < 3; ++i)
-            for (int j = 0; j < 3; ++j) rco[3 * i + j] = S.T_co[4 * i + j] / sc;
-        // r_oc = inverse(r_co); for a rotation this is the transpose up to rounding -- invert generally (3x3, f64)
-        double m[9];
-        for (int i = 0; i < 9; ++i) m[i] = rco[i];
-        const double det = m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) +
-                           m[2] * (m[3] * m[7] - m[4] * m[6]);
-        float roc[9];
-        roc[0] = (float)((m[4] * m[8] - m[5] * m[7]) / det);
-        roc[1] = (float)((m[2] * m[7] - m[1] * m[8]) / det);
-        roc[2] = (float)((m[1] * m[5] - m[2] * m[4]) / det);
-        roc[3] = (float)((m[5] * m[6] - m[3] * m[8]) / det);
-        roc[4] = (float)((m[0] * m[8] - m[2] * m[6]) / det);
-        roc[5] = (float)((m[2] * m[3] - m[0] * m[5]) / det);
-        roc[6] = (float)((m[3] * m[7] - m[4] * m[6]) / det);
-        roc[7] = (float)((m[1] * m[6] - m[0] * m[7]) / det);
-        roc[8] = (float)((m[0] * m[4] - m[1] * m[3]) / det);
-        // ry = r_co e_y ; res = 1 - ry . n_g, n_g = (0,-1,0)
-        const float res_rot = 1.f - (-(rco[4]));
-        float Jr[7] = {0, 0, 0, 0, 0, 0, 0};
-        float rr = 0.f;
-        if (!(res_rot < 1e-7f)) {
-            // (r_oc n_g) x e_y with n_g = (0,-1,0): a = -r_oc[:,1]; a x e_y = (-a_z, 0, a_x)
-            const float ax = -roc[1], az = -roc[7];
-            Jr[3] = -az;
-            Jr[4] = 0.f;
-            Jr[5] = ax;
-            rr = res_rot;
-        }
-        if (trrot) {     // parity-test tap: the rotation prior's own Jacobian and residual (loss.py:155-178)
-            trrot[4 * h + 0] = Jr[3];
-            trrot[4 * h + 1] = Jr[4];
-            trrot[4 * h + 2] = Jr[5];
-            trrot[4 * h + 3] = rr;
-        }
+        // rotation prior on the pose block (formed above), then damping (optimizer.py:240-252)
+        float Jr[7];
+        for (int a = 0; a < 7; ++a) Jr[a] = prior_sh[a];
+        const float rr = prior_sh[7];
         for (int a = 0; a < 7; ++a) {
             for (int b = 0; b < 7; ++b) {
                 float v = (float)Hd[a * (N + 1) + b];
