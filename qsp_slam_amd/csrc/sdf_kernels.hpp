@@ -194,6 +194,10 @@ __device__ unsigned long long qsp_phase_ticks[3][16];    // [kernel][i]: ticks b
 #define QSP_PHASE_EXP 0      // timing experiments only (tools/list_phases.sh: k_sample / k_scan cut short at a phase boundary); 0 in every build that ships
 #endif
 constexpr int SAMPLE_THREADS = 1024;      // k_sample's workgroup: latency, not throughput (a one-object call is ONE workgroup)
+// (Measured in round 4 and not kept: a hypothesis's rays over up to 8 workgroups, the one that finishes last writing the lists from
+//  what the others left in global memory -- k_sample 25.7 -> 23.5 us, k_scan 26.2 -> 30.6 us per launch of a one-object call, the
+//  call unchanged at 2.52 ms: a wave walks its 64 rays in the same 11 us whether seven others walk beside it or not, and the
+//  hand-over between workgroups -- fence, counter, fence, reads that miss -- costs the 3-5 us the shorter mask loop saves.)
 __device__ __forceinline__ void sample_body(HypState* __restrict__ st, const ObjView* __restrict__ objs,
                                             const float* __restrict__ rays, const RefineCfg& cfg,
                                             int32_t* __restrict__ valid_rk, int64_t rk_stride,
