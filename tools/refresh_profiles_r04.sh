@@ -11,6 +11,8 @@ QSP_MARGINS_OUT=$O/r04_test_margins.json timeout -k 10 900 python3 -m pytest tes
 tail -3 $O/tests.log
 QSP_PRECISION=fp16x2 QSP_SCREENING=0.01 QSP_MARGINS_OUT=$O/r04_test_margins_fp16x2_screened.json timeout -k 10 900 python3 -m pytest tests -m gpu -q > $O/tests_fp16x2.log 2>&1 || true
 tail -3 $O/tests_fp16x2.log
+QSP_PRECISION=fp16x2 QSP_SCREENING=0.01 QSP_DEPTH_STAGING=always QSP_MARGINS_OUT=$O/r04_test_margins_fp16x2_screened_staged_always.json timeout -k 10 900 python3 -m pytest tests -m gpu -q > $O/tests_fp16x2_staged.log 2>&1 || true
+tail -3 $O/tests_fp16x2_staged.log
 timeout -k 10 800 python3 bench.py > $O/r04_bench_c4.json 2> $O/bench.err
 echo "bench done"
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o c4 -- python3 bench.py --workload c4 --steps 2 --warmup 1 --no-cpu-baseline --no-sublines --no-extras > $O/trace.log 2>&1
@@ -45,7 +47,9 @@ timeout -k 10 120 python3 tools/lat_calls.py fp16x2 > $O/r04_latency.txt 2>&1
 timeout -k 10 120 python3 tools/lat_calls.py fp16x2 32 >> $O/r04_latency.txt 2>&1
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/lat -o lat -- python3 $R/tools/lat_calls.py fp16x2 > /dev/null 2>&1)
 python3 tools/kstats.py $O/lat > $O/r04_latency_kernels.txt
+python3 tools/call_timeline.py $O/lat > $O/r04_call_timeline.txt 2>&1 || true
 rm -rf $O/lat
+[ -f build/exp/libqsp_phase.so ] && timeout -k 10 120 python3 tools/phase_clock.py > $O/r04_list_kernel_phases.txt 2>&1 || true
 timeout -k 10 300 python3 tools/screen_margin.py 0.01 > $O/r04_screen_margin.txt 2> $O/screen_margin.err || true
 cat $O/r04_latency.txt $O/r04_c4_pmc_clock_w8.txt
 grep -A1 "k_mlp_jtj\|k_mlp_fwd" $O/r04_c4_pmcF_summary.txt $O/r04_c4_pmcW_summary.txt || true
