@@ -261,10 +261,15 @@ int qsp_estimate_pose(qsp_decoder* dec, int32_t n, const float* t_co_se3, const 
  * (convert_sdf_voxels_to_mesh, reconstruct/utils.py:120-141, skimage.measure.marching_cubes_lewiner there).
  * Both stages run on the device; only vertices and faces come back.
  *   voxel_points (dim^3, 3): the grid in the reference's order, point index = i0*dim^2 + i1*dim + i2 (host pointer, copied).
- *   vertices (V,3) float32 = (index coordinates along axes 0,1,2) * 2/(dim-1) - 1, one vertex per sign-changing grid
- *   edge at the linear zero crossing, ordered by owning grid point then axis; faces (F,3) int32 ordered by cell, right-hand
- *   normal towards increasing sdf.  Triangulation rule: csrc/mesh_extract.hpp (not Lewiner's tables: skimage is absent
- *   from the build image; same vertex set, may differ in ambiguous cells). */
+ *   Marching cubes = Lewiner's (Lewiner et al., JGT 2003) as scikit-image 0.18's marching_cubes_lewiner runs it -- the call of
+ *   reconstruct/utils.py:131 --, reproduced on the device with its case tables (csrc/mesh_lewiner.hpp): one vertex per
+ *   sign-changing grid edge (+ the extra vertex of some ambiguous configurations), numbered by first use in a z-outermost sweep
+ *   of the cells; faces in that sweep's order, corners reversed (gradient_direction='descent').  Same vertices, same faces, same
+ *   ORDER as scikit-image on the same volume (tests/golden/mc_lewiner_*.npz hold its output).
+ *   vertices: qsp_mesh_fetch gives (V,3) float32 = float32(index coordinate) * float32(2/(dim-1)) - 1; qsp_mesh_fetch_f64 gives
+ *   the reference's own float64 values, float32(index coordinate) * (2.0/(dim-1)) + (-1.0), bit for bit.
+ *   qsp_mesh_extractor_set_method(m, 1) selects the triangulation of rounds 2-3 instead (face-consistent segments from a
+ *   generated 256-case table, vertices ordered by owning grid point then axis: the same vertex set, other diagonals). */
 typedef struct qsp_mesh_extractor qsp_mesh_extractor;
 int qsp_mesh_extractor_create(qsp_decoder* dec, int32_t voxels_dim, const float* voxel_points, qsp_mesh_extractor** out);
 void qsp_mesh_extractor_destroy(qsp_mesh_extractor* m);
@@ -274,7 +279,11 @@ int qsp_mesh_extract(qsp_mesh_extractor* m, const float* code, int64_t* n_verts,
 int qsp_mesh_from_volume(qsp_mesh_extractor* m, const float* sdf_volume, int64_t* n_verts, int64_t* n_faces);
 /* copy the last result out: verts (n_verts,3), faces (n_faces,3), optionally the (dim^3) volume; any pointer may be NULL */
 int qsp_mesh_fetch(qsp_mesh_extractor* m, float* verts, int32_t* faces, float* sdf_volume);
-/* the generated case table: ntri[256], tri[256][24] cube-edge ids (edge = 4*axis + u + 2v), -1 padded */
+/* the last result's vertices as float64 (n_verts,3), as convert_sdf_voxels_to_mesh returns them */
+int qsp_mesh_fetch_f64(qsp_mesh_extractor* m, double* verts);
+/* 0 (default): Lewiner's marching cubes, what the reference calls; 1: the face-consistent table of rounds 2-3 */
+int qsp_mesh_extractor_set_method(qsp_mesh_extractor* m, int32_t method);
+/* method 1's generated case table: ntri[256], tri[256][24] cube-edge ids (edge = 4*axis + u + 2v), -1 padded */
 int qsp_mc_tables(int8_t* ntri, int8_t* tri);
 
 /* ===============================================================================================================

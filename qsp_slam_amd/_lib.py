@@ -99,7 +99,7 @@ SYMBOLS = [
     "qsp_refine_batch_create", "qsp_refine_batch_destroy", "qsp_refine_batch_set_state", "qsp_refine_batch_run",
     "qsp_refine_batch_get", "qsp_refine_batch_trace", "qsp_refine_batch_trace_rot", "qsp_refine_batch_profile", "qsp_refine_batch_rows",
     "qsp_reconstruct_objects", "qsp_estimate_pose", "qsp_refine_detections",
-    "qsp_mesh_extractor_create", "qsp_mesh_extractor_destroy", "qsp_mesh_extract", "qsp_mesh_from_volume", "qsp_mesh_fetch",
+    "qsp_mesh_extractor_create", "qsp_mesh_extractor_destroy", "qsp_mesh_extract", "qsp_mesh_from_volume", "qsp_mesh_fetch", "qsp_mesh_fetch_f64", "qsp_mesh_extractor_set_method",
     "qsp_mc_tables",
     "qsp_pose_optimizer_create", "qsp_pose_optimizer_destroy", "qsp_pose_optimize", "qsp_ellipsoid_fit_planes", "qsp_ellipsoid_fit_prior",
     "qsp_ba_create", "qsp_ba_destroy", "qsp_ba_set_levels", "qsp_ba_optimize", "qsp_ba_local_joint",
@@ -155,6 +155,8 @@ def lib():
     L.qsp_mesh_extract.argtypes = [vp, c_float_p, c_int64_p, c_int64_p]
     L.qsp_mesh_from_volume.argtypes = [vp, c_float_p, c_int64_p, c_int64_p]
     L.qsp_mesh_fetch.argtypes = [vp, c_float_p, c_int32_p, c_float_p]
+    L.qsp_mesh_fetch_f64.argtypes = [vp, C.POINTER(C.c_double)]
+    L.qsp_mesh_extractor_set_method.argtypes = [vp, C.c_int32]
     L.qsp_mc_tables.argtypes = [C.POINTER(C.c_int8), C.POINTER(C.c_int8)]
     L.qsp_pose_optimizer_create.argtypes = [C.c_int, C.c_int32, C.POINTER(vp)]
     L.qsp_pose_optimizer_destroy.argtypes = [vp]

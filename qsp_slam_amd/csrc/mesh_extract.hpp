@@ -279,8 +279,14 @@ __global__ __launch_bounds__(256) void k_mc_emit(const float* __restrict__ sdf, 
 }  // namespace mc
 }  // namespace qsp
 
+#include "mesh_lewiner.hpp"
+
 struct qsp_mesh_extractor {
     qsp_decoder* dec = nullptr;
+    int marched_method = 0; // of the mesh that is resident
+    int method = 0;         // 0: Lewiner's marching cubes, what the reference calls (mesh_lewiner.hpp); 1: the face-consistent table of rounds 2-3
+    float* vidx = nullptr;  // Lewiner: the vertices as float32 index coordinates (the float64 mesh of the reference is these x spacing - 1)
+    int32_t* vmap = nullptr;   // Lewiner: (axis, grid point) -> vertex number
     int dim = 0;
     int64_t n = 0, n_pad = 0;
     int nb = 0;
@@ -298,7 +304,7 @@ struct qsp_mesh_extractor {
 extern "C" void qsp_mesh_extractor_destroy(qsp_mesh_extractor* m) {
     if (!m) return;
     (void)hipSetDevice(m->device);
-    void* ptrs[] = {m->xyz, m->sdf, m->code, m->verts, m->faces, m->flags, m->cnt, m->bsum, m->total, m->tables};
+    void* ptrs[] = {m->xyz, m->sdf, m->code, m->verts, m->faces, m->flags, m->cnt, m->bsum, m->total, m->tables, m->vidx, m->vmap};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete m;
@@ -336,6 +342,7 @@ extern "C" int qsp_mesh_extractor_create(qsp_decoder* dec, int32_t voxels_dim, c
     MAL(bsum, sizeof(unsigned long long) * 1024);
     MAL(total, sizeof(unsigned long long));
     MAL(tables, sizeof(mc::Tables));
+    MAL(vmap, sizeof(int32_t) * 3 * m->n);
 #undef MAL
     if (!rc) {
         hipError_t e = hipMemcpy(m->xyz, voxel_points, sizeof(float) * 3 * m->n, hipMemcpyHostToDevice);
@@ -354,7 +361,9 @@ static int mesh_march(qsp_mesh_extractor* m, int64_t* n_verts, int64_t* n_faces)
     using namespace qsp;
     hipStream_t s = m->dec->stream;
     const int g = (int)(m->n_pad / 256);
-    hipLaunchKernelGGL(mc::k_mc_flags, dim3(g), dim3(256), 0, s, m->sdf, m->dim, m->tables, m->flags, m->cnt, m->n_pad);
+    const bool lewiner = m->method == 0;
+    if (lewiner) hipLaunchKernelGGL(lew::k_lew_count, dim3(g), dim3(256), 0, s, m->sdf, m->dim, m->cnt, m->n_pad);
+    else hipLaunchKernelGGL(mc::k_mc_flags, dim3(g), dim3(256), 0, s, m->sdf, m->dim, m->tables, m->flags, m->cnt, m->n_pad);
     hipLaunchKernelGGL(mc::k_mc_scan_blocks, dim3(m->nb), dim3(256), 0, s, m->cnt, m->bsum);
     hipLaunchKernelGGL(mc::k_mc_scan_top, dim3(1), dim3(1024), 0, s, m->bsum, m->nb, m->total);
     unsigned long long tot = 0;
@@ -364,9 +373,11 @@ static int mesh_march(qsp_mesh_extractor* m, int64_t* n_verts, int64_t* n_faces)
     m->n_faces = (int64_t)(tot >> 32);
     if (m->n_verts > m->cap_verts) {
         if (m->verts) (void)hipFree(m->verts);
-        m->verts = nullptr;
+        if (m->vidx) (void)hipFree(m->vidx);
+        m->verts = m->vidx = nullptr;
         m->cap_verts = m->n_verts + m->n_verts / 4 + 1024;
         QSP_HIP(hipMalloc((void**)&m->verts, sizeof(float) * 3 * m->cap_verts));
+        QSP_HIP(hipMalloc((void**)&m->vidx, sizeof(float) * 3 * m->cap_verts));
     }
     if (m->n_faces > m->cap_faces) {
         if (m->faces) (void)hipFree(m->faces);
@@ -374,9 +385,15 @@ static int mesh_march(qsp_mesh_extractor* m, int64_t* n_verts, int64_t* n_faces)
         m->cap_faces = m->n_faces + m->n_faces / 4 + 1024;
         QSP_HIP(hipMalloc((void**)&m->faces, sizeof(int32_t) * 3 * m->cap_faces));
     }
-    if (m->n_verts)
+    if (m->n_verts && lewiner) {
+        const int gp = (int)((m->n + 255) / 256);
+        hipLaunchKernelGGL(lew::k_lew_verts, dim3(gp), dim3(256), 0, s, m->sdf, m->dim, m->voxel_size, m->cnt, m->bsum, mc::SCAN_BLOCK,
+                           m->vidx, m->verts, m->vmap);
+        hipLaunchKernelGGL(lew::k_lew_faces, dim3(gp), dim3(256), 0, s, m->sdf, m->dim, m->cnt, m->bsum, mc::SCAN_BLOCK, m->vmap, m->faces);
+    } else if (m->n_verts)
         hipLaunchKernelGGL(mc::k_mc_emit, dim3((int)((m->n + 255) / 256)), dim3(256), 0, s, m->sdf, m->dim, m->voxel_size, m->tables,
                            m->flags, m->cnt, m->bsum, m->verts, m->faces);
+    m->marched_method = m->method;
     QSP_HIP(hipGetLastError());
     QSP_HIP(hipStreamSynchronize(s));
     m->have_volume = true;
@@ -447,6 +464,29 @@ extern "C" int qsp_mesh_fetch(qsp_mesh_extractor* m, float* verts, int32_t* face
     if (faces && m->n_faces) QSP_HIP(hipMemcpyAsync(faces, m->faces, sizeof(int32_t) * 3 * m->n_faces, hipMemcpyDeviceToHost, s));
     if (sdf_volume) QSP_HIP(hipMemcpyAsync(sdf_volume, m->sdf, sizeof(float) * m->n, hipMemcpyDeviceToHost, s));
     QSP_HIP(hipStreamSynchronize(s));
+    return QSP_OK;
+}
+
+extern "C" int qsp_mesh_extractor_set_method(qsp_mesh_extractor* m, int32_t method) {
+    if (!m) return qsp_fail(QSP_ERR_INVALID, "qsp_mesh_extractor_set_method: null extractor");
+    if (method != 0 && method != 1) return qsp_fail(QSP_ERR_INVALID, "mesh method: 0 (Lewiner's marching cubes, the reference's) or 1 (face-consistent table)");
+    m->method = method;
+    return QSP_OK;
+}
+
+// the vertices as the reference holds them: float64 = float32 index coordinate x (2 / (n - 1)) + (-1) (skimage multiplies its
+// float32 vertices by the float64 spacing, reconstruct/utils.py:131-139 adds the origin)
+extern "C" int qsp_mesh_fetch_f64(qsp_mesh_extractor* m, double* verts) {
+    if (!m || !verts) return qsp_fail(QSP_ERR_INVALID, "qsp_mesh_fetch_f64: null argument");
+    if (!m->have_volume) return qsp_fail(QSP_ERR_INVALID, "qsp_mesh_fetch_f64: nothing extracted yet");
+    if (!m->n_verts) return QSP_OK;
+    QSP_HIP(hipSetDevice(m->dec->device));
+    std::vector<float> tmp((size_t)3 * m->n_verts);
+    const bool lewiner = m->marched_method == 0;
+    QSP_HIP(hipMemcpyAsync(tmp.data(), lewiner ? m->vidx : m->verts, sizeof(float) * tmp.size(), hipMemcpyDeviceToHost, m->dec->stream));
+    QSP_HIP(hipStreamSynchronize(m->dec->stream));
+    const double spacing = 2.0 / (double)(m->dim - 1);
+    for (size_t i = 0; i < tmp.size(); ++i) verts[i] = lewiner ? (double)tmp[i] * spacing + (-1.0) : (double)tmp[i];
     return QSP_OK;
 }
 

@@ -133,9 +133,11 @@ struct MeshExtractor {
         if ((int)code.size() < code_len) throw std::invalid_argument("code shorter than code_len");
         int64_t nv = 0, nf = 0;
         check(qsp_mesh_extract(m, code.data(), &nv, &nf));
-        py::array_t<float> verts({(py::ssize_t)nv, (py::ssize_t)3});
+        if (nv == 0) throw std::runtime_error("No surface found at the given iso value.");      // (as skimage's marching_cubes_lewiner)
+        py::array_t<double> verts({(py::ssize_t)nv, (py::ssize_t)3});       // float64, as convert_sdf_voxels_to_mesh returns them
         py::array_t<int32_t> faces({(py::ssize_t)nf, (py::ssize_t)3});
-        check(qsp_mesh_fetch(m, verts.mutable_data(), faces.mutable_data(), nullptr));
+        check(qsp_mesh_fetch(m, nullptr, faces.mutable_data(), nullptr));
+        check(qsp_mesh_fetch_f64(m, verts.mutable_data()));
         py::object cls = py::module_::import("qsp_slam_amd.reconstruct.utils").attr("ForceKeyErrorDict");
         py::dict kw;
         kw["vertices"] = verts;

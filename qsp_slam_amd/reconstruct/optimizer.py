@@ -327,17 +327,24 @@ def create_voxel_grid(vol_dim=128):
 
 class MeshExtractor(object):
     """reconstruct/optimizer.py:284-304.  The SDF volume over create_voxel_grid(voxels_dim) is decoded and triangulated on
-    the GPU (qsp_mesh_extract: MLP tile kernel + marching cubes, include/qsp_hip.h); only vertices (V,3) float32 and faces
-    (F,3) int32 come back, as in the reference's result object."""
+    the GPU (qsp_mesh_extract: MLP tile kernel + Lewiner's marching cubes, include/qsp_hip.h); only vertices and faces come
+    back: vertices (V,3) float64 and faces (F,3) int32, the values and the order skimage.measure.marching_cubes_lewiner +
+    convert_sdf_voxels_to_mesh (reconstruct/utils.py:120-141) give for the same volume.  Like there, a volume without a zero
+    crossing raises (ValueError when 0 is outside its range, RuntimeError when no cell is crossed).
+    method="table": the triangulation of rounds 2-3 (float32 vertices ordered by grid point; no exception for an empty mesh)."""
 
-    def __init__(self, decoder, code_len=64, voxels_dim=64):
+    def __init__(self, decoder, code_len=64, voxels_dim=64, method="lewiner"):
+        if method not in ("lewiner", "table"):
+            raise ValueError("method: 'lewiner' or 'table'")
         self.decoder = decoder
         self.code_len = code_len
         self.voxels_dim = voxels_dim
+        self.method = method
         self.voxel_points = create_voxel_grid(vol_dim=self.voxels_dim)
         self.handle = C.c_void_p()
         pts = _lib.f32c(self.voxel_points)
         _lib.check(_lib.lib().qsp_mesh_extractor_create(decoder.handle, voxels_dim, _lib.fptr(pts), C.byref(self.handle)))
+        _lib.check(_lib.lib().qsp_mesh_extractor_set_method(self.handle, 0 if method == "lewiner" else 1))
 
     def __del__(self):
         h = getattr(self, "handle", None)
@@ -346,12 +353,21 @@ class MeshExtractor(object):
             self.handle = C.c_void_p()
 
     def _fetch(self, nv, nf, volume=False):
+        lewiner = self.method == "lewiner"
         verts = np.empty((nv.value, 3), np.float32)
         faces = np.empty((nf.value, 3), np.int32)
-        vol = np.empty((self.voxels_dim,) * 3, np.float32) if volume else None
+        want_vol = volume or (lewiner and nv.value == 0)
+        vol = np.empty((self.voxels_dim,) * 3, np.float32) if want_vol else None
         _lib.check(_lib.lib().qsp_mesh_fetch(self.handle, _lib.fptr(verts), _lib.i32ptr(faces),
-                                             _lib.fptr(vol) if volume else None))
-        return verts, faces, vol
+                                             _lib.fptr(vol) if want_vol else None))
+        if lewiner:
+            if nv.value == 0:      # skimage/measure/_marching_cubes_lewiner.py: the two ways an empty surface is reported
+                if 0.0 < float(vol.min()) or 0.0 > float(vol.max()):
+                    raise ValueError("Surface level must be within volume data range.")
+                raise RuntimeError("No surface found at the given iso value.")
+            verts = np.empty((nv.value, 3), np.float64)
+            _lib.check(_lib.lib().qsp_mesh_fetch_f64(self.handle, verts.ctypes.data_as(C.POINTER(C.c_double))))
+        return verts, faces, vol if volume else None
 
     def extract_sdf_grid(self, code):
         """(dim,dim,dim) SDF volume the reference hands to convert_sdf_voxels_to_mesh (optimizer.py:296-297)."""

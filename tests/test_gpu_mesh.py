@@ -1,13 +1,16 @@
 """GPU parity tests of the device mesh extraction through the C-ABI: qsp_mesh_from_volume /
-qsp_mesh_extract against oracle/mc_oracle.py.  Index work (faces, vertex order, counts) is bit-exact; vertex coordinates
-are bit-exact too (same float32 operations, no contraction); the decoded volume is compared with the numpy decoder to
-the decoder tolerance of tests/test_gpu_sdf.py (2e-5 abs on tanh outputs)."""
+qsp_mesh_extract.  The default method is Lewiner's marching cubes -- what the reference calls (reconstruct/utils.py:131) --:
+compared with scikit-image 0.18.3's own output (tests/golden/mc_lewiner_*.npz, oracle/gen_golden_mc.py) and with the CPU
+restatement oracle/mc_lewiner_oracle.py, vertices (float64) and faces bit for bit, IN ORDER.  method="table" (rounds 2-3)
+against oracle/mc_oracle.py as before.  The decoded volume is compared with the numpy decoder to the decoder tolerance of
+tests/test_gpu_sdf.py (2e-5 abs on tanh outputs)."""
 import os
 import time
 
 import numpy as np
 import pytest
 
+from oracle import mc_lewiner_oracle as ml
 from oracle import mc_oracle as mo
 from oracle import sdf_oracle as so
 from tests.test_oracle_mesh import canonical_mesh, noise_volume, sphere_volume
@@ -23,9 +26,95 @@ def gpu_decoder(golden_dir):
     d.close()
 
 
-def extractor(dec, dim):
+def extractor(dec, dim, method="table"):
     from qsp_slam_amd.reconstruct.optimizer import MeshExtractor
-    return MeshExtractor(dec, code_len=64, voxels_dim=dim)
+    return MeshExtractor(dec, code_len=64, voxels_dim=dim, method=method)
+
+
+# ---- Lewiner's marching cubes (the default): against scikit-image's output and the CPU restatement -------------------------
+def test_lewiner_equals_scikit_image_on_the_golden_volumes(gpu_decoder, golden_dir):
+    """vertices float64 and faces int32, the same values in the same order as skimage.measure.marching_cubes_lewiner +
+    convert_sdf_voxels_to_mesh on: the decoder's 32^3 grid (three codes), a sphere, a smooth open field, two white-noise volumes
+    (every ambiguous configuration), a volume with grid values exactly on the level"""
+    g = np.load(os.path.join(golden_dir, "mc_lewiner_volumes.npz"))
+    names = [k[4:] for k in g.files if k.startswith("vol_")]
+    assert len(names) == 8
+    for k in names:
+        vol = g["vol_" + k]
+        me = extractor(gpu_decoder, vol.shape[0], "lewiner")
+        v, f = me.mesh_from_volume(vol)
+        assert v.dtype == np.float64 and f.dtype == np.int32, k
+        assert v.shape == g[k + "_verts"].shape and f.shape == g[k + "_faces"].shape, k
+        assert np.array_equal(f, g[k + "_faces"]), k
+        assert np.array_equal(v.view(np.uint64), g[k + "_verts"].view(np.uint64)), k
+        ov, of = ml.convert_sdf_voxels_to_mesh(vol)
+        assert np.array_equal(f, of) and np.array_equal(v, ov), k
+
+
+def test_lewiner_equals_scikit_image_cell_by_cell(gpu_decoder, golden_dir):
+    """~4000 single cells (random corner values, a seventh nearly degenerate, some with a corner exactly 0; 1000 with the corner
+    signs of the ambiguous cases): the sub-cases of the face and interior tests of the 33 cases, decided and triangulated as
+    scikit-image does"""
+    g = np.load(os.path.join(golden_dir, "mc_lewiner_cells.npz"))
+    me = extractor(gpu_decoder, 2, "lewiner")
+    n_faces = set()
+    for i in range(len(g["vals"])):
+        nf, nv = int(g["cells_nf"][i]), int(g["cells_nv"][i])
+        if nf == 0:
+            with pytest.raises((ValueError, RuntimeError)):
+                me.mesh_from_volume(g["vals"][i])
+            continue
+        v, f = me.mesh_from_volume(g["vals"][i])
+        assert len(f) == nf and len(v) == nv, i
+        assert np.array_equal(f, g["cells_faces"][i, :nf]), i
+        assert np.array_equal(v, g["cells_verts"][i, :nv]), i
+        n_faces.add(nf)
+    assert n_faces == {1, 2, 3, 4, 5, 6, 8, 9, 10, 12}       # (every triangle count the 33 cases produce)
+
+
+@pytest.mark.parametrize("dim,kind", [(64, "sphere"), (33, "noise"), (128, "smooth")])
+def test_lewiner_equals_the_restatement_at_larger_sizes(gpu_decoder, dim, kind):
+    if kind == "sphere":
+        vol = sphere_volume(dim)
+    elif kind == "noise":
+        vol = noise_volume(dim, dim)
+    else:
+        g = np.linspace(-1, 1, dim, dtype=np.float32)
+        x, y, z = np.meshgrid(g, g, g, indexing="ij")
+        vol = (np.sin(3 * x) * np.cos(2 * y) + 0.5 * np.sin(4 * z + x) - 0.1).astype(np.float32)
+    v, f = extractor(gpu_decoder, dim, "lewiner").mesh_from_volume(vol)
+    ov, of = ml.convert_sdf_voxels_to_mesh(vol)
+    assert np.array_equal(f, of) and np.array_equal(v, ov)
+    dup, missing = mo.directed_edge_defects(f)
+    assert dup == 0 and (missing == 0 or kind != "sphere")
+
+
+def test_lewiner_empty_surfaces_raise_like_scikit_image(gpu_decoder):
+    me = extractor(gpu_decoder, 8, "lewiner")
+    with pytest.raises(ValueError):          # level outside the volume's range
+        me.mesh_from_volume(np.ones((8, 8, 8), np.float32))
+    with pytest.raises(ValueError):
+        me.mesh_from_volume(np.full((8, 8, 8), -1.0, np.float32))
+    vol = np.ones((8, 8, 8), np.float32)
+    vol[3, 3, 3] = 0.0                       # 0 is within the range, but no corner is > 0 on one side and <= 0 ... one cell is crossed
+    v, f = me.mesh_from_volume(vol)
+    ov, of = ml.convert_sdf_voxels_to_mesh(vol)
+    assert np.array_equal(f, of) and np.array_equal(v, ov) and len(f) == 8
+    v, f = me.mesh_from_volume(sphere_volume(8, r=0.6))      # the same extractor grows its buffers
+    ov, of = ml.convert_sdf_voxels_to_mesh(sphere_volume(8, r=0.6))
+    assert np.array_equal(f, of) and np.array_equal(v, ov)
+
+
+def test_lewiner_mesh_from_code_is_the_default(gpu_decoder, golden_dir):
+    """MeshExtractor.extract_mesh_from_code as the reference calls it (reconstruct/optimizer.py:284-304): the mesh of the very
+    volume the GPU decoded, as scikit-image would triangulate it"""
+    from qsp_slam_amd.reconstruct.optimizer import MeshExtractor
+    me = MeshExtractor(gpu_decoder, code_len=64, voxels_dim=32)
+    code = (0.05 * np.random.default_rng(5).standard_normal(64)).astype(np.float32)
+    out = me.extract_mesh_from_code(code, return_volume=True)
+    ov, of = ml.convert_sdf_voxels_to_mesh(out["sdf_volume"])
+    assert out.vertices.dtype == np.float64 and np.array_equal(out.vertices, ov) and np.array_equal(out.faces, of)
+    assert len(of) > 100 and mo.signed_volume(ov, of) > 0
 
 
 @pytest.mark.parametrize("dim,kind", [(16, "sphere"), (32, "sphere"), (64, "sphere"), (12, "noise"), (33, "noise"),

@@ -180,3 +180,70 @@ def test_decoder_volumes_have_no_ambiguous_marching_cubes_faces(oracle_decoder):
             a, b, cc, d = [c[i] for i in f]
             amb |= (a == cc) & (b == d) & (a != b)
         assert int((amb & surface).sum()) == 0
+
+
+# ---- Lewiner's marching cubes: the CPU restatement pinned by scikit-image's own output ---------------------------------------
+def test_lewiner_restatement_equals_scikit_image_on_the_golden_volumes(golden_dir):
+    """oracle/mc_lewiner_oracle.py against tests/golden/mc_lewiner_volumes.npz (scikit-image 0.18.3 run by oracle/gen_golden_mc.py,
+    the dependency reconstruct/utils.py:131 calls): vertices float64 and faces int32 bit for bit, in scikit-image's order"""
+    from oracle import mc_lewiner_oracle as ml
+    g = np.load(os.path.join(golden_dir, "mc_lewiner_volumes.npz"))
+    assert str(g["skimage_version"]) == "0.18.3"
+    names = [k[4:] for k in g.files if k.startswith("vol_")]
+    assert len(names) == 8
+    for k in names:
+        v, f = ml.convert_sdf_voxels_to_mesh(g["vol_" + k])
+        assert v.dtype == np.float64 and f.dtype == np.int32
+        assert np.array_equal(f, g[k + "_faces"]), k
+        assert np.array_equal(v.view(np.uint64), g[k + "_verts"].view(np.uint64)), k
+
+
+def test_lewiner_restatement_equals_scikit_image_cell_by_cell(golden_dir):
+    """... and on single cells: every case and sub-case of the 33 (which tiling table a cell took is recorded and must cover every
+    table), corner values exactly 0, nearly degenerate saddles"""
+    from oracle import mc_lewiner_oracle as ml
+    g = np.load(os.path.join(golden_dir, "mc_lewiner_cells.npz"))
+    T = ml.tables()
+    used = set()
+    orig = ml.cell_triangles
+
+    def spy(Tt, index, v):
+        out = orig(Tt, index, v)
+        used.add((Tt["CASES"][index][0], len(out) // 3))
+        return out
+    ml.cell_triangles = spy
+    try:
+        for i in range(len(g["vals"])):
+            nf, nv = int(g["cells_nf"][i]), int(g["cells_nv"][i])
+            if nf == 0:
+                continue
+            v, f = ml.convert_sdf_voxels_to_mesh(g["vals"][i])
+            assert len(f) == nf and len(v) == nv, i
+            assert np.array_equal(f, g["cells_faces"][i, :nf]) and np.array_equal(v, g["cells_verts"][i, :nv]), i
+    finally:
+        ml.cell_triangles = orig
+    # (case, triangles) pairs the 33 cases can produce: all of them occur in the fixture
+    # (6.1.2 -- nine triangles -- needs a false face test AND a false interior test; it did not occur in 200 000 random case-6 cells)
+    want = {(1, 1), (2, 2), (3, 2), (3, 4), (4, 2), (4, 6), (5, 3), (6, 3), (6, 5), (7, 3), (7, 5), (7, 9), (8, 2), (9, 4),
+            (10, 4), (10, 8), (11, 4), (12, 4), (12, 8), (13, 4), (13, 6), (13, 10), (13, 12), (14, 4)}
+    assert want <= used, sorted(want - used)
+    assert T["CASES"][0][0] == 0 and T["CASES"][255][0] == 0
+
+
+def test_lewiner_and_the_table_method_share_their_vertices_on_smooth_volumes():
+    """what rounds 2-3 shipped (oracle/mc_oracle.py: face-consistent table) against Lewiner's: the same vertices (to float32
+    rounding of two different interpolation formulas) and the same number of faces on a smooth closed surface; about half of the
+    triangles are the same, the others pick the other diagonal of a polygon -- the reason the table method is no longer the default"""
+    from oracle import mc_lewiner_oracle as ml
+    from scipy.spatial import cKDTree
+    vol = sphere_volume(24)
+    v, f = mo.marching_cubes(vol)
+    lv, lf = ml.convert_sdf_voxels_to_mesh(vol)
+    assert v.shape == lv.shape and f.shape == lf.shape
+    dist, idx = cKDTree(lv).query(v.astype(np.float64))
+    assert dist.max() < 5e-7 and len(set(idx.tolist())) == len(idx)
+
+    def canon(F):
+        return {tuple(np.roll(t, -int(np.argmin(t)))) for t in F.tolist()}
+    same = len(canon(idx[f]) & canon(lf))
+    assert 0.3 * len(f) < same < 0.8 * len(f)
