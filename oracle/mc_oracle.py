@@ -5,13 +5,12 @@ What it restates: convert_sdf_voxels_to_mesh (reference reconstruct/utils.py:120
 (n,n,n) SDF volume with spacing 2/(n-1), then `+ voxel_grid_origin` (-1,-1,-1) -- vertices are in INDEX coordinates of the
 volume axes (0,1,2), not in the skewed coordinates create_voxel_grid hands to the decoder (utils.py:98-117).
 
-PARITY UNPINNED against the reference's third-party algorithm: the reference calls skimage.measure.marching_cubes_lewiner
-(scikit-image, version unpinned in environment.yml; the function exists in 0.14-0.18), which is not installed in the build
-image and whose 33-case tables are not in /root/reference.  What IS common to every marching-cubes variant, and checked:
-one vertex per sign-changing grid edge at the linear zero crossing.  The triangulation rule restated here is the one
-documented in qsp_slam_amd/csrc/mesh_extract.hpp (face-consistent segments, loops, fans, outward orientation); this file
-derives its case table independently from that description, and tests/test_oracle_mesh.py checks the table for all 256
-cases plus closedness / orientation / volume of whole meshes.
+This file restates the TABLE method of rounds 2-3 (qsp_mesh_extractor_set_method(m, 1), MeshExtractor(method="table")): one vertex
+per sign-changing grid edge at the linear zero crossing, triangulated by the rule documented in qsp_slam_amd/csrc/mesh_extract.hpp
+(face-consistent segments, loops, fans, outward orientation); the case table is derived here independently from that description,
+and tests/test_oracle_mesh.py checks it for all 256 cases plus closedness / orientation / volume of whole meshes.  It is NOT what
+the reference calls: that is skimage.measure.marching_cubes_lewiner, restated in oracle/mc_lewiner_oracle.py and pinned by
+scikit-image's own output (tests/golden/mc_lewiner_*.npz) -- the library's default since round 4.
 """
 import numpy as np
 
