@@ -3,8 +3,9 @@
 // reconstruct/utils.py:120-141; MeshExtractor.extract_mesh_from_code, reconstruct/optimizer.py:284-304).
 // Included at the end of sdf_refine.hip (same translation unit: it launches k_decode and reads qsp_decoder).
 //
-// skimage (>= 0.17, unpinned in the reference's environment.yml) is absent from the build image, so Lewiner's 33-case tables
-// cannot be checked against; the triangulation here is generated from first principles instead:
+// Marching cubes: method 0 (default, round 4) is Lewiner's, exactly as scikit-image's marching_cubes_lewiner runs it -- mesh_lewiner.hpp,
+// pinned by scikit-image's own output.  Method 1 is the triangulation rounds 2-3 shipped when the dependency had not been found in the
+// image, generated from first principles:
 //   * a vertex on every grid edge whose end points differ in sign (inside = sdf < 0), at the linear zero crossing --
 //     the same vertex set every marching-cubes variant has, shared between the cells around the edge;
 //   * per cell, each cube face with 2 crossings contributes one segment, a face with 4 (ambiguous) two segments that
@@ -12,8 +13,8 @@
 //     cells always agree and the surface is watertight; the segments close into loops, each loop is oriented so that
 //     the right-hand normal points to increasing sdf (outwards) and fan-triangulated from the first vertex whose fan has
 //     no diagonal inside a cube face (such a fan exists for every loop of every case).
-// Where Lewiner differs: interior ambiguity tests and the extra centre vertex of a few of the 33 cases (rare on smooth
-// SDFs), face order, vertex order.  Vertex coordinates follow the reference: index * voxel_size + (-1).
+// Where Lewiner differs from method 1: the diagonals inside a cell's polygons, interior ambiguity tests and the extra centre vertex
+// of a few of the 33 cases, face order, vertex order.  Both share the scan kernels and the buffers of this file.
 #pragma once
 
 namespace qsp {
