@@ -190,9 +190,6 @@ __device__ unsigned long long qsp_phase_ticks[3][16];    // [kernel][i]: ticks b
 #define PHASE_MARK(kern, i)
 #define PHASE_END(kern, n)
 #endif
-#ifndef QSP_PHASE_EXP
-#define QSP_PHASE_EXP 0      // timing experiments only (tools/list_phases.sh: k_sample / k_scan cut short at a phase boundary); 0 in every build that ships
-#endif
 constexpr int SAMPLE_THREADS = 1024;      // k_sample's workgroup: latency, not throughput (a one-object call is ONE workgroup)
 // (Measured in round 4 and not kept: a hypothesis's rays over up to 8 workgroups, the one that finishes last writing the lists from
 //  what the others left in global memory -- k_sample 25.7 -> 23.5 us, k_scan 26.2 -> 30.6 us per launch of a one-object call, the
@@ -242,9 +239,6 @@ __device__ __forceinline__ void sample_body(HypState* __restrict__ st, const Obj
     }
     __syncthreads();
     PHASE_MARK(0, 3);
-#if QSP_PHASE_EXP == 11
-    return;
-#endif
     const ObjView ov = objs[S.obj];
     const int D = cfg.n_depth;
     const float* R = rays + 3 * ov.ray_off;
@@ -498,9 +492,6 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void k_sample(HypState* __restrict_
                                                 const MlpParams* __restrict__ Pm, float* __restrict__ c0_all, PlanTail pt) {
     PHASE_MARK(0, 0);
     sample_body(st, objs, rays, cfg, valid_rk, rk_stride, ray_voff, ray_stride, Pm, c0_all);
-#if QSP_PHASE_EXP == 11 || QSP_PHASE_EXP == 12
-    return;
-#endif
     PHASE_MARK(0, 7);
     plan_tail<SAMPLE_THREADS>(pt, st, objs);        // the forward kernel's item list (k_plan mode 0)
     PHASE_END(0, 8);
@@ -875,13 +866,13 @@ __device__ __forceinline__ void scan_body(float* __restrict__ rows /*[SCAN_RAYS]
         float* row = rows + threadIdx.x * SCAN_LD;
         if (r < ov.n_rays) {
             dobs = (r < ov.n_fg) ? dep[r] : 1.1f * d_max;   // optimizer.py:153
-            if (voff[r + 1] > voff[r] && QSP_PHASE_EXP != 21) n = scan_ray(row, D, d_min, d_max, cfg.cut_off, dobs, kept, res);
+            if (voff[r + 1] > voff[r]) n = scan_ray(row, D, d_min, d_max, cfg.cut_off, dobs, kept, res);
         }
         int tot;
         PHASE_MARK(1, 3);
         const int ex = block_excl_scan_256(n, sc, &tot);
         PHASE_MARK(1, 4);
-        if (QSP_PHASE_EXP != 22) {
+        {
             int w = carry + ex;
             for (uint64_t m = kept; m; m &= m - 1, ++w) {
                 e_rk[w] = (r << 6) | (__ffsll((long long)m) - 1);
@@ -892,7 +883,7 @@ __device__ __forceinline__ void scan_body(float* __restrict__ rows /*[SCAN_RAYS]
         carry += tot;
     }
     PHASE_MARK(1, 5);
-    if (threadIdx.x == 0) S.n_render = (QSP_PHASE_EXP == 22) ? 0 : carry;
+    if (threadIdx.x == 0) S.n_render = carry;
 }
 __global__ __launch_bounds__(SCAN_RAYS) void k_scan(HypState* __restrict__ st, const ObjView* __restrict__ objs,
                                                     const float* __restrict__ depth, RefineCfg cfg,
@@ -906,9 +897,6 @@ __global__ __launch_bounds__(SCAN_RAYS) void k_scan(HypState* __restrict__ st, c
     for (int e = threadIdx.x; e < SCAN_RAYS * SCAN_LD / 4; e += SCAN_RAYS)
         reinterpret_cast<float4*>(rows)[e] = make_float4(SCAN_NONE, SCAN_NONE, SCAN_NONE, SCAN_NONE);
     scan_body(rows, st, objs, depth, cfg, valid_rk, rk_stride, ray_voff, ray_stride, sdf_valid, rend_rk, rend_deds, rend_res);
-#if QSP_PHASE_EXP == 23
-    return;
-#endif
     PHASE_MARK(1, 6);
     plan_tail<SCAN_RAYS>(pt, st, objs);      // the Jacobian kernel's item list (k_plan mode 1)
     PHASE_END(1, 7);
