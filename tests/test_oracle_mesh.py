@@ -247,3 +247,38 @@ def test_lewiner_and_the_table_method_share_their_vertices_on_smooth_volumes():
         return {tuple(np.roll(t, -int(np.argmin(t)))) for t in F.tolist()}
     same = len(canon(idx[f]) & canon(lf))
     assert 0.3 * len(f) < same < 0.8 * len(f)
+
+
+def test_every_lewiner_tiling_uses_exactly_the_sign_changing_edges():
+    """The premise of the device kernel's vertex numbering (csrc/mesh_lewiner.hpp): a vertex is created by the FIRST cell of the
+    sweep that uses it, and the kernel takes that to be the first of the cells around the edge -- true iff every tiling a cell can
+    take refers to the vertex of each of its sign-changing edges (and to no other edge).  Checked for every corner pattern against
+    every tiling of its case: 728 (pattern, tiling) pairs."""
+    from oracle import mc_lewiner_oracle as ml
+    T = ml.tables()
+    e1, e2 = [0, 1, 2, 3, 4, 5, 6, 7, 0, 1, 2, 3], [1, 2, 3, 0, 5, 6, 7, 4, 4, 5, 6, 7]
+    cand = {1: [("TILING1", 1, ())], 2: [("TILING2", 2, ())], 3: [("TILING3_1", 2, ()), ("TILING3_2", 4, ())],
+            4: [("TILING4_1", 2, ()), ("TILING4_2", 6, ())], 5: [("TILING5", 3, ())],
+            6: [("TILING6_1_1", 3, ()), ("TILING6_1_2", 9, ()), ("TILING6_2", 5, ())],
+            7: [("TILING7_1", 3, ())] + [("TILING7_2", 5, (k,)) for k in range(3)] + [("TILING7_3", 9, (k,)) for k in range(3)]
+            + [("TILING7_4_1", 5, ()), ("TILING7_4_2", 9, ())],
+            8: [("TILING8", 2, ())], 9: [("TILING9", 4, ())],
+            10: [("TILING10_1_1", 4, ()), ("TILING10_1_1_", 4, ()), ("TILING10_1_2", 8, ()), ("TILING10_2", 8, ()), ("TILING10_2_", 8, ())],
+            11: [("TILING11", 4, ())],
+            12: [("TILING12_1_1", 4, ()), ("TILING12_1_1_", 4, ()), ("TILING12_1_2", 8, ()), ("TILING12_2", 8, ()), ("TILING12_2_", 8, ())],
+            13: [("TILING13_1", 4, ()), ("TILING13_1_", 4, ())] + [("TILING13_2", 6, (k,)) for k in range(6)]
+            + [("TILING13_2_", 6, (k,)) for k in range(6)] + [("TILING13_3", 10, (k,)) for k in range(12)]
+            + [("TILING13_3_", 10, (k,)) for k in range(12)] + [("TILING13_4", 12, (k,)) for k in range(4)]
+            + [("TILING13_5_1", 6, (k,)) for k in range(4)] + [("TILING13_5_2", 10, (k,)) for k in range(4)],
+            14: [("TILING14", 4, ())]}
+    n = 0
+    for index in range(1, 255):
+        case, config = T["CASES"][index]
+        crossing = {e for e in range(12) if ((index >> e1[e]) & 1) != ((index >> e2[e]) & 1)}
+        for name, nt, sub in cand[case]:
+            row = T[name][config]
+            for s_ in sub:
+                row = row[s_]
+            assert {e for e in row[:3 * nt] if e != 12} == crossing, (index, name, sub)
+            n += 1
+    assert n == 728
