@@ -3098,6 +3098,15 @@ static int chol_chain_setup(qsp_ba_problem* p) {
 }
 
 extern "C" int qsp_ba_create(const qsp_ba_scene* s, int device, qsp_ba_problem** out) {
+    // QSP_BA_CREATE_TIMING=1: host-side phases of this call on stderr (tools/time_ba_create.py)
+    static const bool timing = getenv("QSP_BA_CREATE_TIMING") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!timing) return;
+        const auto t = std::chrono::steady_clock::now();
+        fprintf(stderr, "qsp_ba_create: %-34s %7.1f us\n", what, std::chrono::duration<double, std::micro>(t - t_prev).count());
+        t_prev = t;
+    };
     if (!s || !out) return qsp_fail(QSP_ERR_INVALID, "qsp_ba_create: null argument");
     if (s->n_kf <= 0 || s->n_pt < 0 || s->n_obj < 0 || s->n_mono < 0 || s->n_stereo < 0 || s->n_objedge < 0)
         return qsp_fail(QSP_ERR_INVALID, "qsp_ba_create: negative count");
@@ -3124,6 +3133,7 @@ extern "C" int qsp_ba_create(const qsp_ba_scene* s, int device, qsp_ba_problem**
         if (host_alloc_cached(p->device, (void**)&p->stage, want, hipHostMallocDefault, &p->stage_alloc) == hipSuccess) p->stage_cap = p->stage_alloc;
         else { (void)hipGetLastError(); p->stage = nullptr; }
     }
+    lap("checks, stream, staging buffer");
     Dev& d = p->d;
     d.n_kf = s->n_kf; d.n_pt = s->n_pt; d.n_obj = s->n_obj; d.n_oe = s->n_objedge;
     d.n_edge = s->n_mono + s->n_stereo;
@@ -3199,6 +3209,7 @@ extern "C" int qsp_ba_create(const qsp_ba_scene* s, int device, qsp_ba_problem**
     p->edge_level_h.assign(d.n_edge, 0);
     p->oe_level_h.assign(d.n_oe, 0);
     p->dimp_max = ((6 * (d.n_kf + d.n_obj) + NB - 1) / NB) * NB;
+    lap("edge order, CSRs, chunks (host)");
     int rc = QSP_OK;
 #define UP(field, src, n) if (!rc) rc = dupload(p, &d.field, src, (size_t)(n))
 #define AL(field, n) if (!rc) rc = dalloc(p, &d.field, (size_t)(n))
@@ -3274,7 +3285,9 @@ extern "C" int qsp_ba_create(const qsp_ba_scene* s, int device, qsp_ba_problem**
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_obj_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCHUR_ROW_LDS_MAX);
         if (e != hipSuccess) rc = qsp_fail(QSP_ERR_DEVICE, hipGetErrorString(e));
     }
+    lap("allocations + staged uploads");
     if (!rc) rc = chol_chain_setup(p);
+    lap("chain set-up");
     if (rc) {
         qsp_ba_destroy(p);
         return rc;
@@ -3289,8 +3302,10 @@ extern "C" int qsp_ba_create(const qsp_ba_scene* s, int device, qsp_ba_problem**
         }
         p->deterministic = true;
     }
+    lap("pair lists (host) + uploads");
     {   // every upload and memset above was asynchronous on the problem's stream: one wait, then the staging buffer goes back
         const hipError_t e = hipStreamSynchronize(p->stream);
+        lap("wait for the uploads");
         if (p->stage && !buf_cache_put(g_host_cache, p->device, p->stage, p->stage_alloc, hipHostMallocDefault, (size_t)64 << 20)) (void)hipHostFree(p->stage);
         p->stage = nullptr;
         p->stage_cap = p->stage_used = 0;
