@@ -514,6 +514,25 @@ def latency_block(dec):
         ba_call()
     out["ms_local_joint_ba_problem_per_call"] = 1e3 * (time.perf_counter() - t0) / 10
     out["ba_workload"] = "C4's graph (%s), created from host arrays and destroyed in every call" % w["desc"].split(":")[0]
+    # the call that follows every successful refinement (src/LocalMapping_util.cc:832): MeshExtractor.extract_mesh_from_code --
+    # decode over the voxel grid + Lewiner's marching cubes on the device (32^3: the reference's KITTI setting, 64^3: the others)
+    import builtins
+    from qsp_slam_amd.reconstruct.optimizer import MeshExtractor
+    code = np.zeros(64, np.float32)
+    _print = builtins.print
+    builtins.print = lambda *a, **k: None       # (the mirror prints the reference's "Extract mesh takes ..." line per call)
+    try:
+        for dim in (32, 64):
+            me = MeshExtractor(dec, 64, dim)
+            for _ in range(2):
+                me.extract_mesh_from_code(code)
+            t0 = time.perf_counter()
+            for _ in range(10):
+                m = me.extract_mesh_from_code(code)
+            out["ms_extract_mesh_%d" % dim] = 1e3 * (time.perf_counter() - t0) / 10
+            out["mesh_%d" % dim] = "%d vertices, %d faces" % (len(m.vertices), len(m.faces))
+    finally:
+        builtins.print = _print
     return out
 
 
