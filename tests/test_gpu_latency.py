@@ -118,3 +118,43 @@ def test_two_host_threads_sharing_one_decoder_get_the_serial_results(golden_dir)
         t.join()
     dec.close()
     assert not errors, errors
+
+
+def test_state_lives_on_the_device_between_calls(golden_dir):
+    """The batch's inputs are written to a pinned mirror and uploaded by the next consumer (csrc/sdf_refine.hip:batch_upload).  What
+    must hold whatever the order of calls: a state that was set and never run reads back as set; a run continues from the state the
+    previous run left on the DEVICE (the mirror still holds the older one and must not be uploaded again); setting a state between
+    two runs replaces it."""
+    from qsp_slam_amd import DeepSdfDecoder, synth
+    from qsp_slam_amd.reconstruct.optimizer import Optimizer, RefineBatch, _joint_cfg
+    dec = DeepSdfDecoder.from_npz(os.path.join(golden_dir, "decoder_8x512.npz"))
+    opt = Optimizer(dec, make_cfg(so.JointConfig(n_iter=5)))
+    o = synth.make_object_views(4242, 1, 500, n_fg=128, n_bg=64)[0]
+    T0 = o["t_cam_obj"][None].astype(np.float32)
+    code0 = (0.02 * np.random.default_rng(1).standard_normal((1, 64))).astype(np.float32)
+
+    def batch():
+        return RefineBatch(dec, _joint_cfg(opt), [o["pts"]], [o["rays"]], [o["depth"]], [0])
+    b = batch()
+    b.set_state(T0, code0)
+    T, code, _, good = b.get()                                  # (no run in between: the upload happens for the read-back)
+    assert np.array_equal(code[0], code0[0]) and bool(good[0]) and np.abs(T[0] - T0[0]).max() < 1e-5
+    b.run(5)
+    five = b.get()
+    b.close()
+    b = batch()
+    b.set_state(T0, code0)
+    b.run(2)
+    two = b.get()
+    b.run(3)                                                    # continues from the device's state, not from the mirror's
+    cont = b.get()
+    assert not np.array_equal(two[1], five[1])
+    for x, y in zip(cont, five):
+        assert np.array_equal(np.asarray(x), np.asarray(y), equal_nan=True)
+    b.set_state(T0, code0)                                      # ... and a new state replaces it
+    b.run(5)
+    again = b.get()
+    b.close()
+    for x, y in zip(again, five):
+        assert np.array_equal(np.asarray(x), np.asarray(y), equal_nan=True)
+    dec.close()
